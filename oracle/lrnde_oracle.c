@@ -1,0 +1,664 @@
+/*
+ * lrnde_oracle.c — CPU restatement of the LocalRegNeuralDE.jl adaptive Tsit5
+ * neural-ODE path.  TEST INFRASTRUCTURE ONLY; see lrnde_oracle.h for the
+ * file:line map into /root/reference and the "parity unpinned" statement.
+ *
+ * Build: gcc -O2 -march=x86-64-v3 -ffp-contract=off -fopenmp -shared -fPIC
+ * (-ffp-contract=off: Julia never contracts a*b+c on its own, so every fused
+ * multiply-add below is an explicit fmaf()).
+ */
+#include "lrnde_oracle.h"
+
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* canonical fp32 math                                                        */
+/* ------------------------------------------------------------------------- */
+
+static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+static inline float u2f(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
+
+/* coefficients from oracle/gen_coeffs.py */
+static const float EXP_P[6] = {0x1.000000p-1f, 0x1.555556p-3f, 0x1.5554eap-5f,
+                               0x1.1110e0p-7f, 0x1.6d4324p-10f, 0x1.a124f2p-13f};
+static const float TANH_Q[7] = {-0x1.555556p-2f, 0x1.111110p-3f,  -0x1.ba1a58p-5f, 0x1.662708p-6f,
+                                -0x1.201022p-7f, 0x1.b159b6p-9f, -0x1.c4070cp-11f};
+#define LRO_LOG2E 0x1.715476p+0f
+#define LRO_LN2_HI 0x1.63p-1f
+#define LRO_LN2_LO -0x1.bd0106p-13f
+
+/* exp(x) for x clamped to [-87, 87]:  2^n * (1 + r + r^2 P(r)),  n = rint(x log2 e) */
+float lro_expf(float x) {
+  if (x > 87.0f) x = 87.0f;
+  if (x < -87.0f) x = -87.0f;
+  float n = rintf(x * LRO_LOG2E);
+  float r = fmaf(n, -LRO_LN2_HI, x);
+  r = fmaf(n, -LRO_LN2_LO, r);
+  float p = EXP_P[5];
+  p = fmaf(p, r, EXP_P[4]);
+  p = fmaf(p, r, EXP_P[3]);
+  p = fmaf(p, r, EXP_P[2]);
+  p = fmaf(p, r, EXP_P[1]);
+  p = fmaf(p, r, EXP_P[0]);
+  float r2 = r * r;
+  float e = fmaf(p, r2, r);
+  e = e + 1.0f;
+  if (e != e) return e; /* NaN in, NaN out */
+  int32_t ni = (int32_t)n;
+  return u2f(f2u(e) + ((uint32_t)ni << 23));
+}
+
+/* tanh: odd polynomial for |x| < 0.625, 1 - 2/(exp(2|x|)+1) up to 9, then +-1 */
+float lro_tanhf(float x) {
+  float ax = fabsf(x);
+  if (ax < 0.625f) {
+    float s = x * x;
+    float q = TANH_Q[6];
+    q = fmaf(q, s, TANH_Q[5]);
+    q = fmaf(q, s, TANH_Q[4]);
+    q = fmaf(q, s, TANH_Q[3]);
+    q = fmaf(q, s, TANH_Q[2]);
+    q = fmaf(q, s, TANH_Q[1]);
+    q = fmaf(q, s, TANH_Q[0]);
+    float xs = x * s;
+    return fmaf(xs, q, x);
+  }
+  if (ax >= 9.0f) return copysignf(1.0f, x);
+  float e = lro_expf(2.0f * ax);
+  float r = 1.0f - 2.0f / (e + 1.0f);
+  return copysignf(r, x);
+}
+
+/* NNlib gelu (tanh form written as x*sigmoid(2*sqrt(2/pi)*(x + 0.044715 x^3))) */
+float lro_geluf(float x) {
+  const float two_lambda = 1.5957691216057308f; /* 2*sqrt(2/pi) */
+  float x2 = x * x;
+  float inner = fmaf(x2, 0.044715f, 1.0f);
+  float arg = (two_lambda * x) * inner;
+  return x / (1.0f + lro_expf(-arg));
+}
+
+static inline float act_apply(int act, float v) {
+  switch (act) {
+    case LRO_ACT_TANH: return lro_tanhf(v);
+    case LRO_ACT_GELU: return lro_geluf(v);
+    default: return v;
+  }
+}
+
+/* DiffEqBase fastpow: fastpow2(y * fastlog2(x)), pure fp32/int ops */
+float lro_fastlog2(float x) {
+  const float a = 0.338953f, b = 2.198599f, c = 1.523692f;
+  uint32_t ux1i = f2u(x);
+  int32_t ex = (int32_t)((ux1i & 0x7F800000u) >> 23);
+  uint32_t greater = ux1i & 0x00400000u;
+  float signif, fexp;
+  if (greater != 0u) {
+    signif = u2f((ux1i & 0x007FFFFFu) | 0x3f000000u);
+    fexp = (float)ex - 126.0f;
+  } else {
+    signif = u2f((ux1i & 0x007FFFFFu) | 0x3f800000u);
+    fexp = (float)ex - 127.0f;
+  }
+  signif = signif - 1.0f;
+  float num = signif * (a * signif + b);
+  float lg2 = fexp + num / (signif + c);
+  return lg2;
+}
+
+float lro_fastpow2(float x) {
+  float offset = (x < 0.0f) ? 1.0f : 0.0f;
+  float clipp = (x < -126.0f) ? -126.0f : x;
+  int32_t w = (int32_t)clipp; /* trunc */
+  float z = (clipp - (float)w) + offset;
+  float s = ((clipp + 121.2740575f) + 27.7280233f / (4.84252568f - z)) - 1.49012907f * z;
+  uint32_t v = (uint32_t)(8388608.0f * s);
+  return u2f(v);
+}
+
+float lro_fastpow(float x, float y) {
+  if (x == 0.0f) return 0.0f;
+  return lro_fastpow2(y * lro_fastlog2(x));
+}
+
+/* Tsit5 tableau, Float64 literals converted to Float32 at use (src/perform_step.jl:6-8) */
+static const double TS_C[6] = {0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
+static const double TS_A[21] = {
+    /* a21 */ 0.161,
+    /* a31 a32 */ -0.008480655492356989, 0.335480655492357,
+    /* a41.. */ 2.8971530571054935, -6.359448489975075, 4.3622954328695815,
+    /* a51.. */ 5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525,
+    /* a61.. */ 5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401,
+    -0.028269050394068383,
+    /* a71.. */ 0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742,
+    -3.290069515436081, 2.324710524099774};
+static const double TS_BT[7] = {-0.00178001105222577714, -0.0008164344596567469,
+                                0.007880878010261995,    -0.1447110071732629,
+                                0.5823571654525552,      -0.45808210592918697,
+                                0.015151515151515152};
+/* dense output: b1(th) = th*(r11 + th*(r12 + th*(r13 + th*r14))), bi(th) = th^2*(ri2 + th*(ri3 + th*ri4)) */
+static const double TS_R[28] = {
+    1.0, -2.763706197274826, 2.9132554618219126, -1.0530884977290216,
+    0.0, 0.13169999999999998, -0.2234, 0.1017,
+    0.0, 3.9302962368947516, -5.941033872131505, 2.490627285651253,
+    0.0, -12.411077166933676, 30.33818863028232, -16.548102889244902,
+    0.0, 37.50931341651104, -88.1789048947664, 47.37952196281928,
+    0.0, -27.896526289197286, 65.09189467479366, -34.87065786149661,
+    0.0, 1.5, -4.0, 2.5};
+
+int lro_tsit5_tableau(double* a, double* c, double* btilde, double* r) {
+  if (a) memcpy(a, TS_A, sizeof(TS_A));
+  if (c) memcpy(c, TS_C, sizeof(TS_C));
+  if (btilde) memcpy(btilde, TS_BT, sizeof(TS_BT));
+  if (r) memcpy(r, TS_R, sizeof(TS_R));
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* vector field: TDChain(Dense(D+td -> H, act), Dense(H+td -> D))             */
+/* src/layers/common.jl:10-40; experiments/src/construct.jl:180-189           */
+/* ------------------------------------------------------------------------- */
+
+int lro_mlp_param_count(int D, int H, int td) { return H * (D + td) + H + D * (H + td) + D; }
+
+void lro_mlp_rhs(const lro_mlp* m, const float* u, float t, int B, float* du) {
+  const int D = m->D, H = m->H, td = m->time_dep ? 1 : 0;
+  const float* W1 = m->p;                    /* H x (D+td), column-major */
+  const float* b1 = W1 + (size_t)H * (D + td);
+  const float* W2 = b1 + H;                  /* D x (H+td), column-major */
+  const float* b2 = W2 + (size_t)D * (H + td);
+  int nth = m->nthreads > 0 ? m->nthreads : 1;
+  (void)nth;
+#pragma omp parallel num_threads(nth)
+  {
+    float* h = (float*)malloc(sizeof(float) * (size_t)(H > D ? H : D));
+#pragma omp for schedule(static)
+    for (int n = 0; n < B; ++n) {
+      const float* x = u + (size_t)n * D;
+      float* y = du + (size_t)n * D;
+      /* layer 1: one fma chain per output in increasing k, t column last, then + bias */
+      for (int o = 0; o < H; ++o) h[o] = 0.0f;
+      for (int k = 0; k < D; ++k) {
+        const float xv = x[k];
+        const float* w = W1 + (size_t)k * H;
+        for (int o = 0; o < H; ++o) h[o] = fmaf(w[o], xv, h[o]);
+      }
+      if (td) {
+        const float* w = W1 + (size_t)D * H;
+        for (int o = 0; o < H; ++o) h[o] = fmaf(w[o], t, h[o]);
+      }
+      for (int o = 0; o < H; ++o) h[o] = act_apply(m->act, h[o] + b1[o]);
+      /* layer 2 */
+      for (int o = 0; o < D; ++o) y[o] = 0.0f;
+      for (int k = 0; k < H; ++k) {
+        const float hv = h[k];
+        const float* w = W2 + (size_t)k * D;
+        for (int o = 0; o < D; ++o) y[o] = fmaf(w[o], hv, y[o]);
+      }
+      if (td) {
+        const float* w = W2 + (size_t)H * D;
+        for (int o = 0; o < D; ++o) y[o] = fmaf(w[o], t, y[o]);
+      }
+      for (int o = 0; o < D; ++o) y[o] = y[o] + b2[o];
+    }
+    free(h);
+  }
+}
+
+static void mlp_field_tramp(void* ctx, const float* u, float t, int B, float* du) {
+  lro_mlp_rhs((const lro_mlp*)ctx, u, t, B, du);
+}
+void lro_mlp_as_field(const lro_mlp* m, lro_field* out) {
+  out->fn = mlp_field_tramp;
+  out->ctx = (void*)m;
+  out->D = m->D;
+}
+
+/* ------------------------------------------------------------------------- */
+/* norms and residuals (src/perform_step.jl:208-212)                          */
+/* ------------------------------------------------------------------------- */
+
+/* sqrt(sum(x^2)/n): fp32 squares accumulated in fp64, final value rounded to fp32 */
+static float rms_from_sumsq(double acc, long n) { return (float)sqrt(acc / (double)n); }
+
+static double sumsq_resid(const float* ut, const float* u0, const float* u1, float abstol,
+                          float reltol, long n) {
+  double acc = 0.0;
+  for (long i = 0; i < n; ++i) {
+    float sc = abstol + fmaxf(fabsf(u0[i]), fabsf(u1[i])) * reltol;
+    float r = ut[i] / sc;
+    float sq = r * r;
+    acc += (double)sq;
+  }
+  return acc;
+}
+
+static double sumsq_diff(const float* a, const float* b, long n) {
+  double acc = 0.0;
+  for (long i = 0; i < n; ++i) {
+    float d = a[i] - b[i];
+    float sq = d * d;
+    acc += (double)sq;
+  }
+  return acc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* one Tsit5 step (src/perform_step.jl:3-47)                                  */
+/* ------------------------------------------------------------------------- */
+
+int lro_tsit5_step(const lro_field* f, const float* uprev, const float* k1, float t, float dt,
+                   float abstol, float reltol, int B, float* u, float* k7, float* ks, float* g6o,
+                   float* eest, float* reg_error, float* reg_stiff) {
+  const long n = (long)f->D * B;
+  const float c1 = (float)TS_C[0], c2 = (float)TS_C[1], c3 = (float)TS_C[2], c4 = (float)TS_C[3];
+  float A[21], BT[7];
+  for (int i = 0; i < 21; ++i) A[i] = (float)TS_A[i];
+  for (int i = 0; i < 7; ++i) BT[i] = (float)TS_BT[i];
+  float* own = NULL;
+  float *k2, *k3, *k4, *k5, *k6;
+  if (ks) {
+    k2 = ks; k3 = ks + n; k4 = ks + 2 * n; k5 = ks + 3 * n; k6 = ks + 4 * n;
+  } else {
+    own = (float*)malloc(sizeof(float) * 5 * (size_t)n);
+    k2 = own; k3 = own + n; k4 = own + 2 * n; k5 = own + 3 * n; k6 = own + 4 * n;
+  }
+  float* tmp = (float*)malloc(sizeof(float) * (size_t)n);
+  float* g6 = g6o ? g6o : (float*)malloc(sizeof(float) * (size_t)n);
+  float* utilde = (float*)malloc(sizeof(float) * (size_t)n);
+
+  /* :11-12  a = dt*a21; k2 = f(uprev + a*k1, t + c1*dt) */
+  const float a = dt * A[0];
+  for (long i = 0; i < n; ++i) tmp[i] = uprev[i] + a * k1[i];
+  f->fn(f->ctx, tmp, t + c1 * dt, B, k2);
+  /* :13 */
+  for (long i = 0; i < n; ++i) tmp[i] = uprev[i] + dt * (A[1] * k1[i] + A[2] * k2[i]);
+  f->fn(f->ctx, tmp, t + c2 * dt, B, k3);
+  /* :14 */
+  for (long i = 0; i < n; ++i)
+    tmp[i] = uprev[i] + dt * ((A[3] * k1[i] + A[4] * k2[i]) + A[5] * k3[i]);
+  f->fn(f->ctx, tmp, t + c3 * dt, B, k4);
+  /* :15 */
+  for (long i = 0; i < n; ++i)
+    tmp[i] = uprev[i] + dt * (((A[6] * k1[i] + A[7] * k2[i]) + A[8] * k3[i]) + A[9] * k4[i]);
+  f->fn(f->ctx, tmp, t + c4 * dt, B, k5);
+  /* :16-17 */
+  for (long i = 0; i < n; ++i)
+    g6[i] = uprev[i] +
+            dt * ((((A[10] * k1[i] + A[11] * k2[i]) + A[12] * k3[i]) + A[13] * k4[i]) + A[14] * k5[i]);
+  f->fn(f->ctx, g6, t + dt, B, k6);
+  /* :18 */
+  for (long i = 0; i < n; ++i)
+    u[i] = uprev[i] + dt * (((((A[15] * k1[i] + A[16] * k2[i]) + A[17] * k3[i]) + A[18] * k4[i]) +
+                             A[19] * k5[i]) +
+                            A[20] * k6[i]);
+  /* :19-20 */
+  f->fn(f->ctx, u, t + dt, B, k7);
+  /* :21-27 */
+  for (long i = 0; i < n; ++i)
+    utilde[i] = dt * ((((((BT[0] * k1[i] + BT[1] * k2[i]) + BT[2] * k3[i]) + BT[3] * k4[i]) +
+                        BT[4] * k5[i]) +
+                       BT[5] * k6[i]) +
+                      BT[6] * k7[i]);
+  /* EEst (upstream perform_step!) and :34-38 error_estimate = EEst*dt */
+  float ee = rms_from_sumsq(sumsq_resid(utilde, uprev, u, abstol, reltol, n), n);
+  if (eest) *eest = ee;
+  if (reg_error) *reg_error = ee * dt;
+  /* :40-47 stiffness_estimate */
+  if (reg_stiff) {
+    float den = rms_from_sumsq(sumsq_diff(u, g6, n), n);
+    if (den == 0.0f) {
+      *reg_stiff = 0.0f;
+    } else {
+      float num = rms_from_sumsq(sumsq_diff(k7, k6, n), n);
+      *reg_stiff = fabsf(num / (den + 1.1920929e-7f)) / 3.5068f;
+    }
+  }
+  free(utilde);
+  if (!g6o) free(g6);
+  free(tmp);
+  free(own);
+  return LRO_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* initial dt (OrdinaryDiffEq ode_determine_initdt, out-of-place) */
+/* ------------------------------------------------------------------------- */
+
+int lro_init_dt(const lro_field* f, const float* u0, float t0, float tend, float abstol,
+                float reltol, int B, float* f0_out, float* dt_out) {
+  const long n = (long)f->D * B;
+  const float dtmax = tend - t0;
+  float* f0 = f0_out ? f0_out : (float*)malloc(sizeof(float) * (size_t)n);
+  float* u1 = (float*)malloc(sizeof(float) * (size_t)n);
+  float* f1 = (float*)malloc(sizeof(float) * (size_t)n);
+  f->fn(f->ctx, u0, t0, B, f0);
+  double a0 = 0.0, a1 = 0.0;
+  for (long i = 0; i < n; ++i) {
+    float sk = abstol + fabsf(u0[i]) * reltol;
+    float r0 = u0[i] / sk;
+    float r1 = f0[i] / sk;
+    float s0 = r0 * r0, s1 = r1 * r1;
+    a0 += (double)s0;
+    a1 += (double)s1;
+  }
+  float d0 = rms_from_sumsq(a0, n), d1 = rms_from_sumsq(a1, n);
+  float dt0;
+  if ((double)d0 < 1e-5 || (double)d1 < 1e-5)
+    dt0 = 1e-6f;
+  else
+    dt0 = (d0 / d1) / 100.0f;
+  dt0 = fminf(dt0, dtmax);
+  for (long i = 0; i < n; ++i) u1[i] = u0[i] + dt0 * f0[i];
+  f->fn(f->ctx, u1, t0 + dt0, B, f1);
+  double a2 = 0.0;
+  for (long i = 0; i < n; ++i) {
+    float sk = abstol + fabsf(u0[i]) * reltol;
+    float r2 = (f1[i] - f0[i]) / sk;
+    float s2 = r2 * r2;
+    a2 += (double)s2;
+  }
+  float d2 = rms_from_sumsq(a2, n) / dt0;
+  float maxd = fmaxf(d1, d2);
+  float dt1;
+  if ((double)maxd <= 1e-15) {
+    dt1 = fmaxf(1e-6f, dt0 * 1e-3f);
+  } else {
+    float l10 = (float)log10((double)maxd);
+    float e = (-(2.0f + l10)) / 5.0f;
+    dt1 = (float)pow(10.0, (double)e);
+  }
+  *dt_out = fminf(fminf(100.0f * dt0, dt1), dtmax);
+  free(f1);
+  free(u1);
+  if (!f0_out) free(f0);
+  return LRO_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Tsit5 dense output (OrdinaryDiffEq tsit5 interpolant)          */
+/* ------------------------------------------------------------------------- */
+
+static void tsit5_bweights(float th, float b[7]) {
+  float R[28];
+  for (int i = 0; i < 28; ++i) R[i] = (float)TS_R[i];
+  float th2 = th * th;
+  /* evalpoly (Horner with muladd) */
+  b[0] = th * fmaf(th, fmaf(th, fmaf(th, R[3], R[2]), R[1]), R[0]);
+  for (int i = 1; i < 7; ++i) {
+    const float* r = R + 4 * i;
+    b[i] = th2 * fmaf(th, fmaf(th, r[3], r[2]), r[1]);
+  }
+}
+
+void lro_tsit5_interp(float theta, float dt, const float* y0, const float* const k[7], long n,
+                      float* out) {
+  float b[7];
+  tsit5_bweights(theta, b);
+  for (long i = 0; i < n; ++i) {
+    float s = k[0][i] * b[0] + k[1][i] * b[1];
+    s = s + k[2][i] * b[2];
+    s = s + k[3][i] * b[3];
+    s = s + k[4][i] * b[4];
+    s = s + k[5][i] * b[5];
+    s = s + k[6][i] * b[6];
+    out[i] = y0[i] + dt * s;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* adaptive solve (OrdinaryDiffEq solve!/loopheader!/loopfooter!) */
+/* ------------------------------------------------------------------------- */
+
+static float eps_f(float x) { /* Julia eps(::Float32) via bit ops (same code on the GPU) */
+  uint32_t b = f2u(x) & 0x7fffffffu;
+  uint32_t e = b >> 23;
+  if (e == 0xffu) return NAN;
+  if (e == 0u) return u2f(1u);
+  if (e <= 23u) return u2f(1u << (e - 1u));
+  return u2f((e - 23u) << 23);
+}
+
+int lro_solve(const lro_field* f, const float* u0, int B, float t0, float t1, const lro_opts* o,
+              const float* saveat, int nsave, float* u_saved, float* t_saved, int cap_saved,
+              lro_stats* st, lro_trace_row* trace, int cap_trace) {
+  const long n = (long)f->D * B;
+  const float abstol = o->abstol, reltol = o->reltol;
+  const float gamma = 0.9f, qmin = 0.2f, qmax = 10.0f, qoldinit = 1e-4f;
+  const float beta1 = (float)(7.0 / 50.0), beta2 = (float)(2.0 / 25.0);
+  memset(st, 0, sizeof(*st));
+  if (!(t1 > t0) || B <= 0) return (st->retcode = LRO_BADARG);
+  for (int i = 1; i < nsave; ++i)
+    if (!(saveat[i] >= saveat[i - 1])) return (st->retcode = LRO_BADARG);
+
+  float* buf = (float*)malloc(sizeof(float) * (size_t)n * 10);
+  float* uprev = buf;
+  float* u = buf + n;
+  float* k1 = buf + 2 * n;
+  float* ks = buf + 3 * n; /* k2..k6 */
+  float* k7 = buf + 8 * n;
+  float* interp = buf + 9 * n;
+  int rc = LRO_OK;
+  int nsaved = 0, isave = 0, ntrace = 0;
+
+#define PUSH_SAVE(tt, uu)                                            \
+  do {                                                               \
+    if (nsaved >= cap_saved) { rc = LRO_CAPACITY; goto done; }       \
+    memcpy(u_saved + (size_t)nsaved * n, (uu), sizeof(float) * n);   \
+    if (t_saved) t_saved[nsaved] = (tt);                             \
+    nsaved++;                                                        \
+  } while (0)
+
+  memcpy(uprev, u0, sizeof(float) * n);
+  float t = t0;
+  const float dtmax = t1 - t0;
+  const float dtmin = fmaxf(eps_f(t1), eps_f(t0));
+  float dt;
+  lro_init_dt(f, uprev, t0, t1, abstol, reltol, B, k1, &dt); /* k1 = f(u0,t0) = fsalfirst */
+  st->nf = 3; /* initdt: 2, initialize!: 1 */
+  st->dt_init = dt;
+  float qold = qoldinit, q11 = 1.0f, dtpropose = dt;
+  int accept = 0, iter = 0;
+  if (o->save_start) PUSH_SAVE(t0, u0);
+  while (isave < nsave && saveat[isave] <= t0) isave++; /* points at/before t0 are the start */
+
+  while (t < t1) {
+    /* loopheader! */
+    if (iter > 0) {
+      if (accept) {
+        float* sw = uprev; uprev = u; u = sw;   /* uprev <- u */
+        sw = k1; k1 = k7; k7 = sw;              /* fsalfirst <- fsallast */
+        dt = dtpropose;
+      } else {
+        dt = dt / fminf(1.0f / qmin, q11 / gamma);
+      }
+    }
+    iter++;
+    dt = fminf(dtmax, dt);
+    dt = fmaxf(dt, dtmin);
+    dt = fminf(fabsf(dt), fabsf(t1 - t));
+    /* check_error! */
+    if (iter > o->maxiters) { rc = LRO_MAXITERS; break; }
+    if (dt != dt) { rc = LRO_DT_NAN; break; }
+    if (fabsf(dt) <= fabsf(dtmin)) { rc = LRO_DT_LESS_THAN_MIN; break; }
+    /* perform_step! */
+    float eest;
+    lro_tsit5_step(f, uprev, k1, t, dt, abstol, reltol, B, u, k7, ks, NULL, &eest, NULL, NULL);
+    st->nf += 6;
+    /* loopfooter!: PI controller */
+    float ttmp = t + dt;
+    float q;
+    if (eest == 0.0f) {
+      q = 1.0f / qmax;
+    } else {
+      if (o->exact_pow) {
+        q11 = (float)pow((double)eest, (double)beta1);
+        q = q11 / (float)pow((double)qold, (double)beta2);
+      } else {
+        q11 = lro_fastpow(eest, beta1);
+        q = q11 / lro_fastpow(qold, beta2);
+      }
+      q = fmaxf(1.0f / qmax, fminf(1.0f / qmin, q / gamma));
+    }
+    accept = (eest <= 1.0f);
+    if (trace && ntrace < cap_trace) {
+      trace[ntrace].t = t; trace[ntrace].dt = dt; trace[ntrace].eest = eest;
+      trace[ntrace].accepted = accept; ntrace++;
+    }
+    st->eest_last = eest;
+    if (accept) {
+      st->naccept++;
+      float dtnew = dt / q;
+      qold = fmaxf(eest, qoldinit);
+      float tprev = t;
+      t = (fabsf(ttmp - t1) < 100.0f * eps_f(fmaxf(t, t1))) ? t1 : ttmp;
+      dtpropose = fmaxf(fminf(dtmax, dtnew), fmaxf(eps_f(t), dtmin));
+      /* savevalues! */
+      while (isave < nsave && saveat[isave] <= t) {
+        float ts = saveat[isave++];
+        if (ts != t) {
+          float theta = (ts - tprev) / dt;
+          const float* kk[7] = {k1, ks, ks + n, ks + 2 * n, ks + 3 * n, ks + 4 * n, k7};
+          lro_tsit5_interp(theta, dt, uprev, kk, n, interp);
+          PUSH_SAVE(ts, interp);
+        } else {
+          PUSH_SAVE(t, u);
+        }
+      }
+      if (o->save_everystep) PUSH_SAVE(t, u);
+    } else {
+      st->nreject++;
+    }
+  }
+done:
+  st->retcode = rc;
+  st->iters = iter;
+  st->nsaved = nsaved;
+  st->t_final = t;
+  st->dt_final = dt;
+  free(buf);
+  return rc;
+#undef PUSH_SAVE
+}
+
+/* ------------------------------------------------------------------------- */
+/* NeuralODE layer forward (src/layers/neural_ode.jl:56-100)                   */
+/* ------------------------------------------------------------------------- */
+
+int lro_node_forward(const lro_field* f, const float* x, int B, float t0, float t2,
+                     const lro_opts* o, int mode, int reg_type, float t1_or_rand, float* u_end,
+                     float* reg_val, int* nfe, lro_stats* st, float* t1_used) {
+  const long n = (long)f->D * B;
+  lro_opts oo = *o;
+  int rc;
+  *reg_val = 0.0f;
+  if (t1_used) *t1_used = t2;
+  if (mode == LRO_MODE_NONE) { /* _vanilla_node_fallback :56-60 */
+    float sv[1] = {t2};
+    float ts[2];
+    oo.save_everystep = 0;
+    float* us = (float*)malloc(sizeof(float) * (size_t)n * 2);
+    rc = lro_solve(f, x, B, t0, t2, &oo, sv, 1, us, ts, 2, st, NULL, 0);
+    if (st->nsaved > 0) memcpy(u_end, us + (size_t)(st->nsaved - 1) * n, sizeof(float) * n);
+    *nfe = st->nf;
+    free(us);
+    return rc;
+  }
+  float t1;
+  float* u1 = (float*)malloc(sizeof(float) * (size_t)n);
+  if (mode == LRO_MODE_UNBIASED) { /* :68-84, saveat = [t1, t2] */
+    t1 = t1_or_rand;
+    float sv[2] = {t1, t2};
+    float ts[3];
+    oo.save_everystep = 0;
+    float* us = (float*)malloc(sizeof(float) * (size_t)n * 3);
+    rc = lro_solve(f, x, B, t0, t2, &oo, sv, 2, us, ts, 3, st, NULL, 0);
+    if (rc != LRO_OK) { free(us); free(u1); return rc; }
+    int i1 = oo.save_start ? 1 : 0;
+    memcpy(u1, us + (size_t)i1 * n, sizeof(float) * n);     /* sol(t1): the saved knot */
+    memcpy(u_end, us + (size_t)(st->nsaved - 1) * n, sizeof(float) * n);
+    free(us);
+  } else { /* :88-100 biased, saveat = [] => every accepted step */
+    oo.save_everystep = 1;
+    int cap = oo.maxiters + 2;
+    if (cap > 4096) cap = 4096;
+    float* us = (float*)malloc(sizeof(float) * (size_t)n * cap);
+    float* ts = (float*)malloc(sizeof(float) * (size_t)cap);
+    rc = lro_solve(f, x, B, t0, t2, &oo, NULL, 0, us, ts, cap, st, NULL, 0);
+    if (rc != LRO_OK || st->nsaved < 2) {
+      free(us); free(ts); free(u1);
+      return rc != LRO_OK ? rc : LRO_BADARG;
+    }
+    int m = st->nsaved - 1;                 /* rand(rng, sol.t[1:end-1]) */
+    int idx = (int)(t1_or_rand * (float)m);
+    if (idx >= m) idx = m - 1;
+    if (idx < 0) idx = 0;
+    t1 = ts[idx];
+    memcpy(u1, us + (size_t)idx * n, sizeof(float) * n);
+    memcpy(u_end, us + (size_t)(st->nsaved - 1) * n, sizeof(float) * n);
+    free(us); free(ts);
+  }
+  if (t1_used) *t1_used = t1;
+  /* _get_ode_integrator :33-38 => init on (t1,t2): initdt (2 f) + fsalfirst (1 f) */
+  float* k1 = (float*)malloc(sizeof(float) * (size_t)n);
+  float* ub = (float*)malloc(sizeof(float) * (size_t)n);
+  float* k7 = (float*)malloc(sizeof(float) * (size_t)n);
+  float dtl, ee, re, rs;
+  lro_init_dt(f, u1, t1, t2, oo.abstol, oo.reltol, B, k1, &dtl);
+  /* _perform_step :77 */
+  lro_tsit5_step(f, u1, k1, t1, dtl, oo.abstol, oo.reltol, B, ub, k7, NULL, NULL, &ee, &re, &rs);
+  *reg_val = (reg_type == LRO_REG_STIFFNESS_ESTIMATE) ? rs : re;
+  *nfe = st->nf + (6 + 3); /* :79 with src/perform_step.jl:31 */
+  free(k7); free(ub); free(k1); free(u1);
+  return LRO_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* adaptive Euler-Heun SDE step, diagonal noise (src/perform_step.jl:172-206)  */
+/* ------------------------------------------------------------------------- */
+
+int lro_euler_heun_step(const lro_field* fd, const lro_field* gd, const float* uprev,
+                        const float* dW, float t, float dt, float abstol, float reltol, float delta,
+                        int B, float* u, float* eest, float* reg_val) {
+  const long n = (long)fd->D * B;
+  float* w = (float*)malloc(sizeof(float) * (size_t)n * 8);
+  float *du1 = w, *K = w + n, *L = w + 2 * n, *tmp = w + 3 * n, *g2 = w + 4 * n, *f2 = w + 5 * n,
+        *du2 = w + 6 * n, *ut = w + 7 * n;
+  const float sqdt = sqrtf(dt);
+  fd->fn(fd->ctx, uprev, t, B, du1);                               /* :174 */
+  for (long i = 0; i < n; ++i) K[i] = uprev[i] + dt * du1[i];      /* :175 */
+  gd->fn(gd->ctx, uprev, t, B, L);                                 /* :176 */
+  for (long i = 0; i < n; ++i) tmp[i] = K[i] + L[i] * dW[i];       /* :179,183 */
+  gd->fn(gd->ctx, tmp, t + dt, B, g2);                             /* :184 */
+  fd->fn(fd->ctx, tmp, t + dt, B, f2);                             /* :191 */
+  const float hdt = dt / 2.0f;
+  for (long i = 0; i < n; ++i) {
+    float gtmp2 = 0.5f * (L[i] + g2[i]);
+    float noise2 = gtmp2 * dW[i];
+    u[i] = (uprev[i] + hdt * (du1[i] + f2[i])) + noise2;
+  }
+  fd->fn(fd->ctx, K, t + dt, B, du2);                              /* :193 */
+  for (long i = 0; i < n; ++i) ut[i] = uprev[i] + L[i] * sqdt;     /* :196 */
+  gd->fn(gd->ctx, ut, t, B, g2);                                   /* :197 */
+  double acc = 0.0;
+  for (long i = 0; i < n; ++i) {
+    float Ed = (dt * (du2[i] - du1[i])) / 2.0f;                    /* :194 */
+    float ggp = (g2[i] - L[i]) / sqdt;
+    float En = (ggp * (dW[i] * dW[i])) / 2.0f;                     /* :198 */
+    float sc = abstol + fmaxf(fabsf(uprev[i]), fabsf(u[i])) * reltol;
+    float r = (delta * Ed + En) / sc;                              /* :214-216 */
+    float sq = r * r;
+    acc += (double)sq;
+  }
+  float ee = rms_from_sumsq(acc, n);
+  if (eest) *eest = ee;
+  if (reg_val) *reg_val = ee * dt;                                 /* :205 */
+  free(w);
+  return LRO_OK;
+}

@@ -1,0 +1,253 @@
+"""ctypes binding of the CPU oracle (oracle/lrnde_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg — never by the product package.
+Arrays are numpy float32, column-major (D x B) states passed as C-contiguous
+(B, D) arrays (sample-major), which is the same memory.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblrnde_oracle.so")
+
+ACT = {"identity": 0, "tanh": 1, "gelu": 2}
+REG = {"error_estimate": 0, "stiffness_estimate": 1}
+MODE = {"none": 0, "unbiased": 1, "biased": 2}
+RETCODES = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "DtNaN", 4: "BadArg", 5: "Capacity"}
+
+FIELD_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_int, C.POINTER(C.c_float))
+
+
+class Field(C.Structure):
+    _fields_ = [("fn", FIELD_FN), ("ctx", C.c_void_p), ("D", C.c_int)]
+
+
+class Mlp(C.Structure):
+    _fields_ = [("D", C.c_int), ("H", C.c_int), ("time_dep", C.c_int), ("act", C.c_int),
+                ("p", C.POINTER(C.c_float)), ("nthreads", C.c_int)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("abstol", C.c_float), ("reltol", C.c_float), ("maxiters", C.c_int),
+                ("save_start", C.c_int), ("save_everystep", C.c_int), ("exact_pow", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("retcode", C.c_int), ("nf", C.c_int), ("naccept", C.c_int), ("nreject", C.c_int),
+                ("iters", C.c_int), ("nsaved", C.c_int), ("t_final", C.c_float),
+                ("dt_final", C.c_float), ("eest_last", C.c_float), ("dt_init", C.c_float)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class TraceRow(C.Structure):
+    _fields_ = [("t", C.c_float), ("dt", C.c_float), ("eest", C.c_float), ("accepted", C.c_int)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "lrnde_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B" if force else "all"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        fp = C.POINTER(C.c_float)
+        for name in ("lro_expf", "lro_tanhf", "lro_geluf", "lro_fastlog2", "lro_fastpow2"):
+            getattr(L, name).restype = C.c_float
+            getattr(L, name).argtypes = [C.c_float]
+        L.lro_fastpow.restype = C.c_float
+        L.lro_fastpow.argtypes = [C.c_float, C.c_float]
+        L.lro_mlp_param_count.argtypes = [C.c_int] * 3
+        L.lro_mlp_rhs.restype = None
+        L.lro_mlp_rhs.argtypes = [C.POINTER(Mlp), fp, C.c_float, C.c_int, fp]
+        L.lro_mlp_as_field.restype = None
+        L.lro_mlp_as_field.argtypes = [C.POINTER(Mlp), C.POINTER(Field)]
+        L.lro_tsit5_step.argtypes = [C.POINTER(Field), fp, fp, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_int, fp, fp, fp, fp, fp, fp, fp]
+        L.lro_init_dt.argtypes = [C.POINTER(Field), fp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_int, fp, fp]
+        L.lro_tsit5_interp.restype = None
+        L.lro_tsit5_interp.argtypes = [C.c_float, C.c_float, fp, C.POINTER(fp), C.c_long, fp]
+        L.lro_solve.argtypes = [C.POINTER(Field), fp, C.c_int, C.c_float, C.c_float, C.POINTER(Opts),
+                                fp, C.c_int, fp, fp, C.c_int, C.POINTER(Stats), C.POINTER(TraceRow),
+                                C.c_int]
+        L.lro_node_forward.argtypes = [C.POINTER(Field), fp, C.c_int, C.c_float, C.c_float,
+                                       C.POINTER(Opts), C.c_int, C.c_int, C.c_float, fp, fp,
+                                       C.POINTER(C.c_int), C.POINTER(Stats), fp]
+        L.lro_euler_heun_step.argtypes = [C.POINTER(Field), C.POINTER(Field), fp, fp, C.c_float,
+                                          C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fp, fp,
+                                          fp]
+        L.lro_tsit5_tableau.argtypes = [C.POINTER(C.c_double)] * 4
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def vec_fn(name, x):
+    f = getattr(lib(), name)
+    x = np.asarray(x, dtype=np.float32)
+    return np.array([f(float(v)) for v in x.ravel()], dtype=np.float32).reshape(x.shape)
+
+
+def tableau():
+    a = (C.c_double * 21)(); c = (C.c_double * 6)(); bt = (C.c_double * 7)(); r = (C.c_double * 28)()
+    lib().lro_tsit5_tableau(a, c, bt, r)
+    return np.array(a), np.array(c), np.array(bt), np.array(r).reshape(7, 4)
+
+
+class MlpField:
+    """TDChain(Dense(D+td->H, act), Dense(H+td->D)) with flat Lux-ordered params."""
+
+    def __init__(self, D, H, params, time_dep=True, act="tanh", nthreads=1):
+        self.D, self.H = int(D), int(H)
+        self.params = _f32(params)
+        assert self.params.size == lib().lro_mlp_param_count(D, H, int(time_dep)), "param count"
+        self.m = Mlp(D, H, int(time_dep), ACT[act], _fp(self.params), int(nthreads))
+        self.field = Field()
+        lib().lro_mlp_as_field(C.byref(self.m), C.byref(self.field))
+
+    def rhs(self, u, t):
+        u = _f32(u)
+        B = u.size // self.D
+        du = np.empty_like(u)
+        lib().lro_mlp_rhs(C.byref(self.m), _fp(u), float(t), B, _fp(du))
+        return du
+
+
+class PyField:
+    """Arbitrary python vector field f(u[(B,D)], t) -> du, for known-answer tests."""
+
+    def __init__(self, D, fn):
+        self.D = int(D)
+
+        def tramp(_ctx, up, t, B, dup):
+            u = np.ctypeslib.as_array(up, shape=(B, self.D))
+            du = np.ctypeslib.as_array(dup, shape=(B, self.D))
+            du[...] = np.asarray(fn(u.copy(), np.float32(t)), dtype=np.float32)
+
+        self._cb = FIELD_FN(tramp)
+        self.field = Field(self._cb, None, self.D)
+
+
+def make_opts(abstol, reltol, maxiters=1000, save_start=False, save_everystep=False, exact_pow=False):
+    return Opts(float(abstol), float(reltol), int(maxiters), int(save_start), int(save_everystep),
+                int(exact_pow))
+
+
+def tsit5_step(fld, uprev, k1, t, dt, abstol, reltol, want_stages=False):
+    uprev = _f32(uprev); k1 = _f32(k1)
+    D = fld.D; B = uprev.size // D
+    u = np.empty_like(uprev); k7 = np.empty_like(uprev)
+    ks = np.empty((5,) + uprev.shape, dtype=np.float32)
+    g6 = np.empty_like(uprev)
+    ee = C.c_float(); re = C.c_float(); rs = C.c_float()
+    rc = lib().lro_tsit5_step(C.byref(fld.field), _fp(uprev), _fp(k1), float(t), float(dt),
+                              float(abstol), float(reltol), B, _fp(u), _fp(k7), _fp(ks), _fp(g6),
+                              C.byref(ee), C.byref(re), C.byref(rs))
+    assert rc == 0
+    out = dict(u=u, k7=k7, eest=np.float32(ee.value), reg_error=np.float32(re.value),
+               reg_stiff=np.float32(rs.value))
+    if want_stages:
+        out["ks"] = ks
+        out["g6"] = g6
+    return out
+
+
+def init_dt(fld, u0, t0, tend, abstol, reltol):
+    u0 = _f32(u0)
+    B = u0.size // fld.D
+    f0 = np.empty_like(u0)
+    dt = C.c_float()
+    lib().lro_init_dt(C.byref(fld.field), _fp(u0), float(t0), float(tend), float(abstol),
+                      float(reltol), B, _fp(f0), C.byref(dt))
+    return np.float32(dt.value), f0
+
+
+def interp(theta, dt, y0, ks7):
+    y0 = _f32(y0)
+    arrs = [_f32(k) for k in ks7]
+    ptrs = (C.POINTER(C.c_float) * 7)(*[_fp(a) for a in arrs])
+    out = np.empty_like(y0)
+    lib().lro_tsit5_interp(float(theta), float(dt), _fp(y0), ptrs, y0.size, _fp(out))
+    return out
+
+
+def solve(fld, u0, t0, t1, abstol, reltol, saveat=(), maxiters=1000, save_start=False,
+          save_everystep=None, exact_pow=False, cap=None, trace_cap=20000):
+    u0 = _f32(u0)
+    D = fld.D; B = u0.size // D
+    saveat = np.ascontiguousarray(saveat, dtype=np.float32)
+    if save_everystep is None:
+        save_everystep = saveat.size == 0
+    if cap is None:
+        cap = saveat.size + 2 + (min(maxiters, 4096) if save_everystep else 0)
+    o = make_opts(abstol, reltol, maxiters, save_start, save_everystep, exact_pow)
+    us = np.empty((cap,) + u0.shape, dtype=np.float32)
+    ts = np.empty(cap, dtype=np.float32)
+    st = Stats()
+    tr = (TraceRow * trace_cap)()
+    rc = lib().lro_solve(C.byref(fld.field), _fp(u0), B, float(t0), float(t1), C.byref(o),
+                         _fp(saveat) if saveat.size else None, int(saveat.size), _fp(us), _fp(ts),
+                         cap, C.byref(st), tr, trace_cap)
+    nt = st.naccept + st.nreject
+    trace = np.array([(tr[i].t, tr[i].dt, tr[i].eest, tr[i].accepted) for i in range(min(nt, trace_cap))],
+                     dtype=[("t", "f4"), ("dt", "f4"), ("eest", "f4"), ("accepted", "i4")])
+    return dict(retcode=rc, u=us[:st.nsaved], t=ts[:st.nsaved], stats=st.asdict(), trace=trace)
+
+
+def node_forward(fld, x, t0, t2, abstol, reltol, mode="unbiased", reg_type="error_estimate",
+                 t1_or_rand=0.5, maxiters=1000, save_start=False, exact_pow=False):
+    x = _f32(x)
+    B = x.size // fld.D
+    o = make_opts(abstol, reltol, maxiters, save_start, False, exact_pow)
+    u_end = np.empty_like(x)
+    reg = C.c_float(); nfe = C.c_int(); st = Stats(); t1u = C.c_float()
+    rc = lib().lro_node_forward(C.byref(fld.field), _fp(x), B, float(t0), float(t2), C.byref(o),
+                                MODE[mode], REG[reg_type], float(t1_or_rand), _fp(u_end),
+                                C.byref(reg), C.byref(nfe), C.byref(st), C.byref(t1u))
+    return dict(retcode=rc, u_end=u_end, reg_val=np.float32(reg.value), nfe=nfe.value,
+                stats=st.asdict(), t1=np.float32(t1u.value))
+
+
+def euler_heun_step(drift, diffusion, uprev, dW, t, dt, abstol, reltol, delta):
+    uprev = _f32(uprev); dW = _f32(dW)
+    B = uprev.size // drift.D
+    u = np.empty_like(uprev)
+    ee = C.c_float(); rv = C.c_float()
+    lib().lro_euler_heun_step(C.byref(drift.field), C.byref(diffusion.field), _fp(uprev), _fp(dW),
+                              float(t), float(dt), float(abstol), float(reltol), float(delta), B,
+                              _fp(u), C.byref(ee), C.byref(rv))
+    return dict(u=u, eest=np.float32(ee.value), reg_val=np.float32(rv.value))
+
+
+def glorot_mlp_params(D, H, time_dep=True, seed=0):
+    """Lux Dense init: W ~ glorot_uniform = (rand-0.5)*sqrt(24/(in+out)), b = 0
+    (SURVEY.md §3.5); numpy stream (the Julia RNG streams cannot be reproduced here)."""
+    rng = np.random.default_rng(seed)
+    td = int(time_dep)
+    def glorot(out, inn):
+        return ((rng.random((inn, out), dtype=np.float32) - np.float32(0.5)) *
+                np.float32(np.sqrt(24.0 / (inn + out)))).astype(np.float32)  # (in,out) C-order == column-major out x in
+    W1 = glorot(H, D + td); b1 = np.zeros(H, np.float32)
+    W2 = glorot(D, H + td); b2 = np.zeros(D, np.float32)
+    return np.concatenate([W1.ravel(), b1, W2.ravel(), b2]).astype(np.float32)
