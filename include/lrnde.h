@@ -1,0 +1,154 @@
+/*
+ * lrnde.h — C ABI of liblrnde: the MI355X (gfx950) implementation of the
+ * LocalRegNeuralDE.jl adaptive Tsit5 neural-ODE path.
+ *
+ * The reference has no FFI seam of its own (it is pure Julia); the seam this
+ * library replaces is the Julia-level one listed in SURVEY.md §8(b).  Each
+ * entry point names the reference interface it stands in for (paths relative
+ * to the reference repository).  A Julia maintainer binds these with `ccall`
+ * (see INTEGRATION.md); this repo's host mirror binds them with ctypes.
+ *
+ * Conventions
+ *   - opaque handle, one per (device, stream); not thread-safe; distinct
+ *     handles are independent;
+ *   - every array pointer is a DEVICE pointer (hipMalloc'd / torch.cuda) unless
+ *     the name ends in _host; the caller owns all buffers;
+ *   - states are fp32, column-major (D x B) "batch last" exactly as the Julia
+ *     arrays are laid out, i.e. sample-major contiguous rows of D floats;
+ *   - parameters are the flat Lux/ComponentArray vector
+ *     [vec(W1) (H x (D+td)); b1 (H); vec(W2) (D x (H+td)); b2 (D)];
+ *   - every call returns an lrnde_status (0 = ok) and never throws; the text of
+ *     the last error is available from lrnde_last_error();
+ *   - calls are stream-ordered on the handle's HIP stream; calls that return
+ *     host-side results (stats, scalars) synchronise that stream.
+ */
+#ifndef LRNDE_H
+#define LRNDE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lrnde_ctx lrnde_ctx;
+
+typedef enum {
+  LRNDE_OK = 0,
+  LRNDE_MAXITERS = 1,          /* ReturnCode.MaxIters  (iter > maxiters)            */
+  LRNDE_DT_LESS_THAN_MIN = 2,  /* ReturnCode.DtLessThanMin                          */
+  LRNDE_DT_NAN = 3,            /* ReturnCode.DtNaN / Unstable (NaN reached the norm) */
+  LRNDE_BADARG = 4,            /* ArgumentError (src/utils.jl:53-58 and shape checks) */
+  LRNDE_CAPACITY = 5,          /* caller's save buffer too small                     */
+  LRNDE_HIP_ERROR = 6,
+  LRNDE_NCCL_ERROR = 7,
+  LRNDE_UNSUPPORTED = 8
+} lrnde_status;
+
+enum { LRNDE_ACT_IDENTITY = 0, LRNDE_ACT_TANH = 1, LRNDE_ACT_GELU = 2 };
+enum { LRNDE_REG_ERROR_ESTIMATE = 0, LRNDE_REG_STIFFNESS_ESTIMATE = 1 };
+enum { LRNDE_MODE_NONE = 0, LRNDE_MODE_UNBIASED = 1, LRNDE_MODE_BIASED = 2 };
+
+/* Vector field description.  Replaces the Lux model captured by the `dudt`
+ * closure, src/layers/neural_ode.jl:45-48, for the field the MNIST experiment
+ * builds: TDChain(Dense(D+td => H, act), Dense(H+td => D)),
+ * experiments/src/construct.jl:180-189 and src/layers/common.jl:10-40. */
+typedef struct {
+  int32_t state_dim;   /* D: rows of the state per sample (784 for MNIST)        */
+  int32_t hidden_dim;  /* H (100)                                               */
+  int32_t time_dep;    /* 1: TDChain appends t as the last input row of each Dense */
+  int32_t act;         /* LRNDE_ACT_* applied after the first Dense              */
+} lrnde_model_desc;
+
+/* Solver options.  Replaces the kwargs NeuralODE forwards to `solve`,
+ * src/layers/neural_ode.jl:10-13,51 and experiments/src/construct.jl:192-197. */
+typedef struct {
+  float abstol, reltol;
+  int32_t maxiters;
+  int32_t save_start;      /* Julia kwarg save_start (experiments pass false)     */
+  int32_t save_everystep;  /* saveat == [] (the :biased mode)                     */
+  int32_t exact_pow;       /* 0: DiffEqBase fastpow in the PI controller; 1: pow  */
+} lrnde_solve_opts;
+
+/* sol.destats / retcode / the last attempted step (src/utils.jl:7-9). */
+typedef struct {
+  int32_t retcode;  /* lrnde_status of the solve itself */
+  int32_t nf, naccept, nreject, iters;
+  int32_t nsaved;
+  float t_final, dt_final, eest_last, dt_init;
+} lrnde_stats;
+
+typedef struct { /* one row per attempted step (diagnostics / parity tests) */
+  float t, dt, eest;
+  int32_t accepted;
+} lrnde_trace_row;
+
+/* lifecycle.  `stream` is a hipStream_t (NULL = the null stream). */
+int lrnde_create(lrnde_ctx** out, const lrnde_model_desc* desc, int device, void* stream);
+int lrnde_destroy(lrnde_ctx* ctx);
+const char* lrnde_last_error(const lrnde_ctx* ctx);
+size_t lrnde_param_count(const lrnde_model_desc* desc);
+const char* lrnde_version(void);
+
+/* Hands the flat parameter vector `ps` (what ODEProblem(dudt, x, tspan, ps)
+ * carries, src/layers/neural_ode.jl:50) to the library; repacked on device
+ * into the MFMA operand layout.  Call again whenever ps changes. */
+int lrnde_set_params(lrnde_ctx* ctx, const float* p, size_t n);
+
+/* du = dudt(u, p, t)  — src/layers/neural_ode.jl:45-48, src/layers/common.jl:10-40. */
+int lrnde_rhs(lrnde_ctx* ctx, const float* u, float t, int32_t B, float* du);
+
+/* `init(prob, Tsit5(); ...)` as used by _get_ode_integrator,
+ * src/layers/neural_ode.jl:33-38: the automatic initial dt (2 f-evals) and
+ * fsalfirst = f(u0, t0).  dt_host receives integrator.dt. */
+int lrnde_init_dt(lrnde_ctx* ctx, const float* u0, int32_t B, float t0, float tend, float abstol,
+                  float reltol, float* k1, float* dt_host);
+
+/* `_perform_step(integrator, cache::Tsit5ConstantCache, p, Val(reg_type))`,
+ * src/perform_step.jl:3-47.  Reads uprev, k1 (= integrator.fsalfirst), t, dt;
+ * writes u and k7 (= integrator.fsallast); returns EEst and both regularisation
+ * values on the host (reg_error = EEst*dt, :34-38; reg_stiff, :40-47). */
+int lrnde_perform_step(lrnde_ctx* ctx, const float* uprev, const float* k1, int32_t B, float t,
+                       float dt, float abstol, float reltol, float* u, float* k7,
+                       float* eest_host, float* reg_error_host, float* reg_stiff_host);
+
+/* `solve(ODEProblem(dudt, x, tspan, ps), Tsit5(); maxiters, saveat, reltol,
+ * abstol, save_start)`, src/layers/neural_ode.jl:50-51.  saveat_host: nsave
+ * ascending times (may be NULL/0 with save_everystep).  u_saved: device buffer
+ * of cap_saved states; t_saved_host: cap_saved floats (sol.t).  trace_host may be
+ * NULL. */
+int lrnde_solve(lrnde_ctx* ctx, const float* u0, int32_t B, float t0, float t1,
+                const lrnde_solve_opts* opts, const float* saveat_host, int32_t nsave,
+                float* u_saved, float* t_saved_host, int32_t cap_saved, lrnde_stats* stats_host,
+                lrnde_trace_row* trace_host, int32_t cap_trace);
+
+/* `(n::NeuralODE{regularize, regularize_type})(x, ps, st)`,
+ * src/layers/neural_ode.jl:56-100: solve on (t0,t2), pick t1 (mode unbiased:
+ * t1_or_rand is t1 itself, drawn by the host RNG as :71; mode biased: a uniform
+ * [0,1) draw used as an index into sol.t[1:end-1], :92), fresh init at
+ * (sol(t1), t1), one local _perform_step, nfe = sol.destats.nf + 6 + 3.
+ * u_end receives sol.u[end] (diffeqsol_to_array, src/utils.jl:37). */
+int lrnde_node_forward(lrnde_ctx* ctx, const float* x, int32_t B, float t0, float t2,
+                       const lrnde_solve_opts* opts, int32_t mode, int32_t reg_type,
+                       float t1_or_rand, float* u_end, float* reg_val_host, int32_t* nfe_host,
+                       lrnde_stats* stats_host, float* t1_used_host);
+
+/* Batch sharding across GPUs (one process per GPU).  Not in the reference
+ * (SURVEY.md §2 rows 16-17): each rank owns B columns of a global batch of
+ * nranks*B; the only exchange is one RCCL all-reduce of the per-tile fp64
+ * partial sums of the error norm per attempted step (plus two at init).
+ * unique_id: the 128 bytes of an ncclUniqueId made by lrnde_comm_unique_id on
+ * rank 0 and broadcast by the host (torch.distributed). */
+int lrnde_comm_unique_id(void* unique_id_128_host);
+int lrnde_comm_init(lrnde_ctx* ctx, const void* unique_id_128_host, int32_t rank, int32_t nranks);
+int lrnde_comm_destroy(lrnde_ctx* ctx);
+
+/* Timing hooks for bench.py: HIP events on the handle's stream around the
+ * kernels of the last solve (ms), and the number of step-kernel launches. */
+int lrnde_last_solve_kernel_ms(lrnde_ctx* ctx, float* total_ms_host, int32_t* step_launches_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+"""ctypes binding of liblrnde.so (include/lrnde.h).  No fallback: if the HIP
+library is missing or fails to load, importing this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblrnde.so")
+
+STATUS = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "DtNaN", 4: "BadArg", 5: "Capacity",
+          6: "HipError", 7: "NcclError", 8: "Unsupported"}
+ACT = {"identity": 0, "tanh": 1, "gelu": 2}
+REG_TYPE = {"error_estimate": 0, "stiffness_estimate": 1}
+MODE = {"none": 0, "unbiased": 1, "biased": 2}
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("state_dim", C.c_int32), ("hidden_dim", C.c_int32), ("time_dep", C.c_int32),
+                ("act", C.c_int32)]
+
+
+class SolveOpts(C.Structure):
+    _fields_ = [("abstol", C.c_float), ("reltol", C.c_float), ("maxiters", C.c_int32),
+                ("save_start", C.c_int32), ("save_everystep", C.c_int32), ("exact_pow", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("retcode", C.c_int32), ("nf", C.c_int32), ("naccept", C.c_int32),
+                ("nreject", C.c_int32), ("iters", C.c_int32), ("nsaved", C.c_int32),
+                ("t_final", C.c_float), ("dt_final", C.c_float), ("eest_last", C.c_float),
+                ("dt_init", C.c_float)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class TraceRow(C.Structure):
+    _fields_ = [("t", C.c_float), ("dt", C.c_float), ("eest", C.c_float), ("accepted", C.c_int32)]
+
+
+# every symbol include/lrnde.h declares: (name, restype, argtypes)
+_vp, _fp, _i32, _f = C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float
+SYMBOLS = [
+    ("lrnde_create", C.c_int, [C.POINTER(_vp), C.POINTER(ModelDesc), C.c_int, _vp]),
+    ("lrnde_destroy", C.c_int, [_vp]),
+    ("lrnde_last_error", C.c_char_p, [_vp]),
+    ("lrnde_param_count", C.c_size_t, [C.POINTER(ModelDesc)]),
+    ("lrnde_version", C.c_char_p, []),
+    ("lrnde_set_params", C.c_int, [_vp, _vp, C.c_size_t]),
+    ("lrnde_rhs", C.c_int, [_vp, _vp, _f, _i32, _vp]),
+    ("lrnde_init_dt", C.c_int, [_vp, _vp, _i32, _f, _f, _f, _f, _vp, _fp]),
+    ("lrnde_perform_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _vp, _vp, _fp, _fp, _fp]),
+    ("lrnde_solve", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _fp, _i32, _vp, _fp, _i32,
+                              C.POINTER(Stats), C.POINTER(TraceRow), _i32]),
+    ("lrnde_node_forward", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _i32, _i32, _f, _vp,
+                                     _fp, C.POINTER(_i32), C.POINTER(Stats), _fp]),
+    ("lrnde_comm_unique_id", C.c_int, [_vp]),
+    ("lrnde_comm_init", C.c_int, [_vp, _vp, _i32, _i32]),
+    ("lrnde_comm_destroy", C.c_int, [_vp]),
+    ("lrnde_last_solve_kernel_ms", C.c_int, [_vp, _fp, C.POINTER(_i32)]),
+]
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: the HIP library is the product path and there is no fallback. "
+        "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C localregneuralde.jl_amd/csrc`).")
+
+lib = C.CDLL(LIB_PATH)
+for _name, _res, _args in SYMBOLS:
+    _fn = getattr(lib, _name)  # AttributeError here = ABI drift, fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class LrndeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"lrnde status {code} ({STATUS.get(code, '?')}): {msg}")
+        self.code = code
+
+
+def check(ctx, rc):
+    if rc != 0:
+        msg = lib.lrnde_last_error(ctx)
+        raise LrndeError(rc, msg.decode() if msg else "")

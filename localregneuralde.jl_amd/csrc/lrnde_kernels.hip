@@ -1,0 +1,1362 @@
+// lrnde_kernels.hip — gfx950 (MI355X / CDNA4) kernels of the adaptive Tsit5
+// neural-ODE path of LocalRegNeuralDE.jl, and the C ABI around them.
+//
+// Reference behaviour (paths relative to the reference repository):
+//   src/perform_step.jl:3-47      one Tsit5 step + regularisation values
+//   src/layers/common.jl:10-40    TDChain: t appended to the input of every Dense
+//   src/layers/neural_ode.jl:33-100  init / solve / local step orchestration
+//   OrdinaryDiffEq (un-vendored)  initdt, PI controller, loop header/footer,
+//                                 saveat interpolation — SURVEY.md §3.5
+//
+// Design (DESIGN.md has the long form):
+//   * The vector field is per-sample independent, so a workgroup owns a tile of
+//     NB = 16 batch columns and runs a WHOLE attempted Tsit5 step for them in one
+//     launch: six vector-field evaluations (two fp32-MFMA GEMMs each, weights
+//     streamed from L2 in a pre-packed fragment layout, activations in LDS),
+//     the stage combinations, the embedded error residual and the
+//     regularisation residuals.  No inter-workgroup traffic inside a step.
+//   * The only cross-sample coupling is the RMS error norm.  Each workgroup
+//     writes one fp64 partial sum; the NEXT launch's prologue (every workgroup
+//     redundantly, in the same fixed order) reduces them and runs the PI
+//     controller / accept-reject / saveat logic on the device.  The host just
+//     enqueues step launches and polls a status word once per chunk.
+//   * Sharded batches exchange only those partial sums (one RCCL all-reduce of
+//     a zero-padded fp64 vector per attempted step), so every rank takes the
+//     same decisions bit for bit.
+//   * Numerics are canonical (lrnde_math.hpp): each dot product is one fp32 fma
+//     chain in increasing k — exactly what v_mfma_f32_16x16x4_f32 computes —
+//     so results are reproducible and equal to the CPU oracle's.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "lrnde.h"
+#include "lrnde_math.hpp"
+
+namespace {
+
+using namespace lrnde;
+
+constexpr int NB = 16;       // batch columns per workgroup tile = MFMA N
+constexpr int NW = 8;        // waves per workgroup
+constexpr int NT = NW * 64;  // threads per workgroup
+constexpr int PSTRIDE = 4;   // doubles per workgroup in a partial-sum vector
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { ST_RUNNING = 0, ST_DONE = 100 };                // Ctrl.status: else an lrnde_status error
+enum { MODE_SOLVE = 0, MODE_SINGLE_GIVEN_DT = 1, MODE_SINGLE_INIT_DT = 2 };
+
+struct ModelDev {
+  int D, H, Dp, Hp, MT1, KG1, MT2, KG2, act, td;
+  const f32x4* W1p;  // [MT1][KG1][64] x 4: A fragments of Dense-1, 4 k-steps per load
+  const f32x4* W2p;  // [MT2][KG2][64] x 4
+  const float* w1t;  // [Hp] time column of W1
+  const float* b1;   // [Hp]
+  const float* w2t;  // [Dp]
+  const float* b2;   // [Dp]
+};
+
+struct Ctrl {  // device-resident integrator state, double-buffered by attempt parity
+  int status, first;
+  int iter, naccept, nreject, nf;
+  int cur;  // uprev = ubuf[cur], k1 = kfsal[cur]; the step writes u -> ubuf[cur^1], k7 -> kfsal[cur^1]
+  int isave, nsaved;
+  float t, dt;  // start time and dt of the last attempted step
+  float qold, q11, dtpropose;
+  float eest_last, dt_init;
+  float reg_error, reg_stiff;  // single-step modes: filled by k_finalize
+};
+
+struct StepArgs {
+  ModelDev m;
+  float* ubuf[2];
+  float* kfsal[2];
+  float* ks[5];  // k2..k6
+  float* g6;
+  int B;          // local batch columns
+  int wg_offset;  // index of this rank's first tile in the global partial vector
+  int nwg_global;
+  double n_global;  // D * B_global, the norm's element count
+  float t0, t1, abstol, reltol;
+  int maxiters, save_everystep, exact_pow, want_stiff, mode;
+  int nsave, cap_saved, cap_trace;
+  const float* saveat;  // device copy
+  float* u_saved;
+  float* t_saved;  // device
+  Ctrl* ctrl;      // [2]
+  double* part_send;        // [2][nwg_global*PSTRIDE] (this rank writes its own segment)
+  const double* part_recv;  // [2][...]  == part_send when nranks == 1
+  double* pinit_send;       // [2][...]  init phases 1 and 2
+  const double* pinit_recv;
+  lrnde_trace_row* trace;
+};
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+
+template <int W> struct Vec { float v[W]; };
+
+template <int W> __device__ __forceinline__ Vec<W> vload(const float* p) {
+  Vec<W> r;
+  if constexpr (W == 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else {
+    r.v[0] = *p;
+  }
+  return r;
+}
+template <int W> __device__ __forceinline__ Vec<W> vzero() {
+  Vec<W> r;
+#pragma unroll
+  for (int h = 0; h < W; ++h) r.v[h] = 0.f;
+  return r;
+}
+template <int W> __device__ __forceinline__ void vstore(float* p, const Vec<W>& r) {
+  if constexpr (W == 4) {
+    f32x4 t; t.x = r.v[0]; t.y = r.v[1]; t.z = r.v[2]; t.w = r.v[3];
+    *reinterpret_cast<f32x4*>(p) = t;
+  } else {
+    *p = r.v[0];
+  }
+}
+
+// x-tile / h-tile LDS image: [kgroup][lane = (k&3)*16 + n][q = (k>>2)&3], i.e. exactly the
+// B operand of four consecutive 16x16x4 MFMA k-steps per ds_read_b128.
+__device__ __forceinline__ int lds_index(int row, int n) {
+  return (((row >> 4) * 64 + (row & 3) * 16 + n) << 2) + ((row >> 2) & 3);
+}
+
+// Visit every (row-chunk, sample) of this workgroup's tile.  W=4: lanes read 16 B of 4
+// consecutive rows; 16 lanes cover the 16 samples, 4 lane groups cover 64 B of each sample.
+template <int W, class F>
+__device__ __forceinline__ void tile_foreach(const ModelDev& m, int b0, int nvalid, F&& fn) {
+  const int n = threadIdx.x & 15;
+  const int cc = threadIdx.x >> 4;  // 0..31
+  const int nch = m.Dp / W;
+  for (int c = cc; c < nch; c += NT / 16) {
+    const int row = c * W;
+    const bool valid = (n < nvalid) && (row < m.D);
+    const size_t g = (size_t)(b0 + n) * m.D + row;
+    fn(row, n, valid, g);
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void lds_put(float* xl, int row, int n, const Vec<W>& x) {
+#pragma unroll
+  for (int h = 0; h < W; ++h) xl[lds_index(row + h, n)] = x.v[h];
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// fixed-order block reduction of up to 3 doubles; result valid on thread 0
+__device__ __forceinline__ void block_sum3(double* red, double& a, double& b, double& c) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  if (lane == 0) { red[wave * 3 + 0] = a; red[wave * 3 + 1] = b; red[wave * 3 + 2] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0.0, sb = 0.0, sc = 0.0;
+    for (int w = 0; w < NW; ++w) { sa += red[w * 3]; sb += red[w * 3 + 1]; sc += red[w * 3 + 2]; }
+    a = sa; b = sb; c = sc;
+  }
+  __syncthreads();
+}
+
+// every workgroup reduces the global partial vector in the same fixed order (wave 0)
+__device__ __forceinline__ void reduce_partials(const double* p, int nwg, double out[3]) {
+  const int lane = threadIdx.x & 63;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int i = lane; i < nwg; i += 64) {
+    // agent-scope loads: the vector was written by the previous launch / by RCCL
+    s0 += __hip_atomic_load(p + (size_t)i * PSTRIDE + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s1 += __hip_atomic_load(p + (size_t)i * PSTRIDE + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s2 += __hip_atomic_load(p + (size_t)i * PSTRIDE + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+  out[0] = __shfl(s0, 0, 64); out[1] = __shfl(s1, 0, 64); out[2] = __shfl(s2, 0, 64);
+}
+
+__device__ __forceinline__ float rms_from(double sumsq, double n) { return (float)sqrt(sumsq / n); }
+
+// ---------------------------------------------------------------------------
+// vector field on one tile:  k = W2 * act(W1 * [x; t] + b1) (+ t column) + b2
+// xl holds the 16-sample x tile; results go to kout (global, sample-major).
+// Every dot product is one fp32 fma chain in increasing k (MFMA 16x16x4 f32).
+// ---------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void feval_tile(const ModelDev& m, const float* xl, float* hl, float ts,
+                                           float* __restrict__ kout, int b0, int nvalid) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 15, rq = lane >> 4;
+  constexpr int U = 7;
+  // ---- Dense 1: [Hp x Dp] * [Dp x 16] ----
+  for (int mt = wave; mt < m.MT1; mt += NW) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* Wp = m.W1p + (size_t)mt * m.KG1 * 64 + lane;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(xl) + lane;
+    int kg = 0;
+#pragma unroll 1
+    for (; kg + U <= m.KG1; kg += U) {
+      f32x4 a[U], b[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) { a[j] = Wp[(size_t)(kg + j) * 64]; b[j] = xp[(kg + j) * 64]; }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b[j].w, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll 1
+    for (; kg < m.KG1; ++kg) {
+      const f32x4 a = Wp[(size_t)kg * 64], b = xp[kg * 64];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    // epilogue: time column, bias, activation -> h tile (B operand layout of Dense 2)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = mt * 16 + rq * 4 + r;
+      float pre = m.td ? fma_(m.w1t[o], ts, acc[r]) : acc[r];
+      pre = pre + m.b1[o];
+      hl[((mt * 64 + r * 16 + n) << 2) + rq] = act_apply(m.act, pre);
+    }
+  }
+  __syncthreads();
+  // ---- Dense 2: [Dp x Hp] * [Hp x 16] ----
+  const f32x4* hp = reinterpret_cast<const f32x4*>(hl) + lane;
+  for (int mt = wave; mt < m.MT2; mt += NW) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* Wp = m.W2p + (size_t)mt * m.KG2 * 64 + lane;
+    int kg = 0;
+#pragma unroll 1
+    for (; kg + U <= m.KG2; kg += U) {
+      f32x4 a[U], b[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) { a[j] = Wp[(size_t)(kg + j) * 64]; b[j] = hp[(kg + j) * 64]; }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b[j].w, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll 1
+    for (; kg < m.KG2; ++kg) {
+      const f32x4 a = Wp[(size_t)kg * 64], b = hp[kg * 64];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    const int row0 = mt * 16 + rq * 4;
+    float kv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pre = m.td ? fma_(m.w2t[row0 + r], ts, acc[r]) : acc[r];
+      kv[r] = pre + m.b2[row0 + r];
+    }
+    if (n < nvalid) {
+      float* dst = kout + (size_t)(b0 + n) * m.D + row0;
+      if constexpr (W == 4) {
+        if (row0 < m.D) { f32x4 t; t.x = kv[0]; t.y = kv[1]; t.z = kv[2]; t.w = kv[3];
+                          *reinterpret_cast<f32x4*>(dst) = t; }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (row0 + r < m.D) dst[r] = kv[r];
+      }
+    }
+  }
+  __syncthreads();  // k stores are visible to the whole workgroup; xl/hl may be overwritten
+}
+
+// ---------------------------------------------------------------------------
+// stage inputs (src/perform_step.jl:11-18), left-to-right, no contraction
+// ---------------------------------------------------------------------------
+template <int S> __device__ __forceinline__ float stage_value(float up, const float* kv, float dt) {
+  constexpr int off = (S - 2) * (S - 1) / 2;
+  if constexpr (S == 2) {
+    const float a = dt * (float)Tsit5::A[0];
+    return up + a * kv[0];
+  } else {
+    float s = (float)Tsit5::A[off] * kv[0] + (float)Tsit5::A[off + 1] * kv[1];
+#pragma unroll
+    for (int j = 2; j < S - 1; ++j) s = s + (float)Tsit5::A[off + j] * kv[j];
+    return up + dt * s;
+  }
+}
+
+template <int S, int W>
+__device__ __forceinline__ void stage_combine(const StepArgs& a, float* xl, const float* uprev,
+                                              const float* k1, float* uout, float dt, int b0,
+                                              int nvalid) {
+  tile_foreach<W>(a.m, b0, nvalid, [&](int row, int n, bool valid, size_t g) {
+    Vec<W> x;
+    if (valid) {
+      const Vec<W> up = vload<W>(uprev + g);
+      Vec<W> kk[S - 1];
+      kk[0] = vload<W>(k1 + g);
+#pragma unroll
+      for (int j = 1; j < S - 1; ++j) kk[j] = vload<W>(a.ks[j - 1] + g);
+#pragma unroll
+      for (int h = 0; h < W; ++h) {
+        float kv[S - 1];
+#pragma unroll
+        for (int j = 0; j < S - 1; ++j) kv[j] = kk[j].v[h];
+        x.v[h] = stage_value<S>(up.v[h], kv, dt);
+      }
+      if constexpr (S == 6) { if (a.want_stiff) vstore<W>(a.g6 + g, x); }
+      if constexpr (S == 7) vstore<W>(uout + g, x);
+    } else {
+      x = vzero<W>();
+    }
+    lds_put<W>(xl, row, n, x);
+  });
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// device-side integrator logic (OrdinaryDiffEq loopfooter!/loopheader!, PI
+// controller, ode_determine_initdt).  Run by wave 0 of every
+// workgroup on identical inputs; block 0 publishes the next control block.
+// ---------------------------------------------------------------------------
+struct Bcast {
+  int do_step, cur;
+  float t, dt;
+  // footer of the previous attempt (save actions)
+  int accepted_prev, cur_prev, isave0, nsaved0;
+  float t_new, tprev, dt_prev;
+  float dt0;  // init phase 2
+};
+
+__device__ __forceinline__ float init_dt0(const double s[3], double n, float dtmax) {
+  const float d0 = rms_from(s[0], n), d1 = rms_from(s[1], n);
+  float dt0;
+  if ((double)d0 < 1e-5 || (double)d1 < 1e-5) dt0 = 1e-6f;
+  else dt0 = (d0 / d1) / 100.0f;
+  return fminf_(dt0, dtmax);
+}
+
+__device__ __forceinline__ float init_dt_final(const double s1[3], const double s2[3], double n,
+                                               float dtmax) {
+  const float d1 = rms_from(s1[1], n);
+  const float dt0 = init_dt0(s1, n, dtmax);
+  const float d2 = rms_from(s2[0], n) / dt0;
+  const float maxd = fmaxf_(d1, d2);
+  float dt1;
+  if ((double)maxd <= 1e-15) {
+    dt1 = fmaxf_(1e-6f, dt0 * 1e-3f);
+  } else {
+    const float l10 = (float)log10((double)maxd);
+    const float e = (-(2.0f + l10)) / 5.0f;
+    dt1 = (float)pow(10.0, (double)e);
+  }
+  return fminf_(fminf_(100.0f * dt0, dt1), dtmax);
+}
+
+__device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* bc) {
+  // wave 0 only
+  const int lane = threadIdx.x & 63;
+  const Ctrl* cin = a.ctrl + (j & 1);
+  Ctrl c = *cin;
+  Ctrl* cout = a.ctrl + ((j + 1) & 1);
+  if (c.status != ST_RUNNING) {
+    if (blockIdx.x == 0 && lane == 0) *cout = c;
+    if (lane == 0) bc->do_step = 0, bc->accepted_prev = 0;
+    return;
+  }
+  const float gamma = 0.9f, qmin = 0.2f, qmax = 10.0f, qoldinit = 1e-4f;
+  const float beta1 = (float)(7.0 / 50.0), beta2 = (float)(2.0 / 25.0);
+  const float dtmax = a.t1 - a.t0;
+  const float dtmin = fmaxf_(eps_f(a.t1), eps_f(a.t0));
+  int accepted = 0, do_step = 0;
+  float t = c.t, dt = c.dt;
+  Bcast b;
+  b.accepted_prev = 0; b.cur_prev = c.cur; b.isave0 = c.isave; b.nsaved0 = c.nsaved;
+  b.t_new = c.t; b.tprev = c.t; b.dt_prev = c.dt; b.dt0 = 0.f;
+
+  if (c.first) {
+    if (a.mode != MODE_SINGLE_GIVEN_DT) {
+      double s1[3], s2[3];
+      reduce_partials(a.pinit_recv, a.nwg_global, s1);
+      reduce_partials(a.pinit_recv + (size_t)a.nwg_global * PSTRIDE, a.nwg_global, s2);
+      dt = init_dt_final(s1, s2, a.n_global, dtmax);
+      c.nf = 3;  // initdt: 2 f-evals, initialize!: fsalfirst
+    }
+    c.dt_init = dt;
+    c.dtpropose = dt;
+  } else {
+    double s[3];
+    reduce_partials(a.part_recv + (size_t)(j & 1) * a.nwg_global * PSTRIDE, a.nwg_global, s);
+    const float eest = rms_from(s[0], a.n_global);
+    c.eest_last = eest;
+    float q;
+    if (eest == 0.0f) {
+      q = 1.0f / qmax;
+    } else {
+      if (a.exact_pow) {
+        c.q11 = (float)pow((double)eest, (double)beta1);
+        q = c.q11 / (float)pow((double)c.qold, (double)beta2);
+      } else {
+        c.q11 = fastpow(eest, beta1);
+        q = c.q11 / fastpow(c.qold, beta2);
+      }
+      q = fmaxf_(1.0f / qmax, fminf_(1.0f / qmin, q / gamma));
+    }
+    accepted = (eest <= 1.0f);
+    const int ntr = c.naccept + c.nreject;
+    if (blockIdx.x == 0 && lane == 0 && a.trace && ntr < a.cap_trace) {
+      lrnde_trace_row r; r.t = c.t; r.dt = c.dt; r.eest = eest; r.accepted = accepted;
+      a.trace[ntr] = r;
+    }
+    if (eest != eest) {
+      c.status = LRNDE_DT_NAN;
+    } else if (accepted) {
+      c.naccept++;
+      const float dtnew = c.dt / q;
+      c.qold = fmaxf_(eest, qoldinit);
+      const float ttmp = c.t + c.dt;
+      b.tprev = c.t; b.dt_prev = c.dt;
+      t = (__builtin_fabsf(ttmp - a.t1) < 100.0f * eps_f(fmaxf_(c.t, a.t1))) ? a.t1 : ttmp;
+      c.dtpropose = fmaxf_(fminf_(dtmax, dtnew), fmaxf_(eps_f(t), dtmin));
+      b.accepted_prev = 1; b.t_new = t;
+      // savevalues!: count what this step saves (performed by all threads afterwards)
+      int is = c.isave, ns = c.nsaved;
+      while (is < a.nsave && a.saveat[is] <= t) { ++is; ++ns; }
+      if (a.save_everystep) ++ns;
+      if (ns > a.cap_saved) c.status = LRNDE_CAPACITY, b.accepted_prev = 0;
+      else { c.isave = is; c.nsaved = ns; }
+    } else {
+      c.nreject++;
+    }
+  }
+
+  if (c.status == ST_RUNNING && a.mode == MODE_SOLVE) {
+    if (!(t < a.t1)) {
+      c.status = ST_DONE;
+    } else {
+      // loopheader!
+      if (!c.first) {
+        if (accepted) { c.cur ^= 1; dt = c.dtpropose; }
+        else dt = c.dt / fminf_(1.0f / qmin, c.q11 / gamma);
+      }
+      c.iter++;
+      dt = fminf_(dtmax, dt);
+      dt = fmaxf_(dt, dtmin);
+      dt = fminf_(__builtin_fabsf(dt), __builtin_fabsf(a.t1 - t));
+      if (c.iter > a.maxiters) c.status = LRNDE_MAXITERS;
+      else if (dt != dt) c.status = LRNDE_DT_NAN;
+      else if (__builtin_fabsf(dt) <= __builtin_fabsf(dtmin)) c.status = LRNDE_DT_LESS_THAN_MIN;
+      else { do_step = 1; c.nf += 6; }
+    }
+  } else if (c.status == ST_RUNNING) {  // single-step modes: integrator.dt as is
+    if (c.first) { do_step = 1; c.iter = 1; c.nf += 6; }
+    else c.status = ST_DONE;
+  }
+  c.t = t; c.dt = dt; c.first = 0;
+  b.do_step = do_step; b.cur = c.cur; b.t = t; b.dt = dt;
+  if (lane == 0) {
+    *bc = b;
+    if (blockIdx.x == 0) *cout = c;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+struct Smem {
+  float* xl; float* hl; double* red; Bcast* bc;
+};
+__device__ __forceinline__ Smem carve(const ModelDev& m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Smem s;
+  s.xl = reinterpret_cast<float*>(smem);
+  s.hl = s.xl + (size_t)m.Dp * NB;
+  s.red = reinterpret_cast<double*>(s.hl + (size_t)m.Hp * NB);
+  s.bc = reinterpret_cast<Bcast*>(s.red + NW * 3);
+  return s;
+}
+static size_t smem_bytes(int Dp, int Hp) {
+  return (size_t)(Dp + Hp) * NB * sizeof(float) + NW * 3 * sizeof(double) + sizeof(Bcast) + 16;
+}
+
+// du = f(u, t) for the whole batch (lrnde_rhs)
+template <int W> __global__ __launch_bounds__(NT) void k_rhs(StepArgs a, const float* u, float t, float* du) {
+  const Smem s = carve(a.m);
+  const int b0 = blockIdx.x * NB, nvalid = min(NB, a.B - b0);
+  tile_foreach<W>(a.m, b0, nvalid, [&](int row, int n, bool valid, size_t g) {
+    const Vec<W> x = valid ? vload<W>(u + g) : vzero<W>();
+    lds_put<W>(s.xl, row, n, x);
+  });
+  __syncthreads();
+  feval_tile<W>(a.m, s.xl, s.hl, t, du, b0, nvalid);
+}
+
+// init phase 1: f0 = f(u0, t0) -> k1; partial sums of (u0/sk)^2 and (f0/sk)^2
+template <int W> __global__ __launch_bounds__(NT) void k_init1(StepArgs a) {
+  const Smem s = carve(a.m);
+  const int b0 = blockIdx.x * NB, nvalid = min(NB, a.B - b0);
+  const Ctrl c = a.ctrl[0];
+  const float* u0 = a.ubuf[c.cur];
+  float* f0 = a.kfsal[c.cur];
+  tile_foreach<W>(a.m, b0, nvalid, [&](int row, int n, bool valid, size_t g) {
+    const Vec<W> x = valid ? vload<W>(u0 + g) : vzero<W>();
+    lds_put<W>(s.xl, row, n, x);
+  });
+  __syncthreads();
+  feval_tile<W>(a.m, s.xl, s.hl, c.t, f0, b0, nvalid);
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
+    if (!valid) return;
+    const Vec<W> u = vload<W>(u0 + g), f = vload<W>(f0 + g);
+#pragma unroll
+    for (int h = 0; h < W; ++h) {
+      const float sk = a.abstol + __builtin_fabsf(u.v[h]) * a.reltol;
+      const float r0 = u.v[h] / sk, r1 = f.v[h] / sk;
+      const float q0 = r0 * r0, q1 = r1 * r1;
+      a0 += (double)q0; a1 += (double)q1;
+    }
+  });
+  block_sum3(s.red, a0, a1, a2);
+  if (threadIdx.x == 0) {
+    double* p = a.pinit_send + (size_t)(a.wg_offset + blockIdx.x) * PSTRIDE;
+    p[0] = a0; p[1] = a1; p[2] = 0.0;
+  }
+}
+
+// init phase 2: u1 = u0 + dt0*f0, f1 = f(u1, t0+dt0); partial sum of ((f1-f0)/sk)^2
+template <int W> __global__ __launch_bounds__(NT) void k_init2(StepArgs a) {
+  const Smem s = carve(a.m);
+  const int b0 = blockIdx.x * NB, nvalid = min(NB, a.B - b0);
+  const Ctrl c = a.ctrl[0];
+  if (threadIdx.x < 64) {
+    double s1[3];
+    reduce_partials(a.pinit_recv, a.nwg_global, s1);
+    if (threadIdx.x == 0) s.bc->dt0 = init_dt0(s1, a.n_global, a.t1 - a.t0);
+  }
+  __syncthreads();
+  const float dt0 = s.bc->dt0;
+  const float* u0 = a.ubuf[c.cur];
+  const float* f0 = a.kfsal[c.cur];
+  float* f1 = a.ks[0];
+  tile_foreach<W>(a.m, b0, nvalid, [&](int row, int n, bool valid, size_t g) {
+    Vec<W> x;
+    if (valid) {
+      const Vec<W> u = vload<W>(u0 + g), f = vload<W>(f0 + g);
+#pragma unroll
+      for (int h = 0; h < W; ++h) x.v[h] = u.v[h] + dt0 * f.v[h];
+    } else {
+      x = vzero<W>();
+    }
+    lds_put<W>(s.xl, row, n, x);
+  });
+  __syncthreads();
+  feval_tile<W>(a.m, s.xl, s.hl, c.t + dt0, f1, b0, nvalid);
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
+    if (!valid) return;
+    const Vec<W> u = vload<W>(u0 + g), f = vload<W>(f0 + g), ff = vload<W>(f1 + g);
+#pragma unroll
+    for (int h = 0; h < W; ++h) {
+      const float sk = a.abstol + __builtin_fabsf(u.v[h]) * a.reltol;
+      const float r2 = (ff.v[h] - f.v[h]) / sk;
+      const float q2 = r2 * r2;
+      a0 += (double)q2;
+    }
+  });
+  block_sum3(s.red, a0, a1, a2);
+  if (threadIdx.x == 0) {
+    double* p = a.pinit_send + (size_t)(a.nwg_global + a.wg_offset + blockIdx.x) * PSTRIDE;
+    p[0] = a0; p[1] = 0.0; p[2] = 0.0;
+  }
+}
+
+// one attempted Tsit5 step for the whole batch (src/perform_step.jl:3-47), preceded by the
+// device-side footer of the previous attempt and header of this one.
+template <int W> __global__ __launch_bounds__(NT) void k_step(StepArgs a, int j) {
+  const Smem s = carve(a.m);
+  const int b0 = blockIdx.x * NB, nvalid = min(NB, a.B - b0);
+  if (threadIdx.x < 64) step_prologue(a, j, s.bc);
+  __syncthreads();
+  const Bcast bc = *s.bc;
+
+  // savevalues! of the step accepted by the prologue (Tsit5 dense output / copy)
+  if (bc.accepted_prev) {
+    const float* up = a.ubuf[bc.cur_prev];
+    const float* un = a.ubuf[bc.cur_prev ^ 1];
+    const float* k1 = a.kfsal[bc.cur_prev];
+    const float* k7 = a.kfsal[bc.cur_prev ^ 1];
+    int slot = bc.nsaved0;
+    for (int is = bc.isave0; is < a.nsave && a.saveat[is] <= bc.t_new; ++is, ++slot) {
+      const float ts = a.saveat[is];
+      float* dst = a.u_saved + (size_t)slot * a.B * a.m.D;
+      if (ts != bc.t_new) {
+        const float theta = (ts - bc.tprev) / bc.dt_prev;
+        float bw[7];
+        tsit5_bweights(theta, bw);
+        tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
+          if (!valid) return;
+          const Vec<W> y0 = vload<W>(up + g), v1 = vload<W>(k1 + g), v2 = vload<W>(a.ks[0] + g),
+                       v3 = vload<W>(a.ks[1] + g), v4 = vload<W>(a.ks[2] + g),
+                       v5 = vload<W>(a.ks[3] + g), v6 = vload<W>(a.ks[4] + g), v7 = vload<W>(k7 + g);
+          Vec<W> o;
+#pragma unroll
+          for (int h = 0; h < W; ++h) {
+            float sum = v1.v[h] * bw[0] + v2.v[h] * bw[1];
+            sum = sum + v3.v[h] * bw[2];
+            sum = sum + v4.v[h] * bw[3];
+            sum = sum + v5.v[h] * bw[4];
+            sum = sum + v6.v[h] * bw[5];
+            sum = sum + v7.v[h] * bw[6];
+            o.v[h] = y0.v[h] + bc.dt_prev * sum;
+          }
+          vstore<W>(dst + g, o);
+        });
+      } else {
+        tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
+          if (valid) vstore<W>(dst + g, vload<W>(un + g));
+        });
+      }
+      if (blockIdx.x == 0 && threadIdx.x == 0) a.t_saved[slot] = ts;
+    }
+    if (a.save_everystep) {
+      float* dst = a.u_saved + (size_t)slot * a.B * a.m.D;
+      tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
+        if (valid) vstore<W>(dst + g, vload<W>(un + g));
+      });
+      if (blockIdx.x == 0 && threadIdx.x == 0) a.t_saved[slot] = bc.t_new;
+    }
+  }
+  if (!bc.do_step) return;
+
+  const float t = bc.t, dt = bc.dt;
+  const float* uprev = a.ubuf[bc.cur];
+  float* unew = a.ubuf[bc.cur ^ 1];
+  const float* k1 = a.kfsal[bc.cur];
+  float* k7 = a.kfsal[bc.cur ^ 1];
+  const float c1 = (float)Tsit5::C[0], c2 = (float)Tsit5::C[1], c3 = (float)Tsit5::C[2],
+              c4 = (float)Tsit5::C[3];
+
+  stage_combine<2, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
+  feval_tile<W>(a.m, s.xl, s.hl, t + c1 * dt, a.ks[0], b0, nvalid);
+  stage_combine<3, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
+  feval_tile<W>(a.m, s.xl, s.hl, t + c2 * dt, a.ks[1], b0, nvalid);
+  stage_combine<4, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
+  feval_tile<W>(a.m, s.xl, s.hl, t + c3 * dt, a.ks[2], b0, nvalid);
+  stage_combine<5, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
+  feval_tile<W>(a.m, s.xl, s.hl, t + c4 * dt, a.ks[3], b0, nvalid);
+  stage_combine<6, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
+  feval_tile<W>(a.m, s.xl, s.hl, t + dt, a.ks[4], b0, nvalid);
+  stage_combine<7, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
+  feval_tile<W>(a.m, s.xl, s.hl, t + dt, k7, b0, nvalid);
+
+  // utilde, scaled residual, regularisation residuals (src/perform_step.jl:21-47, 210-212)
+  double aerr = 0.0, anum = 0.0, aden = 0.0;
+  tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
+    if (!valid) return;
+    const Vec<W> up = vload<W>(uprev + g), un = vload<W>(unew + g), v1 = vload<W>(k1 + g),
+                 v2 = vload<W>(a.ks[0] + g), v3 = vload<W>(a.ks[1] + g), v4 = vload<W>(a.ks[2] + g),
+                 v5 = vload<W>(a.ks[3] + g), v6 = vload<W>(a.ks[4] + g), v7 = vload<W>(k7 + g);
+    Vec<W> gg;
+    if (a.want_stiff) gg = vload<W>(a.g6 + g);
+#pragma unroll
+    for (int h = 0; h < W; ++h) {
+      float sum = (float)Tsit5::BT[0] * v1.v[h] + (float)Tsit5::BT[1] * v2.v[h];
+      sum = sum + (float)Tsit5::BT[2] * v3.v[h];
+      sum = sum + (float)Tsit5::BT[3] * v4.v[h];
+      sum = sum + (float)Tsit5::BT[4] * v5.v[h];
+      sum = sum + (float)Tsit5::BT[5] * v6.v[h];
+      sum = sum + (float)Tsit5::BT[6] * v7.v[h];
+      const float utilde = dt * sum;
+      const float sc = a.abstol + fmaxf_(__builtin_fabsf(up.v[h]), __builtin_fabsf(un.v[h])) * a.reltol;
+      const float r = utilde / sc;
+      const float sq = r * r;
+      aerr += (double)sq;
+      if (a.want_stiff) {
+        const float d1 = un.v[h] - gg.v[h];
+        const float d2 = v7.v[h] - v6.v[h];
+        const float q1 = d1 * d1, q2 = d2 * d2;
+        aden += (double)q1; anum += (double)q2;
+      }
+    }
+  });
+  block_sum3(s.red, aerr, anum, aden);
+  if (threadIdx.x == 0) {
+    double* p = a.part_send + ((size_t)((j + 1) & 1) * a.nwg_global + a.wg_offset + blockIdx.x) * PSTRIDE;
+    p[0] = aerr; p[1] = anum; p[2] = aden;
+  }
+}
+
+// single-step modes: EEst and the two regularisation values from the partial sums
+__global__ void k_finalize(StepArgs a, int j) {
+  if (threadIdx.x >= 64) return;
+  double s[3];
+  reduce_partials(a.part_recv + (size_t)(j & 1) * a.nwg_global * PSTRIDE, a.nwg_global, s);
+  if (threadIdx.x == 0) {
+    Ctrl* c = a.ctrl + (j & 1);
+    const float eest = rms_from(s[0], a.n_global);
+    c->eest_last = eest;
+    c->reg_error = eest * c->dt;
+    const float den = rms_from(s[2], a.n_global);
+    float rs = 0.0f;
+    if (den != 0.0f) {
+      const float num = rms_from(s[1], a.n_global);
+      rs = __builtin_fabsf(num / (den + 1.1920929e-7f)) / 3.5068f;
+    }
+    c->reg_stiff = rs;
+    c->status = ST_DONE;
+  }
+}
+
+__global__ void k_ctrl_init(Ctrl* ctrl, float t0, float dt, int cur, int nsaved) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Ctrl c;
+  memset(&c, 0, sizeof(c));
+  c.status = ST_RUNNING; c.first = 1; c.cur = cur; c.nsaved = nsaved;
+  c.t = t0; c.dt = dt; c.qold = 1e-4f; c.q11 = 1.0f; c.dtpropose = dt;
+  ctrl[0] = c;
+  ctrl[1] = c;
+}
+
+// flat Lux parameter vector -> MFMA A-fragment layout (zero padded)
+__global__ void k_pack(const float* p, int D, int H, int td, int Dp, int Hp, float* W1p, float* w1t,
+                       float* b1, float* W2p, float* w2t, float* b2) {
+  const size_t n1 = (size_t)Hp * Dp, n2 = (size_t)Dp * Hp;
+  const size_t base2 = (size_t)H * (D + td) + H;
+  const int KG1 = Dp / 16, KG2 = Hp / 16;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n1 + n2 + Hp + Dp;
+       i += (size_t)gridDim.x * blockDim.x) {
+    if (i < n1) {
+      const int q = i & 3, lane = (i >> 2) & 63;
+      const size_t blk = i >> 8;
+      const int kg = blk % KG1, mt = blk / KG1;
+      const int o = mt * 16 + (lane & 15), k = kg * 16 + q * 4 + (lane >> 4);
+      W1p[i] = (o < H && k < D) ? p[(size_t)o + (size_t)H * k] : 0.f;
+    } else if (i < n1 + n2) {
+      const size_t e = i - n1;
+      const int q = e & 3, lane = (e >> 2) & 63;
+      const size_t blk = e >> 8;
+      const int kg = blk % KG2, mt = blk / KG2;
+      const int o = mt * 16 + (lane & 15), k = kg * 16 + q * 4 + (lane >> 4);
+      W2p[e] = (o < D && k < H) ? p[base2 + (size_t)o + (size_t)D * k] : 0.f;
+    } else if (i < n1 + n2 + Hp) {
+      const int o = i - n1 - n2;
+      w1t[o] = (td && o < H) ? p[(size_t)o + (size_t)H * D] : 0.f;
+      b1[o] = (o < H) ? p[(size_t)H * (D + td) + o] : 0.f;
+    } else {
+      const int o = i - n1 - n2 - Hp;
+      w2t[o] = (td && o < D) ? p[base2 + (size_t)o + (size_t)D * H] : 0.f;
+      b2[o] = (o < D) ? p[base2 + (size_t)D * (H + td) + o] : 0.f;
+    }
+  }
+}
+
+}  // namespace
+
+// ===========================================================================
+// host side
+// ===========================================================================
+
+struct lrnde_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  lrnde_model_desc desc{};
+  ModelDev m{};
+  bool have_params = false;
+  // packed weights
+  float *W1p = nullptr, *W2p = nullptr, *w1t = nullptr, *b1 = nullptr, *w2t = nullptr, *b2 = nullptr;
+  // workspace
+  int wsB = 0;
+  float* state = nullptr;  // 10 * B * D floats: ubuf[2], kfsal[2], ks[5], g6
+  Ctrl* ctrl = nullptr;
+  double* part = nullptr;      // send [2][nwg_global*PSTRIDE]
+  double* part_rx = nullptr;   // recv (nranks > 1)
+  double* pinit = nullptr;
+  double* pinit_rx = nullptr;
+  float* saveat_dev = nullptr;
+  int saveat_cap = 0;
+  float* tsaved_dev = nullptr;
+  int tsaved_cap = 0;
+  lrnde_trace_row* trace_dev = nullptr;
+  int trace_cap = 0;
+  float* usave = nullptr;  // internal save slots for node_forward
+  size_t usave_slots = 0, usave_slot_elems = 0;
+  Ctrl* ctrl_host = nullptr;  // pinned [2]
+  // comm
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+  // timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evp[2] = {nullptr, nullptr};
+  float last_ms = 0.f;
+  int last_launches = 0;
+  std::string err;
+};
+
+namespace {
+
+int fail(lrnde_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+
+#define HIPCHK(c, x)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (x);                                                                      \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(c, LRNDE_HIP_ERROR, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_),     \
+                  __FILE__, __LINE__);                                                        \
+  } while (0)
+#define NCCLCHK(c, x)                                                                         \
+  do {                                                                                        \
+    ncclResult_t r_ = (x);                                                                    \
+    if (r_ != ncclSuccess)                                                                    \
+      return fail(c, LRNDE_NCCL_ERROR, "%s failed: %s (%s:%d)", #x, ncclGetErrorString(r_),   \
+                  __FILE__, __LINE__);                                                        \
+  } while (0)
+
+inline int ceil16(int x) { return (x + 15) & ~15; }
+inline int vecw(const lrnde_ctx* c) { return (c->desc.state_dim % 4 == 0) ? 4 : 1; }
+
+int ensure_workspace(lrnde_ctx* c, int B) {
+  const size_t n = (size_t)B * c->desc.state_dim;
+  const int nwg = (B + NB - 1) / NB;
+  const int nwg_global = nwg * c->nranks;
+  if (B != c->wsB) {
+    if (c->state) HIPCHK(c, hipFree(c->state));
+    if (c->part) HIPCHK(c, hipFree(c->part));
+    if (c->part_rx) HIPCHK(c, hipFree(c->part_rx));
+    if (c->pinit) HIPCHK(c, hipFree(c->pinit));
+    if (c->pinit_rx) HIPCHK(c, hipFree(c->pinit_rx));
+    c->state = nullptr; c->part = c->part_rx = c->pinit = c->pinit_rx = nullptr;
+    HIPCHK(c, hipMalloc(&c->state, sizeof(float) * n * 10));
+    const size_t pb = sizeof(double) * 2 * (size_t)nwg_global * PSTRIDE;
+    HIPCHK(c, hipMalloc(&c->part, pb));
+    HIPCHK(c, hipMalloc(&c->pinit, pb));
+    HIPCHK(c, hipMemsetAsync(c->part, 0, pb, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pinit, 0, pb, c->stream));
+    if (c->nranks > 1) {
+      HIPCHK(c, hipMalloc(&c->part_rx, pb));
+      HIPCHK(c, hipMalloc(&c->pinit_rx, pb));
+      HIPCHK(c, hipMemsetAsync(c->part_rx, 0, pb, c->stream));
+      HIPCHK(c, hipMemsetAsync(c->pinit_rx, 0, pb, c->stream));
+    }
+    c->wsB = B;
+  }
+  if (!c->ctrl) HIPCHK(c, hipMalloc(&c->ctrl, sizeof(Ctrl) * 2));
+  if (!c->ctrl_host) HIPCHK(c, hipHostMalloc(&c->ctrl_host, sizeof(Ctrl) * 2));
+  return LRNDE_OK;
+}
+
+void fill_args(lrnde_ctx* c, StepArgs& a, int B) {
+  memset(&a, 0, sizeof(a));
+  const size_t n = (size_t)B * c->desc.state_dim;
+  const int nwg = (B + NB - 1) / NB;
+  a.m = c->m;
+  a.ubuf[0] = c->state; a.ubuf[1] = c->state + n;
+  a.kfsal[0] = c->state + 2 * n; a.kfsal[1] = c->state + 3 * n;
+  for (int i = 0; i < 5; ++i) a.ks[i] = c->state + (4 + i) * n;
+  a.g6 = c->state + 9 * n;
+  a.B = B;
+  a.nwg_global = nwg * c->nranks;
+  a.wg_offset = nwg * c->rank;
+  a.n_global = (double)c->desc.state_dim * (double)B * (double)c->nranks;
+  a.ctrl = c->ctrl;
+  a.part_send = c->part;
+  a.part_recv = c->nranks > 1 ? c->part_rx : c->part;
+  a.pinit_send = c->pinit;
+  a.pinit_recv = c->nranks > 1 ? c->pinit_rx : c->pinit;
+}
+
+template <class K> int launch_tile_kernel(lrnde_ctx* c, K kern, int B, const StepArgs& a) {
+  const int nwg = (B + NB - 1) / NB;
+  const size_t sm = smem_bytes(c->m.Dp, c->m.Hp);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NT), sm, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  return LRNDE_OK;
+}
+
+int launch_step(lrnde_ctx* c, int B, const StepArgs& a, int j) {
+  const int nwg = (B + NB - 1) / NB;
+  const size_t sm = smem_bytes(c->m.Dp, c->m.Hp);
+  if (vecw(c) == 4) hipLaunchKernelGGL(k_step<4>, dim3(nwg), dim3(NT), sm, c->stream, a, j);
+  else hipLaunchKernelGGL(k_step<1>, dim3(nwg), dim3(NT), sm, c->stream, a, j);
+  HIPCHK(c, hipGetLastError());
+  return LRNDE_OK;
+}
+
+// exchange of the per-tile fp64 partial sums between ranks: ONE all-reduce (sum) of a vector
+// in which every rank has zeros outside its own segment, so the result is the exact gather.
+int exchange(lrnde_ctx* c, double* send, double* recv, size_t count) {
+  if (c->nranks <= 1) return LRNDE_OK;
+  NCCLCHK(c, ncclAllReduce(send, recv, count, ncclDouble, ncclSum, c->comm, c->stream));
+  return LRNDE_OK;
+}
+
+int run_init(lrnde_ctx* c, int B, const StepArgs& a) {
+  int rc;
+  const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
+  if (vecw(c) == 4) rc = launch_tile_kernel(c, k_init1<4>, B, a);
+  else rc = launch_tile_kernel(c, k_init1<1>, B, a);
+  if (rc) return rc;
+  if ((rc = exchange(c, c->pinit, c->pinit_rx, cnt))) return rc;
+  if (vecw(c) == 4) rc = launch_tile_kernel(c, k_init2<4>, B, a);
+  else rc = launch_tile_kernel(c, k_init2<1>, B, a);
+  if (rc) return rc;
+  return exchange(c, c->pinit + cnt, c->pinit_rx + cnt, cnt);
+}
+
+int set_smem_attr() {
+  static bool done = false;
+  if (done) return 0;
+  const int maxb = 160 * 1024;
+  hipFuncSetAttribute((const void*)k_step<4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_step<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_init1<4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_init1<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_init2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_init2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_rhs<4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_rhs<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  done = true;
+  return 0;
+}
+
+int check_ready(lrnde_ctx* c, int B) {
+  if (!c) return LRNDE_BADARG;
+  if (!c->have_params) return fail(c, LRNDE_BADARG, "lrnde_set_params has not been called");
+  if (B <= 0) return fail(c, LRNDE_BADARG, "batch must be positive (got %d)", B);
+  HIPCHK(c, hipSetDevice(c->device));
+  return LRNDE_OK;
+}
+
+void stats_from_ctrl(const Ctrl& k, lrnde_stats* st) {
+  st->retcode = (k.status == ST_DONE || k.status == ST_RUNNING) ? LRNDE_OK : k.status;
+  st->nf = k.nf; st->naccept = k.naccept; st->nreject = k.nreject; st->iters = k.iter;
+  st->nsaved = k.nsaved; st->t_final = k.t; st->dt_final = k.dt; st->eest_last = k.eest_last;
+  st->dt_init = k.dt_init;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lrnde_version(void) { return "lrnde-mi355x 0.1 (gfx950)"; }
+
+size_t lrnde_param_count(const lrnde_model_desc* d) {
+  if (!d) return 0;
+  const size_t D = d->state_dim, H = d->hidden_dim, td = d->time_dep ? 1 : 0;
+  return H * (D + td) + H + D * (H + td) + D;
+}
+
+const char* lrnde_last_error(const lrnde_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int lrnde_create(lrnde_ctx** out, const lrnde_model_desc* d, int device, void* stream) {
+  if (!out || !d) return LRNDE_BADARG;
+  *out = nullptr;
+  if (d->state_dim <= 0 || d->hidden_dim <= 0 || d->act < 0 || d->act > 2) return LRNDE_BADARG;
+  lrnde_ctx* c = new lrnde_ctx();
+  c->device = device;
+  c->stream = (hipStream_t)stream;
+  c->desc = *d;
+  const int Dp = ceil16(d->state_dim), Hp = ceil16(d->hidden_dim);
+  if (smem_bytes(Dp, Hp) > 160 * 1024) {
+    delete c;
+    return LRNDE_UNSUPPORTED;  // state tile does not fit LDS
+  }
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) { delete c; return LRNDE_HIP_ERROR; }
+  set_smem_attr();
+  ModelDev& m = c->m;
+  m.D = d->state_dim; m.H = d->hidden_dim; m.Dp = Dp; m.Hp = Hp;
+  m.MT1 = Hp / 16; m.KG1 = Dp / 16; m.MT2 = Dp / 16; m.KG2 = Hp / 16;
+  m.act = d->act; m.td = d->time_dep ? 1 : 0;
+  bool ok = hipMalloc(&c->W1p, sizeof(float) * (size_t)Hp * Dp) == hipSuccess &&
+            hipMalloc(&c->W2p, sizeof(float) * (size_t)Hp * Dp) == hipSuccess &&
+            hipMalloc(&c->w1t, sizeof(float) * Hp) == hipSuccess &&
+            hipMalloc(&c->b1, sizeof(float) * Hp) == hipSuccess &&
+            hipMalloc(&c->w2t, sizeof(float) * Dp) == hipSuccess &&
+            hipMalloc(&c->b2, sizeof(float) * Dp) == hipSuccess &&
+            hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+            hipEventCreate(&c->evp[0]) == hipSuccess && hipEventCreate(&c->evp[1]) == hipSuccess;
+  if (!ok) { lrnde_destroy(c); return LRNDE_HIP_ERROR; }
+  m.W1p = reinterpret_cast<const f32x4*>(c->W1p);
+  m.W2p = reinterpret_cast<const f32x4*>(c->W2p);
+  m.w1t = c->w1t; m.b1 = c->b1; m.w2t = c->w2t; m.b2 = c->b2;
+  *out = c;
+  return LRNDE_OK;
+}
+
+int lrnde_destroy(lrnde_ctx* c) {
+  if (!c) return LRNDE_OK;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
+  if (c->comm) ncclCommDestroy(c->comm);
+  void* ptrs[] = {c->W1p, c->W2p, c->w1t, c->b1, c->w2t, c->b2, c->state, c->ctrl, c->part,
+                  c->part_rx, c->pinit, c->pinit_rx, c->saveat_dev, c->tsaved_dev, c->trace_dev,
+                  c->usave};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (c->ctrl_host) hipHostFree(c->ctrl_host);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->evp[0]) hipEventDestroy(c->evp[0]);
+  if (c->evp[1]) hipEventDestroy(c->evp[1]);
+  delete c;
+  return LRNDE_OK;
+}
+
+int lrnde_set_params(lrnde_ctx* c, const float* p, size_t n) {
+  if (!c || !p) return LRNDE_BADARG;
+  if (n != lrnde_param_count(&c->desc))
+    return fail(c, LRNDE_BADARG, "parameter count %zu != expected %zu", n, lrnde_param_count(&c->desc));
+  HIPCHK(c, hipSetDevice(c->device));
+  const ModelDev& m = c->m;
+  hipLaunchKernelGGL(k_pack, dim3(256), dim3(256), 0, c->stream, p, m.D, m.H, m.td, m.Dp, m.Hp, c->W1p,
+                     c->w1t, c->b1, c->W2p, c->w2t, c->b2);
+  HIPCHK(c, hipGetLastError());
+  c->have_params = true;
+  return LRNDE_OK;
+}
+
+int lrnde_rhs(lrnde_ctx* c, const float* u, float t, int32_t B, float* du) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!u || !du) return fail(c, LRNDE_BADARG, "null state pointer");
+  StepArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m = c->m; a.B = B;
+  const int nwg = (B + NB - 1) / NB;
+  const size_t sm = smem_bytes(c->m.Dp, c->m.Hp);
+  if (vecw(c) == 4) hipLaunchKernelGGL(k_rhs<4>, dim3(nwg), dim3(NT), sm, c->stream, a, u, t, du);
+  else hipLaunchKernelGGL(k_rhs<1>, dim3(nwg), dim3(NT), sm, c->stream, a, u, t, du);
+  HIPCHK(c, hipGetLastError());
+  return LRNDE_OK;
+}
+
+int lrnde_init_dt(lrnde_ctx* c, const float* u0, int32_t B, float t0, float tend, float abstol,
+                  float reltol, float* k1, float* dt_host) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!u0 || !dt_host) return fail(c, LRNDE_BADARG, "null pointer");
+  if (!(tend > t0)) return fail(c, LRNDE_BADARG, "tspan must be increasing");
+  if ((rc = ensure_workspace(c, B))) return rc;
+  StepArgs a;
+  fill_args(c, a, B);
+  a.t0 = t0; a.t1 = tend; a.abstol = abstol; a.reltol = reltol; a.mode = MODE_SINGLE_INIT_DT;
+  const size_t n = (size_t)B * c->desc.state_dim;
+  HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t0, 0.f, 0, 0);
+  if ((rc = run_init(c, B, a))) return rc;
+  // the first-step prologue computes dt; run it through the single-step kernel path would cost a
+  // step, so evaluate the (deterministic) formula on the host from the reduced partial sums.
+  const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
+  std::vector<double> h(2 * cnt);
+  HIPCHK(c, hipMemcpyAsync(h.data(), a.pinit_recv, sizeof(double) * 2 * cnt, hipMemcpyDeviceToHost, c->stream));
+  if (k1) HIPCHK(c, hipMemcpyAsync(k1, a.kfsal[0], sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // same fixed reduction order as reduce_partials (lane-strided, then shuffle tree)
+  auto reduce = [&](const double* p, double out[3]) {
+    double lanes[3][64];
+    for (int l = 0; l < 64; ++l) for (int q = 0; q < 3; ++q) {
+      double s = 0.0;
+      for (int i = l; i < a.nwg_global; i += 64) s += p[(size_t)i * PSTRIDE + q];
+      lanes[q][l] = s;
+    }
+    for (int q = 0; q < 3; ++q) {
+      for (int off = 32; off > 0; off >>= 1)
+        for (int l = 0; l < off; ++l) lanes[q][l] += lanes[q][l + off];
+      out[q] = lanes[q][0];
+    }
+  };
+  double s1[3], s2[3];
+  reduce(h.data(), s1);
+  reduce(h.data() + cnt, s2);
+  {
+    const float dtmax = tend - t0;
+    const float d0 = (float)sqrt(s1[0] / a.n_global), d1 = (float)sqrt(s1[1] / a.n_global);
+    float dt0 = ((double)d0 < 1e-5 || (double)d1 < 1e-5) ? 1e-6f : (d0 / d1) / 100.0f;
+    dt0 = fminf(dt0, dtmax);
+    const float d2 = (float)sqrt(s2[0] / a.n_global) / dt0;
+    const float maxd = fmaxf(d1, d2);
+    float dt1;
+    if ((double)maxd <= 1e-15) dt1 = fmaxf(1e-6f, dt0 * 1e-3f);
+    else {
+      const float l10 = (float)log10((double)maxd);
+      const float e = (-(2.0f + l10)) / 5.0f;
+      dt1 = (float)pow(10.0, (double)e);
+    }
+    *dt_host = fminf(fminf(100.0f * dt0, dt1), dtmax);
+  }
+  return LRNDE_OK;
+}
+
+int lrnde_perform_step(lrnde_ctx* c, const float* uprev, const float* k1, int32_t B, float t,
+                       float dt, float abstol, float reltol, float* u, float* k7, float* eest_host,
+                       float* reg_error_host, float* reg_stiff_host) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!uprev || !k1) return fail(c, LRNDE_BADARG, "null state pointer");
+  if ((rc = ensure_workspace(c, B))) return rc;
+  StepArgs a;
+  fill_args(c, a, B);
+  a.t0 = t; a.t1 = t + 1.0f; a.abstol = abstol; a.reltol = reltol; a.mode = MODE_SINGLE_GIVEN_DT;
+  a.want_stiff = 1; a.maxiters = 1;
+  const size_t n = (size_t)B * c->desc.state_dim;
+  HIPCHK(c, hipMemcpyAsync(a.ubuf[0], uprev, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(a.kfsal[0], k1, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t, dt, 0, 0);
+  if ((rc = launch_step(c, B, a, 0))) return rc;
+  const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
+  if ((rc = exchange(c, c->part + cnt, c->part_rx + cnt, cnt))) return rc;
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, a, 1);
+  HIPCHK(c, hipGetLastError());
+  if (u) HIPCHK(c, hipMemcpyAsync(u, a.ubuf[1], sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  if (k7) HIPCHK(c, hipMemcpyAsync(k7, a.kfsal[1], sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->ctrl_host, c->ctrl + 1, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (eest_host) *eest_host = c->ctrl_host[0].eest_last;
+  if (reg_error_host) *reg_error_host = c->ctrl_host[0].reg_error;
+  if (reg_stiff_host) *reg_stiff_host = c->ctrl_host[0].reg_stiff;
+  return LRNDE_OK;
+}
+
+int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
+                const lrnde_solve_opts* o, const float* saveat_host, int32_t nsave, float* u_saved,
+                float* t_saved_host, int32_t cap_saved, lrnde_stats* st, lrnde_trace_row* trace_host,
+                int32_t cap_trace) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!u0 || !o || !st) return fail(c, LRNDE_BADARG, "null pointer");
+  memset(st, 0, sizeof(*st));
+  if (!(t1 > t0)) return fail(c, LRNDE_BADARG, "tspan must be increasing");
+  if (nsave < 0 || (nsave > 0 && !saveat_host)) return fail(c, LRNDE_BADARG, "bad saveat");
+  for (int i = 1; i < nsave; ++i)
+    if (!(saveat_host[i] >= saveat_host[i - 1])) return fail(c, LRNDE_BADARG, "saveat must be ascending");
+  if (cap_saved > 0 && !u_saved) return fail(c, LRNDE_BADARG, "null save buffer");
+  if ((rc = ensure_workspace(c, B))) return rc;
+  const size_t n = (size_t)B * c->desc.state_dim;
+  if (nsave > c->saveat_cap) {
+    if (c->saveat_dev) HIPCHK(c, hipFree(c->saveat_dev));
+    HIPCHK(c, hipMalloc(&c->saveat_dev, sizeof(float) * nsave));
+    c->saveat_cap = nsave;
+  }
+  if (cap_saved > c->tsaved_cap) {
+    if (c->tsaved_dev) HIPCHK(c, hipFree(c->tsaved_dev));
+    HIPCHK(c, hipMalloc(&c->tsaved_dev, sizeof(float) * cap_saved));
+    c->tsaved_cap = cap_saved;
+  }
+  if (trace_host && cap_trace > c->trace_cap) {
+    if (c->trace_dev) HIPCHK(c, hipFree(c->trace_dev));
+    HIPCHK(c, hipMalloc(&c->trace_dev, sizeof(lrnde_trace_row) * cap_trace));
+    c->trace_cap = cap_trace;
+  }
+  StepArgs a;
+  fill_args(c, a, B);
+  a.t0 = t0; a.t1 = t1; a.abstol = o->abstol; a.reltol = o->reltol;
+  a.maxiters = o->maxiters; a.save_everystep = o->save_everystep; a.exact_pow = o->exact_pow;
+  a.want_stiff = 0; a.mode = MODE_SOLVE;
+  a.cap_saved = cap_saved; a.u_saved = u_saved; a.t_saved = c->tsaved_dev;
+  a.trace = trace_host ? c->trace_dev : nullptr; a.cap_trace = trace_host ? cap_trace : 0;
+  // saveat points at/before t0 are the start value (save_start), as in the oracle
+  int skip = 0;
+  while (skip < nsave && saveat_host[skip] <= t0) ++skip;
+  a.nsave = nsave - skip;
+  a.saveat = c->saveat_dev;
+  if (a.nsave > 0)
+    HIPCHK(c, hipMemcpyAsync(c->saveat_dev, saveat_host + skip, sizeof(float) * a.nsave,
+                             hipMemcpyHostToDevice, c->stream));
+  int nsaved0 = 0;
+  if (o->save_start) {
+    if (cap_saved < 1) return fail(c, LRNDE_CAPACITY, "save buffer too small for save_start");
+    HIPCHK(c, hipMemcpyAsync(u_saved, u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->tsaved_dev, &t0, sizeof(float), hipMemcpyHostToDevice, c->stream));
+    nsaved0 = 1;
+  }
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t0, 0.f, 0, nsaved0);
+  if ((rc = run_init(c, B, a))) return rc;
+
+  // enqueue attempted steps in chunks; poll the device status word one chunk behind
+  const int CH = 8;
+  const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
+  int j = 0, pending = -1, launches = 0;
+  bool done = false;
+  const long hard_cap = (long)o->maxiters + 8;
+  while (!done) {
+    for (int i = 0; i < CH; ++i, ++j) {
+      if ((rc = launch_step(c, B, a, j))) return rc;
+      ++launches;
+      const size_t par = (size_t)((j + 1) & 1);
+      if ((rc = exchange(c, c->part + par * cnt, c->part_rx + par * cnt, cnt))) return rc;
+    }
+    const int slot = (j / CH) & 1;
+    HIPCHK(c, hipMemcpyAsync(c->ctrl_host + slot, c->ctrl + (j & 1), sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->evp[slot], c->stream));
+    if (pending >= 0) {
+      HIPCHK(c, hipEventSynchronize(c->evp[pending]));
+      if (c->ctrl_host[pending].status != ST_RUNNING) done = true;
+    }
+    pending = slot;
+    if (j > hard_cap + 2 * CH) break;
+  }
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->ctrl_host, c->ctrl + (j & 1), sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const Ctrl fin = c->ctrl_host[0];
+  stats_from_ctrl(fin, st);
+  if (fin.status == ST_RUNNING) st->retcode = LRNDE_MAXITERS;
+  if (t_saved_host && fin.nsaved > 0)
+    HIPCHK(c, hipMemcpy(t_saved_host, c->tsaved_dev, sizeof(float) * fin.nsaved, hipMemcpyDeviceToHost));
+  if (trace_host) {
+    int nt = fin.naccept + fin.nreject;
+    if (nt > cap_trace) nt = cap_trace;
+    if (nt > 0) HIPCHK(c, hipMemcpy(trace_host, c->trace_dev, sizeof(lrnde_trace_row) * nt, hipMemcpyDeviceToHost));
+  }
+  hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1);
+  c->last_launches = launches;
+  if (st->retcode != LRNDE_OK)
+    return fail(c, st->retcode, "solve stopped with retcode %d at t=%g (iter %d)", st->retcode, (double)fin.t, fin.iter);
+  return LRNDE_OK;
+}
+
+int lrnde_node_forward(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2,
+                       const lrnde_solve_opts* o, int32_t mode, int32_t reg_type, float t1_or_rand,
+                       float* u_end, float* reg_val_host, int32_t* nfe_host, lrnde_stats* st,
+                       float* t1_used_host) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!x || !o || !u_end || !st) return fail(c, LRNDE_BADARG, "null pointer");
+  // src/utils.jl:53-58 _check_valid_regularize
+  if (mode < LRNDE_MODE_NONE || mode > LRNDE_MODE_BIASED)
+    return fail(c, LRNDE_BADARG, "regularize must be one of (:none, :unbiased, :biased)");
+  if (reg_type != LRNDE_REG_ERROR_ESTIMATE && reg_type != LRNDE_REG_STIFFNESS_ESTIMATE)
+    return fail(c, LRNDE_BADARG, "regularize must be one of (:error_estimate, :stiffness_estimate)");
+  const size_t n = (size_t)B * c->desc.state_dim;
+  lrnde_solve_opts oo = *o;
+  size_t need = 3;
+  if (mode == LRNDE_MODE_BIASED) need = (size_t)(oo.maxiters < 510 ? oo.maxiters + 2 : 512);
+  if (c->usave_slots < need || c->usave_slot_elems != n) {
+    if (c->usave) HIPCHK(c, hipFree(c->usave));
+    c->usave = nullptr;
+    HIPCHK(c, hipMalloc(&c->usave, sizeof(float) * n * need));
+    c->usave_slots = need; c->usave_slot_elems = n;
+  }
+  if (reg_val_host) *reg_val_host = 0.0f;
+  if (t1_used_host) *t1_used_host = t2;
+  std::vector<float> ts(c->usave_slots);
+  float t1 = t2;
+  const float* u1 = nullptr;
+  if (mode == LRNDE_MODE_NONE) {  // _vanilla_node_fallback, neural_ode.jl:56-60
+    const float sv[1] = {t2};
+    oo.save_everystep = 0;
+    rc = lrnde_solve(c, x, B, t0, t2, &oo, sv, 1, c->usave, ts.data(), 2, st, nullptr, 0);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(u_end, c->usave + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+    if (nfe_host) *nfe_host = st->nf;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LRNDE_OK;
+  } else if (mode == LRNDE_MODE_UNBIASED) {  // neural_ode.jl:68-84, saveat = [t1, t2]
+    t1 = t1_or_rand;
+    const float sv[2] = {t1, t2};
+    oo.save_everystep = 0;
+    rc = lrnde_solve(c, x, B, t0, t2, &oo, sv, 2, c->usave, ts.data(), 3, st, nullptr, 0);
+    if (rc) return rc;
+    u1 = c->usave + (size_t)(oo.save_start ? 1 : 0) * n;
+  } else {  // neural_ode.jl:88-100, saveat = [] => every accepted step
+    oo.save_everystep = 1;
+    rc = lrnde_solve(c, x, B, t0, t2, &oo, nullptr, 0, c->usave, ts.data(), (int)c->usave_slots, st, nullptr, 0);
+    if (rc) return rc;
+    if (st->nsaved < 2) return fail(c, LRNDE_BADARG, "biased mode needs at least two saved times");
+    const int mm = st->nsaved - 1;
+    int idx = (int)(t1_or_rand * (float)mm);
+    if (idx >= mm) idx = mm - 1;
+    if (idx < 0) idx = 0;
+    t1 = ts[idx];
+    u1 = c->usave + (size_t)idx * n;
+  }
+  HIPCHK(c, hipMemcpyAsync(u_end, c->usave + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  if (t1_used_host) *t1_used_host = t1;
+  // _get_ode_integrator (neural_ode.jl:33-38): fresh init on (t1, t2); then _perform_step (:77)
+  StepArgs a;
+  fill_args(c, a, B);
+  a.t0 = t1; a.t1 = t2; a.abstol = oo.abstol; a.reltol = oo.reltol; a.mode = MODE_SINGLE_INIT_DT;
+  a.want_stiff = (reg_type == LRNDE_REG_STIFFNESS_ESTIMATE); a.maxiters = 1;
+  HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u1, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t1, 0.f, 0, 0);
+  if ((rc = run_init(c, B, a))) return rc;
+  if ((rc = launch_step(c, B, a, 0))) return rc;
+  const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
+  if ((rc = exchange(c, c->part + cnt, c->part_rx + cnt, cnt))) return rc;
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, a, 1);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->ctrl_host, c->ctrl + 1, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const Ctrl k = c->ctrl_host[0];
+  if (reg_val_host) *reg_val_host = a.want_stiff ? k.reg_stiff : k.reg_error;
+  if (nfe_host) *nfe_host = st->nf + k.nf;  // sol.destats.nf + (6 + 3), perform_step.jl:31
+  return LRNDE_OK;
+}
+
+int lrnde_comm_unique_id(void* out) {
+  if (!out) return LRNDE_BADARG;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return LRNDE_NCCL_ERROR;
+  memcpy(out, &id, sizeof(id));
+  return LRNDE_OK;
+}
+
+int lrnde_comm_init(lrnde_ctx* c, const void* uid, int32_t rank, int32_t nranks) {
+  if (!c || !uid || nranks < 1 || rank < 0 || rank >= nranks) return LRNDE_BADARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+  c->rank = rank; c->nranks = nranks;
+  c->wsB = 0;  // partial vectors are sized by nranks
+  if (nranks > 1 || getenv("LRNDE_FORCE_COMM")) {
+    ncclUniqueId id;
+    memcpy(&id, uid, sizeof(id));
+    NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+  }
+  return LRNDE_OK;
+}
+
+int lrnde_comm_destroy(lrnde_ctx* c) {
+  if (!c) return LRNDE_BADARG;
+  if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+  c->rank = 0; c->nranks = 1; c->wsB = 0;
+  return LRNDE_OK;
+}
+
+int lrnde_last_solve_kernel_ms(lrnde_ctx* c, float* ms, int32_t* launches) {
+  if (!c) return LRNDE_BADARG;
+  if (ms) *ms = c->last_ms;
+  if (launches) *launches = c->last_launches;
+  return LRNDE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+"""NeuralODE layer mirror (src/layers/neural_ode.jl) over the liblrnde C ABI.
+
+States are torch.cuda float32 tensors of shape (B, D), contiguous: the same
+memory as the reference's column-major D x B Julia arrays (batch last).
+"""
+import copy
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_VALID_REGULARIZE = ("none", "unbiased", "biased")
+_VALID_REG_TYPES = ("error_estimate", "stiffness_estimate")
+
+
+def _sym(s):
+    return s[1:] if isinstance(s, str) and s.startswith(":") else s
+
+
+def _check_valid_regularize(regularize, valid_modes=_VALID_REGULARIZE):
+    """src/utils.jl:53-58 — ArgumentError -> ValueError with the same text."""
+    if regularize not in valid_modes:
+        names = ", ".join(":" + m for m in valid_modes)
+        raise ValueError(f"regularize must be one of ({names})")
+
+
+# ----- model description (shape source: experiments/src/construct.jl:180-189) -----
+class Dense:
+    """Lux.Dense(in => out, activation) as a shape/activation spec."""
+
+    def __init__(self, in_dims, out_dims, activation="identity"):
+        if activation not in L.ACT:
+            raise ValueError(f"unsupported activation {activation!r} (have {sorted(L.ACT)})")
+        self.in_dims, self.out_dims, self.activation = int(in_dims), int(out_dims), activation
+
+
+class Chain:
+    def __init__(self, *layers):
+        self.layers = list(layers)
+
+
+class TDChain:
+    """src/layers/common.jl:2-45 — `t` is concatenated to the input of EVERY sub-layer."""
+
+    def __init__(self, chain):
+        self.layers = list(chain.layers if isinstance(chain, Chain) else chain)
+
+
+def _mlp_desc(model):
+    td = isinstance(model, TDChain)
+    if not isinstance(model, (Chain, TDChain)) or len(model.layers) != 2 or \
+            not all(isinstance(l, Dense) for l in model.layers):
+        raise NotImplementedError("liblrnde implements the 2-layer Dense vector field "
+                                  "(TDChain/Chain(Dense, Dense)) of experiments/src/construct.jl:180-189")
+    l1, l2 = model.layers
+    D, H = l1.in_dims - int(td), l1.out_dims
+    if l2.in_dims != H + int(td) or l2.out_dims != D:
+        raise ValueError("Dense shapes do not chain: need (D+td => H), (H+td => D)")
+    if l2.activation != "identity":
+        raise NotImplementedError("activation on the output Dense is not part of the reference fields")
+    return L.ModelDesc(D, H, int(td), L.ACT[l1.activation])
+
+
+def flatten_params(W1, b1, W2, b2):
+    """(out, in) torch/numpy weights -> the flat Lux/ComponentArray vector (column-major vec)."""
+    parts = [torch.as_tensor(W1).t().reshape(-1), torch.as_tensor(b1).reshape(-1),
+             torch.as_tensor(W2).t().reshape(-1), torch.as_tensor(b2).reshape(-1)]
+    return torch.cat([p.to(torch.float32) for p in parts]).contiguous()
+
+
+def glorot_params(model, seed=0):
+    """Lux default init (glorot_uniform weights, zero bias) from a numpy stream — the Julia RNG
+    streams cannot be reproduced, so parity tests pass the same vector to both sides."""
+    d = _mlp_desc(model)
+    rng = np.random.default_rng(seed)
+    td = d.time_dep
+
+    def glorot(out, inn):
+        return ((rng.random((inn, out), dtype=np.float32) - np.float32(0.5)) *
+                np.float32(np.sqrt(24.0 / (inn + out)))).astype(np.float32)
+
+    W1 = glorot(d.hidden_dim, d.state_dim + td)
+    W2 = glorot(d.state_dim, d.hidden_dim + td)
+    return np.concatenate([W1.ravel(), np.zeros(d.hidden_dim, np.float32), W2.ravel(),
+                           np.zeros(d.state_dim, np.float32)])
+
+
+def _dev_ptr(t, name, shape_tail=None):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous float32 CUDA tensor")
+    if shape_tail is not None and (t.dim() < 1 or t.shape[-1] != shape_tail):
+        raise ValueError(f"{name} must have trailing dimension {shape_tail} (got {tuple(t.shape)})")
+    return C.c_void_p(t.data_ptr())
+
+
+# ----- thin object over lrnde_ctx -----
+class Handle:
+    def __init__(self, desc, device=None, stream=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("liblrnde needs a GPU (gfx950); there is no CPU fallback")
+        self.desc = desc
+        self.D = desc.state_dim
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self._stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        self._ctx = C.c_void_p()
+        rc = L.lib.lrnde_create(C.byref(self._ctx), C.byref(desc), self.device,
+                                C.c_void_p(self._stream.cuda_stream))
+        if rc != 0:
+            raise L.LrndeError(rc, "lrnde_create failed")
+        self._params = None
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            L.lib.lrnde_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        L.check(self._ctx, rc)
+
+    def set_params(self, ps):
+        ps = ps if isinstance(ps, torch.Tensor) else torch.as_tensor(np.asarray(ps, dtype=np.float32))
+        ps = ps.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous().reshape(-1)
+        self._params = ps  # keep alive until packed
+        self._chk(L.lib.lrnde_set_params(self._ctx, C.c_void_p(ps.data_ptr()), ps.numel()))
+
+    def rhs(self, u, t):
+        B = u.numel() // self.D
+        du = torch.empty_like(u)
+        self._chk(L.lib.lrnde_rhs(self._ctx, _dev_ptr(u, "u", self.D), float(t), B, _dev_ptr(du, "du")))
+        return du
+
+    def init_dt(self, u0, t0, tend, abstol, reltol):
+        B = u0.numel() // self.D
+        k1 = torch.empty_like(u0)
+        dt = C.c_float()
+        self._chk(L.lib.lrnde_init_dt(self._ctx, _dev_ptr(u0, "u0", self.D), B, float(t0), float(tend),
+                                      float(abstol), float(reltol), _dev_ptr(k1, "k1"), C.byref(dt)))
+        return np.float32(dt.value), k1
+
+    def perform_step(self, uprev, k1, t, dt, abstol, reltol):
+        B = uprev.numel() // self.D
+        u = torch.empty_like(uprev)
+        k7 = torch.empty_like(uprev)
+        ee, re, rs = C.c_float(), C.c_float(), C.c_float()
+        self._chk(L.lib.lrnde_perform_step(self._ctx, _dev_ptr(uprev, "uprev", self.D), _dev_ptr(k1, "k1", self.D),
+                                           B, float(t), float(dt), float(abstol), float(reltol),
+                                           _dev_ptr(u, "u"), _dev_ptr(k7, "k7"), C.byref(ee), C.byref(re),
+                                           C.byref(rs)))
+        return dict(u=u, k7=k7, eest=np.float32(ee.value), reg_error=np.float32(re.value),
+                    reg_stiff=np.float32(rs.value))
+
+    def solve(self, u0, t0, t1, abstol, reltol, saveat=(), maxiters=1000, save_start=False,
+              save_everystep=None, exact_pow=False, cap=None, trace=False, raise_on_retcode=True):
+        B = u0.numel() // self.D
+        sv = np.ascontiguousarray(saveat, dtype=np.float32)
+        if save_everystep is None:
+            save_everystep = sv.size == 0
+        if cap is None:
+            cap = int(sv.size) + 2 + (min(int(maxiters), 512) if save_everystep else 0)
+        o = L.SolveOpts(float(abstol), float(reltol), int(maxiters), int(save_start),
+                        int(save_everystep), int(exact_pow))
+        us = torch.empty((cap,) + tuple(u0.shape), dtype=torch.float32, device=u0.device)
+        ts = np.empty(cap, dtype=np.float32)
+        st = L.Stats()
+        ntr = int(maxiters) + 8 if trace else 0
+        tr = (L.TraceRow * max(ntr, 1))()
+        rc = L.lib.lrnde_solve(self._ctx, _dev_ptr(u0, "u0", self.D), B, float(t0), float(t1), C.byref(o),
+                               sv.ctypes.data_as(C.POINTER(C.c_float)) if sv.size else None, int(sv.size),
+                               C.c_void_p(us.data_ptr()), ts.ctypes.data_as(C.POINTER(C.c_float)), cap,
+                               C.byref(st), tr if trace else None, ntr)
+        if rc != 0 and (raise_on_retcode or rc >= 4):
+            self._chk(rc)
+        out = dict(retcode=rc, u=us[:st.nsaved], t=ts[:st.nsaved].copy(), stats=st.asdict())
+        if trace:
+            nt = min(st.naccept + st.nreject, ntr)
+            out["trace"] = np.array([(tr[i].t, tr[i].dt, tr[i].eest, tr[i].accepted) for i in range(nt)],
+                                    dtype=[("t", "f4"), ("dt", "f4"), ("eest", "f4"), ("accepted", "i4")])
+        return out
+
+    def node_forward(self, x, t0, t2, abstol, reltol, mode="unbiased", reg_type="error_estimate",
+                     t1_or_rand=0.5, maxiters=1000, save_start=False, exact_pow=False):
+        B = x.numel() // self.D
+        o = L.SolveOpts(float(abstol), float(reltol), int(maxiters), int(save_start), 0, int(exact_pow))
+        u_end = torch.empty_like(x)
+        reg, nfe, st, t1u = C.c_float(), C.c_int32(), L.Stats(), C.c_float()
+        self._chk(L.lib.lrnde_node_forward(self._ctx, _dev_ptr(x, "x", self.D), B, float(t0), float(t2),
+                                           C.byref(o), L.MODE[mode], L.REG_TYPE[reg_type], float(t1_or_rand),
+                                           _dev_ptr(u_end, "u_end"), C.byref(reg), C.byref(nfe), C.byref(st),
+                                           C.byref(t1u)))
+        return dict(u_end=u_end, reg_val=np.float32(reg.value), nfe=int(nfe.value), stats=st.asdict(),
+                    t1=np.float32(t1u.value))
+
+    def last_solve_kernel_ms(self):
+        ms, n = C.c_float(), C.c_int32()
+        L.lib.lrnde_last_solve_kernel_ms(self._ctx, C.byref(ms), C.byref(n))
+        return float(ms.value), int(n.value)
+
+
+# ----- solution object: the fields the reference reads (src/utils.jl:7-9,25-46) -----
+class ODESolution:
+    def __init__(self, u, t, nf, naccept=0, nreject=0, retcode="Success"):
+        self.u, self.t = list(u), [np.float32(v) for v in t]
+        self.destats = SimpleNamespace(nf=int(nf), naccept=int(naccept), nreject=int(nreject))
+        self.retcode = retcode
+
+    def __call__(self, t):  # saveat-only solutions answer at their knots (neural_ode.jl:34)
+        for ti, ui in zip(self.t, self.u):
+            if ti == np.float32(t):
+                return ui
+        raise ValueError("this solution only stores its saveat knots")
+
+
+def diffeqsol_to_array(sol):
+    """src/utils.jl:37-40."""
+    return sol.u[-1] if isinstance(sol, ODESolution) else sol
+
+
+def diffeqsol_to_timeseries(sol):
+    """src/utils.jl:42-46: states stacked along a new second-to-last (Julia) dimension."""
+    return torch.stack(list(sol.u), dim=0)
+
+
+class NeuralODE:
+    """src/layers/neural_ode.jl:1-116.  `(sol, st) = node(x, ps, st)`."""
+
+    def __init__(self, model, *, solver="Tsit5", sensealg=None, tspan=(0.0, 1.0), regularize=True,
+                 maxiters=1000, regularize_type="error_estimate", **kwargs):
+        if isinstance(regularize, bool):  # :14-16
+            regularize = "unbiased" if regularize else "none"
+        regularize, regularize_type = _sym(regularize), _sym(regularize_type)
+        _check_valid_regularize(regularize)
+        _check_valid_regularize(regularize_type, _VALID_REG_TYPES)
+        if solver not in ("Tsit5", "tsit5"):
+            raise NotImplementedError("only Tsit5() is implemented on the device path")
+        self.model, self.solver, self.sensealg = model, "Tsit5", sensealg
+        self.tspan = (np.float32(tspan[0]), np.float32(tspan[1]))
+        self.maxiters, self.kwargs = int(maxiters), dict(kwargs)
+        self.regularize, self.regularize_type = regularize, regularize_type
+        self.desc = _mlp_desc(model)
+        self._handle = None
+        self._ps_key = None
+
+    def initialstates(self, rng):
+        """:27-31 — burns one normal draw, then replicates the rng."""
+        rng.standard_normal()
+        return dict(model={}, nfe=-1, reg_val=np.float32(0.0), rng=copy.deepcopy(rng), training=True)
+
+    def handle(self):
+        if self._handle is None:
+            self._handle = Handle(self.desc)
+        return self._handle
+
+    def _bind(self, ps):
+        h = self.handle()
+        key = (ps.data_ptr(), ps._version) if isinstance(ps, torch.Tensor) else None
+        if key is None or key != self._ps_key:
+            h.set_params(ps)
+            self._ps_key = key
+        return h
+
+    def __call__(self, x, ps, st):
+        h = self._bind(ps)
+        t0, t2 = self.tspan
+        kw = self.kwargs
+        abstol, reltol = kw.get("abstol", 1e-6), kw.get("reltol", 1e-3)  # OrdinaryDiffEq defaults
+        save_start = kw.get("save_start", True)
+        saveat = kw.get("saveat", None)
+        mode = self.regularize if st["training"] else "none"  # :62-66,86
+        common = dict(maxiters=self.maxiters, save_start=save_start)
+        if mode == "none":  # _vanilla_node_fallback :56-60
+            sv = [t2] if saveat is None else list(saveat)
+            r = h.solve(x, t0, t2, abstol, reltol, saveat=sv, save_everystep=False, **common)
+            sol = ODESolution(r["u"], r["t"], r["stats"]["nf"], r["stats"]["naccept"], r["stats"]["nreject"])
+            return sol, dict(model=st["model"], nfe=r["stats"]["nf"], reg_val=np.float32(0.0), rng=st["rng"],
+                             training=st["training"])
+        rng = copy.deepcopy(st["rng"])  # Lux.replicate(st.rng)
+        if mode == "unbiased":  # :68-84
+            t1 = np.float32(rng.random(dtype=np.float32) * (t2 - t0) + t0)
+            needs_correction = saveat is not None
+            sv = sorted(list(saveat) + [t1]) if needs_correction else [t1, t2]
+            r = h.solve(x, t0, t2, abstol, reltol, saveat=sv, save_everystep=False, **common)
+            ts = list(r["t"])
+            i1 = max(i for i, tv in enumerate(ts) if tv == t1)
+            u1 = r["u"][i1]
+        else:  # :88-100
+            r = h.solve(x, t0, t2, abstol, reltol, saveat=() if saveat is None else saveat,
+                        save_everystep=saveat is None, cap=min(self.maxiters, 510) + 2, **common)
+            ts = list(r["t"])
+            needs_correction = False
+            i1 = int(rng.integers(0, len(ts) - 1))  # rand(rng, sol.t[1:end-1])
+            t1, u1 = ts[i1], r["u"][i1]
+        # _get_ode_integrator :33-38 + _perform_step :77
+        dt, k1 = h.init_dt(u1.contiguous(), t1, t2, abstol, reltol)
+        ps_out = h.perform_step(u1.contiguous(), k1, t1, dt, abstol, reltol)
+        reg_val = ps_out["reg_stiff"] if self.regularize_type == "stiffness_estimate" else ps_out["reg_error"]
+        nfe = r["stats"]["nf"] + 6 + 3  # :79 with src/perform_step.jl:31
+        us, tt = list(r["u"]), ts
+        if needs_correction:  # _CorrectedDESolution, src/utils.jl:31-33
+            keep = [i for i, tv in enumerate(tt) if tv != t1]
+            us, tt = [us[i] for i in keep], [tt[i] for i in keep]
+        sol = ODESolution(us, tt, r["stats"]["nf"], r["stats"]["naccept"], r["stats"]["nreject"])
+        return sol, dict(model=st["model"], nfe=nfe, reg_val=reg_val, rng=rng, training=st["training"])

@@ -1,0 +1,131 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  The bar is BIT-EXACT for every fp32 output and every step count: both sides use the
+canonical arithmetic (one fp32 fma chain per dot product = v_mfma_f32_16x16x4_f32 semantics,
+fixed-polynomial activations, fp64-accumulated norms)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(O, pkg, D, H, B, act="tanh", td=True, seed=0, scale=1.0):
+    import torch
+    chain = pkg.Chain(pkg.Dense(D + int(td), H, act), pkg.Dense(H + int(td), D))
+    model = pkg.TDChain(chain) if td else chain
+    p = pkg.glorot_params(model, seed=seed) * np.float32(scale)
+    rng = np.random.default_rng(seed + 1)
+    p = p + (rng.standard_normal(p.size).astype(np.float32) * np.float32(0.01))  # non-zero biases
+    x = rng.random((B, D), dtype=np.float32)
+    fld = O.MlpField(D, H, p, time_dep=td, act=act, nthreads=8)
+    from localregneuralde_jl_amd.layers import Handle, _mlp_desc
+    h = Handle(_mlp_desc(model))
+    h.set_params(torch.from_numpy(p))
+    return fld, h, p, x, model
+
+
+def _eq(a, b, what):
+    a = np.asarray(a); b = np.asarray(b)
+    assert a.shape == b.shape, what
+    bad = ~((a == b) | (np.isnan(a) & np.isnan(b)))
+    assert not bad.any(), f"{what}: {bad.sum()} of {a.size} differ, max abs {np.abs(a - b)[bad].max()}"
+
+
+CASES = [(784, 100, 64, "tanh", True), (784, 100, 50, "tanh", True), (2, 4, 1, "gelu", True),
+         (2, 4, 3, "gelu", False), (32, 64, 33, "tanh", True), (20, 40, 17, "tanh", False)]
+
+
+@pytest.mark.parametrize("D,H,B,act,td", CASES)
+def test_rhs_bit_exact(oracle, gpu_pkg, D, H, B, act, td):
+    import torch
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, D, H, B, act, td)
+    for t in (0.0, 0.37):
+        ref = fld.rhs(x, t)
+        got = h.rhs(torch.from_numpy(x).cuda(), t).cpu().numpy()
+        _eq(got, ref, f"rhs t={t}")
+
+
+@pytest.mark.parametrize("D,H,B,act,td", CASES)
+def test_perform_step_bit_exact(oracle, gpu_pkg, D, H, B, act, td):
+    import torch
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, D, H, B, act, td)
+    k1 = fld.rhs(x, 0.1)
+    ref = oracle.tsit5_step(fld, x, k1, 0.1, 0.05, 1e-4, 1e-4)
+    got = h.perform_step(torch.from_numpy(x).cuda(), torch.from_numpy(k1).cuda(), 0.1, 0.05, 1e-4, 1e-4)
+    _eq(got["u"].cpu().numpy(), ref["u"], "u")
+    _eq(got["k7"].cpu().numpy(), ref["k7"], "k7")
+    for k in ("eest", "reg_error", "reg_stiff"):
+        assert got[k] == ref[k], (k, got[k], ref[k])
+
+
+@pytest.mark.parametrize("D,H,B,act,td", CASES)
+def test_init_dt_bit_exact(oracle, gpu_pkg, D, H, B, act, td):
+    import torch
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, D, H, B, act, td)
+    dt_ref, f0_ref = oracle.init_dt(fld, x, 0.0, 1.0, 1e-4, 1e-4)
+    dt, k1 = h.init_dt(torch.from_numpy(x).cuda(), 0.0, 1.0, 1e-4, 1e-4)
+    assert dt == dt_ref, (dt, dt_ref)
+    _eq(k1.cpu().numpy(), f0_ref, "fsalfirst")
+
+
+@pytest.mark.parametrize("D,H,B,act,td,tol", [(784, 100, 64, "tanh", True, 1.4e-8), (784, 100, 50, "tanh", True, 1e-4),
+                                              (2, 4, 1, "gelu", True, 1e-6), (32, 64, 33, "tanh", True, 1e-5)])
+def test_solve_bit_exact_step_counts(oracle, gpu_pkg, D, H, B, act, td, tol):
+    import torch
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, D, H, B, act, td, scale=2.0)
+    sv = [0.3, 0.61, 1.0]
+    ref = oracle.solve(fld, x, 0.0, 1.0, tol, tol, saveat=sv, maxiters=10000)
+    got = h.solve(torch.from_numpy(x).cuda(), 0.0, 1.0, tol, tol, saveat=sv, maxiters=10000, trace=True)
+    for k in ("nf", "naccept", "nreject", "iters", "nsaved", "dt_init", "t_final"):
+        assert got["stats"][k] == ref["stats"][k], (k, got["stats"], ref["stats"])
+    for f in ("t", "dt", "eest", "accepted"):
+        _eq(got["trace"][f], ref["trace"][f], "trace." + f)
+    _eq(got["t"], ref["t"], "sol.t")
+    _eq(got["u"].cpu().numpy(), ref["u"], "sol.u")
+
+
+def test_solve_with_rejections(oracle, gpu_pkg):
+    """Stiffer random field (weights x30) forces rejected steps; counts must still match."""
+    import torch
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, 32, 64, 20, "tanh", True, scale=30.0)
+    ref = oracle.solve(fld, x, 0.0, 1.0, 1e-3, 1e-3, saveat=[1.0], maxiters=10000)
+    got = h.solve(torch.from_numpy(x).cuda(), 0.0, 1.0, 1e-3, 1e-3, saveat=[1.0], maxiters=10000, trace=True)
+    assert ref["stats"]["nreject"] > 0
+    assert got["stats"] == {**ref["stats"], "retcode": 0}
+    _eq(got["u"].cpu().numpy(), ref["u"], "u(t1)")
+
+
+def test_solve_everystep_and_save_start(oracle, gpu_pkg):
+    import torch
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, 32, 64, 16, "tanh", True, scale=2.0)
+    ref = oracle.solve(fld, x, 0.0, 1.0, 1e-5, 1e-5, saveat=(), save_start=True, maxiters=1000)
+    got = h.solve(torch.from_numpy(x).cuda(), 0.0, 1.0, 1e-5, 1e-5, saveat=(), save_start=True, maxiters=1000)
+    _eq(got["t"], ref["t"], "sol.t")
+    _eq(got["u"].cpu().numpy(), ref["u"], "sol.u")
+
+
+def test_maxiters_retcode(oracle, gpu_pkg):
+    import torch
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, 32, 64, 16, "tanh", True, scale=2.0)
+    ref = oracle.solve(fld, x, 0.0, 1.0, 1e-7, 1e-7, saveat=[1.0], maxiters=3)
+    got = h.solve(torch.from_numpy(x).cuda(), 0.0, 1.0, 1e-7, 1e-7, saveat=[1.0], maxiters=3, raise_on_retcode=False)
+    assert ref["retcode"] == 1 and got["retcode"] == 1
+    assert got["stats"]["naccept"] == ref["stats"]["naccept"]
+
+
+@pytest.mark.parametrize("mode,reg_type", [("none", "error_estimate"), ("unbiased", "error_estimate"),
+                                           ("unbiased", "stiffness_estimate"), ("biased", "error_estimate"),
+                                           ("biased", "stiffness_estimate")])
+def test_node_forward_bit_exact(oracle, gpu_pkg, mode, reg_type):
+    import torch
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, 784, 100, 32, "tanh", True)
+    ref = oracle.node_forward(fld, x, 0.0, 1.0, 1e-4, 1e-4, mode=mode, reg_type=reg_type, t1_or_rand=0.43,
+                              maxiters=10000)
+    got = h.node_forward(torch.from_numpy(x).cuda(), 0.0, 1.0, 1e-4, 1e-4, mode=mode, reg_type=reg_type,
+                         t1_or_rand=0.43, maxiters=10000)
+    assert got["nfe"] == ref["nfe"] and got["t1"] == ref["t1"]
+    assert got["reg_val"] == ref["reg_val"], (got["reg_val"], ref["reg_val"])
+    if mode == "none":
+        assert got["reg_val"] == 0.0
+    else:
+        assert got["reg_val"] != 0.0
+    _eq(got["u_end"].cpu().numpy(), ref["u_end"], "sol.u[end]")
