@@ -175,37 +175,54 @@ void lro_mlp_rhs(const lro_mlp* m, const float* u, float t, int B, float* du) {
   const float* b2 = W2 + (size_t)D * (H + td);
   int nth = m->nthreads > 0 ? m->nthreads : 1;
   (void)nth;
+  enum { SB = 8 }; /* samples per weight pass: same per-element fma chain, better cache reuse */
+  const int nblk = (B + SB - 1) / SB;
 #pragma omp parallel num_threads(nth)
   {
-    float* h = (float*)malloc(sizeof(float) * (size_t)(H > D ? H : D));
+    float* h = (float*)malloc(sizeof(float) * (size_t)SB * (size_t)(H > D ? H : D));
 #pragma omp for schedule(static)
-    for (int n = 0; n < B; ++n) {
-      const float* x = u + (size_t)n * D;
-      float* y = du + (size_t)n * D;
+    for (int blk = 0; blk < nblk; ++blk) {
+      const int n0 = blk * SB;
+      const int ns = (B - n0) < SB ? (B - n0) : SB;
       /* layer 1: one fma chain per output in increasing k, t column last, then + bias */
-      for (int o = 0; o < H; ++o) h[o] = 0.0f;
+      for (int i = 0; i < ns * H; ++i) h[i] = 0.0f;
       for (int k = 0; k < D; ++k) {
-        const float xv = x[k];
         const float* w = W1 + (size_t)k * H;
-        for (int o = 0; o < H; ++o) h[o] = fmaf(w[o], xv, h[o]);
+        for (int s = 0; s < ns; ++s) {
+          const float xv = u[(size_t)(n0 + s) * D + k];
+          float* hs = h + (size_t)s * H;
+          for (int o = 0; o < H; ++o) hs[o] = fmaf(w[o], xv, hs[o]);
+        }
       }
-      if (td) {
-        const float* w = W1 + (size_t)D * H;
-        for (int o = 0; o < H; ++o) h[o] = fmaf(w[o], t, h[o]);
+      for (int s = 0; s < ns; ++s) {
+        float* hs = h + (size_t)s * H;
+        if (td) {
+          const float* w = W1 + (size_t)D * H;
+          for (int o = 0; o < H; ++o) hs[o] = fmaf(w[o], t, hs[o]);
+        }
+        for (int o = 0; o < H; ++o) hs[o] = act_apply(m->act, hs[o] + b1[o]);
       }
-      for (int o = 0; o < H; ++o) h[o] = act_apply(m->act, h[o] + b1[o]);
       /* layer 2 */
-      for (int o = 0; o < D; ++o) y[o] = 0.0f;
+      for (int s = 0; s < ns; ++s) {
+        float* y = du + (size_t)(n0 + s) * D;
+        for (int o = 0; o < D; ++o) y[o] = 0.0f;
+      }
       for (int k = 0; k < H; ++k) {
-        const float hv = h[k];
         const float* w = W2 + (size_t)k * D;
-        for (int o = 0; o < D; ++o) y[o] = fmaf(w[o], hv, y[o]);
+        for (int s = 0; s < ns; ++s) {
+          const float hv = h[(size_t)s * H + k];
+          float* y = du + (size_t)(n0 + s) * D;
+          for (int o = 0; o < D; ++o) y[o] = fmaf(w[o], hv, y[o]);
+        }
       }
-      if (td) {
-        const float* w = W2 + (size_t)H * D;
-        for (int o = 0; o < D; ++o) y[o] = fmaf(w[o], t, y[o]);
+      for (int s = 0; s < ns; ++s) {
+        float* y = du + (size_t)(n0 + s) * D;
+        if (td) {
+          const float* w = W2 + (size_t)H * D;
+          for (int o = 0; o < D; ++o) y[o] = fmaf(w[o], t, y[o]);
+        }
+        for (int o = 0; o < D; ++o) y[o] = y[o] + b2[o];
       }
-      for (int o = 0; o < D; ++o) y[o] = y[o] + b2[o];
     }
     free(h);
   }
@@ -256,6 +273,31 @@ static double sumsq_diff(const float* a, const float* b, long n) {
 int lro_tsit5_step(const lro_field* f, const float* uprev, const float* k1, float t, float dt,
                    float abstol, float reltol, int B, float* u, float* k7, float* ks, float* g6o,
                    float* eest, float* reg_error, float* reg_stiff) {
+  double sums[3];
+  const long n = (long)f->D * B;
+  int rc = lro_tsit5_step_sums(f, uprev, k1, t, dt, abstol, reltol, B, u, k7, ks, g6o, sums);
+  /* EEst (upstream perform_step!) and :34-38 error_estimate = EEst*dt */
+  float ee = rms_from_sumsq(sums[0], n);
+  if (eest) *eest = ee;
+  if (reg_error) *reg_error = ee * dt;
+  /* :40-47 stiffness_estimate */
+  if (reg_stiff) {
+    float den = rms_from_sumsq(sums[2], n);
+    if (den == 0.0f) {
+      *reg_stiff = 0.0f;
+    } else {
+      float num = rms_from_sumsq(sums[1], n);
+      *reg_stiff = fabsf(num / (den + 1.1920929e-7f)) / 3.5068f;
+    }
+  }
+  return rc;
+}
+
+/* the step itself; sums = {sum r^2 (error residual), sum (k7-k6)^2, sum (u-g6)^2} over THIS
+ * array only (fp64), so that a batch-sharded caller can add the sums of all shards */
+int lro_tsit5_step_sums(const lro_field* f, const float* uprev, const float* k1, float t, float dt,
+                        float abstol, float reltol, int B, float* u, float* k7, float* ks,
+                        float* g6o, double* sums) {
   const long n = (long)f->D * B;
   const float c1 = (float)TS_C[0], c2 = (float)TS_C[1], c3 = (float)TS_C[2], c4 = (float)TS_C[3];
   float A[21], BT[7];
@@ -306,20 +348,9 @@ int lro_tsit5_step(const lro_field* f, const float* uprev, const float* k1, floa
                         BT[4] * k5[i]) +
                        BT[5] * k6[i]) +
                       BT[6] * k7[i]);
-  /* EEst (upstream perform_step!) and :34-38 error_estimate = EEst*dt */
-  float ee = rms_from_sumsq(sumsq_resid(utilde, uprev, u, abstol, reltol, n), n);
-  if (eest) *eest = ee;
-  if (reg_error) *reg_error = ee * dt;
-  /* :40-47 stiffness_estimate */
-  if (reg_stiff) {
-    float den = rms_from_sumsq(sumsq_diff(u, g6, n), n);
-    if (den == 0.0f) {
-      *reg_stiff = 0.0f;
-    } else {
-      float num = rms_from_sumsq(sumsq_diff(k7, k6, n), n);
-      *reg_stiff = fabsf(num / (den + 1.1920929e-7f)) / 3.5068f;
-    }
-  }
+  sums[0] = sumsq_resid(utilde, uprev, u, abstol, reltol, n);
+  sums[1] = sumsq_diff(k7, k6, n);
+  sums[2] = sumsq_diff(u, g6, n);
   free(utilde);
   if (!g6o) free(g6);
   free(tmp);
@@ -491,6 +522,7 @@ int lro_solve(const lro_field* f, const float* u0, int B, float t0, float t1, co
     float eest;
     lro_tsit5_step(f, uprev, k1, t, dt, abstol, reltol, B, u, k7, ks, NULL, &eest, NULL, NULL);
     st->nf += 6;
+    if (eest != eest) { rc = LRO_DT_NAN; st->eest_last = eest; break; } /* unstable_check */
     /* loopfooter!: PI controller */
     float ttmp = t + dt;
     float q;

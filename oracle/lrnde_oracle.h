@@ -113,6 +113,9 @@ void lro_mlp_as_field(const lro_mlp* m, lro_field* out);
 int lro_tsit5_step(const lro_field* f, const float* uprev, const float* k1, float t, float dt,
                    float abstol, float reltol, int B, float* u, float* k7, float* ks, float* g6,
                    float* eest, float* reg_error, float* reg_stiff);
+int lro_tsit5_step_sums(const lro_field* f, const float* uprev, const float* k1, float t, float dt,
+                        float abstol, float reltol, int B, float* u, float* k7, float* ks,
+                        float* g6, double* sums3);
 int lro_init_dt(const lro_field* f, const float* u0, float t0, float tend, float abstol,
                 float reltol, int B, float* f0_out, float* dt_out);
 void lro_tsit5_interp(float theta, float dt, const float* y0, const float* const k[7], long n,

@@ -77,6 +77,8 @@ def lib():
         L.lro_mlp_as_field.argtypes = [C.POINTER(Mlp), C.POINTER(Field)]
         L.lro_tsit5_step.argtypes = [C.POINTER(Field), fp, fp, C.c_float, C.c_float, C.c_float,
                                      C.c_float, C.c_int, fp, fp, fp, fp, fp, fp, fp]
+        L.lro_tsit5_step_sums.argtypes = [C.POINTER(Field), fp, fp, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, C.c_int, fp, fp, fp, fp, C.POINTER(C.c_double)]
         L.lro_init_dt.argtypes = [C.POINTER(Field), fp, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_int, fp, fp]
         L.lro_tsit5_interp.restype = None
@@ -171,6 +173,19 @@ def tsit5_step(fld, uprev, k1, t, dt, abstol, reltol, want_stages=False):
         out["ks"] = ks
         out["g6"] = g6
     return out
+
+
+def tsit5_step_sums(fld, uprev, k1, t, dt, abstol, reltol):
+    """One step on this array; returns u, k7 and the raw fp64 sums (for batch-sharded callers)."""
+    uprev = _f32(uprev); k1 = _f32(k1)
+    B = uprev.size // fld.D
+    u = np.empty_like(uprev); k7 = np.empty_like(uprev)
+    ks = np.empty((5,) + uprev.shape, dtype=np.float32)
+    sums = (C.c_double * 3)()
+    rc = lib().lro_tsit5_step_sums(C.byref(fld.field), _fp(uprev), _fp(k1), float(t), float(dt),
+                                   float(abstol), float(reltol), B, _fp(u), _fp(k7), _fp(ks), None, sums)
+    assert rc == 0
+    return dict(u=u, k7=k7, ks=ks, sums=np.array(sums, dtype=np.float64))
 
 
 def init_dt(fld, u0, t0, tend, abstol, reltol):

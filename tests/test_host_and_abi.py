@@ -1,0 +1,100 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/lrnde.h declares
+(no compute calls without a GPU), and the host mirror's argument handling."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "lrnde.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lrnde_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    import lrnde_amd  # noqa: F401
+    from localregneuralde_jl_amd import _lib
+    decl = _declared_symbols()
+    assert len(decl) >= 15
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in decl:
+        assert hasattr(raw, name), f"{name} declared in include/lrnde.h but not exported"
+    assert sorted(n for n, _, _ in _lib.SYMBOLS) == decl, "ctypes table and header drifted apart"
+    assert b"gfx950" in _lib.lib.lrnde_version()
+
+
+def test_struct_layouts_match_header():
+    from localregneuralde_jl_amd import _lib
+    assert ctypes.sizeof(_lib.ModelDesc) == 16 and ctypes.sizeof(_lib.SolveOpts) == 24
+    assert ctypes.sizeof(_lib.Stats) == 40 and ctypes.sizeof(_lib.TraceRow) == 16
+    d = _lib.ModelDesc(784, 100, 1, 1)
+    assert _lib.lib.lrnde_param_count(ctypes.byref(d)) == 158568  # 158 568 fp32
+
+
+def test_bad_handle_arguments_return_status_not_crash():
+    from localregneuralde_jl_amd import _lib
+    assert _lib.lib.lrnde_destroy(None) == 0
+    assert _lib.lib.lrnde_set_params(None, None, 0) == 4
+    bad = _lib.ModelDesc(0, 100, 1, 1)
+    ctx = ctypes.c_void_p()
+    assert _lib.lib.lrnde_create(ctypes.byref(ctx), ctypes.byref(bad), 0, None) == 4
+
+
+def test_regularize_validation_messages():
+    import lrnde_amd as P
+    m = P.TDChain(P.Chain(P.Dense(3, 4, "gelu"), P.Dense(5, 2)))
+    with pytest.raises(ValueError, match=r"regularize must be one of \(:none, :unbiased, :biased\)"):
+        P.NeuralODE(m, regularize="sometimes")
+    with pytest.raises(ValueError, match=r":error_estimate, :stiffness_estimate"):
+        P.NeuralODE(m, regularize_type="jacobian")
+    assert P.NeuralODE(m, regularize=True).regularize == "unbiased"      # neural_ode.jl:14-16
+    assert P.NeuralODE(m, regularize=False).regularize == "none"
+    assert P.NeuralODE(m, regularize=":biased").regularize == "biased"
+    with pytest.raises(NotImplementedError):
+        P.NeuralODE(P.Chain(P.Dense(2, 4), P.Dense(4, 4), P.Dense(4, 2)))
+    with pytest.raises(ValueError):
+        P.NeuralODE(P.TDChain(P.Chain(P.Dense(3, 4), P.Dense(4, 2))))  # second Dense lacks the t row
+
+
+def test_initialstates_and_param_flattening():
+    import torch
+    import lrnde_amd as P
+    m = P.TDChain(P.Chain(P.Dense(3, 4, "gelu"), P.Dense(5, 2)))
+    node = P.NeuralODE(m)
+    st = node.initialstates(np.random.default_rng(0))
+    assert st["nfe"] == -1 and st["reg_val"] == 0 and st["training"] is True
+    W1 = torch.arange(12.).reshape(4, 3); b1 = torch.zeros(4); W2 = torch.arange(10.).reshape(2, 5); b2 = torch.ones(2)
+    flat = P.flatten_params(W1, b1, W2, b2)
+    assert flat.numel() == 12 + 4 + 10 + 2
+    assert flat[:4].tolist() == [0., 3., 6., 9.]   # column-major vec(W1): first input column
+    assert P.glorot_params(m, seed=1).size == 28
+
+
+def test_solution_helpers_and_sharding():
+    import torch
+    import lrnde_amd as P
+    sol = P.ODESolution([torch.zeros(2, 3), torch.ones(2, 3)], [0.5, 1.0], nf=15)
+    assert P.diffeqsol_to_array(sol) is sol.u[-1] and sol.destats.nf == 15
+    assert P.diffeqsol_to_timeseries(sol).shape == (2, 2, 3)
+    assert sol(0.5) is sol.u[0]
+    with pytest.raises(ValueError):
+        sol(0.7)
+    x = np.arange(24).reshape(8, 3)
+    assert np.array_equal(P.shard_columns(x, 1, 4), x[2:4])
+    with pytest.raises(ValueError):
+        P.shard_columns(x, 0, 3)
+
+
+def test_product_path_does_not_touch_the_oracle():
+    """No file of the shipped package or bench's GPU leg may import / link oracle/."""
+    pkg = os.path.join(ROOT, "localregneuralde.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in txt and "lrnde_oracle" not in txt, os.path.join(dirpath, f)

@@ -1,0 +1,195 @@
+"""Known-answer tests that pin the CPU oracle (the reference's own tests hold no numeric
+vectors — SURVEY.md §4 — so these are the pins): tableau identities, convergence order,
+an independent numpy restatement, scipy, and the committed golden fixtures."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+from np_restatement import NpMlp, tsit5_step as np_step
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _butcher(O):
+    a, c, bt, r = O.tableau()
+    Am = np.zeros((7, 7))
+    idx = 0
+    for i in range(1, 7):
+        for j in range(i):
+            Am[i, j] = a[idx]; idx += 1
+    cv = np.concatenate([[0.0], c])
+    b = Am[6].copy()
+    return Am, cv, b, bt, r
+
+
+def test_tableau_row_sums_and_fsal(oracle):
+    Am, c, b, bt, r = _butcher(oracle)
+    assert np.allclose(Am.sum(axis=1), c, atol=1e-15)
+    assert abs(bt.sum()) < 1e-16
+    assert c[6] == 1.0 and b[6] == 0.0
+
+
+def test_tableau_order_conditions_through_5(oracle):
+    """All 17 rooted-tree conditions up to order 5 for b = a7.."""
+    Am, c, b, bt, r = _butcher(oracle)
+    Ac = Am @ c
+    conds = [
+        (b.sum(), 1), (b @ c, 1 / 2), (b @ c ** 2, 1 / 3), (b @ Ac, 1 / 6),
+        (b @ c ** 3, 1 / 4), (b @ (c * Ac), 1 / 8), (b @ (Am @ c ** 2), 1 / 12), (b @ (Am @ Ac), 1 / 24),
+        (b @ c ** 4, 1 / 5), (b @ (c ** 2 * Ac), 1 / 10), (b @ (Ac * Ac), 1 / 20),
+        (b @ (c * (Am @ c ** 2)), 1 / 15), (b @ (Am @ c ** 3), 1 / 20), (b @ (c * (Am @ Ac)), 1 / 30),
+        (b @ (Am @ (c * Ac)), 1 / 40), (b @ (Am @ (Am @ c ** 2)), 1 / 60), (b @ (Am @ (Am @ Ac)), 1 / 120)]
+    for i, (lhs, rhs) in enumerate(conds):
+        assert abs(lhs - rhs) < 5e-15, (i, lhs, rhs)
+    # the embedded weights b - btilde satisfy the conditions through order 4
+    bh = b - bt
+    for lhs, rhs in [(bh.sum(), 1), (bh @ c, 1 / 2), (bh @ c ** 2, 1 / 3), (bh @ Ac, 1 / 6), (bh @ c ** 3, 1 / 4),
+                     (bh @ (c * Ac), 1 / 8), (bh @ (Am @ c ** 2), 1 / 12), (bh @ (Am @ Ac), 1 / 24)]:
+        assert abs(lhs - rhs) < 5e-15
+
+
+def test_dense_output_identities(oracle):
+    Am, c, b, bt, r = _butcher(oracle)
+    def bth(th):
+        out = np.empty(7)
+        out[0] = th * (r[0, 0] + th * (r[0, 1] + th * (r[0, 2] + th * r[0, 3])))
+        for i in range(1, 7):
+            out[i] = th * th * (r[i, 1] + th * (r[i, 2] + th * r[i, 3]))
+        return out
+    assert np.allclose(bth(1.0), b, atol=2e-14)
+    Ac = Am @ c
+    for th in (0.25, 0.5, 0.8):
+        w = bth(th)
+        assert abs(w.sum() - th) < 1e-13
+        assert abs(w @ c - th ** 2 / 2) < 1e-13
+        assert abs(w @ c ** 2 - th ** 3 / 3) < 1e-13
+        assert abs(w @ Ac - th ** 3 / 6) < 1e-13
+        assert abs(w @ c ** 3 - th ** 4 / 4) < 1e-13
+
+
+def test_local_error_order_and_eest_scaling(oracle):
+    """u' = -u: local error at least O(dt^6) (Tsit5's dt^6 coefficient is tiny on linear problems,
+    so the observed ratio sits between 2^6 and 2^7), embedded estimate ~ dt^5 (5(4) pair)."""
+    f = oracle.PyField(4, lambda u, t: -u)
+    u0 = np.array([[1.0, 2.0, -0.5, 0.25]], dtype=np.float32)
+    errs, ees = [], []
+    for dt in (0.8, 0.4):
+        r = oracle.tsit5_step(f, u0, -u0, 0.0, dt, 1e-3, 1e-3)
+        errs.append(np.abs(r["u"].astype(np.float64) - u0 * np.exp(-dt)).max())
+        ees.append(float(r["eest"]))
+    assert 60 < errs[0] / errs[1] < 135, errs     # between 2^6 and 2^7
+    assert 25 < ees[0] / ees[1] < 50, ees         # ~2^5 (scaled by the |u| weights)
+
+
+def test_harmonic_oscillator_solve_matches_scipy(oracle):
+    from scipy.integrate import solve_ivp
+    f = oracle.PyField(2, lambda u, t: np.stack([u[:, 1], -u[:, 0]], axis=1))
+    u0 = np.array([[1.0, 0.0], [0.3, -0.7]], dtype=np.float32)
+    s = oracle.solve(f, u0, 0.0, 3.0, 1e-6, 1e-6, saveat=[1.0, 3.0], maxiters=1000)
+    assert s["retcode"] == 0 and s["stats"]["nf"] == 3 + 6 * (s["stats"]["naccept"] + s["stats"]["nreject"])
+    for row in range(2):
+        ref = solve_ivp(lambda t, y: [y[1], -y[0]], (0, 3), u0[row].astype(float), rtol=1e-10, atol=1e-12,
+                        t_eval=[1.0, 3.0])
+        assert np.allclose(s["u"][:, row, :], ref.y.T, atol=2e-5)
+
+
+def test_saveat_interpolation_accuracy(oracle):
+    """saveat points are filled by the 4th-order Tsit5 interpolant, not by stepping to them."""
+    f = oracle.PyField(1, lambda u, t: -u)
+    u0 = np.ones((1, 1), np.float32)
+    sv = np.linspace(0.05, 2.0, 40).astype(np.float32)
+    s = oracle.solve(f, u0, 0.0, 2.0, 1e-5, 1e-5, saveat=sv, maxiters=1000)
+    assert s["stats"]["naccept"] < 20 and len(s["t"]) == 40
+    assert np.allclose(s["u"][:, 0, 0], np.exp(-sv.astype(np.float64)), atol=5e-5)
+
+
+@pytest.mark.parametrize("D,H,B,act,td,dt", [(784, 100, 8, "tanh", True, 0.1), (2, 4, 1, "gelu", True, 0.6),
+                                             (20, 40, 5, "gelu", False, 0.3)])
+def test_numpy_restatement_agrees(oracle, D, H, B, act, td, dt):
+    # weights x6: the truncation error must dominate fp32 rounding noise in utilde, otherwise
+    # EEst is noise and two correct implementations legitimately disagree
+    p = oracle.glorot_mlp_params(D, H, time_dep=td, seed=3) * np.float32(6.0)
+    p[:] += np.random.default_rng(4).standard_normal(p.size).astype(np.float32) * 0.01
+    x = np.random.default_rng(5).random((B, D), dtype=np.float32)
+    fo = oracle.MlpField(D, H, p, time_dep=td, act=act)
+    fn = NpMlp(D, H, p, time_dep=td, act=act)
+    def close(a, b, rtol):  # rtol relative to the array scale (dot products cancel)
+        return np.abs(a.astype(np.float64) - b).max() <= rtol * np.abs(b).max()
+    assert close(fo.rhs(x, 0.3), fn(x, np.float32(0.3)), 1e-5)
+    k1 = fo.rhs(x, 0.1)
+    a = oracle.tsit5_step(fo, x, k1, 0.1, dt, 1e-3, 1e-3)
+    b = np_step(fn, x, k1, 0.1, dt, 1e-3, 1e-3)
+    assert close(a["u"], b["u"], 1e-5)
+    assert close(a["k7"], b["k7"], 1e-5)
+    for k in ("eest", "reg_error", "reg_stiff"):
+        assert np.isclose(a[k], b[k], rtol=2e-3), (k, a[k], b[k])
+
+
+def test_activations_accuracy(oracle):
+    x = np.concatenate([np.linspace(-12, 12, 4001), np.linspace(-0.7, 0.7, 2001)]).astype(np.float32)
+    t = oracle.vec_fn("lro_tanhf", x)
+    ref = np.tanh(x.astype(np.float64))
+    assert np.max(np.abs(t - ref) / np.maximum(np.abs(ref), 1e-30)) < 2.5e-7
+    g = oracle.vec_fn("lro_geluf", x)
+    xd = x.astype(np.float64)
+    refg = 0.5 * xd * (1 + np.tanh(np.sqrt(2 / np.pi) * (xd + 0.044715 * xd ** 3)))
+    assert np.max(np.abs(g - refg)) < 1e-6
+    e = oracle.vec_fn("lro_expf", np.linspace(-87, 87, 3001).astype(np.float32))
+    assert np.max(np.abs(e / np.exp(np.linspace(-87, 87, 3001).astype(np.float32).astype(np.float64)) - 1)) < 2e-7
+
+
+def test_fastpow_is_the_diffeqbase_approximation(oracle):
+    L = oracle.lib()
+    for x, y in itertools.product((1e-4, 0.03, 0.5, 1.0, 3.7, 250.0), (0.14, 0.08)):
+        got = L.lro_fastpow(x, y)
+        assert abs(got / x ** y - 1) < 2e-3          # documented relative error ~1e-4..1e-3
+    assert L.lro_fastpow(0.0, 0.14) == 0.0
+    assert L.lro_fastpow2(0.0) == pytest.approx(1.0, rel=1e-4)
+
+
+def test_step_counts_formula_and_retcodes(oracle):
+    p = oracle.glorot_mlp_params(16, 32, seed=0) * np.float32(20)
+    x = np.random.default_rng(0).random((4, 16), dtype=np.float32)
+    f = oracle.MlpField(16, 32, p)
+    s = oracle.solve(f, x, 0, 1, 1e-4, 1e-4, saveat=[1.0], maxiters=10000)
+    st = s["stats"]
+    assert st["nf"] == 3 + 6 * (st["naccept"] + st["nreject"]) and st["nreject"] > 0
+    assert np.all(s["trace"]["eest"][s["trace"]["accepted"] == 1] <= 1.0)
+    assert np.all(s["trace"]["eest"][s["trace"]["accepted"] == 0] > 1.0)
+    s2 = oracle.solve(f, x, 0, 1, 1e-4, 1e-4, saveat=[1.0], maxiters=3)
+    assert s2["retcode"] == 1
+
+
+def test_node_forward_behaviour_pins(oracle):
+    """The assertions test/runtests.jl makes on the forward pass (:21-22, :118): reg_val is
+    zero iff regularize == :none; nfe = sol.nf + 9 in the regularised modes."""
+    D, H, B = 2, 4, 1
+    p = oracle.glorot_mlp_params(D, H, seed=0)
+    x = np.random.default_rng(0).standard_normal((B, D)).astype(np.float32)
+    f = oracle.MlpField(D, H, p, act="gelu")
+    none = oracle.node_forward(f, x, 0, 1, 1e-6, 1e-3, mode="none")
+    assert none["reg_val"] == 0 and none["nfe"] == none["stats"]["nf"] and none["u_end"].dtype == np.float32
+    for mode in ("unbiased", "biased"):
+        for rt in ("error_estimate", "stiffness_estimate"):
+            r = oracle.node_forward(f, x, 0, 1, 1e-6, 1e-3, mode=mode, reg_type=rt, t1_or_rand=0.41)
+            assert r["reg_val"] != 0 and np.isfinite(r["reg_val"])
+            assert r["nfe"] == r["stats"]["nf"] + 9
+            assert np.array_equal(r["u_end"], none["u_end"]) or mode == "biased"
+
+
+def test_golden_fixtures(oracle):
+    """Regression pins generated by tests/golden/make_golden.py from this oracle."""
+    g = np.load(os.path.join(GOLD, "mnist_mlp_b16.npz"))
+    f = oracle.MlpField(784, 100, g["params"])
+    r = oracle.tsit5_step(f, g["x"], g["k1"], float(g["t"]), float(g["dt"]), float(g["tol"]), float(g["tol"]))
+    assert np.array_equal(r["u"], g["step_u"]) and np.array_equal(r["k7"], g["step_k7"])
+    assert r["eest"] == g["step_eest"] and r["reg_error"] == g["step_reg_error"] and r["reg_stiff"] == g["step_reg_stiff"]
+    s = oracle.solve(f, g["x"], 0.0, 1.0, float(g["tol"]), float(g["tol"]), saveat=[0.5, 1.0], maxiters=10000)
+    assert np.array_equal(s["trace"]["dt"], g["solve_dt_trace"])
+    assert np.array_equal(s["u"], g["solve_u"])
+    assert s["stats"]["nf"] == int(g["solve_nf"])
+    n = oracle.node_forward(f, g["x"], 0.0, 1.0, float(g["tol"]), float(g["tol"]), mode="unbiased", t1_or_rand=0.37,
+                            maxiters=10000)
+    assert n["reg_val"] == g["node_reg_val"] and n["nfe"] == int(g["node_nfe"])
