@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the hot path on MI355X.
+
+One "step" = one NeuralODE forward pass over one batch: the adaptive Tsit5 solve of the MNIST-ODE
+MLP field on (0,1) at abstol=reltol=1.4e-8 (experiments/mnist_ode/mlp.yml) plus the local
+regularisation step (regularize=:unbiased, :error_estimate), B=512 columns per GPU, inputs
+resident in HBM.  Metric: NFE/s = vector-field evaluations (of one 512-column shard) per second,
+summed over ranks.  Launch: `python bench.py --gpus 1` or, for N>1,
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+D, H = 784, 100
+FLOP_PER_FEVAL_PER_COL = 2 * (785 * 100 + 101 * 784)  # 315 368
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def cpu_baseline(params, x, tol, t1, cores):
+    """The oracle (a port, not the Julia reference — no julia in the image) timed on the host
+    cores on one full forward pass of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    fld = O.MlpField(D, H, params, nthreads=cores)
+    t0 = time.time()
+    r = O.node_forward(fld, x, 0.0, 1.0, tol, tol, mode="unbiased", reg_type="error_estimate", t1_or_rand=t1,
+                       maxiters=10000)
+    el = time.time() - t0
+    return r, el
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="columns per GPU (weak scaling)")
+    ap.add_argument("--tol", type=float, default=1.4e-8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=512)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import lrnde_amd as P
+    from localregneuralde_jl_amd.layers import Handle, _mlp_desc
+
+    model = P.TDChain(P.Chain(P.Dense(D + 1, H, "tanh"), P.Dense(H + 1, D)))
+    params = P.glorot_params(model, seed=0)  # random-init weights of the reference architecture
+    Bg = args.batch * world
+    xg = np.random.default_rng(0).random((Bg, D), dtype=np.float32)  # MNIST pixels lie in [0,1]
+    x = torch.from_numpy(np.ascontiguousarray(P.shard_columns(xg, rank, world))).cuda()
+    h = Handle(_mlp_desc(model))
+    h.set_params(torch.from_numpy(params))
+    if world > 1:
+        P.init_comm(h, rank, world)
+    t1s = np.random.default_rng(1).random(args.steps + args.warmup, dtype=np.float32)  # host RNG draw of t1
+
+    def one_pass(i):
+        return h.node_forward(x, 0.0, 1.0, args.tol, args.tol, mode="unbiased", reg_type="error_estimate",
+                              t1_or_rand=float(t1s[i]), maxiters=10000)
+
+    for i in range(args.warmup):
+        one_pass(i)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nfe_total, steps_total = 0, 0
+    for i in range(args.steps):
+        r = one_pass(args.warmup + i)
+        nfe_total += r["nfe"]
+        steps_total += r["stats"]["naccept"] + r["stats"]["nreject"] + 1
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+
+    # roofline leg: the dominant kernel (one full Tsit5 step per launch), HIP events on its stream
+    k1 = h.rhs(x, 0.0)
+    dt_typ = float(r["stats"]["dt_final"]) if r["stats"]["dt_final"] > 0 else 0.02
+    us = h.bench_step(x, k1, 0.0, dt_typ, args.tol, args.tol, reps=100)
+    flop_per_launch = 6 * FLOP_PER_FEVAL_PER_COL * args.batch
+    achieved = flop_per_launch / (us * 1e-6) / 1e12
+
+    out = {
+        "metric": "NFE/s (vector-field evals/s inside the adaptive Tsit5 NeuralODE forward, MNIST-ODE B=512/GPU)",
+        "value": world * nfe_total / el,
+        "unit": "NFE/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": el / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "MNIST-ODE MLP field TDChain(Dense(785=>100,tanh),Dense(101=>784)), "
+                               f"B={args.batch}/GPU, Tsit5 adaptive abstol=reltol={args.tol:g}, tspan=(0,1), "
+                               "regularize=unbiased/error_estimate, forward pass (solve + local reg step)",
+                   "global_batch": Bg, "parallelism": f"batch-shard x{world}",
+                   "nfe_per_pass": nfe_total / args.steps, "rk_steps_per_sec": world * steps_total / el,
+                   "fwd_ms_per_batch": el / args.steps * 1e3},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "kernel": "k_step<4,false> (one attempted Tsit5 step: 6 f-evals + combine + error norm)",
+                     "us_per_launch": us, "flop_per_launch": flop_per_launch},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        cb = min(args.cpu_batch, args.batch)
+        ref, cel = cpu_baseline(params, xg[:cb], args.tol, float(t1s[args.warmup + args.steps - 1]), cores)
+        out["cpu_baseline"] = {"value": ref["nfe"] / cel * (cb / args.batch), "unit": "NFE/s", "cores": cores,
+                               "kind": "port",
+                               "sample": f"one forward pass ({ref['nfe']} f-evals) at B={cb} with the C oracle "
+                                         f"(OpenMP, {cores} threads) in {cel:.1f} s; value scaled to B={args.batch} columns"}
+        if cb == args.batch:
+            same = (ref["nfe"] == r["nfe"]) and bool(np.array_equal(ref["u_end"], r["u_end"].cpu().numpy()))
+            out["cpu_baseline"]["gpu_matches_oracle_bitwise"] = same
+    if rank == 0:
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

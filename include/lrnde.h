@@ -146,6 +146,10 @@ int lrnde_comm_destroy(lrnde_ctx* ctx);
 
 /* Timing hooks for bench.py: HIP events on the handle's stream around the
  * kernels of the last solve (ms), and the number of step-kernel launches. */
+/* `reps` back-to-back launches of the full Tsit5 step kernel on fixed (uprev, k1, t, dt), timed
+ * with HIP events on the handle's stream; avg_us_host = microseconds per launch (roofline leg). */
+int lrnde_bench_step(lrnde_ctx* ctx, const float* uprev, const float* k1, int32_t B, float t, float dt,
+                     float abstol, float reltol, int32_t reps, float* avg_us_host);
 int lrnde_last_solve_kernel_ms(lrnde_ctx* ctx, float* total_ms_host, int32_t* step_launches_host);
 
 #ifdef __cplusplus

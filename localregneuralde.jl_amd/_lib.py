@@ -56,6 +56,7 @@ SYMBOLS = [
     ("lrnde_comm_unique_id", C.c_int, [_vp]),
     ("lrnde_comm_init", C.c_int, [_vp, _vp, _i32, _i32]),
     ("lrnde_comm_destroy", C.c_int, [_vp]),
+    ("lrnde_bench_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _fp]),
     ("lrnde_last_solve_kernel_ms", C.c_int, [_vp, _fp, C.POINTER(_i32)]),
 ]
 

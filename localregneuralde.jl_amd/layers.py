@@ -199,6 +199,14 @@ class Handle:
         return dict(u_end=u_end, reg_val=np.float32(reg.value), nfe=int(nfe.value), stats=st.asdict(),
                     t1=np.float32(t1u.value))
 
+    def bench_step(self, uprev, k1, t, dt, abstol, reltol, reps=50):
+        """microseconds per launch of the full-step kernel (HIP events on the handle's stream)."""
+        B = uprev.numel() // self.D
+        us = C.c_float()
+        self._chk(L.lib.lrnde_bench_step(self._ctx, _dev_ptr(uprev, "uprev", self.D), _dev_ptr(k1, "k1", self.D), B,
+                                         float(t), float(dt), float(abstol), float(reltol), int(reps), C.byref(us)))
+        return float(us.value)
+
     def last_solve_kernel_ms(self):
         ms, n = C.c_float(), C.c_int32()
         L.lib.lrnde_last_solve_kernel_ms(self._ctx, C.byref(ms), C.byref(n))

@@ -165,6 +165,8 @@ int lro_tsit5_tableau(double* a, double* c, double* btilde, double* r) {
 /* src/layers/common.jl:10-40; experiments/src/construct.jl:180-189           */
 /* ------------------------------------------------------------------------- */
 
+#define LRO_KSEG 112 /* rows per fma-chain segment of the canonical dot product */
+
 int lro_mlp_param_count(int D, int H, int td) { return H * (D + td) + H + D * (H + td) + D; }
 
 void lro_mlp_rhs(const lro_mlp* m, const float* u, float t, int B, float* du) {
@@ -179,20 +181,30 @@ void lro_mlp_rhs(const lro_mlp* m, const float* u, float t, int B, float* du) {
   const int nblk = (B + SB - 1) / SB;
 #pragma omp parallel num_threads(nth)
   {
-    float* h = (float*)malloc(sizeof(float) * (size_t)SB * (size_t)(H > D ? H : D));
+    float* h = (float*)malloc(sizeof(float) * (size_t)SB * (size_t)(2 * H + D));
+    float* hp = h + (size_t)SB * H;
+    float* yp = hp + (size_t)SB * H;
 #pragma omp for schedule(static)
     for (int blk = 0; blk < nblk; ++blk) {
       const int n0 = blk * SB;
       const int ns = (B - n0) < SB ? (B - n0) : SB;
-      /* layer 1: one fma chain per output in increasing k, t column last, then + bias */
+      /* layer 1: canonical dot product = fma chains over consecutive segments of LRO_KSEG rows
+       * (each from 0, increasing k), segment partials added left to right; then the t column
+       * (fma), then + bias */
       for (int i = 0; i < ns * H; ++i) h[i] = 0.0f;
-      for (int k = 0; k < D; ++k) {
-        const float* w = W1 + (size_t)k * H;
-        for (int s = 0; s < ns; ++s) {
-          const float xv = u[(size_t)(n0 + s) * D + k];
-          float* hs = h + (size_t)s * H;
-          for (int o = 0; o < H; ++o) hs[o] = fmaf(w[o], xv, hs[o]);
+      for (int k0 = 0; k0 < D; k0 += LRO_KSEG) {
+        const int k1 = (k0 + LRO_KSEG < D) ? k0 + LRO_KSEG : D;
+        for (int i = 0; i < ns * H; ++i) hp[i] = 0.0f;
+        for (int k = k0; k < k1; ++k) {
+          const float* w = W1 + (size_t)k * H;
+          for (int s = 0; s < ns; ++s) {
+            const float xv = u[(size_t)(n0 + s) * D + k];
+            float* hs = hp + (size_t)s * H;
+            for (int o = 0; o < H; ++o) hs[o] = fmaf(w[o], xv, hs[o]);
+          }
         }
+        if (k0 == 0) for (int i = 0; i < ns * H; ++i) h[i] = hp[i];
+        else for (int i = 0; i < ns * H; ++i) h[i] = h[i] + hp[i];
       }
       for (int s = 0; s < ns; ++s) {
         float* hs = h + (size_t)s * H;
@@ -202,17 +214,23 @@ void lro_mlp_rhs(const lro_mlp* m, const float* u, float t, int B, float* du) {
         }
         for (int o = 0; o < H; ++o) hs[o] = act_apply(m->act, hs[o] + b1[o]);
       }
-      /* layer 2 */
-      for (int s = 0; s < ns; ++s) {
-        float* y = du + (size_t)(n0 + s) * D;
-        for (int o = 0; o < D; ++o) y[o] = 0.0f;
-      }
-      for (int k = 0; k < H; ++k) {
-        const float* w = W2 + (size_t)k * D;
+      /* layer 2 (same canonical order over the hidden index) */
+      for (int k0 = 0; k0 < H; k0 += LRO_KSEG) {
+        const int k1 = (k0 + LRO_KSEG < H) ? k0 + LRO_KSEG : H;
+        for (int i = 0; i < ns * D; ++i) yp[i] = 0.0f;
+        for (int k = k0; k < k1; ++k) {
+          const float* w = W2 + (size_t)k * D;
+          for (int s = 0; s < ns; ++s) {
+            const float hv = h[(size_t)s * H + k];
+            float* y = yp + (size_t)s * D;
+            for (int o = 0; o < D; ++o) y[o] = fmaf(w[o], hv, y[o]);
+          }
+        }
         for (int s = 0; s < ns; ++s) {
-          const float hv = h[(size_t)s * H + k];
           float* y = du + (size_t)(n0 + s) * D;
-          for (int o = 0; o < D; ++o) y[o] = fmaf(w[o], hv, y[o]);
+          const float* ys = yp + (size_t)s * D;
+          if (k0 == 0) for (int o = 0; o < D; ++o) y[o] = ys[o];
+          else for (int o = 0; o < D; ++o) y[o] = y[o] + ys[o];
         }
       }
       for (int s = 0; s < ns; ++s) {

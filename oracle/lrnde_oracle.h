@@ -31,8 +31,10 @@
  *   lro_euler_heun_step   src/perform_step.jl:172-206, 214-216
  *
  * Canonical arithmetic (shared definition with the HIP kernels, so that both
- * produce the same bits): every Dense dot product is ONE fp32 fma chain in
- * increasing k starting from 0, the time column last, then "+ bias"; tanh/gelu
+ * produce the same bits): every Dense dot product is a sum of fp32 fma chains
+ * over consecutive segments of 112 rows (each chain starts from 0 and runs in
+ * increasing k; the segment partials are added left to right — for K <= 112
+ * this is one plain chain), then the time column by fma, then "+ bias"; tanh/gelu
  * are the fixed fp32 polynomial/exp forms below; every norm accumulates the
  * fp32 squares in fp64 and rounds the final sqrt to fp32.  The reference does
  * these with OpenBLAS sgemm / Julia Base tanh / Float32 pairwise sums, whose

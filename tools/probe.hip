@@ -1,0 +1,36 @@
+// Diagnostic probe (not shipped): builds the library source with -DLRNDE_STAMPS and prints where
+// workgroup 0 of k_rhs spends its cycles, plus the shader clock it ran at.
+#include "../localregneuralde.jl_amd/csrc/lrnde_kernels.hip"
+#include <vector>
+#include <cstdio>
+int main(int argc, char** argv) {
+  int B = argc > 1 ? atoi(argv[1]) : 512;
+  lrnde_model_desc d{784, 100, 1, 1};
+  lrnde_ctx* c = nullptr;
+  if (lrnde_create(&c, &d, 0, nullptr)) return 1;
+  size_t np = lrnde_param_count(&d);
+  std::vector<float> hp(np);
+  for (size_t i = 0; i < np; ++i) hp[i] = 0.05f * (float)((i * 2654435761u) % 1000) / 1000.f - 0.025f;
+  float *p, *u, *du;
+  hipMalloc(&p, np * 4); hipMalloc(&u, (size_t)B * 784 * 4); hipMalloc(&du, (size_t)B * 784 * 4);
+  hipMemcpy(p, hp.data(), np * 4, hipMemcpyHostToDevice);
+  std::vector<float> hu((size_t)B * 784, 0.5f);
+  hipMemcpy(u, hu.data(), hu.size() * 4, hipMemcpyHostToDevice);
+  lrnde_set_params(c, p, np);
+  for (int it = 0; it < 200; ++it) lrnde_rhs(c, u, 0.1f, B, du);
+  hipDeviceSynchronize();
+  unsigned long long st[64];
+  hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
+  const char* names[] = {"entry->xtile", "dense1 mfma", "barrier", "epilogue1", "dense2 mfma", "barrier"};
+  double clk = (double)(st[12] - st[0]) / ((double)(st[13] - st[1]) / 100.0);  // MHz
+  printf("B=%d  total %llu cycles, %.2f us, shader clock %.0f MHz\n", B, st[12] - st[0], (st[13] - st[1]) / 100.0, clk);
+  for (int i = 0; i < 6; ++i) printf("  %-14s %8llu cycles\n", names[i], st[2 * (i + 1)] - st[2 * i]);
+  unsigned long long ws[64];
+  hipMemcpyFromSymbol(ws, HIP_SYMBOL(g_wstamps), sizeof(ws));
+  printf("  per-wave cycles: dense1 | epilogue1 | dense2   (start offsets vs wave0)\n");
+  for (int w = 0; w < 8; ++w)
+    printf("   wave %d: start %+6lld  dense1 %6llu  epi1 %6llu  dense2 %6llu\n", w, (long long)(ws[w * 8] - ws[0]),
+           ws[w * 8 + 1] - ws[w * 8], ws[w * 8 + 2] - ws[w * 8 + 1], ws[w * 8 + 4] - ws[w * 8 + 3]);
+  for (int w = 0; w < 8; ++w) printf("   wave %d: per-iteration load-issue block %llu cyc, 28-MFMA block %llu cyc (3 iterations summed: %llu, %llu)\n", w, ws[w*8+5]/3, ws[w*8+6]/3, ws[w*8+5], ws[w*8+6]);
+  return 0;
+}
