@@ -100,6 +100,9 @@ struct Ctrl {  // device-resident integrator state, double-buffered by attempt p
 
 struct StepArgs {
   ModelDev m;
+  float* state;     // one allocation: ubuf[2] kfsal[2] ks[5] g6, each n_local floats
+  long n_local;     // B * D
+  int fused;        // 1: fused Dense-2 epilogue path (D % 16 == 0 and 32-bit offsets suffice)
   float* ubuf[2];
   float* kfsal[2];
   float* ks[5];  // k2..k6
@@ -294,9 +297,161 @@ __device__ __forceinline__ void feval_ctx_init(const ModelDev& m, FevalCtx& fc) 
   for (int j = 0; j < SEGK; ++j) fc.r2[j] = wload(fc.rs2, voff, (mt0 * KG2p + j) * 1024);
 }
 
-template <int W>
+// per-lane access to the state workspace (ubuf / kfsal / ks / g6 live in ONE allocation) through
+// a buffer descriptor: byte address = base + SGPR offset (array, tile) + per-lane VGPR offset.
+// Lanes whose sample column is beyond the batch get an out-of-range offset: their loads return 0
+// and their stores are dropped by the hardware range check.
+#ifdef LRNDE_DBG_PLAIN_IO
+__device__ const char* g_dbg_base;
+#endif
+struct TileIO {
+  __amdgpu_buffer_rsrc_t rs;
+  int voff;
+};
+__device__ __forceinline__ TileIO make_tile_io(const StepArgs& a, int b0, int nvalid) {
+  const int lane = threadIdx.x & 63, n = lane & 15, rq = lane >> 4;
+  TileIO io;
+  io.rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.state, 0, (int)(a.n_local * 40), 0x00020000);
+  io.voff = (n < nvalid) ? ((b0 + n) * a.m.D + rq * 4) * 4 : 0x7ffffff0;
+#ifdef LRNDE_DBG_PLAIN_IO
+  if (threadIdx.x == 0) g_dbg_base = reinterpret_cast<const char*>(a.state);
+  __syncthreads();
+#endif
+  return io;
+}
+#ifdef LRNDE_DBG_PLAIN_IO
+__device__ __forceinline__ f32x4 sload(const TileIO& io, int soff) {
+  if (io.voff == 0x7ffffff0) return f32x4{0, 0, 0, 0};
+  return *reinterpret_cast<const f32x4*>(g_dbg_base + soff + io.voff);
+}
+__device__ __forceinline__ void sstore(const TileIO& io, int soff, const f32x4& v) {
+  if (io.voff == 0x7ffffff0) return;
+  *reinterpret_cast<f32x4*>(const_cast<char*>(g_dbg_base) + soff + io.voff) = v;
+}
+#else
+__device__ __forceinline__ f32x4 sload(const TileIO& io, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(io.rs, io.voff, soff, 0));
+}
+// NOTE (ROCm 7.2 / gfx950): with an SGPR soffset hipcc places VALU writes of the store-data
+// registers directly behind buffer_store_dwordx4 (its hazard recognizer assumes that form is
+// safe); on this chip it is not — lanes 12-15 of dword 1 were stored with the overwritten value.
+// With a literal soffset the compiler inserts the required wait state, so stores fold the uniform
+// offset into the per-lane offset (one v_add) instead.
+__device__ __forceinline__ void sstore(const TileIO& io, int soff, const f32x4& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), io.rs, io.voff + soff, 0, 0);
+}
+#endif
+// byte offset of state array `idx` (0,1: ubuf; 2,3: kfsal; 4..8: ks; 9: g6)
+__device__ __forceinline__ int arr_off(const StepArgs& a, int idx) { return (int)(a.n_local * 4) * idx; }
+
+// ---- Dense-2 epilogue policies -------------------------------------------------------------
+// pre(mt, pb): issue the loads this tile's epilogue needs (one tile ahead of use);
+// post(mt, kv, pb): kv = the four k values of this lane (rows mt*16 + rq*4 .. +3, column n).
+struct EpiStoreK {  // k only (lrnde_rhs, init phases, generic path)
+  static constexpr int NPRE = 1;
+  static constexpr bool DBUF = false;
+  const ModelDev* m; float* kout; int b0, nvalid, w;
+  __device__ __forceinline__ void pre(int, f32x4 (&)[NPRE]) const {}
+  __device__ __forceinline__ void post(int mt, const f32x4& kv, f32x4 (&)[NPRE]) const {
+    const int lane = threadIdx.x & 63, n = lane & 15, rq = lane >> 4;
+    const int row0 = mt * 16 + rq * 4;
+    if (n < nvalid) {
+      float* dst = kout + (size_t)(b0 + n) * m->D + row0;
+      if (w == 4) {
+        if (row0 < m->D) *reinterpret_cast<f32x4*>(dst) = kv;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (row0 + r < m->D) dst[r] = kv[r];
+      }
+    }
+  }
+};
+
+// after k_S (S = 2..6): store k_S and build the NEXT stage input
+//   x_{S+1} = uprev + dt*(a_{S+1,1} k1 + ... + a_{S+1,S} k_S)        (src/perform_step.jl:13-18)
+// left to right, k_S (still in registers) last; x goes to the LDS x tile (and to u / g6).
+template <int S> struct EpiStage {
+  static constexpr int NPRE = S;  // uprev + k1..k_{S-1}
+  static constexpr bool DBUF = true;  // operands prefetched one tile ahead
+  TileIO io;
+  int off_up, off_k[6], off_out, off_x;  // off_x: u (S==6) or g6 (S==5, stiffness) or -1
+  float dt;
+  float* xl;
+  __device__ __forceinline__ void pre(int mt, f32x4 (&pb)[NPRE]) const {
+    pb[0] = sload(io, off_up + mt * 64);
+#pragma unroll
+    for (int j = 0; j < S - 1; ++j) pb[1 + j] = sload(io, off_k[j] + mt * 64);
+  }
+  __device__ __forceinline__ void post(int mt, const f32x4& kv, f32x4 (&pb)[NPRE]) const {
+    const int lane = threadIdx.x & 63, n = lane & 15, rq = lane >> 4;
+    constexpr int off = (S - 1) * S / 2;  // row S+1 of the tableau
+    sstore(io, off_out + mt * 64, kv);
+    f32x4 x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float o[S];
+#pragma unroll
+      for (int j = 0; j < S - 1; ++j) o[j] = pb[1 + j][r];
+      o[S - 1] = kv[r];
+      float sum = (float)Tsit5::A[off] * o[0] + (float)Tsit5::A[off + 1] * o[1];
+#pragma unroll
+      for (int j = 2; j < S; ++j) sum = sum + (float)Tsit5::A[off + j] * o[j];
+      x[r] = pb[0][r] + dt * sum;
+    }
+    if (off_x >= 0) sstore(io, off_x + mt * 64, x);
+    float* dst = xl + ((mt * 64 + n) << 2) + rq;   // lds_index(mt*16 + rq*4 + r, n) = dst + r*64
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r * 64] = x[r];
+  }
+};
+
+// after k7: store k7; utilde, scaled residual and the stiffness differences, accumulated in
+// fp64 per lane (src/perform_step.jl:21-47, 210-212)
+struct EpiFinal {
+  static constexpr int NPRE = 9;  // uprev, u, k1..k6, g6
+  static constexpr bool DBUF = false;  // 9 quads: issued right before the tile's MFMA chain
+  TileIO io;
+  int off_up, off_u, off_k[6], off_g6, off_out;
+  float dt, abstol, reltol;
+  int want_stiff, nvalid;
+  double *aerr, *anum, *aden;
+  __device__ __forceinline__ void pre(int mt, f32x4 (&pb)[NPRE]) const {
+    pb[0] = sload(io, off_up + mt * 64);
+    pb[1] = sload(io, off_u + mt * 64);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) pb[2 + j] = sload(io, off_k[j] + mt * 64);
+    if (want_stiff) pb[8] = sload(io, off_g6 + mt * 64);
+  }
+  __device__ __forceinline__ void post(int mt, const f32x4& kv, f32x4 (&pb)[NPRE]) const {
+    const int lane = threadIdx.x & 63, n = lane & 15;
+    sstore(io, off_out + mt * 64, kv);
+    if (n >= nvalid) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sum = (float)Tsit5::BT[0] * pb[2][r] + (float)Tsit5::BT[1] * pb[3][r];
+      sum = sum + (float)Tsit5::BT[2] * pb[4][r];
+      sum = sum + (float)Tsit5::BT[3] * pb[5][r];
+      sum = sum + (float)Tsit5::BT[4] * pb[6][r];
+      sum = sum + (float)Tsit5::BT[5] * pb[7][r];
+      sum = sum + (float)Tsit5::BT[6] * kv[r];
+      const float utilde = dt * sum;
+      const float sc = abstol + fmaxf_(__builtin_fabsf(pb[0][r]), __builtin_fabsf(pb[1][r])) * reltol;
+      const float rr = utilde / sc;
+      const float sq = rr * rr;
+      *aerr += (double)sq;
+      if (want_stiff) {
+        const float d1 = pb[1][r] - pb[8][r];
+        const float d2 = kv[r] - pb[7][r];
+        const float q1 = d1 * d1, q2 = d2 * d2;
+        *aden += (double)q1; *anum += (double)q2;
+      }
+    }
+  }
+};
+
+template <int W, class Epi>
 __device__ __forceinline__ void feval_tile(const ModelDev& m, const Smem& sm, const FevalCtx& fc,
-                                           float ts, float* __restrict__ kout, int b0, int nvalid) {
+                                           float ts, const Epi& epi) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
   const int n = lane & 15, rq = lane >> 4;
@@ -381,24 +536,25 @@ __device__ __forceinline__ void feval_tile(const ModelDev& m, const Smem& sm, co
   // (B operand layout of Dense 2).  element e = (mt*64 + l)*4 + r of the C fragment:
   // row o = mt*16 + (l>>4)*4 + r, column n = l&15.
   {
-    const int pstride = m.MT1 * 256;
-    for (int e = threadIdx.x; e < pstride; e += NT) {
-      const int r = e & 3, l = (e >> 2) & 63, mt = e >> 8;
-      float v = 0.f;
-      for (int s0 = 0; s0 < nseg1; s0 += 8) {
-        float pv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pv[j] = (s0 + j < nseg1) ? sm.pl[(size_t)(s0 + j) * pstride + e] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (s0 + j == 0) v = pv[j];
-          else if (s0 + j < nseg1) v = v + pv[j];
-        }
+    const int nquad = m.MT1 * 64;  // one C-fragment quad (4 rows x 1 column) per thread
+    const f32x4* pl4 = reinterpret_cast<const f32x4*>(sm.pl);
+    for (int q = threadIdx.x; q < nquad; q += NT) {
+      const int l = q & 63, mt = q >> 6;
+      f32x4 v = pl4[q];
+      for (int sgi = 1; sgi < nseg1; ++sgi) {
+        const f32x4 pv = pl4[(size_t)sgi * nquad + q];
+        v.x = v.x + pv.x; v.y = v.y + pv.y; v.z = v.z + pv.z; v.w = v.w + pv.w;
       }
-      const int o = mt * 16 + (l >> 4) * 4 + r;
-      float pre = m.td ? fma_(w1t[o], ts, v) : v;
-      pre = pre + b1[o];
-      sm.hl[((mt * 64 + r * 16 + (l & 15)) << 2) + (l >> 4)] = act_apply(m.act, pre);
+      const int o0 = mt * 16 + (l >> 4) * 4;
+      const f32x4 wt = *reinterpret_cast<const f32x4*>(w1t + o0);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + o0);
+      float* dst = sm.hl + ((mt * 64 + (l & 15)) << 2) + (l >> 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pre = m.td ? fma_(wt[r], ts, v[r]) : v[r];
+        pre = pre + bb[r];
+        dst[r * 64] = act_apply(m.act, pre);
+      }
     }
   }
   STAMPW(2);
@@ -410,68 +566,62 @@ __device__ __forceinline__ void feval_tile(const ModelDev& m, const Smem& sm, co
     const f32x4* hp = reinterpret_cast<const f32x4*>(sm.hl) + lane;
     const int nseg2 = (m.KG2 + SEGK - 1) / SEGK;
     const int KG2p = nseg2 * SEGK;
-    auto epilogue = [&](int mt, const f32x4& tot) {
+    auto finish = [&](int mt, const f32x4& tot) {  // time column + bias -> k values of this lane
       const int row0 = mt * 16 + rq * 4;
       const f32x4 wt = *reinterpret_cast<const f32x4*>(w2t + row0);
       const f32x4 bb = *reinterpret_cast<const f32x4*>(b2 + row0);
-      float kv[4];
+      f32x4 kv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pre = m.td ? fma_(wt[r], ts, tot[r]) : tot[r];
         kv[r] = pre + bb[r];
       }
-      if (n < nvalid) {
-        float* dst = kout + (size_t)(b0 + n) * m.D + row0;
-        if constexpr (W == 4) {
-          if (row0 < m.D) { f32x4 t; t.x = kv[0]; t.y = kv[1]; t.z = kv[2]; t.w = kv[3];
-                            *reinterpret_cast<f32x4*>(dst) = t; }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (row0 + r < m.D) dst[r] = kv[r];
-        }
-      }
+      return kv;
     };
     if (nseg2 == 1) {
       // one canonical segment (H <= 112): B fragments live in registers for all tiles of this
       // wave; the first tile's A fragments are resident, the next tile's are in flight while the
       // current tile's chain runs.
-      f32x4 b[SEGK], aX[SEGK], aY[SEGK];
+      f32x4 b[SEGK], aX[SEGK], aY[SEGK], pX[Epi::NPRE], pY[Epi::NPRE];
 #pragma unroll
       for (int j = 0; j < SEGK; ++j) b[j] = hp[j * 64];
       const int ntile = (m.MT2 > wave) ? (m.MT2 - wave + NW - 1) / NW : 0;
-#define LRNDE_LOAD2(a, i)                                                                          \
+#define LRNDE_LOAD2(a, pb, i)                                                                      \
   do {                                                                                             \
     _Pragma("unroll") for (int j = 0; j < SEGK; ++j) a[j] = wload(fc.rs2, voff, ((wave + LRNDE_ABL_I(i) * NW) * KG2p + j) * 1024); \
+    if constexpr (Epi::DBUF) epi.pre(wave + (i) * NW, pb);                                         \
     __builtin_amdgcn_sched_barrier(0);                                                             \
   } while (0)
-#define LRNDE_MMA2(a, i)                                          \
+#define LRNDE_MMA2(a, pb, i)                                      \
   do {                                                            \
     f32x4 acc = zero4;                                            \
+    if constexpr (!Epi::DBUF) { epi.pre(wave + (i) * NW, pb); __builtin_amdgcn_sched_barrier(0); } \
     _Pragma("unroll") for (int j = 0; j < SEGK; ++j) acc = mfma4(a[j], b[j], acc); \
-    epilogue(wave + (i) * NW, acc);                               \
+    epi.post(wave + (i) * NW, finish(wave + (i) * NW, acc), pb);  \
     __builtin_amdgcn_sched_barrier(0);                            \
   } while (0)
       if (ntile > 0) {
         int i = 1;
+        if constexpr (Epi::DBUF) epi.pre(wave, pX);
         if (ntile > 1) {
-          LRNDE_LOAD2(aX, 1);
-          LRNDE_MMA2(fc.r2, 0);
+          LRNDE_LOAD2(aY, pY, 1);
+          LRNDE_MMA2(fc.r2, pX, 0);
 #pragma unroll 1
           for (; i + 2 < ntile; i += 2) {
-            LRNDE_LOAD2(aY, i + 1);
-            LRNDE_MMA2(aX, i);
-            LRNDE_LOAD2(aX, i + 2);
-            LRNDE_MMA2(aY, i + 1);
+            LRNDE_LOAD2(aX, pX, i + 1);
+            LRNDE_MMA2(aY, pY, i);
+            LRNDE_LOAD2(aY, pY, i + 2);
+            LRNDE_MMA2(aX, pX, i + 1);
           }
           if (i + 1 < ntile) {
-            LRNDE_LOAD2(aY, i + 1);
-            LRNDE_MMA2(aX, i);
-            LRNDE_MMA2(aY, i + 1);
+            LRNDE_LOAD2(aX, pX, i + 1);
+            LRNDE_MMA2(aY, pY, i);
+            LRNDE_MMA2(aX, pX, i + 1);
           } else {
-            LRNDE_MMA2(aX, i);
+            LRNDE_MMA2(aY, pY, i);
           }
         } else {
-          LRNDE_MMA2(fc.r2, 0);
+          LRNDE_MMA2(fc.r2, pX, 0);
         }
       }
 #undef LRNDE_LOAD2
@@ -488,7 +638,9 @@ __device__ __forceinline__ void feval_tile(const ModelDev& m, const Smem& sm, co
           if (sg == 0) tot = acc;
           else { tot.x = tot.x + acc.x; tot.y = tot.y + acc.y; tot.z = tot.z + acc.z; tot.w = tot.w + acc.w; }
         }
-        epilogue(mt, tot);
+        f32x4 pb[Epi::NPRE];
+        epi.pre(mt, pb);
+        epi.post(mt, finish(mt, tot), pb);
       }
     }
   }
@@ -496,6 +648,15 @@ __device__ __forceinline__ void feval_tile(const ModelDev& m, const Smem& sm, co
   STAMPW(4);
   __syncthreads();  // k stores are visible to the whole workgroup; xl/hl/pl may be overwritten
   STAMP(6);
+}
+
+// vector field with the plain "store k" epilogue
+template <int W>
+__device__ __forceinline__ void feval_store(const ModelDev& m, const Smem& sm, const FevalCtx& fc, float ts,
+                                            float* kout, int b0, int nvalid) {
+  EpiStoreK e;
+  e.m = &m; e.kout = kout; e.b0 = b0; e.nvalid = nvalid; e.w = W;
+  feval_tile<W, EpiStoreK>(m, sm, fc, ts, e);
 }
 
 // ---------------------------------------------------------------------------
@@ -736,7 +897,7 @@ template <int W> __global__ __launch_bounds__(NT) void k_rhs(StepArgs a, const f
     lds_put<W>(s.xl, row, n, x);
   });
   __syncthreads();
-  feval_tile<W>(a.m, s, fc, t, du, b0, nvalid);
+  feval_store<W>(a.m, s, fc, t, du, b0, nvalid);
 }
 
 // init phase 1: f0 = f(u0, t0) -> k1; partial sums of (u0/sk)^2 and (f0/sk)^2
@@ -754,7 +915,7 @@ template <int W> __global__ __launch_bounds__(NT) void k_init1(StepArgs a) {
     lds_put<W>(s.xl, row, n, x);
   });
   __syncthreads();
-  feval_tile<W>(a.m, s, fc, c.t, f0, b0, nvalid);
+  feval_store<W>(a.m, s, fc, c.t, f0, b0, nvalid);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
     if (!valid) return;
@@ -804,7 +965,7 @@ template <int W> __global__ __launch_bounds__(NT) void k_init2(StepArgs a) {
     lds_put<W>(s.xl, row, n, x);
   });
   __syncthreads();
-  feval_tile<W>(a.m, s, fc, c.t + dt0, f1, b0, nvalid);
+  feval_store<W>(a.m, s, fc, c.t + dt0, f1, b0, nvalid);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
     if (!valid) return;
@@ -896,21 +1057,56 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
   const float c1 = (float)Tsit5::C[0], c2 = (float)Tsit5::C[1], c3 = (float)Tsit5::C[2],
               c4 = (float)Tsit5::C[3];
 
+  double aerr = 0.0, anum = 0.0, aden = 0.0;
+  if (a.fused) {
+    // Fused path: each Dense-2 epilogue stores k_S and builds the next stage input (or, after k7,
+    // the error residuals) from operands prefetched through the state buffer descriptor; only
+    // the first stage input needs a stand-alone pass.
+    const TileIO io = make_tile_io(a, b0, nvalid);
+    const int tb = 0;  // tile offsets are added by the policies (mt * 64 bytes)
+    const int o_up = arr_off(a, bc.cur) + tb, o_un = arr_off(a, bc.cur ^ 1) + tb;
+    const int o_k1 = arr_off(a, 2 + bc.cur) + tb, o_k7 = arr_off(a, 2 + (bc.cur ^ 1)) + tb;
+    const int o_g6 = arr_off(a, 9) + tb;
+    stage_combine<2, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
+#define LRNDE_STAGE(S, TS)                                                              \
+  do {                                                                                  \
+    EpiStage<S> e;                                                                      \
+    e.io = io; e.off_up = o_up; e.off_k[0] = o_k1;                                      \
+    _Pragma("unroll") for (int q = 0; q < 5; ++q) e.off_k[1 + q] = arr_off(a, 4 + q) + tb; \
+    e.off_out = arr_off(a, 4 + (S - 2)) + tb;                                           \
+    e.off_x = (S == 6) ? o_un : ((S == 5 && a.want_stiff) ? o_g6 : -1);                 \
+    e.dt = dt; e.xl = s.xl;                                                             \
+    feval_tile<W, EpiStage<S>>(a.m, s, fc, (TS), e);                                    \
+  } while (0)
+    LRNDE_STAGE(2, t + c1 * dt);
+    LRNDE_STAGE(3, t + c2 * dt);
+    LRNDE_STAGE(4, t + c3 * dt);
+    LRNDE_STAGE(5, t + c4 * dt);
+    LRNDE_STAGE(6, t + dt);
+#undef LRNDE_STAGE
+    EpiFinal ef;
+    ef.io = io; ef.off_up = o_up; ef.off_u = o_un; ef.off_k[0] = o_k1;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) ef.off_k[1 + q] = arr_off(a, 4 + q) + tb;
+    ef.off_g6 = o_g6; ef.off_out = o_k7;
+    ef.dt = dt; ef.abstol = a.abstol; ef.reltol = a.reltol; ef.want_stiff = a.want_stiff; ef.nvalid = nvalid;
+    ef.aerr = &aerr; ef.anum = &anum; ef.aden = &aden;
+    feval_tile<W, EpiFinal>(a.m, s, fc, t + dt, ef);
+  } else {
   stage_combine<2, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
-  feval_tile<W>(a.m, s, fc, t + c1 * dt, a.ks[0], b0, nvalid);
+  feval_store<W>(a.m, s, fc, t + c1 * dt, a.ks[0], b0, nvalid);
   stage_combine<3, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
-  feval_tile<W>(a.m, s, fc, t + c2 * dt, a.ks[1], b0, nvalid);
+  feval_store<W>(a.m, s, fc, t + c2 * dt, a.ks[1], b0, nvalid);
   stage_combine<4, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
-  feval_tile<W>(a.m, s, fc, t + c3 * dt, a.ks[2], b0, nvalid);
+  feval_store<W>(a.m, s, fc, t + c3 * dt, a.ks[2], b0, nvalid);
   stage_combine<5, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
-  feval_tile<W>(a.m, s, fc, t + c4 * dt, a.ks[3], b0, nvalid);
+  feval_store<W>(a.m, s, fc, t + c4 * dt, a.ks[3], b0, nvalid);
   stage_combine<6, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
-  feval_tile<W>(a.m, s, fc, t + dt, a.ks[4], b0, nvalid);
+  feval_store<W>(a.m, s, fc, t + dt, a.ks[4], b0, nvalid);
   stage_combine<7, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
-  feval_tile<W>(a.m, s, fc, t + dt, k7, b0, nvalid);
+  feval_store<W>(a.m, s, fc, t + dt, k7, b0, nvalid);
 
   // utilde, scaled residual, regularisation residuals (src/perform_step.jl:21-47, 210-212)
-  double aerr = 0.0, anum = 0.0, aden = 0.0;
   tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
     if (!valid) return;
     const Vec<W> up = vload<W>(uprev + g), un = vload<W>(unew + g), v1 = vload<W>(k1 + g),
@@ -939,6 +1135,7 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
       }
     }
   });
+  }
   block_sum3(s.red, aerr, anum, aden);
   if (threadIdx.x == 0) {
     double* p = a.part_send + ((size_t)((j + 1) & 1) * a.nwg_global + a.wg_offset + blockIdx.x) * PSTRIDE;
@@ -1119,6 +1316,8 @@ void fill_args(lrnde_ctx* c, StepArgs& a, int B) {
   const size_t n = (size_t)B * c->desc.state_dim;
   const int nwg = (B + NB - 1) / NB;
   a.m = c->m;
+  a.state = c->state; a.n_local = (long)n;
+  a.fused = (c->desc.state_dim % 16 == 0) && ((double)n * 40.0 < 2147483000.0) && !getenv("LRNDE_NO_FUSE");
   a.ubuf[0] = c->state; a.ubuf[1] = c->state + n;
   a.kfsal[0] = c->state + 2 * n; a.kfsal[1] = c->state + 3 * n;
   for (int i = 0; i < 5; ++i) a.ks[i] = c->state + (4 + i) * n;
