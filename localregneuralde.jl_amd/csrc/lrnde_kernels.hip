@@ -241,6 +241,11 @@ __device__ __forceinline__ float rms_from(double sumsq, double n) { return (floa
 #define LRNDE_ABL_KG(kg) (kg)
 #define LRNDE_ABL_I(i) (i)
 #endif
+#ifdef LRNDE_STAMPS
+#define LRNDE_D2ACC() do { d2c += u1 - u0; d2p += u2 - u1; } while (0)
+#else
+#define LRNDE_D2ACC() do {} while (0)
+#endif
 constexpr int SEGK = 7;  // k-groups (of 16 rows) per canonical segment
 constexpr int TG = 7;    // M tiles run concurrently by one wave in Dense 1
 
@@ -592,12 +597,23 @@ __device__ __forceinline__ void feval_tile(const ModelDev& m, const Smem& sm, co
     if constexpr (Epi::DBUF) epi.pre(wave + (i) * NW, pb);                                         \
     __builtin_amdgcn_sched_barrier(0);                                                             \
   } while (0)
+#ifdef LRNDE_STAMPS
+#define TQ2(x) do { __builtin_amdgcn_sched_barrier(0); x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+      unsigned long long d2c = 0, d2p = 0, u0, u1, u2;
+#else
+#define TQ2(x) do {} while (0)
+#endif
 #define LRNDE_MMA2(a, pb, i)                                      \
   do {                                                            \
     f32x4 acc = zero4;                                            \
     if constexpr (!Epi::DBUF) { epi.pre(wave + (i) * NW, pb); __builtin_amdgcn_sched_barrier(0); } \
+    TQ2(u0);                                                      \
     _Pragma("unroll") for (int j = 0; j < SEGK; ++j) acc = mfma4(a[j], b[j], acc); \
-    epi.post(wave + (i) * NW, finish(wave + (i) * NW, acc), pb);  \
+    { const f32x4 kv_ = finish(wave + (i) * NW, acc);             \
+    TQ2(u1);                                                      \
+    epi.post(wave + (i) * NW, kv_, pb); }                         \
+    TQ2(u2);                                                      \
+    LRNDE_D2ACC();                                                \
     __builtin_amdgcn_sched_barrier(0);                            \
   } while (0)
       if (ntile > 0) {
@@ -626,6 +642,9 @@ __device__ __forceinline__ void feval_tile(const ModelDev& m, const Smem& sm, co
       }
 #undef LRNDE_LOAD2
 #undef LRNDE_MMA2
+#ifdef LRNDE_STAMPS
+      if (blockIdx.x == 0 && lane == 0) { g_wstamps[wave * 8 + 5] = d2c; g_wstamps[wave * 8 + 6] = d2p; g_wstamps[wave * 8 + 7] = ntile; }
+#endif
     } else {
       // general hidden width: segment chains summed left to right in registers
       for (int mt = wave; mt < m.MT2; mt += NW) {
@@ -996,8 +1015,10 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
   FevalCtx fc;
   feval_ctx_init(a.m, fc);
   const int b0 = blockIdx.x * NB, nvalid = min(NB, a.B - b0);
+  STAMP(10);
   if (threadIdx.x < 64) step_prologue(a, j, s.bc);
   __syncthreads();
+  STAMP(11);
   const Bcast bc = *s.bc;
 
   // savevalues! of the step accepted by the prologue (Tsit5 dense output / copy)
@@ -1068,6 +1089,7 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
     const int o_k1 = arr_off(a, 2 + bc.cur) + tb, o_k7 = arr_off(a, 2 + (bc.cur ^ 1)) + tb;
     const int o_g6 = arr_off(a, 9) + tb;
     stage_combine<2, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
+    STAMP(12);
 #define LRNDE_STAGE(S, TS)                                                              \
   do {                                                                                  \
     EpiStage<S> e;                                                                      \
@@ -1077,6 +1099,7 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
     e.off_x = (S == 6) ? o_un : ((S == 5 && a.want_stiff) ? o_g6 : -1);                 \
     e.dt = dt; e.xl = s.xl;                                                             \
     feval_tile<W, EpiStage<S>>(a.m, s, fc, (TS), e);                                    \
+    STAMP(11 + S);                                                                      \
   } while (0)
     LRNDE_STAGE(2, t + c1 * dt);
     LRNDE_STAGE(3, t + c2 * dt);
@@ -1092,6 +1115,7 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
     ef.dt = dt; ef.abstol = a.abstol; ef.reltol = a.reltol; ef.want_stiff = a.want_stiff; ef.nvalid = nvalid;
     ef.aerr = &aerr; ef.anum = &anum; ef.aden = &aden;
     feval_tile<W, EpiFinal>(a.m, s, fc, t + dt, ef);
+    STAMP(18);
   } else {
   stage_combine<2, W>(a, s.xl, uprev, k1, unew, dt, b0, nvalid);
   feval_store<W>(a.m, s, fc, t + c1 * dt, a.ks[0], b0, nvalid);
@@ -1137,6 +1161,7 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
   });
   }
   block_sum3(s.red, aerr, anum, aden);
+  STAMP(19);
   if (threadIdx.x == 0) {
     double* p = a.part_send + ((size_t)((j + 1) & 1) * a.nwg_global + a.wg_offset + blockIdx.x) * PSTRIDE;
     p[0] = aerr; p[1] = anum; p[2] = aden;
@@ -1678,7 +1703,9 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
       else if (k.dt > 0.f) {
         double est = ceil((double)(t1 - k.t) / (double)k.dt);
         if (est > 1e6) est = 1e6;
-        const int tg = pending_j - 1 + (int)est;
+        // dt usually grows along the solve, so (t1-t)/dt over-estimates: count half of it as
+        // "certainly needed"; launches beyond that carry the speculative kernel name
+        const int tg = pending_j - 1 + (int)(est / 2);
         if (tg > target) target = tg;
       }
     }

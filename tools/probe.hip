@@ -25,12 +25,24 @@ int main(int argc, char** argv) {
   double clk = (double)(st[12] - st[0]) / ((double)(st[13] - st[1]) / 100.0);  // MHz
   printf("B=%d  total %llu cycles, %.2f us, shader clock %.0f MHz\n", B, st[12] - st[0], (st[13] - st[1]) / 100.0, clk);
   for (int i = 0; i < 6; ++i) printf("  %-14s %8llu cycles\n", names[i], st[2 * (i + 1)] - st[2 * i]);
+  {  // one full step through the bench hook
+    float* k1; hipMalloc(&k1, (size_t)B * 784 * 4);
+    lrnde_rhs(c, u, 0.f, B, k1);
+    float us = 0;
+    lrnde_bench_step(c, u, k1, B, 0.f, 0.02f, 1.4e-8f, 1.4e-8f, 50, &us);
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
+    const char* sn[] = {"prologue", "x2 combine", "stage k2", "stage k3", "stage k4", "stage k5", "stage k6", "stage k7+err", "block reduce"};
+    printf("step kernel: %.1f us/launch; wave-0 phase cycles:\n", us);
+    for (int i = 0; i < 9; ++i) printf("  %-14s %8llu cycles\n", sn[i], st[2 * (11 + i)] - st[2 * (10 + i)]);
+    printf("  total          %8llu cycles = %.1f us\n", st[2 * 19] - st[2 * 10], (st[2 * 19 + 1] - st[2 * 10 + 1]) / 100.0);
+  }
   unsigned long long ws[64];
   hipMemcpyFromSymbol(ws, HIP_SYMBOL(g_wstamps), sizeof(ws));
   printf("  per-wave cycles: dense1 | epilogue1 | dense2   (start offsets vs wave0)\n");
   for (int w = 0; w < 8; ++w)
     printf("   wave %d: start %+6lld  dense1 %6llu  epi1 %6llu  dense2 %6llu\n", w, (long long)(ws[w * 8] - ws[0]),
            ws[w * 8 + 1] - ws[w * 8], ws[w * 8 + 2] - ws[w * 8 + 1], ws[w * 8 + 4] - ws[w * 8 + 3]);
-  for (int w = 0; w < 8; ++w) printf("   wave %d: per-iteration load-issue block %llu cyc, 28-MFMA block %llu cyc (3 iterations summed: %llu, %llu)\n", w, ws[w*8+5]/3, ws[w*8+6]/3, ws[w*8+5], ws[w*8+6]);
+  for (int w = 0; w < 8; ++w) printf("   wave %d: dense2 (last f-eval): chain+finish %llu cyc/tile, epilogue post %llu cyc/tile (%llu tiles)\n", w, ws[w*8+5]/(ws[w*8+7]?ws[w*8+7]:1), ws[w*8+6]/(ws[w*8+7]?ws[w*8+7]:1), ws[w*8+7]);
   return 0;
 }
