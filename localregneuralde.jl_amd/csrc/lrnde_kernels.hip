@@ -63,6 +63,10 @@ struct ModelDev {
   const float* b1;   // [Hp]
   const float* w2t;  // [Dp]
   const float* b2;   // [Dp]
+  // 4-column tile family (lrnde_qtile.hpp)
+  const float* W1q;  // [RG1][KQ1p][64][4]
+  const float* W2q;  // [RG2][KQ2p][64][4]
+  int KQ1p, KQ2p, RG1, RG2;
 };
 
 #ifdef LRNDE_STAMPS
@@ -1168,6 +1172,8 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
   }
 }
 
+#include "lrnde_qtile.hpp"
+
 // single-step modes: EEst and the two regularisation values from the partial sums
 __global__ void k_finalize(StepArgs a, int j) {
   if (threadIdx.x >= 64) return;
@@ -1249,6 +1255,8 @@ struct lrnde_ctx {
   bool have_params = false;
   // packed weights
   float *W1p = nullptr, *W2p = nullptr, *w1t = nullptr, *b1 = nullptr, *w2t = nullptr, *b2 = nullptr;
+  float *W1q = nullptr, *W2q = nullptr;
+  int wsNB = 0;  // tile width the workspace (partial-sum vectors) was sized for
   // workspace
   int wsB = 0;
   float* state = nullptr;  // 10 * B * D floats: ubuf[2], kfsal[2], ks[5], g6
@@ -1306,9 +1314,18 @@ int fail(lrnde_ctx* c, int code, const char* fmt, ...) {
 inline int ceil16(int x) { return (x + 15) & ~15; }
 inline int vecw(const lrnde_ctx* c) { return (c->desc.state_dim % 4 == 0) ? 4 : 1; }
 
+// Which tile shape runs this batch: the 4-column family (lrnde_qtile.hpp) when there would be too
+// few 16-column workgroups to fill the chip, the 16-column family otherwise.
+bool use_qtile(const lrnde_ctx* c, int B) {
+  static const int qmax = getenv("LRNDE_QTILE_MAX_B") ? atoi(getenv("LRNDE_QTILE_MAX_B")) : 1024;
+  const int D = c->desc.state_dim, H = c->desc.hidden_dim;
+  return (D % 4 == 0) && (H <= 112) && ((double)B * D * 40.0 < 2147483000.0) && B <= qmax;
+}
+inline int tile_nb(const lrnde_ctx* c, int B) { return use_qtile(c, B) ? QNB : NB; }
+
 int ensure_workspace(lrnde_ctx* c, int B) {
   const size_t n = (size_t)B * c->desc.state_dim;
-  const int nwg = (B + NB - 1) / NB;
+  const int nwg = (B + QNB - 1) / QNB;  // sized for the finer tile: covers both shapes
   const int nwg_global = nwg * c->nranks;
   if (B != c->wsB) {
     if (c->state) HIPCHK(c, hipFree(c->state));
@@ -1339,7 +1356,8 @@ int ensure_workspace(lrnde_ctx* c, int B) {
 void fill_args(lrnde_ctx* c, StepArgs& a, int B) {
   memset(&a, 0, sizeof(a));
   const size_t n = (size_t)B * c->desc.state_dim;
-  const int nwg = (B + NB - 1) / NB;
+  const int nb = tile_nb(c, B);
+  const int nwg = (B + nb - 1) / nb;
   a.m = c->m;
   a.state = c->state; a.n_local = (long)n;
   a.fused = (c->desc.state_dim % 16 == 0) && ((double)n * 40.0 < 2147483000.0) && !getenv("LRNDE_NO_FUSE");
@@ -1358,6 +1376,8 @@ void fill_args(lrnde_ctx* c, StepArgs& a, int B) {
   a.pinit_recv = c->nranks > 1 ? c->pinit_rx : c->pinit;
 }
 
+size_t smem_q(const lrnde_ctx* c) { return smem_bytes_q(c->m.KQ1p, c->m.KQ2p, c->m.RG1, c->m.RG2); }
+
 template <class K> int launch_tile_kernel(lrnde_ctx* c, K kern, int B, const StepArgs& a) {
   const int nwg = (B + NB - 1) / NB;
   const size_t sm = smem_bytes(c->m.Dp, c->m.Hp);
@@ -1367,6 +1387,13 @@ template <class K> int launch_tile_kernel(lrnde_ctx* c, K kern, int B, const Ste
 }
 
 int launch_step(lrnde_ctx* c, int B, const StepArgs& a, int j, bool spec = false) {
+  if (use_qtile(c, B)) {
+    const int nq = (B + QNB - 1) / QNB;
+    if (spec) hipLaunchKernelGGL(k_step_q<true>, dim3(nq), dim3(QNT), smem_q(c), c->stream, a, j);
+    else hipLaunchKernelGGL(k_step_q<false>, dim3(nq), dim3(QNT), smem_q(c), c->stream, a, j);
+    HIPCHK(c, hipGetLastError());
+    return LRNDE_OK;
+  }
   const int nwg = (B + NB - 1) / NB;
   const size_t sm = smem_bytes(c->m.Dp, c->m.Hp);
   if (vecw(c) == 4) {
@@ -1391,11 +1418,15 @@ int exchange(lrnde_ctx* c, double* send, double* recv, size_t count) {
 int run_init(lrnde_ctx* c, int B, const StepArgs& a) {
   int rc;
   const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
-  if (vecw(c) == 4) rc = launch_tile_kernel(c, k_init1<4>, B, a);
+  const bool qt = use_qtile(c, B);
+  const int nq = (B + QNB - 1) / QNB;
+  if (qt) { hipLaunchKernelGGL(k_init1_q, dim3(nq), dim3(QNT), smem_q(c), c->stream, a); rc = LRNDE_OK; HIPCHK(c, hipGetLastError()); }
+  else if (vecw(c) == 4) rc = launch_tile_kernel(c, k_init1<4>, B, a);
   else rc = launch_tile_kernel(c, k_init1<1>, B, a);
   if (rc) return rc;
   if ((rc = exchange(c, c->pinit, c->pinit_rx, cnt))) return rc;
-  if (vecw(c) == 4) rc = launch_tile_kernel(c, k_init2<4>, B, a);
+  if (qt) { hipLaunchKernelGGL(k_init2_q, dim3(nq), dim3(QNT), smem_q(c), c->stream, a); rc = LRNDE_OK; HIPCHK(c, hipGetLastError()); }
+  else if (vecw(c) == 4) rc = launch_tile_kernel(c, k_init2<4>, B, a);
   else rc = launch_tile_kernel(c, k_init2<1>, B, a);
   if (rc) return rc;
   return exchange(c, c->pinit + cnt, c->pinit_rx + cnt, cnt);
@@ -1415,6 +1446,11 @@ int set_smem_attr() {
   hipFuncSetAttribute((const void*)k_init2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_rhs<4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_rhs<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_step_q<false>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_step_q<true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_init1_q, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_init2_q, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_rhs_q, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   done = true;
   return 0;
 }
@@ -1478,7 +1514,14 @@ int lrnde_create(lrnde_ctx** out, const lrnde_model_desc* d, int device, void* s
             hipMalloc(&c->b2, sizeof(float) * Dp) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipEventCreate(&c->evp[0]) == hipSuccess && hipEventCreate(&c->evp[1]) == hipSuccess;
+  m.KQ1p = (((d->state_dim + 3) / 4 + QB1 - 1) / QB1) * QB1;
+  m.KQ2p = (((d->hidden_dim + 3) / 4 + QB2 - 1) / QB2) * QB2;
+  m.RG1 = (d->hidden_dim + 63) / 64;
+  m.RG2 = (d->state_dim + 63) / 64;
+  ok = ok && hipMalloc(&c->W1q, sizeof(float) * (size_t)m.RG1 * m.KQ1p * 256) == hipSuccess &&
+       hipMalloc(&c->W2q, sizeof(float) * (size_t)m.RG2 * m.KQ2p * 256) == hipSuccess;
   if (!ok) { lrnde_destroy(c); return LRNDE_HIP_ERROR; }
+  m.W1q = c->W1q; m.W2q = c->W2q;
   m.W1p = reinterpret_cast<const f32x4*>(c->W1p);
   m.W2p = reinterpret_cast<const f32x4*>(c->W2p);
   m.w1t = c->w1t; m.b1 = c->b1; m.w2t = c->w2t; m.b2 = c->b2;
@@ -1491,7 +1534,7 @@ int lrnde_destroy(lrnde_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
   if (c->comm) ncclCommDestroy(c->comm);
-  void* ptrs[] = {c->W1p, c->W2p, c->w1t, c->b1, c->w2t, c->b2, c->state, c->ctrl, c->part,
+  void* ptrs[] = {c->W1q, c->W2q, c->W1p, c->W2p, c->w1t, c->b1, c->w2t, c->b2, c->state, c->ctrl, c->part,
                   c->part_rx, c->pinit, c->pinit_rx, c->saveat_dev, c->tsaved_dev, c->trace_dev,
                   c->usave};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -1513,6 +1556,9 @@ int lrnde_set_params(lrnde_ctx* c, const float* p, size_t n) {
   hipLaunchKernelGGL(k_pack, dim3(256), dim3(256), 0, c->stream, p, m.D, m.H, m.td, m.Dp, m.Hp, c->W1p,
                      c->w1t, c->b1, c->W2p, c->w2t, c->b2);
   HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(k_pack_q, dim3(256), dim3(256), 0, c->stream, p, m.D, m.H, m.td, m.KQ1p, m.KQ2p, m.RG1, m.RG2,
+                     c->W1q, c->W2q);
+  HIPCHK(c, hipGetLastError());
   c->have_params = true;
   return LRNDE_OK;
 }
@@ -1524,6 +1570,11 @@ int lrnde_rhs(lrnde_ctx* c, const float* u, float t, int32_t B, float* du) {
   StepArgs a;
   memset(&a, 0, sizeof(a));
   a.m = c->m; a.B = B;
+  if (use_qtile(c, B)) {
+    hipLaunchKernelGGL(k_rhs_q, dim3((B + QNB - 1) / QNB), dim3(QNT), smem_q(c), c->stream, a, u, t, du);
+    HIPCHK(c, hipGetLastError());
+    return LRNDE_OK;
+  }
   const int nwg = (B + NB - 1) / NB;
   const size_t sm = smem_bytes(c->m.Dp, c->m.Hp);
   if (vecw(c) == 4) hipLaunchKernelGGL(k_rhs<4>, dim3(nwg), dim3(NT), sm, c->stream, a, u, t, du);
