@@ -16,8 +16,8 @@
 // B operand: x[k][s]; D register r: out[row 64*rg + 4q + r][s].
 
 constexpr int QNB = 4;    // batch columns per workgroup
-constexpr int QNW = 4;    // waves per workgroup (one per SIMD)
-constexpr int QNT = 256;
+constexpr int QNW = 8;    // waves per workgroup
+constexpr int QNT = QNW * 64;
 constexpr int QB1 = 7;    // k-quads per Dense-1 block (a canonical segment = 28 quads = 4 blocks)
 constexpr int QSEG = 28;  // k-quads per canonical segment (112 rows)
 constexpr int QB2 = 5;    // k-quads per Dense-2 block
@@ -218,26 +218,32 @@ __device__ __forceinline__ void feval_q(const ModelDev& m, const SmemQ& sm, cons
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sidx = lane & 3, q = lane >> 2;
   const int voff = lane * 16;
+  // weight rows beyond the real matrix are all-zero padding: give those lanes an out-of-range
+  // offset so the row group's tail is never fetched (H = 100: 28 of 128 Dense-1 rows)
+  auto voff1 = [&](int rg) { return (rg * 64 + lane < m.H) ? voff : 0x7ffffff0; };
+  auto voff2 = [&](int rg) { return (rg * 64 + lane < m.D) ? voff : 0x7ffffff0; };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const int h64 = m.RG1 * 64, d64 = m.RG2 * 64;
   const float* w1t = sm.bias; const float* b1 = w1t + h64;
   const float* w2t = b1 + h64; const float* b2 = w2t + d64;
   const int nseg1 = q_nseg1(m);
-  // Dense-2 work of this wave: passes of QRG2 row groups {g, g+4}: g = wave + 8*pass
+  // Dense-2 work of this wave: passes of QRG2 row groups {g, g+QNW}: g = wave + 2*QNW*pass
   const int nblk2 = m.KQ2p / QB2;
-  const int npass2 = (m.RG2 > wave) ? (m.RG2 - wave + 7) / 8 : 0;
+  const int npass2 = (m.RG2 > wave) ? (m.RG2 - wave + 2 * QNW - 1) / (2 * QNW) : 0;
   const int nitem2 = npass2 * nblk2;
   f32x4 a2X[QB2][QRG2], a2Y[QB2][QRG2];
 #define LRNDE_QLOADA2(a, it)                                                                    \
   do {                                                                                          \
-    const int g_ = wave + 8 * ((it) / nblk2), k0_ = ((it) % nblk2) * QB2;                       \
+    const int g_ = wave + 2 * QNW * ((it) / nblk2), k0_ = ((it) % nblk2) * QB2;                 \
+    const int v0_ = voff2(g_), v1_ = voff2(g_ + QNW);                                           \
     _Pragma("unroll") for (int j = 0; j < QB2; ++j) {                                           \
-      a[j][0] = wload(fc.rs2, voff, q_w2_off(m, g_, k0_ + j));                                  \
-      a[j][1] = wload(fc.rs2, voff, q_w2_off(m, g_ + 4, k0_ + j));                              \
+      a[j][0] = wload(fc.rs2, v0_, q_w2_off(m, g_, k0_ + j));                                   \
+      a[j][1] = wload(fc.rs2, v1_, q_w2_off(m, g_ + QNW, k0_ + j));                             \
     }                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                          \
   } while (0)
-  // ---- Dense 1: waves own canonical segments w, w+4, ...; two row groups run as independent
+  STAMP(1); STAMPW(0);
+  // ---- Dense 1: waves own canonical segments w, w+QNW, ...; two row groups run as independent
   // chains sharing the B operand; weights one block (7 k-quads) ahead ----
   {
     const f32x4* xp = sm.xl + sidx;  // x[k-quad][sample]
@@ -249,9 +255,10 @@ __device__ __forceinline__ void feval_q(const ModelDev& m, const SmemQ& sm, cons
         f32x4 aX[QB1][2], aY[QB1][2];
 #define LRNDE_QLOAD1(a, blk)                                                                    \
   do {                                                                                          \
+    const int v0_ = voff1(rg0), v1_ = voff1(rg0 + 1);                                           \
     _Pragma("unroll") for (int j = 0; j < QB1; ++j) {                                           \
-      a[j][0] = wload(fc.rs1, voff, q_w1_off(m, rg0, kq_lo + (blk) * QB1 + j));                 \
-      a[j][1] = wload(fc.rs1, voff, q_w1_off(m, rg0 + 1, kq_lo + (blk) * QB1 + j));             \
+      a[j][0] = wload(fc.rs1, v0_, q_w1_off(m, rg0, kq_lo + (blk) * QB1 + j));                  \
+      a[j][1] = wload(fc.rs1, v1_, q_w1_off(m, rg0 + 1, kq_lo + (blk) * QB1 + j));              \
     }                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                          \
   } while (0)
@@ -308,30 +315,29 @@ __device__ __forceinline__ void feval_q(const ModelDev& m, const SmemQ& sm, cons
   }
   // the first Dense-2 weight block does not depend on h: in flight across epilogue 1
   if (nitem2 > 0) LRNDE_QLOADA2(a2X, 0);
+  STAMP(2); STAMPW(1);
   __syncthreads();
-  // epilogue 1: segment partials in order, time column, bias, activation -> h tile quads
-  for (int t = threadIdx.x; t < m.RG1 * 64; t += QNT) {
-    const int l = t & 63, rg = t >> 6;
-    f32x4 v = sm.pl[t];
-    for (int sgi = 1; sgi < nseg1; ++sgi) {
-      const f32x4 pv = sm.pl[(size_t)sgi * m.RG1 * 64 + t];
-      v.x = v.x + pv.x; v.y = v.y + pv.y; v.z = v.z + pv.z; v.w = v.w + pv.w;
-    }
-    const int o0 = rg * 64 + (l >> 2) * 4;
-    if ((o0 >> 2) < m.KQ2p) {
-      const f32x4 wt = *reinterpret_cast<const f32x4*>(w1t + o0);
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + o0);
-      f32x4 h;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float pre = m.td ? fma_(wt[r], ts, v[r]) : v[r];
-        pre = pre + bb[r];
-        h[r] = act_apply(m.act, pre);
-      }
-      sm.hl[(o0 >> 2) * 4 + (l & 3)] = h;
+  STAMP(3);
+  // epilogue 1: segment partials in order, time column, bias, activation -> h tile
+  // (one C-fragment element per thread: element e = (rg*64 + l)*4 + r -> row 64rg + 4(l>>2) + r)
+  {
+    const float* plf = reinterpret_cast<const float*>(sm.pl);
+    float* hlf = reinterpret_cast<float*>(sm.hl);
+    const int ne = m.RG1 * 256;
+    for (int e = threadIdx.x; e < ne; e += QNT) {
+      const int r = e & 3, l = (e >> 2) & 63, rg = e >> 8;
+      const int o = rg * 64 + (l >> 2) * 4 + r;
+      if ((o >> 2) >= m.KQ2p) continue;
+      float v = plf[e];
+      for (int sgi = 1; sgi < nseg1; ++sgi) v = v + plf[(size_t)sgi * ne + e];
+      float pre = m.td ? fma_(w1t[o], ts, v) : v;
+      pre = pre + b1[o];
+      hlf[((o >> 2) * 4 + (l & 3)) * 4 + r] = act_apply(m.act, pre);
     }
   }
+  STAMPW(2);
   __syncthreads();
+  STAMP(4); STAMPW(3);
   // ---- Dense 2 (H <= 112, host-checked: one canonical segment = one chain over all KQ2p
   // k-quads).  Wave w runs passes of two row groups {g, g+4}, g = w + 8*pass; the block loop is
   // flattened over passes so that the next block (also the next pass's first) is always in flight.
@@ -352,7 +358,7 @@ __device__ __forceinline__ void feval_q(const ModelDev& m, const SmemQ& sm, cons
     f32x4 acc0 = zero4, acc1 = zero4;
 #define LRNDE_QMMA2(a, it)                                                                      \
   do {                                                                                          \
-    const int blk_ = (it) % nblk2, g_ = wave + 8 * ((it) / nblk2);                              \
+    const int blk_ = (it) % nblk2, g_ = wave + 2 * QNW * ((it) / nblk2);                        \
     f32x4 b_[QB2];                                                                              \
     _Pragma("unroll") for (int j = 0; j < QB2; ++j) b_[j] = hp[(blk_ * QB2 + j) * 4];           \
     _Pragma("unroll") for (int j = 0; j < QB2; ++j) {                                           \
@@ -368,9 +374,9 @@ __device__ __forceinline__ void feval_q(const ModelDev& m, const SmemQ& sm, cons
     if (blk_ == nblk2 - 1) { /* pass complete: epilogue of its two row groups */                \
       f32x4 pb0[Epi::NPRE], pb1[Epi::NPRE];                                                     \
       epi.pre(g_, pb0);                                                                         \
-      if (g_ + 4 < m.RG2) epi.pre(g_ + 4, pb1);                                                 \
+      if (g_ + QNW < m.RG2) epi.pre(g_ + QNW, pb1);                                             \
       epi.post(g_, finish(g_, acc0), pb0);                                                      \
-      if (g_ + 4 < m.RG2) epi.post(g_ + 4, finish(g_ + 4, acc1), pb1);                          \
+      if (g_ + QNW < m.RG2) epi.post(g_ + QNW, finish(g_ + QNW, acc1), pb1);                    \
       acc0 = zero4; acc1 = zero4;                                                               \
     }                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                          \
@@ -395,7 +401,9 @@ __device__ __forceinline__ void feval_q(const ModelDev& m, const SmemQ& sm, cons
 #undef LRNDE_QMMA2
   }
 #undef LRNDE_QLOADA2
+  STAMP(5); STAMPW(4);
   __syncthreads();
+  STAMP(6);
 }
 
 template <class F>
@@ -432,6 +440,7 @@ __device__ __forceinline__ void q_feval_store(const ModelDev& m, const SmemQ& sm
 }
 
 __global__ __launch_bounds__(QNT) void k_rhs_q(StepArgs a, const float* u, float t, float* du) {
+  STAMP(0);
   const SmemQ s = carve_q(a.m);
   smem_init_q(a.m, s);
   FevalCtxQ fc;
@@ -533,14 +542,17 @@ __global__ __launch_bounds__(QNT) void k_init2_q(StepArgs a) {
 
 // one attempted Tsit5 step, 4 columns per workgroup (same flow as k_step's fused path)
 template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a, int j) {
+  STAMP(9);
   const SmemQ s = carve_q(a.m);
   smem_init_q(a.m, s);
   FevalCtxQ fc;
   feval_ctx_init_q(a.m, fc);
   const int b0 = blockIdx.x * QNB, nvalid = min(QNB, a.B - b0);
   const int KQ1 = a.m.D / 4;
+  STAMP(10);
   if (threadIdx.x < 64) step_prologue(a, j, s.bc);
   __syncthreads();
+  STAMP(11);
   const Bcast bc = *s.bc;
 
   if (bc.accepted_prev) {  // savevalues! of the step accepted by the prologue
@@ -614,6 +626,7 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
     });
   }
   __syncthreads();
+  STAMP(12);
 #define LRNDE_QSTAGE(S, TS)                                                             \
   do {                                                                                  \
     EpiStageQ<S> e;                                                                     \
@@ -623,6 +636,7 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
     e.off_x = (S == 6) ? o_un : ((S == 5 && a.want_stiff) ? o_g6 : -1);                 \
     e.dt = dt; e.xl = s.xl; e.KQ1 = KQ1;                                                \
     feval_q<EpiStageQ<S>>(a.m, s, fc, (TS), e);                                         \
+    STAMP(11 + S);                                                                      \
   } while (0)
   LRNDE_QSTAGE(2, t + c1 * dt);
   LRNDE_QSTAGE(3, t + c2 * dt);
@@ -639,7 +653,9 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
   ef.D = a.m.D;
   ef.aerr = &aerr; ef.anum = &anum; ef.aden = &aden;
   feval_q<EpiFinalQ>(a.m, s, fc, t + dt, ef);
+  STAMP(18);
   block_sum3_q(s.red, aerr, anum, aden);
+  STAMP(19);
   if (threadIdx.x == 0) {
     double* p = a.part_send + ((size_t)((j + 1) & 1) * a.nwg_global + a.wg_offset + blockIdx.x) * PSTRIDE;
     p[0] = aerr; p[1] = anum; p[2] = aden;

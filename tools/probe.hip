@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
     const char* sn[] = {"prologue", "x2 combine", "stage k2", "stage k3", "stage k4", "stage k5", "stage k6", "stage k7+err", "block reduce"};
     printf("step kernel: %.1f us/launch; wave-0 phase cycles:\n", us);
+    printf("  %-14s %8llu cycles\n", "launch init", st[2 * 10] - st[2 * 9]);
     for (int i = 0; i < 9; ++i) printf("  %-14s %8llu cycles\n", sn[i], st[2 * (11 + i)] - st[2 * (10 + i)]);
     printf("  total          %8llu cycles = %.1f us\n", st[2 * 19] - st[2 * 10], (st[2 * 19 + 1] - st[2 * 10 + 1]) / 100.0);
   }
