@@ -1322,7 +1322,10 @@ inline int vecw(const lrnde_ctx* c) { return (c->desc.state_dim % 4 == 0) ? 4 : 
 bool use_qtile(const lrnde_ctx* c, int B) {
   static const int qmax = getenv("LRNDE_QTILE_MAX_B") ? atoi(getenv("LRNDE_QTILE_MAX_B")) : 1024;
   const int D = c->desc.state_dim, H = c->desc.hidden_dim;
-  return (D % 4 == 0) && (H <= 112) && ((double)B * D * 40.0 < 2147483000.0) && B <= qmax;
+  // streaming path shape limits: one Dense-1 segment and one Dense-2 pass per wave
+  const bool shape_ok = (D % 4 == 0) && (H <= 112) && (c->m.KQ1p / QSEG <= QNW) && (c->m.RG1 <= 2) &&
+                        (c->m.RG2 <= 2 * QNW);
+  return shape_ok && ((double)B * D * 40.0 < 2147483000.0) && B <= qmax && !getenv("LRNDE_NO_QTILE");
 }
 inline int tile_nb(const lrnde_ctx* c, int B) { return use_qtile(c, B) ? QNB : NB; }
 
@@ -1517,8 +1520,8 @@ int lrnde_create(lrnde_ctx** out, const lrnde_model_desc* d, int device, void* s
             hipMalloc(&c->b2, sizeof(float) * Dp) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
             hipEventCreate(&c->evp[0]) == hipSuccess && hipEventCreate(&c->evp[1]) == hipSuccess;
-  m.KQ1p = (((d->state_dim + 3) / 4 + QB1 - 1) / QB1) * QB1;
-  m.KQ2p = (((d->hidden_dim + 3) / 4 + QB2 - 1) / QB2) * QB2;
+  m.KQ1p = (((d->state_dim + 3) / 4 + QSEG - 1) / QSEG) * QSEG;  // whole canonical segments
+  m.KQ2p = QSEG;                                                  // H <= 112 (q-tile eligibility)
   m.RG1 = (d->hidden_dim + 63) / 64;
   m.RG2 = (d->state_dim + 63) / 64;
   ok = ok && hipMalloc(&c->W1q, sizeof(float) * (size_t)m.RG1 * m.KQ1p * 256) == hipSuccess &&

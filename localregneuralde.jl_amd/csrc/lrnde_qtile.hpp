@@ -20,7 +20,7 @@ constexpr int QNW = 8;    // waves per workgroup
 constexpr int QNT = QNW * 64;
 constexpr int QB1 = 7;    // k-quads per Dense-1 block (a canonical segment = 28 quads = 4 blocks)
 constexpr int QSEG = 28;  // k-quads per canonical segment (112 rows)
-constexpr int QB2 = 5;    // k-quads per Dense-2 block
+constexpr int QB2 = 4;    // k-quads per Dense-2 block
 constexpr int QRGC = 4;   // Dense-2 row groups run concurrently by one wave
 
 struct SmemQ {
@@ -182,144 +182,130 @@ struct EpiFinalQ {
   }
 };
 
-// ---- weights resident in registers for the whole launch ------------------------------------
-constexpr int QRG2 = 2;  // Dense-2 row groups per pass (chains sharing the B operand)
+// W1q: [RG1][KQ1p][64][4]   element (rg,kq,l,j) = W1[row 64rg+l][k 4kq+j],  KQ1p = 28 * nseg1
+// W2q: [RG2][KQ2p][64][4]   KQ2p = 28
+// Loads for row groups beyond RG1 / RG2, and lanes whose weight row is beyond the real matrix,
+// are outside the descriptor's range: they return 0 without touching memory.
 
-struct FevalCtxQ {
-  __amdgpu_buffer_rsrc_t rs1, rs2;
-  f32x4 r1[QB1][2];  // Dense 1: first block of (segment = wave, row groups 0,1), kept all launch
-};
+// ===========================================================================================
+// Streaming fast path (nseg1 <= QNW, RG1 <= 2, RG2 <= 2*QNW: one work item per GEMM phase per
+// wave — MNIST-ODE).  A wave's weights for one f-eval are ONE fixed stream of QSB blocks
+// (7 Dense-1 + 7 Dense-2) of 8 one-KiB buffer loads (4 k-quads x 2 row groups).  The blocks
+// rotate through a 3-slot register ring that always has two blocks in flight: the stream is
+// carried across the GEMM phases, across the barriers (raw s_barrier + lgkmcnt(0): a
+// __syncthreads() would drain vmcnt) and across f-evals (the next f-eval streams the same
+// addresses), so the L2 -> CU pipe does not idle at phase boundaries.  Everything is straight
+// line code with compile-time slots, so hipcc emits counted vmcnt waits.
+// ===========================================================================================
+constexpr int QSQ = 4;            // k-quads per stream block
+constexpr int QSB1 = QSEG / QSQ;  // 7 Dense-1 blocks (one canonical segment)
+constexpr int QSB2 = 7;           // Dense-2 blocks (KQ2p = 28 k-quads)
+constexpr int QSB = QSB1 + QSB2;
+constexpr int QRING = 3;
 
-// W1q: [RG1][KQ1p][64][4]   element (rg,kq,l,j) = W1[row 64rg+l][k 4kq+j]
-// W2q: [RG2][KQ2p][64][4]
-// Loads for row groups beyond RG1 / RG2 are out of the descriptor's range: they return 0 without
-// touching memory, so the unrolled slots need no guards.
-__device__ __forceinline__ int q_w1_off(const ModelDev& m, int rg, int kq) { return (rg * m.KQ1p + kq) * 1024; }
-__device__ __forceinline__ int q_w2_off(const ModelDev& m, int rg, int kq) { return (rg * m.KQ2p + kq) * 1024; }
-
-__device__ __forceinline__ void feval_ctx_init_q(const ModelDev& m, FevalCtxQ& fc) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  fc.rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)m.W1q, 0, m.RG1 * m.KQ1p * 1024, 0x00020000);
-  fc.rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)m.W2q, 0, m.RG2 * m.KQ2p * 1024, 0x00020000);
-  const int voff = lane * 16;
-  const int kq0 = (wave < q_nseg1(m)) ? wave * QSEG : 0;
-#pragma unroll
-  for (int j = 0; j < QB1; ++j)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) fc.r1[j][c] = wload(fc.rs1, voff, q_w1_off(m, c, kq0 + j));
+template <int I> struct IC { static constexpr int value = I; };
+template <int I0, int I1, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I0 < I1) { f(IC<I0>{}); static_for<I0 + 1, I1>(f); }
 }
 
-// one vector-field evaluation on the 4-column tile
-template <class Epi>
-__device__ __forceinline__ void feval_q(const ModelDev& m, const SmemQ& sm, const FevalCtxQ& fc, float ts,
-                                        const Epi& epi) {
+struct StreamQ {
+  __amdgpu_buffer_rsrc_t rs1, rs2;
+  int v1[2], v2[2];          // per-lane offsets of the wave's Dense-1 / Dense-2 row groups (or out of range)
+  int s1[2], s2[2];          // scalar byte offsets of the first quad of those row groups
+  int kq2_real;              // ceil(H/4): Dense-2 quads at/after it are not fetched
+  f32x4 ring[QRING][QSQ][2];
+};
+
+__device__ __forceinline__ void q_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// issue the 8 loads of stream block B (0..QSB-1) into ring slot SLOT
+template <int B, int SLOT>
+__device__ __forceinline__ void q_stream_load(StreamQ& st) {
+  if constexpr (B < QSB1) {
+#pragma unroll
+    for (int j = 0; j < QSQ; ++j) {
+      st.ring[SLOT][j][0] = wload(st.rs1, st.v1[0], st.s1[0] + (B * QSQ + j) * 1024);
+      st.ring[SLOT][j][1] = wload(st.rs1, st.v1[1], st.s1[1] + (B * QSQ + j) * 1024);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < QSQ; ++j) {
+      constexpr int kq = (B - QSB1) * QSQ;
+      const bool real = (kq + j) < st.kq2_real;  // wave-uniform
+      st.ring[SLOT][j][0] = wload(st.rs2, real ? st.v2[0] : 0x7ffffff0, st.s2[0] + (kq + j) * 1024);
+      st.ring[SLOT][j][1] = wload(st.rs2, real ? st.v2[1] : 0x7ffffff0, st.s2[1] + (kq + j) * 1024);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void stream_init_q(const ModelDev& m, StreamQ& st) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int voff = lane * 16;
+  st.rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)m.W1q, 0, m.RG1 * m.KQ1p * 1024, 0x00020000);
+  st.rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)m.W2q, 0, m.RG2 * m.KQ2p * 1024, 0x00020000);
+  const bool has1 = wave < q_nseg1(m);
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    st.v1[c] = (has1 && c < m.RG1 && c * 64 + lane < m.H) ? voff : 0x7ffffff0;
+    st.s1[c] = (c * m.KQ1p + (has1 ? wave * QSEG : 0)) * 1024;
+    const int g = wave + c * QNW;
+    st.v2[c] = (g < m.RG2 && g * 64 + lane < m.D) ? voff : 0x7ffffff0;
+    st.s2[c] = (g < m.RG2 ? g : 0) * m.KQ2p * 1024;
+  }
+  st.kq2_real = (m.H + 3) / 4;
+  q_stream_load<0, 0>(st);
+  q_stream_load<1, 1>(st);
+}
+
+template <class Epi, int SLOT0>
+__device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, StreamQ& st, float ts, const Epi& epi) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sidx = lane & 3, q = lane >> 2;
-  const int voff = lane * 16;
-  // weight rows beyond the real matrix are all-zero padding: give those lanes an out-of-range
-  // offset so the row group's tail is never fetched (H = 100: 28 of 128 Dense-1 rows)
-  auto voff1 = [&](int rg) { return (rg * 64 + lane < m.H) ? voff : 0x7ffffff0; };
-  auto voff2 = [&](int rg) { return (rg * 64 + lane < m.D) ? voff : 0x7ffffff0; };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const int h64 = m.RG1 * 64, d64 = m.RG2 * 64;
   const float* w1t = sm.bias; const float* b1 = w1t + h64;
   const float* w2t = b1 + h64; const float* b2 = w2t + d64;
   const int nseg1 = q_nseg1(m);
-  // Dense-2 work of this wave: passes of QRG2 row groups {g, g+QNW}: g = wave + 2*QNW*pass
-  const int nblk2 = m.KQ2p / QB2;
-  const int npass2 = (m.RG2 > wave) ? (m.RG2 - wave + 2 * QNW - 1) / (2 * QNW) : 0;
-  const int nitem2 = npass2 * nblk2;
-  f32x4 a2X[QB2][QRG2], a2Y[QB2][QRG2];
-#define LRNDE_QLOADA2(a, it)                                                                    \
-  do {                                                                                          \
-    const int g_ = wave + 2 * QNW * ((it) / nblk2), k0_ = ((it) % nblk2) * QB2;                 \
-    const int v0_ = voff2(g_), v1_ = voff2(g_ + QNW);                                           \
-    _Pragma("unroll") for (int j = 0; j < QB2; ++j) {                                           \
-      a[j][0] = wload(fc.rs2, v0_, q_w2_off(m, g_, k0_ + j));                                   \
-      a[j][1] = wload(fc.rs2, v1_, q_w2_off(m, g_ + QNW, k0_ + j));                             \
-    }                                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                          \
-  } while (0)
+  f32x4 acc0 = zero4, acc1 = zero4;
   STAMP(1); STAMPW(0);
-  // ---- Dense 1: waves own canonical segments w, w+QNW, ...; two row groups run as independent
-  // chains sharing the B operand; weights one block (7 k-quads) ahead ----
+  // ---- Dense 1: stream blocks 0..6 (segment = wave, row groups 0 and 1) ----
   {
-    const f32x4* xp = sm.xl + sidx;  // x[k-quad][sample]
-    for (int seg = wave; seg < nseg1; seg += QNW) {
-      const int kq_lo = seg * QSEG, kq_hi = min(m.KQ1p, kq_lo + QSEG);
-      const int nblk = (kq_hi - kq_lo) / QB1;
-      for (int rg0 = 0; rg0 < m.RG1; rg0 += 2) {
-        f32x4 acc0 = zero4, acc1 = zero4;
-        f32x4 aX[QB1][2], aY[QB1][2];
-#define LRNDE_QLOAD1(a, blk)                                                                    \
-  do {                                                                                          \
-    const int v0_ = voff1(rg0), v1_ = voff1(rg0 + 1);                                           \
-    _Pragma("unroll") for (int j = 0; j < QB1; ++j) {                                           \
-      a[j][0] = wload(fc.rs1, v0_, q_w1_off(m, rg0, kq_lo + (blk) * QB1 + j));                  \
-      a[j][1] = wload(fc.rs1, v1_, q_w1_off(m, rg0 + 1, kq_lo + (blk) * QB1 + j));              \
-    }                                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                          \
-  } while (0)
-#define LRNDE_QMMA1(a, blk)                                                                     \
-  do {                                                                                          \
-    f32x4 b_[QB1];                                                                              \
-    _Pragma("unroll") for (int j = 0; j < QB1; ++j) b_[j] = xp[(kq_lo + (blk) * QB1 + j) * 4];  \
-    _Pragma("unroll") for (int j = 0; j < QB1; ++j) {                                           \
-      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].x, b_[j].x, acc0, 0, 0, 0);             \
-      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].x, b_[j].x, acc1, 0, 0, 0);             \
-      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].y, b_[j].y, acc0, 0, 0, 0);             \
-      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].y, b_[j].y, acc1, 0, 0, 0);             \
-      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].z, b_[j].z, acc0, 0, 0, 0);             \
-      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].z, b_[j].z, acc1, 0, 0, 0);             \
-      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].w, b_[j].w, acc0, 0, 0, 0);             \
-      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].w, b_[j].w, acc1, 0, 0, 0);             \
-    }                                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                          \
-  } while (0)
-        int blk = 0;
-        if (seg == wave && rg0 == 0) {  // first block from the resident registers
-          if (nblk > 1) {
-            LRNDE_QLOAD1(aX, 1);
-            LRNDE_QMMA1(fc.r1, 0);
-            blk = 1;
-          } else {
-            LRNDE_QMMA1(fc.r1, 0);
-            blk = nblk;
-          }
-        } else {
-          LRNDE_QLOAD1(aX, 0);
-        }
-#pragma unroll 1
-        for (; blk + 2 < nblk; blk += 2) {
-          LRNDE_QLOAD1(aY, blk + 1);
-          LRNDE_QMMA1(aX, blk);
-          LRNDE_QLOAD1(aX, blk + 2);
-          LRNDE_QMMA1(aY, blk + 1);
-        }
-        if (blk + 1 < nblk) {
-          LRNDE_QLOAD1(aY, blk + 1);
-          LRNDE_QMMA1(aX, blk);
-          LRNDE_QMMA1(aY, blk + 1);
-        } else if (blk < nblk) {
-          LRNDE_QMMA1(aX, blk);
-        }
-#undef LRNDE_QLOAD1
-#undef LRNDE_QMMA1
-        f32x4* pp = sm.pl + ((size_t)seg * m.RG1 + rg0) * 64 + lane;
-        pp[0] = acc0;
-        if (rg0 + 1 < m.RG1) pp[64] = acc1;
+    const f32x4* xp = sm.xl + (size_t)((wave < nseg1 ? wave : 0) * QSEG) * 4 + sidx;
+    static_for<0, QSB1>([&](auto Bc) {
+      constexpr int B = decltype(Bc)::value;
+      constexpr int SL = (SLOT0 + B) % QRING, NSL = (SLOT0 + B + 2) % QRING;
+      q_stream_load<(B + 2) % QSB, NSL>(st);
+      f32x4 b_[QSQ];
+#pragma unroll
+      for (int j = 0; j < QSQ; ++j) b_[j] = xp[(B * QSQ + j) * 4];
+#pragma unroll
+      for (int j = 0; j < QSQ; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].x, b_[j].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].x, b_[j].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].y, b_[j].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].y, b_[j].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].z, b_[j].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].z, b_[j].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].w, b_[j].w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].w, b_[j].w, acc1, 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (wave < nseg1) {
+      f32x4* pp = sm.pl + ((size_t)wave * m.RG1) * 64 + lane;
+      pp[0] = acc0;
+      if (m.RG1 > 1) pp[64] = acc1;
     }
   }
-  // the first Dense-2 weight block does not depend on h: in flight across epilogue 1
-  if (nitem2 > 0) LRNDE_QLOADA2(a2X, 0);
   STAMP(2); STAMPW(1);
-  __syncthreads();
+  q_barrier();
   STAMP(3);
-  // epilogue 1: segment partials in order, time column, bias, activation -> h tile
-  // (one C-fragment element per thread: element e = (rg*64 + l)*4 + r -> row 64rg + 4(l>>2) + r)
+  // epilogue 1 (one C-fragment element per thread)
   {
     const float* plf = reinterpret_cast<const float*>(sm.pl);
     float* hlf = reinterpret_cast<float*>(sm.hl);
@@ -336,13 +322,39 @@ __device__ __forceinline__ void feval_q(const ModelDev& m, const SmemQ& sm, cons
     }
   }
   STAMPW(2);
-  __syncthreads();
+  q_barrier();
   STAMP(4); STAMPW(3);
-  // ---- Dense 2 (H <= 112, host-checked: one canonical segment = one chain over all KQ2p
-  // k-quads).  Wave w runs passes of two row groups {g, g+4}, g = w + 8*pass; the block loop is
-  // flattened over passes so that the next block (also the next pass's first) is always in flight.
+  // ---- Dense 2: stream blocks 7..13 (row groups wave and wave + QNW, one chain over K = H) ----
   {
     const f32x4* hp = sm.hl + sidx;
+    acc0 = zero4; acc1 = zero4;
+    const int g0 = wave, g1 = wave + QNW;
+    f32x4 pb0[Epi::NPRE], pb1[Epi::NPRE];
+    static_for<0, QSB2>([&](auto Bc) {
+      constexpr int B = decltype(Bc)::value;
+      constexpr int SL = (SLOT0 + QSB1 + B) % QRING, NSL = (SLOT0 + QSB1 + B + 2) % QRING;
+      q_stream_load<(QSB1 + B + 2) % QSB, NSL>(st);  // wraps into the next f-eval's Dense-1 blocks
+      if constexpr (B == QSB2 - 3) {  // epilogue operands: issued ~3 blocks before they are needed
+        if (g0 < m.RG2) epi.pre(g0, pb0);
+        if (g1 < m.RG2) epi.pre(g1, pb1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      f32x4 b_[QSQ];
+#pragma unroll
+      for (int j = 0; j < QSQ; ++j) b_[j] = hp[(B * QSQ + j) * 4];
+#pragma unroll
+      for (int j = 0; j < QSQ; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].x, b_[j].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].x, b_[j].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].y, b_[j].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].y, b_[j].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].z, b_[j].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].z, b_[j].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].w, b_[j].w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].w, b_[j].w, acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
     auto finish = [&](int rg, const f32x4& tot) {
       const int row0 = rg * 64 + q * 4;
       const f32x4 wt = *reinterpret_cast<const f32x4*>(w2t + row0);
@@ -355,54 +367,11 @@ __device__ __forceinline__ void feval_q(const ModelDev& m, const SmemQ& sm, cons
       }
       return kv;
     };
-    f32x4 acc0 = zero4, acc1 = zero4;
-#define LRNDE_QMMA2(a, it)                                                                      \
-  do {                                                                                          \
-    const int blk_ = (it) % nblk2, g_ = wave + 2 * QNW * ((it) / nblk2);                        \
-    f32x4 b_[QB2];                                                                              \
-    _Pragma("unroll") for (int j = 0; j < QB2; ++j) b_[j] = hp[(blk_ * QB2 + j) * 4];           \
-    _Pragma("unroll") for (int j = 0; j < QB2; ++j) {                                           \
-      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].x, b_[j].x, acc0, 0, 0, 0);             \
-      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].x, b_[j].x, acc1, 0, 0, 0);             \
-      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].y, b_[j].y, acc0, 0, 0, 0);             \
-      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].y, b_[j].y, acc1, 0, 0, 0);             \
-      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].z, b_[j].z, acc0, 0, 0, 0);             \
-      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].z, b_[j].z, acc1, 0, 0, 0);             \
-      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].w, b_[j].w, acc0, 0, 0, 0);             \
-      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].w, b_[j].w, acc1, 0, 0, 0);             \
-    }                                                                                           \
-    if (blk_ == nblk2 - 1) { /* pass complete: epilogue of its two row groups */                \
-      f32x4 pb0[Epi::NPRE], pb1[Epi::NPRE];                                                     \
-      epi.pre(g_, pb0);                                                                         \
-      if (g_ + QNW < m.RG2) epi.pre(g_ + QNW, pb1);                                             \
-      epi.post(g_, finish(g_, acc0), pb0);                                                      \
-      if (g_ + QNW < m.RG2) epi.post(g_ + QNW, finish(g_ + QNW, acc1), pb1);                    \
-      acc0 = zero4; acc1 = zero4;                                                               \
-    }                                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                          \
-  } while (0)
-    if (nitem2 > 0) {
-      int it = 0;
-#pragma unroll 1
-      for (; it + 2 < nitem2; it += 2) {
-        LRNDE_QLOADA2(a2Y, it + 1);
-        LRNDE_QMMA2(a2X, it);
-        LRNDE_QLOADA2(a2X, it + 2);
-        LRNDE_QMMA2(a2Y, it + 1);
-      }
-      if (it + 1 < nitem2) {
-        LRNDE_QLOADA2(a2Y, it + 1);
-        LRNDE_QMMA2(a2X, it);
-        LRNDE_QMMA2(a2Y, it + 1);
-      } else {
-        LRNDE_QMMA2(a2X, it);
-      }
-    }
-#undef LRNDE_QMMA2
+    if (g0 < m.RG2) epi.post(g0, finish(g0, acc0), pb0);
+    if (g1 < m.RG2) epi.post(g1, finish(g1, acc1), pb1);
   }
-#undef LRNDE_QLOADA2
   STAMP(5); STAMPW(4);
-  __syncthreads();
+  q_barrier();
   STAMP(6);
 }
 
@@ -432,19 +401,20 @@ __device__ __forceinline__ void block_sum3_q(double* red, double& a, double& b, 
   __syncthreads();
 }
 
-__device__ __forceinline__ void q_feval_store(const ModelDev& m, const SmemQ& sm, const FevalCtxQ& fc, float ts,
+__device__ __forceinline__ void q_feval_store(const ModelDev& m, const SmemQ& sm, StreamQ& fc, float ts,
                                               float* kout, int b0, int nvalid) {
   EpiStoreKQ e;
   e.m = &m; e.kout = kout; e.b0 = b0; e.nvalid = nvalid;
-  feval_q<EpiStoreKQ>(m, sm, fc, ts, e);
+  feval_qs<EpiStoreKQ, 0>(m, sm, fc, ts, e);
+  __syncthreads();  // full barrier: the k stores are read back through other lanes by the caller
 }
 
 __global__ __launch_bounds__(QNT) void k_rhs_q(StepArgs a, const float* u, float t, float* du) {
   STAMP(0);
   const SmemQ s = carve_q(a.m);
   smem_init_q(a.m, s);
-  FevalCtxQ fc;
-  feval_ctx_init_q(a.m, fc);
+  StreamQ fc;
+  stream_init_q(a.m, fc);
   const int b0 = blockIdx.x * QNB, nvalid = min(QNB, a.B - b0);
   const int KQ1 = a.m.D / 4;
   __syncthreads();
@@ -459,8 +429,8 @@ __global__ __launch_bounds__(QNT) void k_rhs_q(StepArgs a, const float* u, float
 __global__ __launch_bounds__(QNT) void k_init1_q(StepArgs a) {
   const SmemQ s = carve_q(a.m);
   smem_init_q(a.m, s);
-  FevalCtxQ fc;
-  feval_ctx_init_q(a.m, fc);
+  StreamQ fc;
+  stream_init_q(a.m, fc);
   const int b0 = blockIdx.x * QNB, nvalid = min(QNB, a.B - b0);
   const int KQ1 = a.m.D / 4;
   const Ctrl c = a.ctrl[0];
@@ -495,8 +465,8 @@ __global__ __launch_bounds__(QNT) void k_init1_q(StepArgs a) {
 __global__ __launch_bounds__(QNT) void k_init2_q(StepArgs a) {
   const SmemQ s = carve_q(a.m);
   smem_init_q(a.m, s);
-  FevalCtxQ fc;
-  feval_ctx_init_q(a.m, fc);
+  StreamQ fc;
+  stream_init_q(a.m, fc);
   const int b0 = blockIdx.x * QNB, nvalid = min(QNB, a.B - b0);
   const int KQ1 = a.m.D / 4;
   const Ctrl c = a.ctrl[0];
@@ -545,8 +515,8 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
   STAMP(9);
   const SmemQ s = carve_q(a.m);
   smem_init_q(a.m, s);
-  FevalCtxQ fc;
-  feval_ctx_init_q(a.m, fc);
+  StreamQ fc;
+  stream_init_q(a.m, fc);
   const int b0 = blockIdx.x * QNB, nvalid = min(QNB, a.B - b0);
   const int KQ1 = a.m.D / 4;
   STAMP(10);
@@ -635,7 +605,7 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
     e.off_out = arr_off(a, 4 + (S - 2));                                                \
     e.off_x = (S == 6) ? o_un : ((S == 5 && a.want_stiff) ? o_g6 : -1);                 \
     e.dt = dt; e.xl = s.xl; e.KQ1 = KQ1;                                                \
-    feval_q<EpiStageQ<S>>(a.m, s, fc, (TS), e);                                         \
+    feval_qs<EpiStageQ<S>, (2 * (S - 2)) % QRING>(a.m, s, fc, (TS), e);                 \
     STAMP(11 + S);                                                                      \
   } while (0)
   LRNDE_QSTAGE(2, t + c1 * dt);
@@ -652,7 +622,7 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
   ef.dt = dt; ef.abstol = a.abstol; ef.reltol = a.reltol; ef.want_stiff = a.want_stiff; ef.nvalid = nvalid;
   ef.D = a.m.D;
   ef.aerr = &aerr; ef.anum = &anum; ef.aden = &aden;
-  feval_q<EpiFinalQ>(a.m, s, fc, t + dt, ef);
+  feval_qs<EpiFinalQ, (2 * 5) % QRING>(a.m, s, fc, t + dt, ef);
   STAMP(18);
   block_sum3_q(s.red, aerr, anum, aden);
   STAMP(19);
