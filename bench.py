@@ -132,8 +132,13 @@ def main():
                    "nfe_per_pass": nfe_total / args.steps, "rk_steps_per_sec": world * steps_total / el,
                    "fwd_ms_per_batch": el / args.steps * 1e3},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                     "kernel": "k_step<4,false> (one attempted Tsit5 step: 6 f-evals + combine + error norm)",
+                     "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                     # HBM/fabric bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+                     # (profiles/r1/pmc_summary.txt: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction);
+                     # measured offline for the default B=512 launch only
+                     "traffic": 30.5e6 if (args.batch == 512 and world == 1) else None,
+                     "kernel": "k_step_q<false> (one attempted Tsit5 step: 6 f-evals, fused stage combination, error norm)"
+                               if args.batch <= 1024 else "k_step<4,false>",
                      "us_per_launch": us, "flop_per_launch": flop_per_launch},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
