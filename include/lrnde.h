@@ -144,6 +144,24 @@ int lrnde_comm_unique_id(void* unique_id_128_host);
 int lrnde_comm_init(lrnde_ctx* ctx, const void* unique_id_128_host, int32_t rank, int32_t nranks);
 int lrnde_comm_destroy(lrnde_ctx* ctx);
 
+/* ---- SDE: `_perform_step(integrator, cache::LambaEulerHeunConstantCache, p)`,
+ * src/perform_step.jl:172-206 (residual :214-216), as called by NeuralDSDE,
+ * src/layers/neural_sde.jl:98,118.  drift: Chain(Dense(D=>H,act), Dense(H=>D)); diffusion:
+ * Dense(D=>D) (experiments/src/construct.jl:204-205), diagonal noise; parameters are the two
+ * halves of the ComponentArray (p.drift, p.diffusion = [vec(Wg); bg]).  dW (= W.dW) is supplied by
+ * the caller, delta is integrator.opts.delta.  Returns u, EEst and the regularisation value
+ * EEst*dt on the host.  3 drift + 3 diffusion evaluations per call. */
+typedef struct lrnde_sde lrnde_sde;
+int lrnde_sde_create(lrnde_sde** out, const lrnde_model_desc* drift, int32_t diffusion_bias, int device,
+                     void* stream);
+int lrnde_sde_destroy(lrnde_sde* sde);
+const char* lrnde_sde_last_error(const lrnde_sde* sde);
+int lrnde_sde_set_params(lrnde_sde* sde, const float* p_drift, size_t n_drift, const float* p_diffusion,
+                         size_t n_diffusion);
+int lrnde_sde_euler_heun_step(lrnde_sde* sde, const float* uprev, const float* dW, int32_t B, float t,
+                              float dt, float abstol, float reltol, float delta, float* u,
+                              float* eest_host, float* reg_val_host);
+
 /* Timing hooks for bench.py: HIP events on the handle's stream around the
  * kernels of the last solve (ms), and the number of step-kernel launches. */
 /* `reps` back-to-back launches of the full Tsit5 step kernel on fixed (uprev, k1, t, dt), timed

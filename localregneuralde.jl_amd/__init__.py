@@ -9,4 +9,5 @@ from ._lib import LIB_PATH, LrndeError  # noqa: F401  (raises if liblrnde.so is 
 from .layers import (Chain, Dense, Handle, NeuralODE, ODESolution, TDChain,  # noqa: F401
                      diffeqsol_to_array, diffeqsol_to_timeseries, flatten_params,
                      glorot_params)
+from .sde import NeuralDSDE, SdeHandle  # noqa: F401
 from .sharding import shard_columns, init_comm  # noqa: F401

@@ -56,6 +56,11 @@ SYMBOLS = [
     ("lrnde_comm_unique_id", C.c_int, [_vp]),
     ("lrnde_comm_init", C.c_int, [_vp, _vp, _i32, _i32]),
     ("lrnde_comm_destroy", C.c_int, [_vp]),
+    ("lrnde_sde_create", C.c_int, [C.POINTER(_vp), C.POINTER(ModelDesc), _i32, C.c_int, _vp]),
+    ("lrnde_sde_destroy", C.c_int, [_vp]),
+    ("lrnde_sde_last_error", C.c_char_p, [_vp]),
+    ("lrnde_sde_set_params", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
+    ("lrnde_sde_euler_heun_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _vp, _fp, _fp]),
     ("lrnde_bench_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _fp]),
     ("lrnde_last_solve_kernel_ms", C.c_int, [_vp, _fp, C.POINTER(_i32)]),
 ]

@@ -130,6 +130,13 @@ struct StepArgs {
   double* pinit_send;       // [2][...]  init phases 1 and 2
   const double* pinit_recv;
   lrnde_trace_row* trace;
+  // SDE Euler-Heun step (k_sde_step): second model = diffusion, Brownian increments, scratch
+  ModelDev m2;
+  const float* dW;
+  float delta;
+  float* sde_scratch;  // 9 arrays of n_local floats
+  const float* sde_uprev;
+  float* sde_u;
 };
 
 // ---------------------------------------------------------------------------
@@ -910,6 +917,13 @@ __device__ __forceinline__ void smem_init(const ModelDev& m, const Smem& s) {
   for (int i = threadIdx.x; i < m.Dp; i += NT) { s.bias[2 * m.Hp + i] = m.w2t[i]; s.bias[2 * m.Hp + m.Dp + i] = m.b2[i]; }
 }
 
+__device__ __forceinline__ void smem_init_bias_only(const ModelDev& m, const Smem& s) {
+  const int KG2p = ((m.KG2 + SEGK - 1) / SEGK) * SEGK;
+  for (int i = m.KG2 * 256 + threadIdx.x; i < KG2p * 256; i += NT) s.hl[i] = 0.f;  // padded k-groups
+  for (int i = threadIdx.x; i < m.Hp; i += NT) { s.bias[i] = m.w1t[i]; s.bias[m.Hp + i] = m.b1[i]; }
+  for (int i = threadIdx.x; i < m.Dp; i += NT) { s.bias[2 * m.Hp + i] = m.w2t[i]; s.bias[2 * m.Hp + m.Dp + i] = m.b2[i]; }
+}
+
 // du = f(u, t) for the whole batch (lrnde_rhs)
 template <int W> __global__ __launch_bounds__(NT) void k_rhs(StepArgs a, const float* u, float t, float* du) {
   STAMP(0);
@@ -1175,6 +1189,108 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Adaptive Euler-Heun SDE step with its error estimate, diagonal noise, supplied dW
+// (src/perform_step.jl:172-206, residual :214-216): 3 drift + 3 diffusion evaluations.
+// Drift = a.m (Chain(Dense, Dense)); diffusion = a.m2 (Dense(D=>D) held as identity-Dense + Dense,
+// which is the same canonical arithmetic).  Sizes are tiny (MNIST-SDE: 32 x B state), so this is a
+// latency kernel: one launch per step, 16 columns per workgroup, plain epilogues.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void sde_feval(const ModelDev& m, float ts, float* out, int b0, int nvalid) {
+  const Smem s = carve(m);
+  __syncthreads();
+  smem_init_bias_only(m, s);
+  __syncthreads();
+  FevalCtx fc;
+  feval_ctx_init(m, fc);
+  feval_store<W>(m, s, fc, ts, out, b0, nvalid);
+}
+
+template <int W> __global__ __launch_bounds__(NT) void k_sde_step(StepArgs a) {
+  const Smem s = carve(a.m);  // the x tile image depends only on D: shared by both models
+  const int b0 = blockIdx.x * NB, nvalid = min(NB, a.B - b0);
+  const size_t n = (size_t)a.n_local;
+  float *du1 = a.sde_scratch, *Kb = du1 + n, *L = du1 + 2 * n, *g2 = du1 + 3 * n, *f2 = du1 + 4 * n,
+        *du2 = du1 + 5 * n, *g3 = du1 + 6 * n;
+  const float* up = a.sde_uprev;
+  const float t = a.t0, dt = a.bench_dt;
+  const float sqdt = __builtin_sqrtf(dt);
+  // zero both h tiles' padded k-groups once (the larger model's extent covers both)
+  {
+    const int KG2a = ((a.m.KG2 + SEGK - 1) / SEGK) * SEGK, KG2b = ((a.m2.KG2 + SEGK - 1) / SEGK) * SEGK;
+    const int kmax = KG2a > KG2b ? KG2a : KG2b;
+    for (int i = threadIdx.x; i < kmax * 256; i += NT) s.hl[i] = 0.f;
+  }
+  auto fill = [&](auto&& fn) {
+    __syncthreads();
+    tile_foreach<W>(a.m, b0, nvalid, [&](int row, int nn, bool valid, size_t g) {
+      Vec<W> x = vzero<W>();
+      if (valid) x = fn(g);
+      lds_put<W>(s.xl, row, nn, x);
+    });
+    __syncthreads();
+  };
+  fill([&](size_t g) { return vload<W>(up + g); });
+  sde_feval<W>(a.m, t, du1, b0, nvalid);                      // :174 du1 = f(uprev, t)
+  sde_feval<W>(a.m2, t, L, b0, nvalid);                       // :176 L = g(uprev, t)   (x tile unchanged)
+  fill([&](size_t g) {                                        // :175,179,183 tmp = (uprev + dt*du1) + L*dW
+    const Vec<W> u = vload<W>(up + g), d = vload<W>(du1 + g), l = vload<W>(L + g), w = vload<W>(a.dW + g);
+    Vec<W> k, x;
+#pragma unroll
+    for (int h = 0; h < W; ++h) { k.v[h] = u.v[h] + dt * d.v[h]; x.v[h] = k.v[h] + l.v[h] * w.v[h]; }
+    vstore<W>(Kb + g, k);
+    return x;
+  });
+  sde_feval<W>(a.m2, t + dt, g2, b0, nvalid);                 // :184
+  sde_feval<W>(a.m, t + dt, f2, b0, nvalid);                  // :191
+  const float hdt = dt / 2.0f;
+  fill([&](size_t g) {                                        // :191 u ; x <- K
+    const Vec<W> u = vload<W>(up + g), d = vload<W>(du1 + g), l = vload<W>(L + g), w = vload<W>(a.dW + g),
+                 gg = vload<W>(g2 + g), ff = vload<W>(f2 + g);
+    Vec<W> un;
+#pragma unroll
+    for (int h = 0; h < W; ++h) {
+      const float gtmp2 = 0.5f * (l.v[h] + gg.v[h]);
+      const float noise2 = gtmp2 * w.v[h];
+      un.v[h] = (u.v[h] + hdt * (d.v[h] + ff.v[h])) + noise2;
+    }
+    vstore<W>(a.sde_u + g, un);
+    return vload<W>(Kb + g);
+  });
+  sde_feval<W>(a.m, t + dt, du2, b0, nvalid);                 // :193 du2 = f(K, t+dt)
+  fill([&](size_t g) {                                        // :196 utilde = uprev + L*sqdt
+    const Vec<W> u = vload<W>(up + g), l = vload<W>(L + g);
+    Vec<W> x;
+#pragma unroll
+    for (int h = 0; h < W; ++h) x.v[h] = u.v[h] + l.v[h] * sqdt;
+    return x;
+  });
+  sde_feval<W>(a.m2, t, g3, b0, nvalid);                      // :197
+  double acc = 0.0, z1 = 0.0, z2 = 0.0;
+  tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
+    if (!valid) return;
+    const Vec<W> u = vload<W>(up + g), un = vload<W>(a.sde_u + g), d1 = vload<W>(du1 + g), d2 = vload<W>(du2 + g),
+                 l = vload<W>(L + g), gg = vload<W>(g3 + g), w = vload<W>(a.dW + g);
+#pragma unroll
+    for (int h = 0; h < W; ++h) {
+      const float Ed = (dt * (d2.v[h] - d1.v[h])) / 2.0f;                       // :194
+      const float ggp = (gg.v[h] - l.v[h]) / sqdt;                              // :197
+      const float En = (ggp * (w.v[h] * w.v[h])) / 2.0f;                        // :198
+      const float sc = a.abstol + fmaxf_(__builtin_fabsf(u.v[h]), __builtin_fabsf(un.v[h])) * a.reltol;
+      const float r = (a.delta * Ed + En) / sc;                                 // :214-216
+      const float sq = r * r;
+      acc += (double)sq;
+    }
+  });
+  block_sum3(s.red, acc, z1, z2);
+  if (threadIdx.x == 0) {
+    double* p = a.part_send + ((size_t)a.nwg_global + a.wg_offset + blockIdx.x) * PSTRIDE;  // parity-1 slot
+    p[0] = acc; p[1] = 0.0; p[2] = 0.0;
+  }
+}
+
 #include "lrnde_qtile.hpp"
 
 // single-step modes: EEst and the two regularisation values from the partial sums
@@ -1206,6 +1322,20 @@ __global__ void k_ctrl_init(Ctrl* ctrl, float t0, float dt, int cur, int nsaved)
   c.t = t0; c.dt = dt; c.qold = 1e-4f; c.q11 = 1.0f; c.dtpropose = dt;
   ctrl[0] = c;
   ctrl[1] = c;
+}
+
+// Dense(D=>D) parameters [vec(Wg); bg] -> the 2-layer form [vec(I); 0; vec(Wg); bg] (identity first layer)
+__global__ void k_diff_expand(const float* pd, int D, int has_bias, float* p2) {
+  const size_t nI = (size_t)D * D;
+  const size_t total = 2 * nI + 2 * (size_t)D;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float v;
+    if (i < nI) v = ((i % D) == (i / D)) ? 1.0f : 0.0f;       // W1 = I (column-major)
+    else if (i < nI + D) v = 0.0f;                             // b1 = 0
+    else if (i < 2 * nI + D) v = pd[i - nI - D];               // W2 = Wg
+    else v = has_bias ? pd[nI + (i - 2 * nI - D)] : 0.0f;      // b2 = bg
+    p2[i] = v;
+  }
 }
 
 // flat Lux parameter vector -> MFMA A-fragment layout (zero padded)
@@ -1359,10 +1489,10 @@ int ensure_workspace(lrnde_ctx* c, int B) {
   return LRNDE_OK;
 }
 
-void fill_args(lrnde_ctx* c, StepArgs& a, int B) {
+void fill_args(lrnde_ctx* c, StepArgs& a, int B, int force_nb = 0) {
   memset(&a, 0, sizeof(a));
   const size_t n = (size_t)B * c->desc.state_dim;
-  const int nb = tile_nb(c, B);
+  const int nb = force_nb ? force_nb : tile_nb(c, B);
   const int nwg = (B + nb - 1) / nb;
   a.m = c->m;
   a.state = c->state; a.n_local = (long)n;
@@ -1457,6 +1587,8 @@ int set_smem_attr() {
   hipFuncSetAttribute((const void*)k_init1_q, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_init2_q, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_rhs_q, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_sde_step<4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_sde_step<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   done = true;
   return 0;
 }
@@ -1918,6 +2050,87 @@ int lrnde_bench_step(lrnde_ctx* c, const float* uprev, const float* k1, int32_t 
   float ms = 0.f;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   *avg_us_host = ms * 1000.0f / (float)reps;
+  return LRNDE_OK;
+}
+
+// ---- SDE (src/layers/neural_sde.jl, src/perform_step.jl:172-206) ----
+struct lrnde_sde {
+  lrnde_ctx* drift = nullptr;
+  lrnde_ctx* diff = nullptr;
+  float* p2 = nullptr;  // expanded diffusion parameters
+  int diff_bias = 1;
+};
+
+int lrnde_sde_create(lrnde_sde** out, const lrnde_model_desc* drift, int32_t diffusion_bias, int device, void* stream) {
+  if (!out || !drift) return LRNDE_BADARG;
+  *out = nullptr;
+  lrnde_sde* s = new lrnde_sde();
+  s->diff_bias = diffusion_bias ? 1 : 0;
+  int rc = lrnde_create(&s->drift, drift, device, stream);
+  if (rc) { delete s; return rc; }
+  lrnde_model_desc dd{drift->state_dim, drift->state_dim, 0, LRNDE_ACT_IDENTITY};
+  rc = lrnde_create(&s->diff, &dd, device, stream);
+  if (rc) { lrnde_destroy(s->drift); delete s; return rc; }
+  const size_t n2 = lrnde_param_count(&dd);
+  if (hipMalloc(&s->p2, sizeof(float) * n2) != hipSuccess) { lrnde_destroy(s->drift); lrnde_destroy(s->diff); delete s; return LRNDE_HIP_ERROR; }
+  *out = s;
+  return LRNDE_OK;
+}
+
+int lrnde_sde_destroy(lrnde_sde* s) {
+  if (!s) return LRNDE_OK;
+  lrnde_destroy(s->drift);
+  lrnde_destroy(s->diff);
+  if (s->p2) hipFree(s->p2);
+  delete s;
+  return LRNDE_OK;
+}
+
+const char* lrnde_sde_last_error(const lrnde_sde* s) { return s ? lrnde_last_error(s->drift) : "null sde handle"; }
+
+int lrnde_sde_set_params(lrnde_sde* s, const float* p_drift, size_t n_drift, const float* p_diff, size_t n_diff) {
+  if (!s || !p_drift || !p_diff) return LRNDE_BADARG;
+  const int D = s->drift->desc.state_dim;
+  if (n_diff != (size_t)D * D + (s->diff_bias ? D : 0))
+    return fail(s->drift, LRNDE_BADARG, "diffusion parameter count %zu != %zu", n_diff, (size_t)D * D + (s->diff_bias ? D : 0));
+  int rc = lrnde_set_params(s->drift, p_drift, n_drift);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_diff_expand, dim3(64), dim3(256), 0, s->diff->stream, p_diff, D, s->diff_bias, s->p2);
+  return lrnde_set_params(s->diff, s->p2, lrnde_param_count(&s->diff->desc));
+}
+
+int lrnde_sde_euler_heun_step(lrnde_sde* s, const float* uprev, const float* dW, int32_t B, float t, float dt,
+                              float abstol, float reltol, float delta, float* u, float* eest_host,
+                              float* reg_val_host) {
+  if (!s) return LRNDE_BADARG;
+  lrnde_ctx* c = s->drift;
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!s->diff->have_params) return fail(c, LRNDE_BADARG, "lrnde_sde_set_params has not been called");
+  if (!uprev || !dW || !u) return fail(c, LRNDE_BADARG, "null pointer");
+  if (!(dt > 0.f)) return fail(c, LRNDE_BADARG, "dt must be positive");
+  if ((rc = ensure_workspace(c, B))) return rc;
+  StepArgs a;
+  fill_args(c, a, B, NB);
+  a.m2 = s->diff->m;
+  a.t0 = t; a.bench_dt = dt; a.abstol = abstol; a.reltol = reltol; a.delta = delta;
+  a.dW = dW; a.sde_scratch = c->state; a.sde_uprev = uprev; a.sde_u = u;
+  const int nwg = (B + NB - 1) / NB;
+  size_t sm = smem_bytes(c->m.Dp, c->m.Hp);
+  const size_t sm2 = smem_bytes(s->diff->m.Dp, s->diff->m.Hp);
+  if (sm2 > sm) sm = sm2;
+  hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t, dt, 0, 0);
+  if (vecw(c) == 4) hipLaunchKernelGGL(k_sde_step<4>, dim3(nwg), dim3(NT), sm, c->stream, a);
+  else hipLaunchKernelGGL(k_sde_step<1>, dim3(nwg), dim3(NT), sm, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
+  if ((rc = exchange(c, c->part + cnt, c->part_rx + cnt, cnt))) return rc;
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, a, 1);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->ctrl_host, c->ctrl + 1, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (eest_host) *eest_host = c->ctrl_host[0].eest_last;
+  if (reg_val_host) *reg_val_host = c->ctrl_host[0].reg_error;  // EEst * dt (src/perform_step.jl:205)
   return LRNDE_OK;
 }
 

@@ -1,0 +1,135 @@
+"""NeuralDSDE mirror (src/layers/neural_sde.jl) on the liblrnde SDE entry points.
+
+What is built: the adaptive Euler-Heun local step with its error estimate
+(`_perform_step(::LambaEulerHeunConstantCache)`, src/perform_step.jl:172-206) on the device, and a
+NeuralDSDE-shaped forward that integrates with that step on a FIXED grid with caller-visible
+Brownian increments (BASELINE config 5).  Not built: the reference's default SOSRI solver with
+RSWM adaptive noise (un-vendored StochasticDiffEq) — `solver="SOSRI"` raises.
+"""
+import copy
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .layers import (Chain, Dense, ODESolution, _check_valid_regularize, _dev_ptr, _mlp_desc, _sym)
+
+
+class SdeHandle:
+    def __init__(self, drift_desc, diffusion_bias=True, device=None, stream=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("liblrnde needs a GPU (gfx950); there is no CPU fallback")
+        self.D = drift_desc.state_dim
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self._stream = torch.cuda.current_stream(self.device) if stream is None else stream
+        self._h = C.c_void_p()
+        rc = L.lib.lrnde_sde_create(C.byref(self._h), C.byref(drift_desc), int(bool(diffusion_bias)), self.device,
+                                    C.c_void_p(self._stream.cuda_stream))
+        if rc != 0:
+            raise L.LrndeError(rc, "lrnde_sde_create failed")
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib.lrnde_sde_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = L.lib.lrnde_sde_last_error(self._h)
+            raise L.LrndeError(rc, msg.decode() if msg else "")
+
+    def set_params(self, p_drift, p_diffusion):
+        dev = f"cuda:{self.device}"
+        pd = torch.as_tensor(p_drift, dtype=torch.float32).to(dev).contiguous().reshape(-1)
+        pg = torch.as_tensor(p_diffusion, dtype=torch.float32).to(dev).contiguous().reshape(-1)
+        self._keep = (pd, pg)
+        self._chk(L.lib.lrnde_sde_set_params(self._h, C.c_void_p(pd.data_ptr()), pd.numel(),
+                                             C.c_void_p(pg.data_ptr()), pg.numel()))
+
+    def euler_heun_step(self, uprev, dW, t, dt, abstol, reltol, delta):
+        B = uprev.numel() // self.D
+        u = torch.empty_like(uprev)
+        ee, rv = C.c_float(), C.c_float()
+        self._chk(L.lib.lrnde_sde_euler_heun_step(self._h, _dev_ptr(uprev, "uprev", self.D), _dev_ptr(dW, "dW", self.D),
+                                                  B, float(t), float(dt), float(abstol), float(reltol), float(delta),
+                                                  _dev_ptr(u, "u"), C.byref(ee), C.byref(rv)))
+        return dict(u=u, eest=np.float32(ee.value), reg_val=np.float32(rv.value))
+
+
+class NeuralDSDE:
+    """`(sol, st) = nsde(x, ps, st)`; ps = dict(drift=flat, diffusion=[vec(Wg); bg]).
+    src/layers/neural_sde.jl:1-123 with a fixed-grid Euler-Heun integrator (see module docstring)."""
+
+    def __init__(self, drift, diffusion, *, solver="EulerHeun", sensealg=None, tspan=(0.0, 1.0),
+                 regularize="unbiased", maxiters=1000, nsteps=20, delta=1.0 / 6.0, **kwargs):
+        regularize = _sym(regularize)
+        _check_valid_regularize(regularize)
+        if solver not in ("EulerHeun", "LambaEulerHeun"):
+            raise NotImplementedError("only the Euler-Heun step (src/perform_step.jl:172-206) is on the device")
+        if not isinstance(diffusion, Dense) or diffusion.in_dims != diffusion.out_dims:
+            raise NotImplementedError("diffusion must be Dense(D => D) (experiments/src/construct.jl:205)")
+        self.drift, self.diffusion = drift, diffusion
+        self.desc = _mlp_desc(drift if isinstance(drift, Chain) else drift)
+        if self.desc.state_dim != diffusion.in_dims:
+            raise ValueError("drift and diffusion state sizes differ")
+        self.tspan = (np.float32(tspan[0]), np.float32(tspan[1]))
+        self.regularize, self.maxiters, self.nsteps, self.delta = regularize, int(maxiters), int(nsteps), float(delta)
+        self.kwargs = dict(kwargs)
+        self._handle = None
+
+    def initialstates(self, rng):
+        rng.standard_normal()  # :23
+        return dict(drift={}, diffusion={}, nfe_drift=-1, nfe_diffusion=-1, reg_val=np.float32(0.0),
+                    rng=copy.deepcopy(rng), training=True)
+
+    def handle(self):
+        if self._handle is None:
+            self._handle = SdeHandle(self.desc)
+        return self._handle
+
+    def __call__(self, x, ps, st, noise=None):
+        h = self.handle()
+        h.set_params(ps["drift"], ps["diffusion"])
+        t0, t2 = self.tspan
+        abstol, reltol = self.kwargs.get("abstol", 1e-2), self.kwargs.get("reltol", 1e-2)
+        n = self.nsteps
+        dt = np.float32((t2 - t0) / np.float32(n))
+        rng = copy.deepcopy(st["rng"])
+        if noise is None:  # W.dW ~ sqrt(dt) N(0,1), drawn on the host stream
+            noise = (rng.standard_normal((n + 1,) + tuple(x.shape)).astype(np.float32) * np.float32(np.sqrt(dt)))
+        noise = torch.as_tensor(noise, dtype=torch.float32).to(x.device)
+        us, ts = [], []
+        u, t = x, t0
+        for i in range(n):
+            r = h.euler_heun_step(u, noise[i].contiguous(), t, dt, abstol, reltol, self.delta)
+            u = r["u"]
+            t = np.float32(t0 + np.float32(i + 1) * dt) if i + 1 < n else t2
+            us.append(u); ts.append(t)
+        nfe = 3 * n
+        mode = self.regularize if st["training"] else "none"
+        reg_val = np.float32(0.0)
+        if mode != "none":
+            if mode == "unbiased":  # :88-105: t1 uniform in (t0,t2); sol(t1) by linear interpolation
+                t1 = np.float32(rng.random(dtype=np.float32) * (t2 - t0) + t0)
+                j = min(int((t1 - t0) / dt), n - 1)
+                ta = t0 if j == 0 else ts[j - 1]
+                ua = x if j == 0 else us[j - 1]
+                th = np.float32((t1 - ta) / (ts[j] - ta))
+                u1 = (ua + th * (us[j] - ua)).contiguous()
+            else:  # :109-123: a saved time other than the last
+                j = int(rng.integers(0, max(n - 1, 1)))
+                t1, u1 = ts[j], us[j]
+            r = h.euler_heun_step(u1, noise[n].contiguous(), t1, dt, abstol, reltol, self.delta)  # :98,118
+            reg_val = r["reg_val"]
+            nfe += 3
+        sol = ODESolution([us[-1]], [t2], nfe)
+        return sol, dict(drift=st["drift"], diffusion=st["diffusion"], nfe_drift=nfe, nfe_diffusion=nfe,
+                         reg_val=reg_val, rng=rng, training=st["training"])

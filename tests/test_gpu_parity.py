@@ -129,3 +129,64 @@ def test_node_forward_bit_exact(oracle, gpu_pkg, mode, reg_type):
     else:
         assert got["reg_val"] != 0.0
     _eq(got["u_end"].cpu().numpy(), ref["u_end"], "sol.u[end]")
+
+
+def _sde_fields(O, D, H, seed=0):
+    rng = np.random.default_rng(seed)
+    pd = O.glorot_mlp_params(D, H, time_dep=False, seed=seed) + rng.standard_normal(O.lib().lro_mlp_param_count(D, H, 0)).astype(np.float32) * np.float32(0.02)
+    Wg = ((rng.random((D, D), dtype=np.float32) - np.float32(0.5)) * np.float32(0.6)).astype(np.float32)   # (in,out) = column-major out x in
+    bg = (rng.standard_normal(D) * 0.05).astype(np.float32)
+    pg = np.concatenate([Wg.ravel(), bg])
+    # Dense(D=>D) held as identity-Dense followed by Dense: the same canonical arithmetic
+    p2 = np.concatenate([np.eye(D, dtype=np.float32).ravel(), np.zeros(D, np.float32), Wg.ravel(), bg])
+    drift = O.MlpField(D, H, pd, time_dep=False, act="tanh", nthreads=4)
+    diff = O.MlpField(D, D, p2, time_dep=False, act="identity", nthreads=4)
+    return pd, pg, drift, diff
+
+
+@pytest.mark.parametrize("D,H,B", [(32, 64, 512), (32, 64, 37), (16, 16, 5)])
+def test_sde_euler_heun_step_bit_exact(oracle, gpu_pkg, D, H, B):
+    """src/perform_step.jl:172-206 — MNIST-SDE shapes (experiments/src/construct.jl:204-205)."""
+    import torch
+    from localregneuralde_jl_amd.layers import _mlp_desc
+    pd, pg, drift, diff = _sde_fields(oracle, D, H)
+    rng = np.random.default_rng(7)
+    u = rng.standard_normal((B, D)).astype(np.float32)
+    dt = np.float32(0.05)
+    dW = (rng.standard_normal((B, D)) * np.sqrt(dt)).astype(np.float32)
+    ref = oracle.euler_heun_step(drift, diff, u, dW, 0.2, dt, 0.14, 0.14, 1.0 / 6.0)
+    h = gpu_pkg.SdeHandle(_mlp_desc(gpu_pkg.Chain(gpu_pkg.Dense(D, H, "tanh"), gpu_pkg.Dense(H, D))))
+    h.set_params(pd, pg)
+    got = h.euler_heun_step(torch.from_numpy(u).cuda(), torch.from_numpy(dW).cuda(), 0.2, dt, 0.14, 0.14, 1.0 / 6.0)
+    _eq(got["u"].cpu().numpy(), ref["u"], "u")
+    assert got["eest"] == ref["eest"] and got["reg_val"] == ref["reg_val"], (got, ref["eest"], ref["reg_val"])
+
+
+def test_neural_dsde_forward_behaviour(oracle, gpu_pkg):
+    """NeuralDSDE mirror: reg_val is zero iff regularize == :none / test mode (test/runtests.jl:340-433
+    assert exactly this plus finiteness); the fixed-grid solve equals the same loop over the oracle step."""
+    import torch
+    D, H, B, n = 32, 64, 24, 6
+    pd, pg, drift, diff = _sde_fields(oracle, D, H, seed=3)
+    x = np.random.default_rng(1).standard_normal((B, D)).astype(np.float32)
+    mk = lambda reg: gpu_pkg.NeuralDSDE(gpu_pkg.Chain(gpu_pkg.Dense(D, H, "tanh"), gpu_pkg.Dense(H, D)), gpu_pkg.Dense(D, D),
+                                        regularize=reg, nsteps=n, abstol=0.14, reltol=0.14)
+    noise = (np.random.default_rng(2).standard_normal((n + 1, B, D)) * np.sqrt(1.0 / n)).astype(np.float32)
+    ps = dict(drift=pd, diffusion=pg)
+    outs = {}
+    for reg in ("none", "unbiased", "biased"):
+        node = mk(reg)
+        st = node.initialstates(np.random.default_rng(0))
+        sol, st2 = node(torch.from_numpy(x).cuda(), ps, st, noise=noise)
+        outs[reg] = (gpu_pkg.diffeqsol_to_array(sol).cpu().numpy(), st2)
+        assert np.isfinite(outs[reg][0]).all()
+        assert (st2["reg_val"] == 0) == (reg == "none")
+        assert st2["nfe_drift"] == 3 * n + (0 if reg == "none" else 3)
+    # same loop over the oracle's step
+    u, dt = x, np.float32(np.float32(1.0) / np.float32(n))
+    for i in range(n):
+        t = np.float32(0.0) if i == 0 else np.float32(np.float32(i) * dt)
+        u = oracle.euler_heun_step(drift, diff, u, noise[i], t, dt, 0.14, 0.14, 1.0 / 6.0)["u"]
+    _eq(outs["none"][0], u, "NeuralDSDE end state")
+    with pytest.raises(NotImplementedError):
+        gpu_pkg.NeuralDSDE(gpu_pkg.Chain(gpu_pkg.Dense(D, H), gpu_pkg.Dense(H, D)), gpu_pkg.Dense(D, D), solver="SOSRI")
