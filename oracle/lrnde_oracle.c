@@ -477,6 +477,46 @@ static float eps_f(float x) { /* Julia eps(::Float32) via bit ops (same code on 
 int lro_solve(const lro_field* f, const float* u0, int B, float t0, float t1, const lro_opts* o,
               const float* saveat, int nsave, float* u_saved, float* t_saved, int cap_saved,
               lro_stats* st, lro_trace_row* trace, int cap_trace) {
+  return lro_solve_ex(f, u0, B, t0, t1, o, saveat, nsave, u_saved, t_saved, cap_saved, st, trace, cap_trace,
+                      NULL, 0, NULL);
+}
+
+/* dense recorder: per accepted step t, dt, uprev and k1..k7 (what InterpolatingAdjoint keeps) */
+static int dense_push(lro_dense* d, float t, float dt, const float* uprev, const float* const k[7]) {
+  if (d->nsteps >= d->cap) {
+    int nc = d->cap ? 2 * d->cap : 64;
+    d->t = (float*)realloc(d->t, sizeof(float) * nc);
+    d->dt = (float*)realloc(d->dt, sizeof(float) * nc);
+    d->data = (float*)realloc(d->data, sizeof(float) * (size_t)nc * 8 * d->n);
+    if (!d->t || !d->dt || !d->data) return LRO_CAPACITY;
+    d->cap = nc;
+  }
+  float* dst = d->data + (size_t)d->nsteps * 8 * d->n;
+  memcpy(dst, uprev, sizeof(float) * d->n);
+  for (int j = 0; j < 7; ++j) memcpy(dst + (size_t)(1 + j) * d->n, k[j], sizeof(float) * d->n);
+  d->t[d->nsteps] = t; d->dt[d->nsteps] = dt;
+  d->nsteps++;
+  return LRO_OK;
+}
+void lro_dense_free(lro_dense* d) { free(d->t); free(d->dt); free(d->data); memset(d, 0, sizeof(*d)); }
+
+/* u(t) from the recorded steps (Tsit5 interpolant of the step containing t) */
+void lro_dense_eval(const lro_dense* d, float t, float* out) {
+  int lo = 0, hi = d->nsteps - 1;
+  while (lo < hi) { int mid = (lo + hi + 1) / 2; if (d->t[mid] <= t) lo = mid; else hi = mid - 1; }
+  const float* base = d->data + (size_t)lo * 8 * d->n;
+  const float* kk[7];
+  for (int j = 0; j < 7; ++j) kk[j] = base + (size_t)(1 + j) * d->n;
+  const float theta = (t - d->t[lo]) / d->dt[lo];
+  lro_tsit5_interp(theta, d->dt[lo], base, kk, d->n, out);
+}
+
+/* tstops: ascending times strictly inside (t0,t1) the integrator must hit exactly
+ * (the discrete cotangent times of the adjoint solve); dense: optional recorder */
+int lro_solve_ex(const lro_field* f, const float* u0, int B, float t0, float t1, const lro_opts* o,
+                 const float* saveat, int nsave, float* u_saved, float* t_saved, int cap_saved,
+                 lro_stats* st, lro_trace_row* trace, int cap_trace, const float* tstops, int ntstops,
+                 lro_dense* dense) {
   const long n = (long)f->D * B;
   const float abstol = o->abstol, reltol = o->reltol;
   const float gamma = 0.9f, qmin = 0.2f, qmax = 10.0f, qoldinit = 1e-4f;
@@ -516,8 +556,13 @@ int lro_solve(const lro_field* f, const float* u0, int B, float t0, float t1, co
   int accept = 0, iter = 0;
   if (o->save_start) PUSH_SAVE(t0, u0);
   while (isave < nsave && saveat[isave] <= t0) isave++; /* points at/before t0 are the start */
+  int istop = 0;
+  while (istop < ntstops && tstops[istop] <= t0) istop++;
+  if (dense) { dense->n = n; }
 
   while (t < t1) {
+    while (istop < ntstops && tstops[istop] <= t) istop++;      /* handle_tstop!: pop reached stops */
+    const float tstop = (istop < ntstops && tstops[istop] < t1) ? tstops[istop] : t1;
     /* loopheader! */
     if (iter > 0) {
       if (accept) {
@@ -531,7 +576,7 @@ int lro_solve(const lro_field* f, const float* u0, int B, float t0, float t1, co
     iter++;
     dt = fminf(dtmax, dt);
     dt = fmaxf(dt, dtmin);
-    dt = fminf(fabsf(dt), fabsf(t1 - t));
+    dt = fminf(fabsf(dt), fabsf(tstop - t));
     /* check_error! */
     if (iter > o->maxiters) { rc = LRO_MAXITERS; break; }
     if (dt != dt) { rc = LRO_DT_NAN; break; }
@@ -567,8 +612,12 @@ int lro_solve(const lro_field* f, const float* u0, int B, float t0, float t1, co
       float dtnew = dt / q;
       qold = fmaxf(eest, qoldinit);
       float tprev = t;
-      t = (fabsf(ttmp - t1) < 100.0f * eps_f(fmaxf(t, t1))) ? t1 : ttmp;
+      t = (fabsf(ttmp - tstop) < 100.0f * eps_f(fmaxf(t, tstop))) ? tstop : ttmp;
       dtpropose = fmaxf(fminf(dtmax, dtnew), fmaxf(eps_f(t), dtmin));
+      if (dense) {
+        const float* kk7[7] = {k1, ks, ks + n, ks + 2 * n, ks + 3 * n, ks + 4 * n, k7};
+        if ((rc = dense_push(dense, tprev, dt, uprev, kk7)) != LRO_OK) goto done;
+      }
       /* savevalues! */
       while (isave < nsave && saveat[isave] <= t) {
         float ts = saveat[isave++];
@@ -711,4 +760,285 @@ int lro_euler_heun_step(const lro_field* fd, const lro_field* gd, const float* u
   if (reg_val) *reg_val = ee * dt;                                 /* :205 */
   free(w);
   return LRO_OK;
+}
+
+/* ========================================================================= */
+/* Backward pass: continuous adjoint of the solve            */
+/* (SciMLSensitivity InterpolatingAdjoint(autojacvec=ZygoteVJP()), un-vendored) */
+/* and the reverse sweep of the local regularisation step                      */
+/* (Zygote through src/perform_step.jl:3-47 with k1, dt, uprev constant —      */
+/* src/layers/neural_ode.jl:40, src/utils.jl:60).                              */
+/* ========================================================================= */
+
+static float act_deriv(int act, float pre, float h) {
+  if (act == LRO_ACT_TANH) return 1.0f - h * h;
+  if (act == LRO_ACT_GELU) { /* d/dx [x * sigmoid(a)], a = 2*lambda*x*(1 + 0.044715 x^2) */
+    const float two_lambda = 1.5957691216057308f;
+    float x2 = pre * pre;
+    float a = (two_lambda * pre) * fmaf(x2, 0.044715f, 1.0f);
+    float sg = 1.0f / (1.0f + lro_expf(-a));
+    float da = two_lambda * fmaf(x2, 3.0f * 0.044715f, 1.0f);
+    return sg + pre * sg * (1.0f - sg) * da;
+  }
+  return 1.0f;
+}
+
+/* hidden pre-activation with the canonical dot product (same as lro_mlp_rhs layer 1) */
+static void mlp_hidden_pre(const lro_mlp* m, const float* x, float t, float* pre, float* tmp) {
+  const int D = m->D, H = m->H, td = m->time_dep ? 1 : 0;
+  const float* W1 = m->p;
+  const float* b1 = W1 + (size_t)H * (D + td);
+  for (int o = 0; o < H; ++o) pre[o] = 0.0f;
+  for (int k0 = 0; k0 < D; k0 += LRO_KSEG) {
+    const int k1 = (k0 + LRO_KSEG < D) ? k0 + LRO_KSEG : D;
+    for (int o = 0; o < H; ++o) tmp[o] = 0.0f;
+    for (int k = k0; k < k1; ++k) {
+      const float* w = W1 + (size_t)k * H;
+      for (int o = 0; o < H; ++o) tmp[o] = fmaf(w[o], x[k], tmp[o]);
+    }
+    if (k0 == 0) for (int o = 0; o < H; ++o) pre[o] = tmp[o];
+    else for (int o = 0; o < H; ++o) pre[o] = pre[o] + tmp[o];
+  }
+  if (td) { const float* w = W1 + (size_t)D * H; for (int o = 0; o < H; ++o) pre[o] = fmaf(w[o], t, pre[o]); }
+  for (int o = 0; o < H; ++o) pre[o] = pre[o] + b1[o];
+}
+
+/* dy = (df/dy)^T lam  (B x D);  gp += (df/dp)^T lam  (flat Lux layout; gp may be NULL) */
+void lro_mlp_vjp(const lro_mlp* m, const float* y, float t, const float* lam, int B, float* dy, float* gp) {
+  const int D = m->D, H = m->H, td = m->time_dep ? 1 : 0;
+  const float* W1 = m->p;
+  const float* W2 = W1 + (size_t)H * (D + td) + H;
+  const size_t oW1 = 0, ob1 = (size_t)H * (D + td), oW2 = ob1 + H, ob2 = oW2 + (size_t)D * (H + td);
+  const int P = lro_mlp_param_count(D, H, td);
+  int nth = m->nthreads > 0 ? m->nthreads : 1;
+  float* gpt = gp ? (float*)calloc((size_t)nth * P, sizeof(float)) : NULL;
+#pragma omp parallel num_threads(nth)
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    float* g = gpt ? gpt + (size_t)tid * P : NULL;
+    float* pre = (float*)malloc(sizeof(float) * 4 * (size_t)H);
+    float *tmp = pre + H, *h = pre + 2 * H, *dpre = pre + 3 * H;
+#pragma omp for schedule(static)
+    for (int n = 0; n < B; ++n) {
+      const float* yy = y + (size_t)n * D;
+      const float* ll = lam + (size_t)n * D;
+      float* dd = dy + (size_t)n * D;
+      mlp_hidden_pre(m, yy, t, pre, tmp);
+      for (int o = 0; o < H; ++o) h[o] = act_apply(m->act, pre[o]);
+      /* dh = W2[:, :H]^T lam ; dpre = dh .* act'(pre) */
+      for (int o = 0; o < H; ++o) {
+        const float* w = W2 + (size_t)o * D;
+        float acc = 0.0f;
+        for (int i = 0; i < D; ++i) acc = fmaf(w[i], ll[i], acc);
+        dpre[o] = acc * act_deriv(m->act, pre[o], h[o]);
+      }
+      /* dy = W1[:, :D]^T dpre */
+      for (int k = 0; k < D; ++k) {
+        const float* w = W1 + (size_t)k * H;
+        float acc = 0.0f;
+        for (int o = 0; o < H; ++o) acc = fmaf(w[o], dpre[o], acc);
+        dd[k] = acc;
+      }
+      if (g) {
+        for (int k = 0; k < H; ++k) { float* gw = g + oW2 + (size_t)k * D; const float hv = h[k];
+          for (int i = 0; i < D; ++i) gw[i] = fmaf(ll[i], hv, gw[i]); }
+        if (td) { float* gw = g + oW2 + (size_t)H * D; for (int i = 0; i < D; ++i) gw[i] = fmaf(ll[i], t, gw[i]); }
+        for (int i = 0; i < D; ++i) g[ob2 + i] += ll[i];
+        for (int k = 0; k < D; ++k) { float* gw = g + oW1 + (size_t)k * H; const float yv = yy[k];
+          for (int o = 0; o < H; ++o) gw[o] = fmaf(dpre[o], yv, gw[o]); }
+        if (td) { float* gw = g + oW1 + (size_t)D * H; for (int o = 0; o < H; ++o) gw[o] = fmaf(dpre[o], t, gw[o]); }
+        for (int o = 0; o < H; ++o) g[ob1 + o] += dpre[o];
+      }
+    }
+    free(pre);
+  }
+  if (gp) {
+    for (int th = 0; th < nth; ++th)
+      for (int i = 0; i < P; ++i) gp[i] += gpt[(size_t)th * P + i];
+    free(gpt);
+  }
+}
+
+/* adjoint field in reversed time s = -t:  z = [lambda (n); mu (P)],  dz/ds = [J^T lambda; (df/dp)^T lambda] at y(t) */
+typedef struct { const lro_mlp* m; const lro_dense* dense; int B; long n; int P; float* y; } adj_ctx;
+static void adjoint_field(void* vctx, const float* z, float s, int B1, float* dz) {
+  (void)B1;
+  adj_ctx* c = (adj_ctx*)vctx;
+  const float t = -s;
+  lro_dense_eval(c->dense, t, c->y);
+  memset(dz + c->n, 0, sizeof(float) * (size_t)c->P);
+  lro_mlp_vjp(c->m, c->y, t, z, c->B, dz, dz + c->n);
+}
+
+/* gradient of the local regularisation value w.r.t. p (reverse sweep through one Tsit5 step) */
+int lro_tsit5_step_reg_grad(const lro_mlp* m, const float* uprev, const float* k1, float t, float dt,
+                            float abstol, float reltol, int B, int reg_type, float* gp, float* reg_val) {
+  const int D = m->D;
+  const long n = (long)D * B;
+  const int P = lro_mlp_param_count(m->D, m->H, m->time_dep ? 1 : 0);
+  lro_field f; lro_mlp_as_field(m, &f);
+  float A[21], BT[7];
+  for (int i = 0; i < 21; ++i) A[i] = (float)TS_A[i];
+  for (int i = 0; i < 7; ++i) BT[i] = (float)TS_BT[i];
+  const float cs[6] = {(float)TS_C[0], (float)TS_C[1], (float)TS_C[2], (float)TS_C[3], 1.0f, 1.0f};
+  /* forward, keeping stage inputs x2..x7 (x7 = u) and k2..k7 */
+  float* xs = (float*)malloc(sizeof(float) * 6 * (size_t)n);   /* x2..x7 */
+  float* kk = (float*)malloc(sizeof(float) * 7 * (size_t)n);   /* k1..k7 */
+  memcpy(kk, k1, sizeof(float) * n);
+  for (int s = 2; s <= 7; ++s) {
+    float* x = xs + (size_t)(s - 2) * n;
+    const int off = (s - 2) * (s - 1) / 2;
+    for (long i = 0; i < n; ++i) {
+      float v;
+      if (s == 2) { const float a = dt * A[0]; v = uprev[i] + a * kk[i]; }
+      else { float sum = A[off] * kk[i] + A[off + 1] * kk[n + i];
+             for (int j = 2; j < s - 1; ++j) sum = sum + A[off + j] * kk[(size_t)j * n + i];
+             v = uprev[i] + dt * sum; }
+      x[i] = v;
+    }
+    f.fn(f.ctx, x, t + cs[s - 2] * dt, B, kk + (size_t)(s - 1) * n);
+  }
+  const float* u = xs + 5 * (size_t)n; const float* g6 = xs + 4 * (size_t)n;
+  const float* k6 = kk + 5 * (size_t)n; const float* k7 = kk + 6 * (size_t)n;
+  /* cotangents */
+  float* kb = (float*)calloc(7 * (size_t)n, sizeof(float));    /* kbar_1..7 (kbar_1 unused: constant) */
+  float* ub = (float*)calloc((size_t)n, sizeof(float));
+  float* g6b = (float*)calloc((size_t)n, sizeof(float));
+  float rv;
+  if (reg_type == LRO_REG_ERROR_ESTIMATE) {
+    double acc = 0.0;
+    float* ut = (float*)malloc(sizeof(float) * (size_t)n);
+    for (long i = 0; i < n; ++i) {
+      float sum = BT[0] * kk[i] + BT[1] * kk[n + i];
+      for (int j = 2; j < 7; ++j) sum = sum + BT[j] * kk[(size_t)j * n + i];
+      ut[i] = dt * sum;
+      const float sc = abstol + fmaxf(fabsf(uprev[i]), fabsf(u[i])) * reltol;
+      const float r = ut[i] / sc; acc += (double)(r * r);
+    }
+    const float ee = rms_from_sumsq(acc, n);
+    rv = ee * dt;
+    /* d(ee*dt)/dr_i = dt * r_i / (n * ee) */
+    for (long i = 0; i < n; ++i) {
+      const float sc = abstol + fmaxf(fabsf(uprev[i]), fabsf(u[i])) * reltol;
+      const float r = ut[i] / sc;
+      const float rb = (ee > 0.0f) ? dt * r / ((float)n * ee) : 0.0f;
+      const float utb = rb / sc;
+      const float scb = -rb * ut[i] / (sc * sc);
+      if (fabsf(u[i]) > fabsf(uprev[i])) ub[i] += scb * reltol * (u[i] >= 0.0f ? 1.0f : -1.0f);
+      for (int j = 1; j < 7; ++j) kb[(size_t)j * n + i] += dt * BT[j] * utb;
+    }
+    free(ut);
+  } else {
+    const double sd = sumsq_diff(u, g6, n), sn = sumsq_diff(k7, k6, n);
+    const float den = rms_from_sumsq(sd, n), num = rms_from_sumsq(sn, n);
+    if (den == 0.0f) { rv = 0.0f; }
+    else {
+      const float eps = 1.1920929e-7f;
+      const float qv = num / (den + eps);
+      rv = fabsf(qv) / 3.5068f;
+      const float sgn = (qv >= 0.0f ? 1.0f : -1.0f) / 3.5068f;
+      const float numb = sgn / (den + eps), denb = -sgn * num / ((den + eps) * (den + eps));
+      for (long i = 0; i < n; ++i) {
+        const float dk = k7[i] - k6[i], du_ = u[i] - g6[i];
+        const float a = (num > 0.0f) ? numb * dk / ((float)n * num) : 0.0f;
+        const float b = denb * du_ / ((float)n * den);
+        kb[6 * (size_t)n + i] += a; kb[5 * (size_t)n + i] -= a;
+        ub[i] += b; g6b[i] -= b;
+      }
+    }
+  }
+  memset(gp, 0, sizeof(float) * (size_t)P);
+  float* xb = (float*)malloc(sizeof(float) * (size_t)n);
+  /* reverse through stages 7..2: k_s = f(x_s); x_s = uprev + dt * sum_{j<s} a_sj k_j */
+  for (int s = 7; s >= 2; --s) {
+    const float* x = xs + (size_t)(s - 2) * n;
+    lro_mlp_vjp(m, x, t + cs[s - 2] * dt, kb + (size_t)(s - 1) * n, B, xb, gp);
+    if (s == 7) for (long i = 0; i < n; ++i) xb[i] += ub[i];
+    if (s == 6) for (long i = 0; i < n; ++i) xb[i] += g6b[i];
+    const int off = (s - 2) * (s - 1) / 2;
+    for (int j = 1; j < s - 1; ++j)  /* k_{j+1}, j = 0 is the constant k1 */
+      for (long i = 0; i < n; ++i) kb[(size_t)j * n + i] += dt * A[off + j] * xb[i];
+    if (s == 7) { /* u also feeds the next accumulation: xbar_7 already includes ub */ }
+  }
+  if (reg_val) *reg_val = rv;
+  free(xb); free(g6b); free(ub); free(kb); free(kk); free(xs);
+  return LRO_OK;
+}
+
+/* full backward of `loss = <du_end, sol.u[end]> + w_reg * reg_val` for the NeuralODE layer */
+int lro_node_backward(const lro_mlp* m, const float* x, int B, float t0, float t2, const lro_opts* o, int mode,
+                      int reg_type, float t1_or_rand, const float* du_end, float w_reg, float* dx, float* dp,
+                      lro_stats* st_fwd, lro_stats* st_bwd) {
+  const int D = m->D;
+  const long n = (long)D * B;
+  const int P = lro_mlp_param_count(m->D, m->H, m->time_dep ? 1 : 0);
+  lro_field f; lro_mlp_as_field(m, &f);
+  lro_opts oo = *o;
+  lro_dense dense; memset(&dense, 0, sizeof(dense));
+  int rc;
+  /* forward re-solve with dense storage (what the adjoint interpolates) */
+  float t1 = t2;
+  float* u1 = (float*)malloc(sizeof(float) * (size_t)n);
+  float* tst = NULL; int ntst = 0;
+  if (mode == LRO_MODE_BIASED) {
+    oo.save_everystep = 1;
+    int cap = oo.maxiters + 2; if (cap > 4096) cap = 4096;
+    float* us = (float*)malloc(sizeof(float) * (size_t)n * cap);
+    float* ts = (float*)malloc(sizeof(float) * (size_t)cap);
+    rc = lro_solve_ex(&f, x, B, t0, t2, &oo, NULL, 0, us, ts, cap, st_fwd, NULL, 0, NULL, 0, &dense);
+    if (rc == LRO_OK && st_fwd->nsaved >= 2) {
+      const int mm = st_fwd->nsaved - 1;
+      int idx = (int)(t1_or_rand * (float)mm); if (idx >= mm) idx = mm - 1; if (idx < 0) idx = 0;
+      t1 = ts[idx]; memcpy(u1, us + (size_t)idx * n, sizeof(float) * n);
+      ntst = st_fwd->nsaved - 1;                         /* every saved time is a cotangent time */
+      tst = (float*)malloc(sizeof(float) * (size_t)(ntst > 0 ? ntst : 1));
+      for (int i = 0; i < ntst; ++i) tst[i] = ts[i];
+    } else if (rc == LRO_OK) rc = LRO_BADARG;
+    free(us); free(ts);
+  } else {
+    float sv[2]; int nsv;
+    if (mode == LRO_MODE_UNBIASED) { t1 = t1_or_rand; sv[0] = t1; sv[1] = t2; nsv = 2; }
+    else { sv[0] = t2; nsv = 1; }
+    float ts[3]; float* us = (float*)malloc(sizeof(float) * (size_t)n * 3);
+    oo.save_everystep = 0;
+    rc = lro_solve_ex(&f, x, B, t0, t2, &oo, sv, nsv, us, ts, 3, st_fwd, NULL, 0, NULL, 0, &dense);
+    if (rc == LRO_OK && mode == LRO_MODE_UNBIASED) {
+      memcpy(u1, us + (size_t)(oo.save_start ? 1 : 0) * n, sizeof(float) * n);
+      if (t1 > t0 && t1 < t2) { tst = (float*)malloc(sizeof(float)); tst[0] = t1; ntst = 1; }
+    }
+    free(us);
+  }
+  if (rc != LRO_OK) { free(u1); free(tst); lro_dense_free(&dense); return rc; }
+  /* adjoint solve in s = -t from -t2 to -t0 on z = [lambda; mu] */
+  const long N = n + P;
+  float* z0 = (float*)calloc((size_t)N, sizeof(float));
+  memcpy(z0, du_end, sizeof(float) * n);
+  adj_ctx ac; ac.m = m; ac.dense = &dense; ac.B = B; ac.n = n; ac.P = P; ac.y = (float*)malloc(sizeof(float) * (size_t)n);
+  lro_field af; af.fn = adjoint_field; af.ctx = &ac; af.D = (int)N;
+  float* stops = (float*)malloc(sizeof(float) * (size_t)(ntst > 0 ? ntst : 1));
+  for (int i = 0; i < ntst; ++i) stops[i] = -tst[ntst - 1 - i];   /* ascending in s */
+  lro_opts ob = *o; ob.save_everystep = 0; ob.save_start = 0;
+  float sv[1] = {-t0}; float tsv[2];
+  float* zs = (float*)malloc(sizeof(float) * (size_t)N * 2);
+  rc = lro_solve_ex(&af, z0, 1, -t2, -t0, &ob, sv, 1, zs, tsv, 2, st_bwd, NULL, 0, stops, ntst, NULL);
+  if (rc == LRO_OK) {
+    const float* zf = zs + (size_t)(st_bwd->nsaved - 1) * N;
+    memcpy(dx, zf, sizeof(float) * n);
+    memcpy(dp, zf + n, sizeof(float) * (size_t)P);
+    if (mode != LRO_MODE_NONE && w_reg != 0.0f) {
+      float* k1 = (float*)malloc(sizeof(float) * (size_t)n);
+      float* gr = (float*)malloc(sizeof(float) * (size_t)P);
+      float dtl, rv;
+      lro_init_dt(&f, u1, t1, t2, oo.abstol, oo.reltol, B, k1, &dtl);
+      lro_tsit5_step_reg_grad(m, u1, k1, t1, dtl, oo.abstol, oo.reltol, B, reg_type, gr, &rv);
+      for (int i = 0; i < P; ++i) dp[i] += w_reg * gr[i];
+      free(gr); free(k1);
+    }
+  }
+  free(zs); free(stops); free(ac.y); free(z0); free(u1); free(tst);
+  lro_dense_free(&dense);
+  return rc;
 }

@@ -128,6 +128,18 @@ int lro_solve(const lro_field* f, const float* u0, int B, float t0, float t1, co
               const float* saveat, int nsave, float* u_saved, float* t_saved, int cap_saved,
               lro_stats* st, lro_trace_row* trace, int cap_trace);
 
+typedef struct { /* dense forward storage: per accepted step t, dt, then [uprev, k1..k7] (8*n floats) */
+  int nsteps, cap;
+  long n;
+  float *t, *dt, *data;
+} lro_dense;
+void lro_dense_free(lro_dense* d);
+void lro_dense_eval(const lro_dense* d, float t, float* out);
+int lro_solve_ex(const lro_field* f, const float* u0, int B, float t0, float t1, const lro_opts* o,
+                 const float* saveat, int nsave, float* u_saved, float* t_saved, int cap_saved,
+                 lro_stats* st, lro_trace_row* trace, int cap_trace, const float* tstops, int ntstops,
+                 lro_dense* dense);
+
 /* ---- NeuralODE layer forward (src/layers/neural_ode.jl:56-100) ----
  * mode none/test: saveat=[t1_end]; unbiased: caller passes t1 (host RNG draw);
  * biased: caller passes rand_index in [0,1) used as floor(r*(n-1)) over sol.t[1:end-1].
@@ -135,6 +147,14 @@ int lro_solve(const lro_field* f, const float* u0, int B, float t0, float t1, co
 int lro_node_forward(const lro_field* f, const float* x, int B, float t0, float t2,
                      const lro_opts* o, int mode, int reg_type, float t1_or_rand, float* u_end,
                      float* reg_val, int* nfe, lro_stats* st, float* t1_used);
+
+/* ---- backward pass ---- */
+void lro_mlp_vjp(const lro_mlp* m, const float* y, float t, const float* lam, int B, float* dy, float* gp);
+int lro_tsit5_step_reg_grad(const lro_mlp* m, const float* uprev, const float* k1, float t, float dt,
+                            float abstol, float reltol, int B, int reg_type, float* gp, float* reg_val);
+int lro_node_backward(const lro_mlp* m, const float* x, int B, float t0, float t2, const lro_opts* o, int mode,
+                      int reg_type, float t1_or_rand, const float* du_end, float w_reg, float* dx, float* dp,
+                      lro_stats* st_fwd, lro_stats* st_bwd);
 
 /* ---- SDE: adaptive Euler-Heun local step with supplied dW (src/perform_step.jl:172-206) ---- */
 int lro_euler_heun_step(const lro_field* drift, const lro_field* diffusion, const float* uprev,

@@ -93,6 +93,12 @@ def lib():
                                           C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fp, fp,
                                           fp]
         L.lro_tsit5_tableau.argtypes = [C.POINTER(C.c_double)] * 4
+        L.lro_mlp_vjp.restype = None
+        L.lro_mlp_vjp.argtypes = [C.POINTER(Mlp), fp, C.c_float, fp, C.c_int, fp, fp]
+        L.lro_tsit5_step_reg_grad.argtypes = [C.POINTER(Mlp), fp, fp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                              C.c_int, C.c_int, fp, fp]
+        L.lro_node_backward.argtypes = [C.POINTER(Mlp), fp, C.c_int, C.c_float, C.c_float, C.POINTER(Opts), C.c_int,
+                                        C.c_int, C.c_float, fp, C.c_float, fp, fp, C.POINTER(Stats), C.POINTER(Stats)]
         _lib = L
     return _lib
 
@@ -266,3 +272,37 @@ def glorot_mlp_params(D, H, time_dep=True, seed=0):
     W1 = glorot(H, D + td); b1 = np.zeros(H, np.float32)
     W2 = glorot(D, H + td); b2 = np.zeros(D, np.float32)
     return np.concatenate([W1.ravel(), b1, W2.ravel(), b2]).astype(np.float32)
+
+
+def mlp_vjp(fld, y, t, lam, want_gp=True):
+    y = _f32(y); lam = _f32(lam)
+    B = y.size // fld.D
+    dy = np.empty_like(y)
+    gp = np.zeros(fld.params.size, np.float32) if want_gp else None
+    lib().lro_mlp_vjp(C.byref(fld.m), _fp(y), float(t), _fp(lam), B, _fp(dy), _fp(gp))
+    return dy, gp
+
+
+def step_reg_grad(fld, uprev, k1, t, dt, abstol, reltol, reg_type="error_estimate"):
+    uprev = _f32(uprev); k1 = _f32(k1)
+    B = uprev.size // fld.D
+    gp = np.zeros(fld.params.size, np.float32)
+    rv = C.c_float()
+    rc = lib().lro_tsit5_step_reg_grad(C.byref(fld.m), _fp(uprev), _fp(k1), float(t), float(dt), float(abstol),
+                                       float(reltol), B, REG[reg_type], _fp(gp), C.byref(rv))
+    assert rc == 0
+    return gp, np.float32(rv.value)
+
+
+def node_backward(fld, x, t0, t2, abstol, reltol, du_end, mode="unbiased", reg_type="error_estimate",
+                  t1_or_rand=0.5, w_reg=0.0, maxiters=10000, save_start=False):
+    x = _f32(x); du_end = _f32(du_end)
+    B = x.size // fld.D
+    o = make_opts(abstol, reltol, maxiters, save_start, False, False)
+    dx = np.empty_like(x)
+    dp = np.zeros(fld.params.size, np.float32)
+    sf, sb = Stats(), Stats()
+    rc = lib().lro_node_backward(C.byref(fld.m), _fp(x), B, float(t0), float(t2), C.byref(o), MODE[mode],
+                                 REG[reg_type], float(t1_or_rand), _fp(du_end), float(w_reg), _fp(dx), _fp(dp),
+                                 C.byref(sf), C.byref(sb))
+    return dict(retcode=rc, dx=dx, dp=dp, stats_fwd=sf.asdict(), stats_bwd=sb.asdict())
