@@ -162,6 +162,12 @@ int lrnde_sde_euler_heun_step(lrnde_sde* sde, const float* uprev, const float* d
                               float dt, float abstol, float reltol, float delta, float* u,
                               float* eest_host, float* reg_val_host);
 
+/* ---- backward pass ----
+ * lrnde_vjp: the vector-Jacobian product Zygote.pullback(dudt, y, p, t) computes inside the adjoint
+ * RHS (SciMLSensitivity ZygoteVJP): dy = (df/dy)^T lam, gp = (df/dp)^T lam (flat Lux layout, may be
+ * NULL).  All device pointers. */
+int lrnde_vjp(lrnde_ctx* ctx, const float* y, float t, const float* lam, int32_t B, float* dy, float* gp);
+
 /* Timing hooks for bench.py: HIP events on the handle's stream around the
  * kernels of the last solve (ms), and the number of step-kernel launches. */
 /* `reps` back-to-back launches of the full Tsit5 step kernel on fixed (uprev, k1, t, dt), timed

@@ -1292,6 +1292,7 @@ template <int W> __global__ __launch_bounds__(NT) void k_sde_step(StepArgs a) {
 }
 
 #include "lrnde_qtile.hpp"
+#include "lrnde_backward.hpp"
 
 // single-step modes: EEst and the two regularisation values from the partial sums
 __global__ void k_finalize(StepArgs a, int j) {
@@ -1389,6 +1390,9 @@ struct lrnde_ctx {
   // packed weights
   float *W1p = nullptr, *W2p = nullptr, *w1t = nullptr, *b1 = nullptr, *w2t = nullptr, *b2 = nullptr;
   float *W1q = nullptr, *W2q = nullptr;
+  float *V1p = nullptr, *U2p = nullptr;          // transposed weights for the backward pass
+  float *bw_y = nullptr, *bw_h = nullptr, *bw_dp = nullptr;  // VJP scratch (B*D, B*Hp, B*Hp)
+  int bwB = 0;
   int wsNB = 0;  // tile width the workspace (partial-sum vectors) was sized for
   // workspace
   int wsB = 0;
@@ -1587,6 +1591,8 @@ int set_smem_attr() {
   hipFuncSetAttribute((const void*)k_init1_q, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_init2_q, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_rhs_q, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_vjp<4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_vjp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_sde_step<4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_sde_step<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   done = true;
@@ -1646,6 +1652,8 @@ int lrnde_create(lrnde_ctx** out, const lrnde_model_desc* d, int device, void* s
   const size_t nW2 = (size_t)(Dp / 16) * (((Hp / 16 + SEGK - 1) / SEGK) * SEGK) * 256;
   bool ok = hipMalloc(&c->W1p, sizeof(float) * nW1) == hipSuccess &&
             hipMalloc(&c->W2p, sizeof(float) * nW2) == hipSuccess &&
+            hipMalloc(&c->V1p, sizeof(float) * nW1) == hipSuccess &&
+            hipMalloc(&c->U2p, sizeof(float) * nW2) == hipSuccess &&
             hipMalloc(&c->w1t, sizeof(float) * Hp) == hipSuccess &&
             hipMalloc(&c->b1, sizeof(float) * Hp) == hipSuccess &&
             hipMalloc(&c->w2t, sizeof(float) * Dp) == hipSuccess &&
@@ -1672,7 +1680,7 @@ int lrnde_destroy(lrnde_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
   if (c->comm) ncclCommDestroy(c->comm);
-  void* ptrs[] = {c->W1q, c->W2q, c->W1p, c->W2p, c->w1t, c->b1, c->w2t, c->b2, c->state, c->ctrl, c->part,
+  void* ptrs[] = {c->V1p, c->U2p, c->bw_y, c->bw_h, c->bw_dp, c->W1q, c->W2q, c->W1p, c->W2p, c->w1t, c->b1, c->w2t, c->b2, c->state, c->ctrl, c->part,
                   c->part_rx, c->pinit, c->pinit_rx, c->saveat_dev, c->tsaved_dev, c->trace_dev,
                   c->usave};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -1696,6 +1704,7 @@ int lrnde_set_params(lrnde_ctx* c, const float* p, size_t n) {
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(k_pack_q, dim3(256), dim3(256), 0, c->stream, p, m.D, m.H, m.td, m.KQ1p, m.KQ2p, m.RG1, m.RG2,
                      c->W1q, c->W2q);
+  hipLaunchKernelGGL(k_pack_t, dim3(256), dim3(256), 0, c->stream, p, m.D, m.H, m.td, m.Dp, m.Hp, c->V1p, c->U2p);
   HIPCHK(c, hipGetLastError());
   c->have_params = true;
   return LRNDE_OK;
@@ -2132,6 +2141,56 @@ int lrnde_sde_euler_heun_step(lrnde_sde* s, const float* uprev, const float* dW,
   if (eest_host) *eest_host = c->ctrl_host[0].eest_last;
   if (reg_val_host) *reg_val_host = c->ctrl_host[0].reg_error;  // EEst * dt (src/perform_step.jl:205)
   return LRNDE_OK;
+}
+
+// ---- backward building blocks ----
+static int ensure_bw(lrnde_ctx* c, int B) {
+  if (B == c->bwB) return LRNDE_OK;
+  if (c->bw_y) HIPCHK(c, hipFree(c->bw_y));
+  if (c->bw_h) HIPCHK(c, hipFree(c->bw_h));
+  if (c->bw_dp) HIPCHK(c, hipFree(c->bw_dp));
+  c->bw_y = c->bw_h = c->bw_dp = nullptr;
+  HIPCHK(c, hipMalloc(&c->bw_y, sizeof(float) * (size_t)B * c->desc.state_dim));
+  HIPCHK(c, hipMalloc(&c->bw_h, sizeof(float) * (size_t)B * c->m.Hp));
+  HIPCHK(c, hipMalloc(&c->bw_dp, sizeof(float) * (size_t)B * c->m.Hp));
+  c->bwB = B;
+  return LRNDE_OK;
+}
+
+// dy = J^T lam at (y or the interpolated dense step, t);  gp (optional) = (df/dp)^T lam
+static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float theta, float dense_dt, float t,
+                      const float* lam, int B, float* dy, float* gp) {
+  int rc = ensure_bw(c, B);
+  if (rc) return rc;
+  VjpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m = c->m; a.V1p = reinterpret_cast<const f32x4*>(c->V1p); a.U2p = reinterpret_cast<const f32x4*>(c->U2p);
+  a.B = B; a.t = t; a.y = y; a.dense = dense; a.theta = theta; a.dense_dt = dense_dt; a.lam = lam; a.dy = dy;
+  a.ysc = c->bw_y; a.hsc = c->bw_h; a.dpsc = c->bw_dp;
+  const int nwg = (B + NB - 1) / NB;
+  const size_t sm = smem_bytes(c->m.Dp, c->m.Hp) + (size_t)c->m.Hp * NB * sizeof(float) + 64;
+  if (vecw(c) == 4) hipLaunchKernelGGL(k_vjp<4>, dim3(nwg), dim3(NT), sm, c->stream, a);
+  else hipLaunchKernelGGL(k_vjp<1>, dim3(nwg), dim3(NT), sm, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  if (gp) {
+    PgradArgs g;
+    g.D = c->m.D; g.H = c->m.H; g.Hp = c->m.Hp; g.td = c->m.td; g.B = B; g.t = t;
+    g.lam = lam; g.y = c->bw_y; g.h = c->bw_h; g.dpre = c->bw_dp; g.gp = gp;
+    const int th = (g.H + 15) / 16, td16 = (g.D + 15) / 16;
+    g.ntile1 = th * td16; g.nt1c = td16; g.ntile2 = td16 * th; g.nt2c = th;
+    const int ncs = (g.H + g.D + 63) / 64;
+    const int ntot = g.ntile1 + g.ntile2 + ncs;
+    hipLaunchKernelGGL(k_pgrad, dim3((ntot + 3) / 4), dim3(256), 0, c->stream, g);
+    HIPCHK(c, hipGetLastError());
+  }
+  return LRNDE_OK;
+}
+
+int lrnde_vjp(lrnde_ctx* c, const float* y, float t, const float* lam, int32_t B, float* dy, float* gp) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!y || !lam || !dy) return fail(c, LRNDE_BADARG, "null pointer");
+  return launch_vjp(c, y, nullptr, 0.f, 0.f, t, lam, B, dy, gp);
 }
 
 int lrnde_last_solve_kernel_ms(lrnde_ctx* c, float* ms, int32_t* launches) {

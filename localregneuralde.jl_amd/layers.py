@@ -199,6 +199,15 @@ class Handle:
         return dict(u_end=u_end, reg_val=np.float32(reg.value), nfe=int(nfe.value), stats=st.asdict(),
                     t1=np.float32(t1u.value))
 
+    def vjp(self, y, t, lam, want_gp=True):
+        """(J^T lam, (df/dp)^T lam) of the vector field at (y, t) — the adjoint RHS building block."""
+        B = y.numel() // self.D
+        dy = torch.empty_like(y)
+        gp = torch.zeros(int(L.lib.lrnde_param_count(C.byref(self.desc))), dtype=torch.float32, device=y.device) if want_gp else None
+        self._chk(L.lib.lrnde_vjp(self._ctx, _dev_ptr(y, "y", self.D), float(t), _dev_ptr(lam, "lam", self.D), B,
+                                  _dev_ptr(dy, "dy"), C.c_void_p(gp.data_ptr()) if want_gp else None))
+        return dy, gp
+
     def bench_step(self, uprev, k1, t, dt, abstol, reltol, reps=50):
         """microseconds per launch of the full-step kernel (HIP events on the handle's stream)."""
         B = uprev.numel() // self.D
