@@ -168,6 +168,22 @@ int lrnde_sde_euler_heun_step(lrnde_sde* sde, const float* uprev, const float* d
  * NULL).  All device pointers. */
 int lrnde_vjp(lrnde_ctx* ctx, const float* y, float t, const float* lam, int32_t B, float* dy, float* gp);
 
+/* d reg_val / d ps for one local step: Zygote through `_perform_step` with integrator, k1, dt, uprev
+ * constant (src/layers/neural_ode.jl:40, src/utils.jl:60; asserted by test/runtests.jl:127-131:
+ * no gradient w.r.t. x).  gp: device vector of lrnde_param_count floats. */
+int lrnde_step_reg_grad(lrnde_ctx* ctx, const float* uprev, const float* k1, int32_t B, float t, float dt,
+                        float abstol, float reltol, int32_t reg_type, float* gp, float* reg_val_host);
+
+/* Pullback of the NeuralODE layer for  loss = <du_end, sol.u[end]> + w_reg * reg_val
+ * (what Zygote.pullback computes in experiments/src/utils.jl:104-115): forward re-solve with a dense
+ * record, continuous adjoint of `solve` (SciMLSensitivity InterpolatingAdjoint(autojacvec=ZygoteVJP()):
+ * reversed-time adaptive Tsit5 on [lambda; mu], same tolerances, cotangent times as tstops), plus the
+ * regulariser's reverse sweep.  dx (B,D) and dp (P) are device outputs. */
+int lrnde_node_backward(lrnde_ctx* ctx, const float* x, int32_t B, float t0, float t2,
+                        const lrnde_solve_opts* opts, int32_t mode, int32_t reg_type, float t1_or_rand,
+                        const float* du_end, float w_reg, float* dx, float* dp, lrnde_stats* stats_fwd_host,
+                        lrnde_stats* stats_bwd_host);
+
 /* Timing hooks for bench.py: HIP events on the handle's stream around the
  * kernels of the last solve (ms), and the number of step-kernel launches. */
 /* `reps` back-to-back launches of the full Tsit5 step kernel on fixed (uprev, k1, t, dt), timed

@@ -62,6 +62,9 @@ SYMBOLS = [
     ("lrnde_sde_set_params", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
     ("lrnde_sde_euler_heun_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _vp, _fp, _fp]),
     ("lrnde_vjp", C.c_int, [_vp, _vp, _f, _vp, _i32, _vp, _vp]),
+    ("lrnde_step_reg_grad", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _vp, _fp]),
+    ("lrnde_node_backward", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _i32, _i32, _f, _vp, _f, _vp, _vp,
+                                      C.POINTER(Stats), C.POINTER(Stats)]),
     ("lrnde_bench_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _fp]),
     ("lrnde_last_solve_kernel_ms", C.c_int, [_vp, _fp, C.POINTER(_i32)]),
 ]

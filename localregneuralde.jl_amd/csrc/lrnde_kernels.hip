@@ -103,6 +103,7 @@ struct Ctrl {  // device-resident integrator state, double-buffered by attempt p
   float qold, q11, dtpropose;
   float eest_last, dt_init;
   float reg_error, reg_stiff;  // single-step modes: filled by k_finalize
+  float stiff_num, stiff_den;  // ||k7-k6||_rms, ||u-g6||_rms (for the regulariser's reverse sweep)
 };
 
 struct StepArgs {
@@ -137,6 +138,11 @@ struct StepArgs {
   float* sde_scratch;  // 9 arrays of n_local floats
   const float* sde_uprev;
   float* sde_u;
+  // dense forward record for the adjoint: per accepted step [uprev, k1..k7] (8 * n_local floats)
+  float* dense;
+  float* dense_t;   // device [dense_cap]
+  float* dense_dt;  // device [dense_cap]
+  int dense_cap;
 };
 
 // ---------------------------------------------------------------------------
@@ -749,6 +755,7 @@ struct Bcast {
   int accepted_prev, cur_prev, isave0, nsaved0;
   float t_new, tprev, dt_prev;
   float dt0;  // init phase 2
+  int dense_idx;  // index of the accepted step in the dense record (-1: none)
 };
 
 __device__ __forceinline__ float init_dt0(const double s[3], double n, float dtmax) {
@@ -799,7 +806,7 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
   float t = c.t, dt = c.dt;
   Bcast b;
   b.accepted_prev = 0; b.cur_prev = c.cur; b.isave0 = c.isave; b.nsaved0 = c.nsaved;
-  b.t_new = c.t; b.tprev = c.t; b.dt_prev = c.dt; b.dt0 = 0.f;
+  b.t_new = c.t; b.tprev = c.t; b.dt_prev = c.dt; b.dt0 = 0.f; b.dense_idx = -1;
 
   if (c.first) {
     if (a.mode != MODE_SINGLE_GIVEN_DT) {
@@ -846,6 +853,10 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
       t = (__builtin_fabsf(ttmp - a.t1) < 100.0f * eps_f(fmaxf_(c.t, a.t1))) ? a.t1 : ttmp;
       c.dtpropose = fmaxf_(fminf_(dtmax, dtnew), fmaxf_(eps_f(t), dtmin));
       b.accepted_prev = 1; b.t_new = t;
+      if (a.dense) {
+        b.dense_idx = c.naccept - 1;
+        if (b.dense_idx >= a.dense_cap) { c.status = LRNDE_CAPACITY; b.accepted_prev = 0; b.dense_idx = -1; }
+      }
       // savevalues!: count what this step saves (performed by all threads afterwards)
       int is = c.isave, ns = c.nsaved;
       while (is < a.nsave && a.saveat[is] <= t) { ++is; ++ns; }
@@ -1088,6 +1099,17 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
       });
       if (blockIdx.x == 0 && threadIdx.x == 0) a.t_saved[slot] = bc.t_new;
     }
+    if (bc.dense_idx >= 0) {  // dense record of the accepted step (InterpolatingAdjoint keeps u and k1..k7)
+      const size_t nst = (size_t)a.n_local;
+      float* dd = a.dense + (size_t)bc.dense_idx * 8 * nst;
+      const float* src[8] = {up, k1, a.ks[0], a.ks[1], a.ks[2], a.ks[3], a.ks[4], k7};
+      tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
+        if (!valid) return;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vstore<W>(dd + (size_t)q * nst + g, vload<W>(src[q] + g));
+      });
+      if (blockIdx.x == 0 && threadIdx.x == 0) { a.dense_t[bc.dense_idx] = bc.tprev; a.dense_dt[bc.dense_idx] = bc.dt_prev; }
+    }
   }
   if (!bc.do_step) return;
 
@@ -1311,6 +1333,8 @@ __global__ void k_finalize(StepArgs a, int j) {
       rs = __builtin_fabsf(num / (den + 1.1920929e-7f)) / 3.5068f;
     }
     c->reg_stiff = rs;
+    c->stiff_den = den;
+    c->stiff_num = rms_from(s[1], a.n_global);
     c->status = ST_DONE;
   }
 }
@@ -1393,6 +1417,13 @@ struct lrnde_ctx {
   float *V1p = nullptr, *U2p = nullptr;          // transposed weights for the backward pass
   float *bw_y = nullptr, *bw_h = nullptr, *bw_dp = nullptr;  // VJP scratch (B*D, B*Hp, B*Hp)
   int bwB = 0;
+  // dense forward record + adjoint work vectors
+  float *dense = nullptr, *dense_t = nullptr, *dense_dt = nullptr;
+  int dense_cap = 0; size_t dense_n = 0; bool dense_on = false;
+  float* adj = nullptr; size_t adj_elems = 0;   // 11 vectors of N = B*D + P floats
+  double* adj_part = nullptr; double* adj_part_host = nullptr;
+  std::vector<float> last_ts;  // sol.t of the last node_forward (cotangent times of the adjoint)
+  float last_t1 = 0.f; int last_i1 = 0;
   int wsNB = 0;  // tile width the workspace (partial-sum vectors) was sized for
   // workspace
   int wsB = 0;
@@ -1680,7 +1711,8 @@ int lrnde_destroy(lrnde_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
   if (c->comm) ncclCommDestroy(c->comm);
-  void* ptrs[] = {c->V1p, c->U2p, c->bw_y, c->bw_h, c->bw_dp, c->W1q, c->W2q, c->W1p, c->W2p, c->w1t, c->b1, c->w2t, c->b2, c->state, c->ctrl, c->part,
+  if (c->adj_part_host) hipHostFree(c->adj_part_host);
+  void* ptrs[] = {c->dense, c->dense_t, c->dense_dt, c->adj, c->adj_part, c->V1p, c->U2p, c->bw_y, c->bw_h, c->bw_dp, c->W1q, c->W2q, c->W1p, c->W2p, c->w1t, c->b1, c->w2t, c->b2, c->state, c->ctrl, c->part,
                   c->part_rx, c->pinit, c->pinit_rx, c->saveat_dev, c->tsaved_dev, c->trace_dev,
                   c->usave};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -1852,6 +1884,7 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   a.t0 = t0; a.t1 = t1; a.abstol = o->abstol; a.reltol = o->reltol;
   a.maxiters = o->maxiters; a.save_everystep = o->save_everystep; a.exact_pow = o->exact_pow;
   a.want_stiff = 0; a.mode = MODE_SOLVE;
+  if (c->dense_on) { a.dense = c->dense; a.dense_t = c->dense_t; a.dense_dt = c->dense_dt; a.dense_cap = c->dense_cap; }
   a.cap_saved = cap_saved; a.u_saved = u_saved; a.t_saved = c->tsaved_dev;
   a.trace = trace_host ? c->trace_dev : nullptr; a.cap_trace = trace_host ? cap_trace : 0;
   // saveat points at/before t0 are the start value (save_start), as in the oracle
@@ -1985,7 +2018,11 @@ int lrnde_node_forward(lrnde_ctx* c, const float* x, int32_t B, float t0, float 
     if (idx < 0) idx = 0;
     t1 = ts[idx];
     u1 = c->usave + (size_t)idx * n;
+    c->last_i1 = idx;
   }
+  c->last_ts.assign(ts.begin(), ts.begin() + st->nsaved);
+  c->last_t1 = t1;
+  if (mode == LRNDE_MODE_UNBIASED) c->last_i1 = oo.save_start ? 1 : 0;
   HIPCHK(c, hipMemcpyAsync(u_end, c->usave + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   if (t1_used_host) *t1_used_host = t1;
   // _get_ode_integrator (neural_ode.jl:33-38): fresh init on (t1, t2); then _perform_step (:77)
@@ -2191,6 +2228,295 @@ int lrnde_vjp(lrnde_ctx* c, const float* y, float t, const float* lam, int32_t B
   if (rc) return rc;
   if (!y || !lam || !dy) return fail(c, LRNDE_BADARG, "null pointer");
   return launch_vjp(c, y, nullptr, 0.f, 0.f, t, lam, B, dy, gp);
+}
+
+// ---- backward drivers -----------------------------------------------------------------------
+}  // extern "C"
+namespace {
+
+struct AdjVec {  // device vectors of the augmented adjoint state
+  float *z, *zn, *zs, *ut, *K[7];
+  size_t N;
+};
+
+int adj_alloc(lrnde_ctx* c, size_t N, AdjVec& v) {
+  if (c->adj_elems < 11 * N) {
+    if (c->adj) HIPCHK(c, hipFree(c->adj));
+    c->adj = nullptr;
+    HIPCHK(c, hipMalloc(&c->adj, sizeof(float) * 11 * N));
+    c->adj_elems = 11 * N;
+  }
+  if (!c->adj_part) {
+    HIPCHK(c, hipMalloc(&c->adj_part, sizeof(double) * 256));
+    HIPCHK(c, hipHostMalloc(&c->adj_part_host, sizeof(double) * 256));
+  }
+  v.N = N; v.z = c->adj; v.zn = c->adj + N; v.zs = c->adj + 2 * N; v.ut = c->adj + 3 * N;
+  for (int j = 0; j < 7; ++j) v.K[j] = c->adj + (4 + j) * N;
+  return LRNDE_OK;
+}
+
+int vec_axpy(lrnde_ctx* c, float* out, const float* base, float dt, int nk, const float* const* k, const float* coef, size_t n) {
+  AxArgs a;
+  a.out = out; a.base = base; a.dt = dt; a.nk = nk; a.n = n;
+  for (int j = 0; j < 7; ++j) { a.k[j] = j < nk ? k[j] : nullptr; a.c[j] = j < nk ? coef[j] : 0.f; }
+  int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_axpy, dim3(nb), dim3(256), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  return LRNDE_OK;
+}
+
+// sqrt(sum(((num[-num2]) / (abstol + max(|sa|,|sb|)*reltol))^2) / n), fp64 accumulation
+int vec_norm(lrnde_ctx* c, const float* num, const float* num2, const float* sa, const float* sb, float abstol,
+             float reltol, size_t n, float* out) {
+  NormArgs a;
+  a.num = num; a.num2 = num2; a.sa = sa; a.sb = sb; a.abstol = abstol; a.reltol = reltol; a.n = n; a.part = c->adj_part;
+  hipLaunchKernelGGL(k_norm, dim3(256), dim3(256), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->adj_part_host, c->adj_part, sizeof(double) * 256, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double s = 0.0;
+  for (int i = 0; i < 256; ++i) s += c->adj_part_host[i];
+  *out = (float)sqrt(s / (double)n);
+  return LRNDE_OK;
+}
+
+// adjoint RHS in reversed time s = -t: K = [J^T lambda; (df/dp)^T lambda] at y(t) from the dense record
+int adj_rhs(lrnde_ctx* c, const std::vector<float>& dt_, const std::vector<float>& dd_, int B, size_t n,
+            const float* zs, float sgt, float* K) {
+  const float t = -sgt;
+  int lo = 0, hi = (int)dt_.size() - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (dt_[mid] <= t) lo = mid; else hi = mid - 1; }
+  const float theta = (t - dt_[lo]) / dd_[lo];
+  return launch_vjp(c, nullptr, c->dense + (size_t)lo * 8 * n, theta, dd_[lo], t, zs, B, K, K + n);
+}
+
+// adaptive Tsit5 on device vectors, host-side controller (mirror of the forward loop / the oracle's
+// lro_solve_ex), integrating s from s0 to s1 with tstops; only the end state is kept
+template <class RHS>
+int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, float s0, float s1, float abstol, float reltol, int maxiters,
+                    int exact_pow, const std::vector<float>& tstops, lrnde_stats* st) {
+  const size_t N = v.N;
+  const float gamma = 0.9f, qmin = 0.2f, qmax = 10.0f, qoldinit = 1e-4f;
+  const float beta1 = (float)(7.0 / 50.0), beta2 = (float)(2.0 / 25.0);
+  float A[21], BT[7];
+  for (int i = 0; i < 21; ++i) A[i] = (float)Tsit5::A[i];
+  for (int i = 0; i < 7; ++i) BT[i] = (float)Tsit5::BT[i];
+  const float cs[6] = {(float)Tsit5::C[0], (float)Tsit5::C[1], (float)Tsit5::C[2], (float)Tsit5::C[3], 1.0f, 1.0f};
+  memset(st, 0, sizeof(*st));
+  int rc;
+  float t = s0;
+  const float dtmax = s1 - s0;
+  const float dtmin = fmaxf(eps_f(s1), eps_f(s0));
+  float *z = v.z, *zn = v.zn;
+  float* K[7]; for (int j = 0; j < 7; ++j) K[j] = v.K[j];
+  // ode_determine_initdt
+  float dt;
+  {
+    if ((rc = rhs(z, t, K[0]))) return rc;
+    float d0, d1, d2;
+    if ((rc = vec_norm(c, z, nullptr, z, nullptr, abstol, reltol, N, &d0))) return rc;
+    if ((rc = vec_norm(c, K[0], nullptr, z, nullptr, abstol, reltol, N, &d1))) return rc;
+    float dt0 = ((double)d0 < 1e-5 || (double)d1 < 1e-5) ? 1e-6f : (d0 / d1) / 100.0f;
+    dt0 = fminf(dt0, dtmax);
+    const float one = 1.0f; const float* kk[1] = {K[0]};
+    if ((rc = vec_axpy(c, v.zs, z, dt0, 1, kk, &one, N))) return rc;
+    if ((rc = rhs(v.zs, t + dt0, K[1]))) return rc;
+    if ((rc = vec_norm(c, K[1], K[0], z, nullptr, abstol, reltol, N, &d2))) return rc;
+    d2 = d2 / dt0;
+    const float maxd = fmaxf(d1, d2);
+    float dt1;
+    if ((double)maxd <= 1e-15) dt1 = fmaxf(1e-6f, dt0 * 1e-3f);
+    else { const float l10 = (float)log10((double)maxd); const float e = (-(2.0f + l10)) / 5.0f; dt1 = (float)pow(10.0, (double)e); }
+    dt = fminf(fminf(100.0f * dt0, dt1), dtmax);
+    st->nf = 3; st->dt_init = dt;
+  }
+  float qold = qoldinit, q11 = 1.0f, dtpropose = dt;
+  int accept = 0, iter = 0;
+  size_t istop = 0;
+  while (istop < tstops.size() && tstops[istop] <= s0) ++istop;
+  rc = LRNDE_OK;
+  while (t < s1) {
+    while (istop < tstops.size() && tstops[istop] <= t) ++istop;
+    const float tstop = (istop < tstops.size() && tstops[istop] < s1) ? tstops[istop] : s1;
+    if (iter > 0) {
+      if (accept) { std::swap(z, zn); std::swap(K[0], K[6]); dt = dtpropose; }
+      else dt = dt / fminf(1.0f / qmin, q11 / gamma);
+    }
+    ++iter;
+    dt = fminf(dtmax, dt); dt = fmaxf(dt, dtmin); dt = fminf(fabsf(dt), fabsf(tstop - t));
+    if (iter > maxiters) { rc = LRNDE_MAXITERS; break; }
+    if (dt != dt) { rc = LRNDE_DT_NAN; break; }
+    if (fabsf(dt) <= fabsf(dtmin)) { rc = LRNDE_DT_LESS_THAN_MIN; break; }
+    // stages 2..7 (src/perform_step.jl:11-20 on the augmented state)
+    for (int sidx = 2; sidx <= 7; ++sidx) {
+      const int off = (sidx - 2) * (sidx - 1) / 2;
+      float* out = (sidx == 7) ? zn : v.zs;
+      if ((rc = vec_axpy(c, out, z, dt, sidx - 1, K, A + off, N))) return rc;
+      if ((rc = rhs(out, t + cs[sidx - 2] * dt, K[sidx - 1]))) return rc;
+    }
+    st->nf += 6;
+    if ((rc = vec_axpy(c, v.ut, nullptr, dt, 7, K, BT, N))) return rc;
+    float eest;
+    if ((rc = vec_norm(c, v.ut, nullptr, z, zn, abstol, reltol, N, &eest))) return rc;
+    st->eest_last = eest;
+    if (eest != eest) { rc = LRNDE_DT_NAN; break; }
+    const float ttmp = t + dt;
+    float q;
+    if (eest == 0.0f) q = 1.0f / qmax;
+    else {
+      if (exact_pow) { q11 = (float)pow((double)eest, (double)beta1); q = q11 / (float)pow((double)qold, (double)beta2); }
+      else { q11 = fastpow(eest, beta1); q = q11 / fastpow(qold, beta2); }
+      q = fmaxf(1.0f / qmax, fminf(1.0f / qmin, q / gamma));
+    }
+    accept = (eest <= 1.0f);
+    if (accept) {
+      st->naccept++;
+      const float dtnew = dt / q;
+      qold = fmaxf(eest, qoldinit);
+      t = (fabsf(ttmp - tstop) < 100.0f * eps_f(fmaxf(t, tstop))) ? tstop : ttmp;
+      dtpropose = fmaxf(fminf(dtmax, dtnew), fmaxf(eps_f(t), dtmin));
+    } else {
+      st->nreject++;
+    }
+  }
+  if (accept && rc == LRNDE_OK) std::swap(z, zn);  // z now holds the end state
+  if (z != v.z) HIPCHK(c, hipMemcpyAsync(v.z, z, sizeof(float) * N, hipMemcpyDeviceToDevice, c->stream));
+  st->retcode = rc; st->iters = iter; st->t_final = t; st->dt_final = dt;
+  return rc;
+}
+
+}  // namespace
+extern "C" {
+
+// gradient of the local regularisation value w.r.t. p (reverse sweep through one Tsit5 step with
+// k1, dt, uprev constant: src/layers/neural_ode.jl:40, src/perform_step.jl:3-47).  gp: device (P).
+int lrnde_step_reg_grad(lrnde_ctx* c, const float* uprev, const float* k1, int32_t B, float t, float dt,
+                        float abstol, float reltol, int32_t reg_type, float* gp, float* reg_val_host) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!uprev || !k1 || !gp) return fail(c, LRNDE_BADARG, "null pointer");
+  const size_t n = (size_t)B * c->desc.state_dim;
+  const size_t P = lrnde_param_count(&c->desc);
+  // forward step (keeps k2..k6, g6, u, k7 in the state workspace) and its scalars
+  float ee, re, rs;
+  if ((rc = lrnde_perform_step(c, uprev, k1, B, t, dt, abstol, reltol, nullptr, nullptr, &ee, &re, &rs))) return rc;
+  const Ctrl fin = c->ctrl_host[0];
+  if (reg_val_host) *reg_val_host = (reg_type == LRNDE_REG_STIFFNESS_ESTIMATE) ? rs : re;
+  float* S = c->state;  // ubuf0 (uprev) ubuf1 (u) kfsal0 (k1) kfsal1 (k7) ks0..4 (k2..k6) g6
+  const float* kk[7] = {S + 2 * n, S + 4 * n, S + 5 * n, S + 6 * n, S + 7 * n, S + 8 * n, S + 3 * n};
+  const float* u = S + n; const float* g6 = S + 9 * n;
+  // work vectors: kbar[1..6] (k2..k7), ub, g6b, xs, xb  -> reuse the adjoint buffer
+  AdjVec v;
+  if ((rc = adj_alloc(c, n > P ? n : P, v))) return rc;
+  const size_t N = v.N;
+  float* kb[7] = {nullptr, c->adj + 0 * N, c->adj + 1 * N, c->adj + 2 * N, c->adj + 3 * N, c->adj + 4 * N, c->adj + 5 * N};
+  float* ub = c->adj + 6 * N; float* g6b = c->adj + 7 * N; float* xs = c->adj + 8 * N; float* xb = c->adj + 9 * N;
+  float* gtmp = c->adj + 10 * N;
+  HIPCHK(c, hipMemsetAsync(c->adj, 0, sizeof(float) * 8 * N, c->stream));
+  HIPCHK(c, hipMemsetAsync(gp, 0, sizeof(float) * P, c->stream));
+  RegSeedArgs sa;
+  sa.n = n; sa.uprev = uprev; sa.u = u; sa.g6 = g6;
+  for (int j = 0; j < 7; ++j) sa.k[j] = kk[j];
+  for (int j = 1; j < 7; ++j) sa.kb[j] = kb[j];
+  sa.ub = ub; sa.g6b = g6b; sa.dt = dt; sa.abstol = abstol; sa.reltol = reltol; sa.reg_type = reg_type;
+  sa.eest = fin.eest_last; sa.num = fin.stiff_num; sa.den = fin.stiff_den;
+  { int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_reg_seed, dim3(nb), dim3(256), 0, c->stream, sa); HIPCHK(c, hipGetLastError()); }
+  float A[21];
+  for (int i = 0; i < 21; ++i) A[i] = (float)Tsit5::A[i];
+  const float cs[6] = {(float)Tsit5::C[0], (float)Tsit5::C[1], (float)Tsit5::C[2], (float)Tsit5::C[3], 1.0f, 1.0f};
+  const float one = 1.0f;
+  for (int sidx = 7; sidx >= 2; --sidx) {
+    const int off = (sidx - 2) * (sidx - 1) / 2;
+    const float* x;
+    if (sidx == 7) x = u;
+    else { if ((rc = vec_axpy(c, xs, uprev, dt, sidx - 1, kk, A + off, n))) return rc; x = xs; }
+    if ((rc = launch_vjp(c, x, nullptr, 0.f, 0.f, t + cs[sidx - 2] * dt, kb[sidx - 1], B, xb, gtmp))) return rc;
+    { const float* g1[2] = {gp, gtmp}; const float cc[2] = {1.0f, 1.0f};
+      if ((rc = vec_axpy(c, gp, nullptr, one, 2, g1, cc, P))) return rc; }
+    if (sidx == 7) { const float* g1[2] = {xb, ub}; const float cc[2] = {1.0f, 1.0f}; if ((rc = vec_axpy(c, xb, nullptr, one, 2, g1, cc, n))) return rc; }
+    if (sidx == 6) { const float* g1[2] = {xb, g6b}; const float cc[2] = {1.0f, 1.0f}; if ((rc = vec_axpy(c, xb, nullptr, one, 2, g1, cc, n))) return rc; }
+    for (int j = 1; j < sidx - 1; ++j) {  // kbar_{j+1} += dt * a_{s,j+1} * xbar
+      const float* g1[1] = {xb}; const float cc[1] = {A[off + j]};
+      if ((rc = vec_axpy(c, kb[j], kb[j], dt, 1, g1, cc, n))) return rc;
+    }
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRNDE_OK;
+}
+
+// backward of  loss = <du_end, sol.u[end]> + w_reg * reg_val  through the NeuralODE layer:
+// forward re-solve with a dense record, continuous adjoint (InterpolatingAdjoint restatement), and
+// the regulariser's reverse sweep.  dx (B,D), dp (P): device.
+int lrnde_node_backward(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
+                        int32_t mode, int32_t reg_type, float t1_or_rand, const float* du_end, float w_reg,
+                        float* dx, float* dp, lrnde_stats* st_fwd, lrnde_stats* st_bwd) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!x || !o || !du_end || !dx || !dp || !st_fwd || !st_bwd) return fail(c, LRNDE_BADARG, "null pointer");
+  if (c->nranks > 1) return fail(c, LRNDE_UNSUPPORTED, "the adjoint is single-GPU in this build");
+  const size_t n = (size_t)B * c->desc.state_dim;
+  const size_t P = lrnde_param_count(&c->desc);
+  // 1. forward with dense record (retry with a larger record if it overflows)
+  std::vector<float> u_end_dummy;
+  float* u_end = nullptr;
+  HIPCHK(c, hipMalloc(&u_end, sizeof(float) * n));
+  float regv = 0.f, t1 = t2; int nfe = 0;
+  for (int attempt = 0;; ++attempt) {
+    if (c->dense_cap == 0 || c->dense_n != n) {
+      if (c->dense) { hipFree(c->dense); hipFree(c->dense_t); hipFree(c->dense_dt); c->dense = nullptr; }
+      if (c->dense_cap == 0) c->dense_cap = 64;
+      if (hipMalloc(&c->dense, sizeof(float) * (size_t)c->dense_cap * 8 * n) != hipSuccess ||
+          hipMalloc(&c->dense_t, sizeof(float) * c->dense_cap) != hipSuccess ||
+          hipMalloc(&c->dense_dt, sizeof(float) * c->dense_cap) != hipSuccess) { hipFree(u_end); return fail(c, LRNDE_HIP_ERROR, "dense record allocation failed"); }
+      c->dense_n = n;
+    }
+    c->dense_on = true;
+    rc = lrnde_node_forward(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, u_end, &regv, &nfe, st_fwd, &t1);
+    c->dense_on = false;
+    if (rc == LRNDE_CAPACITY && attempt < 8) { c->dense_cap *= 2; c->dense_n = 0; continue; }
+    break;
+  }
+  hipFree(u_end);
+  if (rc) return rc;
+  const int nsteps = st_fwd->naccept;
+  std::vector<float> dts(nsteps), dds(nsteps);
+  HIPCHK(c, hipMemcpy(dts.data(), c->dense_t, sizeof(float) * nsteps, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(dds.data(), c->dense_dt, sizeof(float) * nsteps, hipMemcpyDeviceToHost));
+  // 2. adjoint solve on z = [lambda; mu] in s = -t from -t2 to -t0, tstops at the saved times
+  const size_t N = n + P;
+  AdjVec v;
+  if ((rc = adj_alloc(c, N, v))) return rc;
+  HIPCHK(c, hipMemsetAsync(v.z, 0, sizeof(float) * N, c->stream));
+  HIPCHK(c, hipMemcpyAsync(v.z, du_end, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  std::vector<float> stops;
+  if (mode != LRNDE_MODE_NONE)
+    for (int i = (int)c->last_ts.size() - 1; i >= 0; --i) {
+      const float tv = c->last_ts[i];
+      if (tv > t0 && tv < t2) stops.push_back(-tv);
+    }
+  auto rhs = [&](const float* zs, float sg, float* K) { return adj_rhs(c, dts, dds, B, n, zs, sg, K); };
+  rc = vec_tsit5_solve(c, v, rhs, -t2, -t0, o->abstol, o->reltol, o->maxiters, o->exact_pow, stops, st_bwd);
+  if (rc) return fail(c, rc, "adjoint solve stopped with retcode %d", rc);
+  HIPCHK(c, hipMemcpyAsync(dx, v.z, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dp, v.z + n, sizeof(float) * P, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // 3. regulariser: dp += w_reg * d reg_val / d p   (no gradient w.r.t. x: test/runtests.jl:129)
+  if (mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
+    float *k1 = nullptr, *gr = nullptr, *u1 = nullptr;
+    HIPCHK(c, hipMalloc(&k1, sizeof(float) * n));
+    HIPCHK(c, hipMalloc(&gr, sizeof(float) * P));
+    HIPCHK(c, hipMalloc(&u1, sizeof(float) * n));
+    HIPCHK(c, hipMemcpy(u1, c->usave + (size_t)c->last_i1 * n, sizeof(float) * n, hipMemcpyDeviceToDevice));
+    float dtl = 0.f, rv = 0.f;
+    rc = lrnde_init_dt(c, u1, B, t1, t2, o->abstol, o->reltol, k1, &dtl);
+    if (!rc) rc = lrnde_step_reg_grad(c, u1, k1, B, t1, dtl, o->abstol, o->reltol, reg_type, gr, &rv);
+    if (!rc) { const float* g1[2] = {dp, gr}; const float cc[2] = {1.0f, w_reg}; rc = vec_axpy(c, dp, nullptr, 1.0f, 2, g1, cc, P); }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(k1); hipFree(gr); hipFree(u1);
+    if (rc) return rc;
+  }
+  return LRNDE_OK;
 }
 
 int lrnde_last_solve_kernel_ms(lrnde_ctx* c, float* ms, int32_t* launches) {

@@ -569,6 +569,17 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
       });
       if (blockIdx.x == 0 && threadIdx.x == 0) a.t_saved[slot] = bc.t_new;
     }
+    if (bc.dense_idx >= 0) {  // dense record of the accepted step for the adjoint
+      const size_t nst = (size_t)a.n_local;
+      float* dd = a.dense + (size_t)bc.dense_idx * 8 * nst;
+      const float* src[8] = {up, k1, a.ks[0], a.ks[1], a.ks[2], a.ks[3], a.ks[4], k7};
+      q_tile_foreach(a.m, b0, nvalid, KQ1, [&](int, int, bool valid, size_t g) {
+        if (!valid) return;
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) st4(dd + (size_t)qq * nst + g, ld4(src[qq] + g));
+      });
+      if (blockIdx.x == 0 && threadIdx.x == 0) { a.dense_t[bc.dense_idx] = bc.tprev; a.dense_dt[bc.dense_idx] = bc.dt_prev; }
+    }
   }
   if (!bc.do_step) return;
 

@@ -208,6 +208,30 @@ class Handle:
                                   _dev_ptr(dy, "dy"), C.c_void_p(gp.data_ptr()) if want_gp else None))
         return dy, gp
 
+    def step_reg_grad(self, uprev, k1, t, dt, abstol, reltol, reg_type="error_estimate"):
+        """d reg_val / d ps of one local Tsit5 step (k1, dt, uprev constant)."""
+        B = uprev.numel() // self.D
+        gp = torch.empty(int(L.lib.lrnde_param_count(C.byref(self.desc))), dtype=torch.float32, device=uprev.device)
+        rv = C.c_float()
+        self._chk(L.lib.lrnde_step_reg_grad(self._ctx, _dev_ptr(uprev, "uprev", self.D), _dev_ptr(k1, "k1", self.D), B,
+                                            float(t), float(dt), float(abstol), float(reltol), L.REG_TYPE[reg_type],
+                                            C.c_void_p(gp.data_ptr()), C.byref(rv)))
+        return gp, np.float32(rv.value)
+
+    def node_backward(self, x, t0, t2, abstol, reltol, du_end, mode="unbiased", reg_type="error_estimate",
+                      t1_or_rand=0.5, w_reg=0.0, maxiters=1000, save_start=False, exact_pow=False):
+        """Pullback of the layer for loss = <du_end, sol.u[end]> + w_reg*reg_val -> (dx, dp)."""
+        B = x.numel() // self.D
+        o = L.SolveOpts(float(abstol), float(reltol), int(maxiters), int(save_start), 0, int(exact_pow))
+        dx = torch.empty_like(x)
+        dp = torch.empty(int(L.lib.lrnde_param_count(C.byref(self.desc))), dtype=torch.float32, device=x.device)
+        sf, sb = L.Stats(), L.Stats()
+        self._chk(L.lib.lrnde_node_backward(self._ctx, _dev_ptr(x, "x", self.D), B, float(t0), float(t2), C.byref(o),
+                                            L.MODE[mode], L.REG_TYPE[reg_type], float(t1_or_rand),
+                                            _dev_ptr(du_end, "du_end", self.D), float(w_reg), _dev_ptr(dx, "dx"),
+                                            C.c_void_p(dp.data_ptr()), C.byref(sf), C.byref(sb)))
+        return dict(dx=dx, dp=dp, stats_fwd=sf.asdict(), stats_bwd=sb.asdict())
+
     def bench_step(self, uprev, k1, t, dt, abstol, reltol, reps=50):
         """microseconds per launch of the full-step kernel (HIP events on the handle's stream)."""
         B = uprev.numel() // self.D
