@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--tol", type=float, default=1.4e-8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=512)
+    ap.add_argument("--adjoint-steps", type=int, default=5, help="timed forward+adjoint passes (single GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,6 +106,28 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
 
+    # forward + adjoint ms/batch (the second half of BASELINE.json's metric): pullback of
+    # ce-like loss + w_reg*reg_val through the layer, as experiments/src/utils.jl:104-115 times it.
+    # Single GPU only in this build (the adjoint's parameter cotangent is not sharded yet).
+    fwd_adj_ms, bwd_stats = None, None
+    if world == 1 and args.adjoint_steps > 0:
+        g = torch.from_numpy(np.random.default_rng(2).standard_normal((args.batch, D)).astype(np.float32)).cuda()
+        tol_b = args.tol
+
+        def one_bwd(i):
+            return h.node_backward(x, 0.0, 1.0, tol_b, tol_b, g, mode="unbiased", reg_type="error_estimate",
+                                   t1_or_rand=float(t1s[i % len(t1s)]), w_reg=2.5, maxiters=10000)
+
+        one_bwd(0)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for i in range(args.adjoint_steps):
+            rb = one_bwd(i)
+        torch.cuda.synchronize()
+        fwd_adj_ms = (time.perf_counter() - tb) / args.adjoint_steps * 1e3
+        bwd_stats = {"adjoint_naccept": rb["stats_bwd"]["naccept"], "adjoint_nreject": rb["stats_bwd"]["nreject"],
+                     "adjoint_nf": rb["stats_bwd"]["nf"]}
+
     # roofline leg: the dominant kernel (one full Tsit5 step per launch), HIP events on its stream
     k1 = h.rhs(x, 0.0)
     dt_typ = float(r["stats"]["dt_final"]) if r["stats"]["dt_final"] > 0 else 0.02
@@ -130,7 +153,8 @@ def main():
                                "regularize=unbiased/error_estimate, forward pass (solve + local reg step)",
                    "global_batch": Bg, "parallelism": f"batch-shard x{world}",
                    "nfe_per_pass": nfe_total / args.steps, "rk_steps_per_sec": world * steps_total / el,
-                   "fwd_ms_per_batch": el / args.steps * 1e3},
+                   "fwd_ms_per_batch": el / args.steps * 1e3,
+                   "fwd_plus_adjoint_ms_per_batch": fwd_adj_ms, "adjoint": bwd_stats},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                      # HBM/fabric bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes

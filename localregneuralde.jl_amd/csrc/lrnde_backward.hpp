@@ -223,49 +223,57 @@ __global__ __launch_bounds__(256) void k_pgrad(PgradArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = blockIdx.x * 4 + wave;
   const int li = lane & 15, lk = lane >> 4;
-  const size_t oW1 = 0, ob1 = (size_t)a.H * (a.D + a.td), oW2 = ob1 + a.H, ob2 = oW2 + (size_t)a.D * (a.H + a.td);
-  if (tile < a.ntile1 + a.ntile2) {
-    // C[i][j] = sum_b A[b][i] * Bm[b][j]:  gW1: A = dpre (rows o), Bm = y (cols k); gW2: A = lam (rows i), Bm = h (cols k)
-    const bool first = tile < a.ntile1;
-    const int tt = first ? tile : tile - a.ntile1;
-    const int ncol = first ? a.nt1c : a.nt2c;
-    const int ti = tt / ncol, tj = tt % ncol;
-    const float* A = first ? a.dpre : a.lam;
-    const float* Bm = first ? a.y : a.h;
-    const int lda = first ? a.Hp : a.D, ldb = first ? a.D : a.Hp;
-    const int M = first ? a.H : a.D, N = first ? a.D : a.H;
-    const int row = ti * 16 + li, col = tj * 16 + li;
-    const bool rok = row < M, cok = col < N;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int b0 = 0; b0 < a.B; b0 += 4) {
-      const int b = b0 + lk;
-      const float av = (rok && b < a.B) ? A[(size_t)b * lda + row] : 0.f;
-      const float bv = (cok && b < a.B) ? Bm[(size_t)b * ldb + col] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-    }
-    // D fragment: row = ti*16 + lk*4 + r, col = tj*16 + li ; flat weight index = row + M*col
-    float* g = a.gp + (first ? oW1 : oW2);
-    const int c = tj * 16 + li;
+  const size_t ob1 = (size_t)a.H * (a.D + a.td), oW2 = ob1 + a.H, ob2 = oW2 + (size_t)a.D * (a.H + a.td);
+  if (tile >= a.ntile1 + a.ntile2) return;
+  // C[i][j] = sum_b A[b][i] * Bm[b][j]:  gW1: A = dpre (rows o), Bm = [y, t, 1];  gW2: A = lam (rows i), Bm = [h, t, 1].
+  // The two virtual columns (value t and value 1 for every sample) give the time column of the
+  // weight gradient and the bias gradient from the same MFMA chain.
+  const bool first = tile < a.ntile1;
+  const int tt = first ? tile : tile - a.ntile1;
+  const int ncol = first ? a.nt1c : a.nt2c;
+  const int ti = tt / ncol, tj = tt % ncol;
+  const float* A = first ? a.dpre : a.lam;
+  const float* Bm = first ? a.y : a.h;
+  const int lda = first ? a.Hp : a.D, ldb = first ? a.D : a.Hp;
+  const int M = first ? a.H : a.D, N = first ? a.D : a.H;
+  const int row = ti * 16 + li, col = tj * 16 + li;
+  const bool rok = row < M, cok = col < N;
+  const float cconst = (col == N) ? a.t : ((col == N + 1) ? 1.0f : 0.0f);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* Ap = A + (rok ? row : 0);
+  const float* Bp = Bm + (cok ? col : 0);
+  constexpr int UN = 8;  // 8 MFMA k-steps (32 samples) per batch of 16 independent loads
+  int b0 = 0;
+  for (; b0 + 4 * UN <= a.B; b0 += 4 * UN) {
+    float av[UN], bv[UN];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rr = ti * 16 + lk * 4 + r;
-      if (rr < M && c < N) g[(size_t)rr + (size_t)M * c] = acc[r];
+    for (int u = 0; u < UN; ++u) {
+      const size_t b = (size_t)(b0 + 4 * u + lk);
+      av[u] = Ap[b * lda];
+      bv[u] = Bp[b * ldb];
     }
-  } else {
-    // column sums: gb1[o] = sum_b dpre[b][o], gb2[i] = sum_b lam[b][i]; time columns = t * those
-    const int base = (tile - a.ntile1 - a.ntile2) * 64 + lane;
-    if (base < a.H) {
-      float sacc = 0.f;
-      for (int b = 0; b < a.B; ++b) sacc = sacc + a.dpre[(size_t)b * a.Hp + base];
-      a.gp[ob1 + base] = sacc;
-      if (a.td) a.gp[oW1 + (size_t)a.H * a.D + base] = sacc * a.t;
-    } else if (base - a.H < a.D && base >= a.H) {
-      const int i = base - a.H;
-      float sacc = 0.f;
-      for (int b = 0; b < a.B; ++b) sacc = sacc + a.lam[(size_t)b * a.D + i];
-      a.gp[ob2 + i] = sacc;
-      if (a.td) a.gp[oW2 + (size_t)a.D * a.H + i] = sacc * a.t;
-    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rok ? av[u] : 0.f, cok ? bv[u] : cconst, acc, 0, 0, 0);
+  }
+  for (; b0 < a.B; b0 += 4) {
+    const int b = b0 + lk;
+    const bool bok = b < a.B;
+    const float av = (rok && bok) ? A[(size_t)b * lda + row] : 0.f;
+    const float bv = bok ? (cok ? Bm[(size_t)b * ldb + col] : cconst) : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+  }
+  // D fragment: row = ti*16 + lk*4 + r, col = tj*16 + li ; flat weight index = row + M*col
+  float* gW = a.gp + (first ? (size_t)0 : oW2);
+  float* gb = a.gp + (first ? ob1 : ob2);
+  const int c = tj * 16 + li;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rr = ti * 16 + lk * 4 + r;
+    if (rr >= M) continue;
+    if (c < N) gW[(size_t)rr + (size_t)M * c] = acc[r];
+    else if (c == N) { if (a.td) gW[(size_t)rr + (size_t)M * N] = acc[r]; }
+    else if (c == N + 1) gb[rr] = acc[r];
   }
 }
 

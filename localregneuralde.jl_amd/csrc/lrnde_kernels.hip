@@ -2213,10 +2213,11 @@ static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float th
     PgradArgs g;
     g.D = c->m.D; g.H = c->m.H; g.Hp = c->m.Hp; g.td = c->m.td; g.B = B; g.t = t;
     g.lam = lam; g.y = c->bw_y; g.h = c->bw_h; g.dpre = c->bw_dp; g.gp = gp;
+    // output tiles incl. the two virtual columns (time column, bias): gW1 is H x (D+2), gW2 is D x (H+2)
     const int th = (g.H + 15) / 16, td16 = (g.D + 15) / 16;
-    g.ntile1 = th * td16; g.nt1c = td16; g.ntile2 = td16 * th; g.nt2c = th;
-    const int ncs = (g.H + g.D + 63) / 64;
-    const int ntot = g.ntile1 + g.ntile2 + ncs;
+    g.nt1c = (g.D + 2 + 15) / 16; g.nt2c = (g.H + 2 + 15) / 16;
+    g.ntile1 = th * g.nt1c; g.ntile2 = td16 * g.nt2c;
+    const int ntot = g.ntile1 + g.ntile2;
     hipLaunchKernelGGL(k_pgrad, dim3((ntot + 3) / 4), dim3(256), 0, c->stream, g);
     HIPCHK(c, hipGetLastError());
   }

@@ -350,3 +350,22 @@ class NeuralODE:
             us, tt = [us[i] for i in keep], [tt[i] for i in keep]
         sol = ODESolution(us, tt, r["stats"]["nf"], r["stats"]["naccept"], r["stats"]["nreject"])
         return sol, dict(model=st["model"], nfe=nfe, reg_val=reg_val, rng=rng, training=st["training"])
+
+    def pullback(self, x, ps, st, du_end, w_reg=0.0):
+        """What `Zygote.pullback` returns for this layer in the reference's training step
+        (experiments/src/utils.jl:104-115) for  loss = <du_end, sol.u[end]> + w_reg * reg_val:
+        (dx, dps).  The forward is re-run with the same rng draw as `__call__` would make."""
+        h = self._bind(ps)
+        t0, t2 = self.tspan
+        kw = self.kwargs
+        if kw.get("saveat", None) is not None:
+            raise NotImplementedError("pullback with user saveat is not built")
+        abstol, reltol = kw.get("abstol", 1e-6), kw.get("reltol", 1e-3)
+        mode = self.regularize if st["training"] else "none"
+        rng = copy.deepcopy(st["rng"])
+        r01 = np.float32(rng.random(dtype=np.float32))
+        t1_or_rand = np.float32(r01 * (t2 - t0) + t0) if mode == "unbiased" else r01
+        out = h.node_backward(x, t0, t2, abstol, reltol, du_end, mode=mode, reg_type=self.regularize_type,
+                              t1_or_rand=t1_or_rand, w_reg=w_reg, maxiters=self.maxiters,
+                              save_start=kw.get("save_start", True))
+        return out["dx"], out["dp"], out
