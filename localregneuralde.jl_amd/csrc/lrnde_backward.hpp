@@ -219,12 +219,12 @@ struct PgradArgs {
 };
 
 __global__ __launch_bounds__(256) void k_pgrad(PgradArgs a) {
+  __shared__ f32x4 red[3][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = blockIdx.x * 4 + wave;
+  const int tile = blockIdx.x;  // one output tile per workgroup, the batch (K) split over its 4 waves
   const int li = lane & 15, lk = lane >> 4;
   const size_t ob1 = (size_t)a.H * (a.D + a.td), oW2 = ob1 + a.H, ob2 = oW2 + (size_t)a.D * (a.H + a.td);
-  if (tile >= a.ntile1 + a.ntile2) return;
   // C[i][j] = sum_b A[b][i] * Bm[b][j]:  gW1: A = dpre (rows o), Bm = [y, t, 1];  gW2: A = lam (rows i), Bm = [h, t, 1].
   // The two virtual columns (value t and value 1 for every sample) give the time column of the
   // weight gradient and the bias gradient from the same MFMA chain.
@@ -243,26 +243,39 @@ __global__ __launch_bounds__(256) void k_pgrad(PgradArgs a) {
   const float* Ap = A + (rok ? row : 0);
   const float* Bp = Bm + (cok ? col : 0);
   constexpr int UN = 8;  // 8 MFMA k-steps (32 samples) per batch of 16 independent loads
-  int b0 = 0;
-  for (; b0 + 4 * UN <= a.B; b0 += 4 * UN) {
+  // blocks of 32 samples go round-robin to the 4 waves (fixed, so the summation order is fixed)
+  const int nblk = (a.B + 4 * UN - 1) / (4 * UN);
+  for (int blk = wave; blk < nblk; blk += 4) {
+    const int b0 = blk * 4 * UN;
     float av[UN], bv[UN];
+    if (b0 + 4 * UN <= a.B) {
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const size_t b = (size_t)(b0 + 4 * u + lk);
-      av[u] = Ap[b * lda];
-      bv[u] = Bp[b * ldb];
+      for (int u = 0; u < UN; ++u) {
+        const size_t b = (size_t)(b0 + 4 * u + lk);
+        av[u] = Ap[b * lda];
+        bv[u] = Bp[b * ldb];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rok ? av[u] : 0.f, cok ? bv[u] : cconst, acc, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int b = b0 + 4 * u + lk;
+        const bool bok = b < a.B;
+        av[u] = (rok && bok) ? Ap[(size_t)b * lda] : 0.f;
+        bv[u] = bok ? (cok ? Bp[(size_t)b * ldb] : cconst) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
     }
-#pragma unroll
-    for (int u = 0; u < UN; ++u)
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rok ? av[u] : 0.f, cok ? bv[u] : cconst, acc, 0, 0, 0);
   }
-  for (; b0 < a.B; b0 += 4) {
-    const int b = b0 + lk;
-    const bool bok = b < a.B;
-    const float av = (rok && bok) ? A[(size_t)b * lda + row] : 0.f;
-    const float bv = bok ? (cok ? Bm[(size_t)b * ldb + col] : cconst) : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-  }
+  if (wave > 0) red[wave - 1][lane] = acc;
+  __syncthreads();
+  if (wave > 0) return;
+  acc = acc + red[0][lane];
+  acc = acc + red[1][lane];
+  acc = acc + red[2][lane];
   // D fragment: row = ti*16 + lk*4 + r, col = tj*16 + li ; flat weight index = row + M*col
   float* gW = a.gp + (first ? (size_t)0 : oW2);
   float* gb = a.gp + (first ? ob1 : ob2);
@@ -366,6 +379,240 @@ __global__ void k_reg_seed(RegSeedArgs a) {
       const float cb = denb * du / (nf * a.den);
       a.kb[6][i] += ca; a.kb[5][i] -= ca;
       a.ub[i] += cb; a.g6b[i] -= cb;
+    }
+  }
+}
+
+// ===========================================================================================
+// 4-column (q-tile) vector-Jacobian product: the same three GEMM phases as k_vjp on the tile shape
+// and weight stream of lrnde_qtile.hpp (128 workgroups at B=512 instead of 32).  One stream of
+// 21 blocks per wave: 7 of W1q (pre-activation), 7 of V1q = W2^T (dh), 7 of U2q = W1^T (dy).
+// ===========================================================================================
+__global__ void k_pack_tq(const float* p, int D, int H, int td, int KQ1p, int KQ2p, int RG1, int RG2,
+                          float* V1q, float* U2q) {
+  const size_t n1 = (size_t)RG1 * KQ1p * 256, n2 = (size_t)RG2 * KQ2p * 256;
+  const size_t base2 = (size_t)H * (D + td) + H;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i < n1 ? i : i - n1;
+    const int jj = e & 3, l = (e >> 2) & 63;
+    const size_t blk = e >> 8;
+    if (i < n1) {  // V1[o][k] = W2[k][o]
+      const int kq = blk % KQ1p, rg = blk / KQ1p;
+      const int o = rg * 64 + l, k = kq * 4 + jj;
+      V1q[e] = (o < H && k < D) ? p[base2 + (size_t)k + (size_t)D * o] : 0.f;
+    } else {       // U2[o][k] = W1[k][o]
+      const int kq = blk % KQ2p, rg = blk / KQ2p;
+      const int o = rg * 64 + l, k = kq * 4 + jj;
+      U2q[e] = (o < D && k < H) ? p[(size_t)k + (size_t)H * o] : 0.f;
+    }
+  }
+}
+
+struct VjpQArgs {
+  ModelDev m;
+  const float* V1q;  // [RG1][KQ1p][64][4]
+  const float* U2q;  // [RG2][KQ2p][64][4]
+  int B;
+  float t;
+  const float* y; const float* dense; float theta, dense_dt;
+  const float* lam;
+  float* dy; float* ysc; float* hsc; float* dpsc;
+};
+
+constexpr int VQB = 3 * QSB1;  // stream blocks of one VJP (QSB2 == QSB1)
+
+struct StreamV {
+  __amdgpu_buffer_rsrc_t rs1, rsv, rsu;
+  int v1[2], v2[2], s1[2], s2[2];
+  int kq2_real;
+  f32x4 ring[QRING][QSQ][2];
+};
+
+template <int B, int SLOT>
+__device__ __forceinline__ void vq_stream_load(StreamV& st) {
+  if constexpr (B < 2 * QSB1) {
+    constexpr int BB = B % QSB1;
+#pragma unroll
+    for (int j = 0; j < QSQ; ++j) {
+      st.ring[SLOT][j][0] = wload(B < QSB1 ? st.rs1 : st.rsv, st.v1[0], st.s1[0] + (BB * QSQ + j) * 1024);
+      st.ring[SLOT][j][1] = wload(B < QSB1 ? st.rs1 : st.rsv, st.v1[1], st.s1[1] + (BB * QSQ + j) * 1024);
+    }
+  } else if constexpr (B < VQB) {
+#pragma unroll
+    for (int j = 0; j < QSQ; ++j) {
+      constexpr int kq = (B - 2 * QSB1) * QSQ;
+      const bool real = (kq + j) < st.kq2_real;  // wave-uniform
+      st.ring[SLOT][j][0] = wload(st.rsu, real ? st.v2[0] : 0x7ffffff0, st.s2[0] + (kq + j) * 1024);
+      st.ring[SLOT][j][1] = wload(st.rsu, real ? st.v2[1] : 0x7ffffff0, st.s2[1] + (kq + j) * 1024);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// 4 k-quads of one stream block against the B operands b_[0..3]
+__device__ __forceinline__ void vq_block_mfma(const f32x4 (&a)[QSQ][2], const f32x4 (&b_)[QSQ], f32x4& acc0, f32x4& acc1) {
+#pragma unroll
+  for (int j = 0; j < QSQ; ++j) {
+    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].x, b_[j].x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].x, b_[j].x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].y, b_[j].y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].y, b_[j].y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].z, b_[j].z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].z, b_[j].z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].w, b_[j].w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].w, b_[j].w, acc1, 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Dense-1-shaped phase: stream blocks BASE..BASE+6, segment = wave, both row groups; partials -> pl
+template <int BASE>
+__device__ __forceinline__ void vq_phase_ksplit(const ModelDev& m, const SmemQ& sm, StreamV& st, const f32x4* tile) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sidx = lane & 3;
+  const int nseg1 = q_nseg1(m);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4* xp = tile + (size_t)((wave < nseg1 ? wave : 0) * QSEG) * 4 + sidx;
+  static_for<0, QSB1>([&](auto Bc) {
+    constexpr int B = decltype(Bc)::value;
+    constexpr int SL = (BASE + B) % QRING, NSL = (BASE + B + 2) % QRING;
+    vq_stream_load<BASE + B + 2, NSL>(st);
+    f32x4 b_[QSQ];
+#pragma unroll
+    for (int j = 0; j < QSQ; ++j) b_[j] = xp[(B * QSQ + j) * 4];
+    vq_block_mfma(st.ring[SL], b_, acc0, acc1);
+  });
+  if (wave < nseg1) {
+    f32x4* pp = sm.pl + ((size_t)wave * m.RG1) * 64 + lane;
+    pp[0] = acc0;
+    if (m.RG1 > 1) pp[64] = acc1;
+  }
+}
+
+static size_t smem_bytes_vq(int KQ1p, int KQ2p, int RG1, int RG2) {
+  return smem_bytes_q(KQ1p, KQ2p, RG1, RG2) + (size_t)KQ1p * 4 * 16 + (size_t)RG1 * 256 * 4 + 32;
+}
+
+__global__ __launch_bounds__(QNT) void k_vjp_q(VjpQArgs a) {
+  const ModelDev& m = a.m;
+  const SmemQ s = carve_q(m);
+  // extra LDS behind the forward layout: the lambda tile and act'(pre)
+  f32x4* ll = reinterpret_cast<f32x4*>((reinterpret_cast<uintptr_t>(s.bc + 1) + 15) & ~(uintptr_t)15);
+  float* dact = reinterpret_cast<float*>(ll + (size_t)m.KQ1p * 4);
+  smem_init_q(m, s);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sidx = lane & 3, q = lane >> 2;
+  const int b0 = blockIdx.x * QNB, nvalid = min(QNB, a.B - b0);
+  const int KQ1 = m.D / 4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  StreamV st;
+  {
+    const int voff = lane * 16;
+    st.rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)m.W1q, 0, m.RG1 * m.KQ1p * 1024, 0x00020000);
+    st.rsv = __builtin_amdgcn_make_buffer_rsrc((void*)a.V1q, 0, m.RG1 * m.KQ1p * 1024, 0x00020000);
+    st.rsu = __builtin_amdgcn_make_buffer_rsrc((void*)a.U2q, 0, m.RG2 * m.KQ2p * 1024, 0x00020000);
+    const bool has1 = wave < q_nseg1(m);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      st.v1[c] = (has1 && c < m.RG1 && c * 64 + lane < m.H) ? voff : 0x7ffffff0;
+      st.s1[c] = (c * m.KQ1p + (has1 ? wave * QSEG : 0)) * 1024;
+      const int g = wave + c * QNW;
+      st.v2[c] = (g < m.RG2 && g * 64 + lane < m.D) ? voff : 0x7ffffff0;
+      st.s2[c] = (g < m.RG2 ? g : 0) * m.KQ2p * 1024;
+    }
+    st.kq2_real = (m.H + 3) / 4;
+    vq_stream_load<0, 0>(st);
+    vq_stream_load<1, 1>(st);
+  }
+  for (int i = threadIdx.x; i < (m.KQ1p - KQ1) * 4; i += QNT) ll[KQ1 * 4 + i] = zero4;
+  // ---- phase 0: y tile (given or interpolated) and lambda tile -> LDS; y -> scratch ----
+  float bw[7];
+  if (!a.y) tsit5_bweights(a.theta, bw);
+  __syncthreads();
+  q_tile_foreach(m, b0, nvalid, KQ1, [&](int kq, int sx, bool valid, size_t g) {
+    f32x4 x = zero4, lv = zero4;
+    if (valid) {
+      if (a.y) {
+        x = ld4(a.y + g);
+      } else {
+        const size_t nst = (size_t)a.B * m.D;
+        const f32x4 y0 = ld4(a.dense + g), v1 = ld4(a.dense + nst + g), v2 = ld4(a.dense + 2 * nst + g),
+                    v3 = ld4(a.dense + 3 * nst + g), v4 = ld4(a.dense + 4 * nst + g), v5 = ld4(a.dense + 5 * nst + g),
+                    v6 = ld4(a.dense + 6 * nst + g), v7 = ld4(a.dense + 7 * nst + g);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          float sum = v1[h] * bw[0] + v2[h] * bw[1];
+          sum = sum + v3[h] * bw[2];
+          sum = sum + v4[h] * bw[3];
+          sum = sum + v5[h] * bw[4];
+          sum = sum + v6[h] * bw[5];
+          sum = sum + v7[h] * bw[6];
+          x[h] = y0[h] + a.dense_dt * sum;
+        }
+      }
+      st4(a.ysc + g, x);
+      lv = ld4(a.lam + g);
+    }
+    s.xl[kq * 4 + sx] = x;
+    ll[kq * 4 + sx] = lv;
+  });
+  __syncthreads();
+  const int h64 = m.RG1 * 64;
+  const float* w1t = s.bias; const float* b1 = w1t + h64;
+  const float* plf = reinterpret_cast<const float*>(s.pl);
+  float* hlf = reinterpret_cast<float*>(s.hl);
+  const int ne = m.RG1 * 256;
+  const int nseg1 = q_nseg1(m);
+  // ---- phase 1: pre = W1 [y;t] + b1 ; h, act' ----
+  vq_phase_ksplit<0>(m, s, st, s.xl);
+  q_barrier();
+  for (int e = threadIdx.x; e < ne; e += QNT) {
+    const int r = e & 3, l = (e >> 2) & 63, rg = e >> 8;
+    const int o = rg * 64 + (l >> 2) * 4 + r, sx = l & 3;
+    if ((o >> 2) >= m.KQ2p) continue;
+    float v = plf[e];
+    for (int sgi = 1; sgi < nseg1; ++sgi) v = v + plf[(size_t)sgi * ne + e];
+    float pre = m.td ? fma_(w1t[o], a.t, v) : v;
+    pre = pre + b1[o];
+    const float h = act_apply(m.act, pre);
+    dact[e] = act_deriv_c(m.act, pre, h);
+    if (sx < nvalid && o < m.Hp) a.hsc[(size_t)(b0 + sx) * m.Hp + o] = h;
+  }
+  q_barrier();
+  // ---- phase 2: dh = W2^T lam ; dpre = dh .* act' -> h tile image + scratch ----
+  vq_phase_ksplit<QSB1>(m, s, st, ll);
+  q_barrier();
+  for (int e = threadIdx.x; e < ne; e += QNT) {
+    const int r = e & 3, l = (e >> 2) & 63, rg = e >> 8;
+    const int o = rg * 64 + (l >> 2) * 4 + r, sx = l & 3;
+    if ((o >> 2) >= m.KQ2p) continue;
+    float v = plf[e];
+    for (int sgi = 1; sgi < nseg1; ++sgi) v = v + plf[(size_t)sgi * ne + e];
+    const float dpre = (o < m.H) ? v * dact[e] : 0.f;
+    hlf[((o >> 2) * 4 + sx) * 4 + r] = dpre;
+    if (sx < nvalid && o < m.Hp) a.dpsc[(size_t)(b0 + sx) * m.Hp + o] = dpre;
+  }
+  q_barrier();
+  // ---- phase 3: dy = W1^T dpre (row groups wave and wave + QNW, one chain over K = H) ----
+  {
+    const f32x4* hp = s.hl + sidx;
+    f32x4 acc0 = zero4, acc1 = zero4;
+    static_for<0, QSB2>([&](auto Bc) {
+      constexpr int B = decltype(Bc)::value;
+      constexpr int SL = (2 * QSB1 + B) % QRING, NSL = (2 * QSB1 + B + 2) % QRING;
+      vq_stream_load<2 * QSB1 + B + 2, NSL>(st);
+      f32x4 b_[QSQ];
+#pragma unroll
+      for (int j = 0; j < QSQ; ++j) b_[j] = hp[(B * QSQ + j) * 4];
+      vq_block_mfma(st.ring[SL], b_, acc0, acc1);
+    });
+    const int g0 = wave, g1 = wave + QNW;
+    if (sidx < nvalid) {
+      float* dst = a.dy + (size_t)(b0 + sidx) * m.D + q * 4;
+      if (g0 < m.RG2 && g0 * 64 + q * 4 < m.D) st4(dst + g0 * 64, acc0);
+      if (g1 < m.RG2 && g1 * 64 + q * 4 < m.D) st4(dst + g1 * 64, acc1);
     }
   }
 }

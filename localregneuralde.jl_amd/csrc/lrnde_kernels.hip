@@ -1415,6 +1415,7 @@ struct lrnde_ctx {
   float *W1p = nullptr, *W2p = nullptr, *w1t = nullptr, *b1 = nullptr, *w2t = nullptr, *b2 = nullptr;
   float *W1q = nullptr, *W2q = nullptr;
   float *V1p = nullptr, *U2p = nullptr;          // transposed weights for the backward pass
+  float *V1q = nullptr, *U2q = nullptr;          // the same in the 4-column layouts
   float *bw_y = nullptr, *bw_h = nullptr, *bw_dp = nullptr;  // VJP scratch (B*D, B*Hp, B*Hp)
   int bwB = 0;
   // dense forward record + adjoint work vectors
@@ -1696,7 +1697,9 @@ int lrnde_create(lrnde_ctx** out, const lrnde_model_desc* d, int device, void* s
   m.RG1 = (d->hidden_dim + 63) / 64;
   m.RG2 = (d->state_dim + 63) / 64;
   ok = ok && hipMalloc(&c->W1q, sizeof(float) * (size_t)m.RG1 * m.KQ1p * 256) == hipSuccess &&
-       hipMalloc(&c->W2q, sizeof(float) * (size_t)m.RG2 * m.KQ2p * 256) == hipSuccess;
+       hipMalloc(&c->W2q, sizeof(float) * (size_t)m.RG2 * m.KQ2p * 256) == hipSuccess &&
+       hipMalloc(&c->V1q, sizeof(float) * (size_t)m.RG1 * m.KQ1p * 256) == hipSuccess &&
+       hipMalloc(&c->U2q, sizeof(float) * (size_t)m.RG2 * m.KQ2p * 256) == hipSuccess;
   if (!ok) { lrnde_destroy(c); return LRNDE_HIP_ERROR; }
   m.W1q = c->W1q; m.W2q = c->W2q;
   m.W1p = reinterpret_cast<const f32x4*>(c->W1p);
@@ -1712,7 +1715,7 @@ int lrnde_destroy(lrnde_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->adj_part_host) hipHostFree(c->adj_part_host);
-  void* ptrs[] = {c->dense, c->dense_t, c->dense_dt, c->adj, c->adj_part, c->V1p, c->U2p, c->bw_y, c->bw_h, c->bw_dp, c->W1q, c->W2q, c->W1p, c->W2p, c->w1t, c->b1, c->w2t, c->b2, c->state, c->ctrl, c->part,
+  void* ptrs[] = {c->dense, c->dense_t, c->dense_dt, c->adj, c->adj_part, c->V1p, c->U2p, c->V1q, c->U2q, c->bw_y, c->bw_h, c->bw_dp, c->W1q, c->W2q, c->W1p, c->W2p, c->w1t, c->b1, c->w2t, c->b2, c->state, c->ctrl, c->part,
                   c->part_rx, c->pinit, c->pinit_rx, c->saveat_dev, c->tsaved_dev, c->trace_dev,
                   c->usave};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -1737,6 +1740,8 @@ int lrnde_set_params(lrnde_ctx* c, const float* p, size_t n) {
   hipLaunchKernelGGL(k_pack_q, dim3(256), dim3(256), 0, c->stream, p, m.D, m.H, m.td, m.KQ1p, m.KQ2p, m.RG1, m.RG2,
                      c->W1q, c->W2q);
   hipLaunchKernelGGL(k_pack_t, dim3(256), dim3(256), 0, c->stream, p, m.D, m.H, m.td, m.Dp, m.Hp, c->V1p, c->U2p);
+  hipLaunchKernelGGL(k_pack_tq, dim3(256), dim3(256), 0, c->stream, p, m.D, m.H, m.td, m.KQ1p, m.KQ2p, m.RG1, m.RG2,
+                     c->V1q, c->U2q);
   HIPCHK(c, hipGetLastError());
   c->have_params = true;
   return LRNDE_OK;
@@ -2194,11 +2199,37 @@ static int ensure_bw(lrnde_ctx* c, int B) {
   return LRNDE_OK;
 }
 
+// (df/dp)^T lam from the scratch left by the last VJP launch (y, h, dpre); gp may be NULL
+static int launch_pgrad(lrnde_ctx* c, int B, float t, const float* lam, float* gp) {
+  if (!gp) return LRNDE_OK;
+  PgradArgs g;
+  g.D = c->m.D; g.H = c->m.H; g.Hp = c->m.Hp; g.td = c->m.td; g.B = B; g.t = t;
+  g.lam = lam; g.y = c->bw_y; g.h = c->bw_h; g.dpre = c->bw_dp; g.gp = gp;
+  // output tiles incl. the two virtual columns (time column, bias): gW1 is H x (D+2), gW2 is D x (H+2)
+  const int th = (g.H + 15) / 16, td16 = (g.D + 15) / 16;
+  g.nt1c = (g.D + 2 + 15) / 16; g.nt2c = (g.H + 2 + 15) / 16;
+  g.ntile1 = th * g.nt1c; g.ntile2 = td16 * g.nt2c;
+  hipLaunchKernelGGL(k_pgrad, dim3(g.ntile1 + g.ntile2), dim3(256), 0, c->stream, g);
+  HIPCHK(c, hipGetLastError());
+  return LRNDE_OK;
+}
+
 // dy = J^T lam at (y or the interpolated dense step, t);  gp (optional) = (df/dp)^T lam
 static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float theta, float dense_dt, float t,
                       const float* lam, int B, float* dy, float* gp) {
   int rc = ensure_bw(c, B);
   if (rc) return rc;
+  if (use_qtile(c, B) && !getenv("LRNDE_NO_QVJP")) {
+    VjpQArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m = c->m; a.V1q = c->V1q; a.U2q = c->U2q;
+    a.B = B; a.t = t; a.y = y; a.dense = dense; a.theta = theta; a.dense_dt = dense_dt; a.lam = lam; a.dy = dy;
+    a.ysc = c->bw_y; a.hsc = c->bw_h; a.dpsc = c->bw_dp;
+    const size_t smq = smem_bytes_vq(c->m.KQ1p, c->m.KQ2p, c->m.RG1, c->m.RG2);
+    hipLaunchKernelGGL(k_vjp_q, dim3((B + QNB - 1) / QNB), dim3(QNT), smq, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return launch_pgrad(c, B, t, lam, gp);
+  }
   VjpArgs a;
   memset(&a, 0, sizeof(a));
   a.m = c->m; a.V1p = reinterpret_cast<const f32x4*>(c->V1p); a.U2p = reinterpret_cast<const f32x4*>(c->U2p);
@@ -2209,19 +2240,7 @@ static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float th
   if (vecw(c) == 4) hipLaunchKernelGGL(k_vjp<4>, dim3(nwg), dim3(NT), sm, c->stream, a);
   else hipLaunchKernelGGL(k_vjp<1>, dim3(nwg), dim3(NT), sm, c->stream, a);
   HIPCHK(c, hipGetLastError());
-  if (gp) {
-    PgradArgs g;
-    g.D = c->m.D; g.H = c->m.H; g.Hp = c->m.Hp; g.td = c->m.td; g.B = B; g.t = t;
-    g.lam = lam; g.y = c->bw_y; g.h = c->bw_h; g.dpre = c->bw_dp; g.gp = gp;
-    // output tiles incl. the two virtual columns (time column, bias): gW1 is H x (D+2), gW2 is D x (H+2)
-    const int th = (g.H + 15) / 16, td16 = (g.D + 15) / 16;
-    g.nt1c = (g.D + 2 + 15) / 16; g.nt2c = (g.H + 2 + 15) / 16;
-    g.ntile1 = th * g.nt1c; g.ntile2 = td16 * g.nt2c;
-    const int ntot = g.ntile1 + g.ntile2;
-    hipLaunchKernelGGL(k_pgrad, dim3((ntot + 3) / 4), dim3(256), 0, c->stream, g);
-    HIPCHK(c, hipGetLastError());
-  }
-  return LRNDE_OK;
+  return launch_pgrad(c, B, t, lam, gp);
 }
 
 int lrnde_vjp(lrnde_ctx* c, const float* y, float t, const float* lam, int32_t B, float* dy, float* gp) {
