@@ -256,6 +256,107 @@ void lro_mlp_as_field(const lro_mlp* m, lro_field* out) {
 }
 
 /* ------------------------------------------------------------------------- */
+/* conv vector field (experiments/src/construct.jl:213-218)                   */
+/* ------------------------------------------------------------------------- */
+int lro_conv_param_count(int C, int Hc) {
+  return 9 * (C + 1) * Hc + 2 * Hc + 9 * (Hc + 1) * Hc + 2 * Hc + 9 * (Hc + 1) * C;
+}
+
+/* out[b][co][y][x] = sum_{ky,kx,ci} w[kx,ky,ci,co] * in[b][ci][y+1-ky][x+1-kx]  (NNlib.conv: flipped
+ * kernel, pad 1), channel ci == cin is the t plane (src/layers/common.jl:10-45).  in: (B, cin, H, W). */
+static void conv3x3_t(const float* in, int B, int cin, int cout, int H, int W, const float* w, float t,
+                      float* out, int nth) {
+  const int cint = cin + 1;
+  const long plane = (long)H * W;
+#pragma omp parallel for collapse(2) schedule(static) num_threads(nth)
+  for (int b = 0; b < B; ++b)
+    for (int co = 0; co < cout; ++co) {
+      float* o = out + ((long)b * cout + co) * plane;
+      for (long i = 0; i < plane; ++i) o[i] = 0.0f;
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx)
+          for (int ci = 0; ci < cint; ++ci) {
+            const float wv = w[kx + 3 * (ky + 3 * (ci + (long)cint * co))];
+            const int dy = 1 - ky, dx = 1 - kx;
+            const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? H - dy : H;
+            const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? W - dx : W;
+            if (ci < cin) {
+              const float* ip = in + ((long)b * cin + ci) * plane;
+              for (int y = y0; y < y1; ++y) {
+                float* orow = o + (long)y * W;
+                const float* irow = ip + (long)(y + dy) * W + dx;
+                for (int x = x0; x < x1; ++x) orow[x] = fmaf(wv, irow[x], orow[x]);
+              }
+            } else {
+              for (int y = y0; y < y1; ++y) {
+                float* orow = o + (long)y * W;
+                for (int x = x0; x < x1; ++x) orow[x] = fmaf(wv, t, orow[x]);
+              }
+            }
+          }
+    }
+}
+
+/* Lux BatchNorm(ch, act) over (W,H,N) per channel, in place on (B, ch, H, W) */
+static void batchnorm_act(float* x, int B, int ch, long plane, const float* scale, const float* bias,
+                          int train, const float* rmean, const float* rvar, float eps, int act, int nth) {
+#pragma omp parallel for schedule(static) num_threads(nth)
+  for (int c = 0; c < ch; ++c) {
+    float mean, inv;
+    if (train) {
+      double s = 0.0;
+      for (int b = 0; b < B; ++b) { const float* p = x + ((long)b * ch + c) * plane; for (long i = 0; i < plane; ++i) s += (double)p[i]; }
+      const double mu = s / ((double)B * (double)plane);
+      double v = 0.0;
+      for (int b = 0; b < B; ++b) { const float* p = x + ((long)b * ch + c) * plane; for (long i = 0; i < plane; ++i) { const double d = (double)p[i] - mu; v += d * d; } }
+      v /= ((double)B * (double)plane);
+      mean = (float)mu;
+      inv = (float)(1.0 / sqrt(v + (double)eps));
+    } else {
+      mean = rmean ? rmean[c] : 0.0f;
+      inv = (float)(1.0 / sqrt((double)(rvar ? rvar[c] : 1.0f) + (double)eps));
+    }
+    for (int b = 0; b < B; ++b) {
+      float* p = x + ((long)b * ch + c) * plane;
+      for (long i = 0; i < plane; ++i) {
+        const float xn = (p[i] - mean) * inv;
+        const float y = xn * scale[c] + bias[c];
+        p[i] = act_apply(act, y);
+      }
+    }
+  }
+}
+
+void lro_conv_rhs(const lro_conv* m, const float* u, float t, int B, float* du) {
+  const int C = m->C, Hc = m->Hc, H = m->H, W = m->W;
+  const long plane = (long)H * W;
+  const int nth = m->nthreads > 0 ? m->nthreads : 1;
+  const float* w1 = m->p;
+  const float* g1 = w1 + 9 * (C + 1) * Hc; const float* b1 = g1 + Hc;
+  const float* w2 = b1 + Hc;
+  const float* g2 = w2 + 9 * (Hc + 1) * Hc; const float* b2 = g2 + Hc;
+  const float* w3 = b2 + Hc;
+  float* y1 = (float*)malloc(sizeof(float) * (size_t)B * Hc * plane);
+  float* y2 = (float*)malloc(sizeof(float) * (size_t)B * Hc * plane);
+  const float* st = m->bn_state;
+  conv3x3_t(u, B, C, Hc, H, W, w1, t, y1, nth);
+  batchnorm_act(y1, B, Hc, plane, g1, b1, m->bn_train, st ? st : NULL, st ? st + Hc : NULL, m->eps, m->act, nth);
+  conv3x3_t(y1, B, Hc, Hc, H, W, w2, t, y2, nth);
+  batchnorm_act(y2, B, Hc, plane, g2, b2, m->bn_train, st ? st + 2 * Hc : NULL, st ? st + 3 * Hc : NULL, m->eps, m->act, nth);
+  conv3x3_t(y2, B, Hc, C, H, W, w3, t, du, nth);
+  free(y1); free(y2);
+}
+
+static void conv_field_tramp(void* ctx, const float* u, float t, int B, float* du) {
+  lro_conv_rhs((const lro_conv*)ctx, u, t, B, du);
+}
+void lro_conv_as_field(const lro_conv* m, lro_field* out) {
+  out->fn = conv_field_tramp;
+  out->ctx = (void*)m;
+  out->D = m->W * m->H * m->C;
+}
+
+/* ------------------------------------------------------------------------- */
 /* norms and residuals (src/perform_step.jl:208-212)                          */
 /* ------------------------------------------------------------------------- */
 

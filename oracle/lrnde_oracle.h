@@ -29,6 +29,15 @@
  *                         as called from src/layers/neural_ode.jl:42-54
  *   lro_node_forward      src/layers/neural_ode.jl:56-116 (none / unbiased / biased)
  *   lro_euler_heun_step   src/perform_step.jl:172-206, 214-216
+ *   lro_conv_rhs          experiments/src/construct.jl:213-218 (the CIFAR10 node_core:
+ *                         TDChain(Chain(Conv3x3 C+1=>Hc no-bias, BatchNorm(Hc, act)),
+ *                         Chain(Conv Hc+1=>Hc, BatchNorm(Hc, act)), Conv Hc+1=>C)),
+ *                         src/layers/common.jl:10-45 (t plane concatenated as the LAST
+ *                         channel before every sub-layer, and therefore zero padded at the
+ *                         image border like any other channel); Lux Conv = NNlib.conv (true
+ *                         convolution: flipped kernel) and Lux BatchNorm (batch statistics
+ *                         with the biased variance in training, running statistics in test
+ *                         mode, epsilon 1f-5) are un-vendored: UPSTREAM-RECALL.
  *
  * Canonical arithmetic (shared definition with the HIP kernels, so that both
  * produce the same bits): every Dense dot product is a sum of fp32 fma chains
@@ -76,6 +85,23 @@ typedef struct {
   int nthreads;
 } lro_mlp;
 
+/* conv field on a (W x H x C) image state per sample, Julia WHCN order (w fastest), i.e. the
+ * (B, W*H*C) sample-major state of everything else here.  Flat params in Lux/ComponentArray
+ * order: conv1.weight (3x3x(C+1)xHc, column-major kx,ky,ci,co), bn1.scale (Hc), bn1.bias (Hc),
+ * conv2.weight (3x3x(Hc+1)xHc), bn2.scale, bn2.bias, conv3.weight (3x3x(Hc+1)xC).
+ * Arithmetic (fp32): each output = one fma chain over (ky, kx, ci) in that nesting order,
+ * out-of-image taps skipped; BN statistics in fp64; y = ((x-mean)*inv)*scale + bias; act.
+ * Parity of the HIP conv path with this is BY TOLERANCE (the batch statistics couple all
+ * samples through sums whose order the GPU does not reproduce), see tests/test_gpu_conv.py. */
+typedef struct {
+  int W, H, C, Hc, act;
+  int bn_train;          /* 1: batch statistics; 0: bn_state = [mean1 var1 mean2 var2] (4*Hc) */
+  float eps;
+  const float* p;
+  const float* bn_state; /* may be NULL in test mode: mean 0, var 1 */
+  int nthreads;
+} lro_conv;
+
 typedef struct {
   float abstol, reltol;
   int maxiters;
@@ -109,6 +135,9 @@ int lro_tsit5_tableau(double* a, double* c, double* btilde, double* r); /* a[21]
 int lro_mlp_param_count(int D, int H, int time_dep);
 void lro_mlp_rhs(const lro_mlp* m, const float* u, float t, int B, float* du);
 void lro_mlp_as_field(const lro_mlp* m, lro_field* out);
+int lro_conv_param_count(int C, int Hc);
+void lro_conv_rhs(const lro_conv* m, const float* u, float t, int B, float* du);
+void lro_conv_as_field(const lro_conv* m, lro_field* out);
 
 /* ---- step kernels ---- */
 /* ks: optional (5*D*B) k2..k6; g6: optional (D*B) */

@@ -31,6 +31,12 @@ class Mlp(C.Structure):
                 ("p", C.POINTER(C.c_float)), ("nthreads", C.c_int)]
 
 
+class Conv(C.Structure):
+    _fields_ = [("W", C.c_int), ("H", C.c_int), ("C", C.c_int), ("Hc", C.c_int), ("act", C.c_int),
+                ("bn_train", C.c_int), ("eps", C.c_float), ("p", C.POINTER(C.c_float)),
+                ("bn_state", C.POINTER(C.c_float)), ("nthreads", C.c_int)]
+
+
 class Opts(C.Structure):
     _fields_ = [("abstol", C.c_float), ("reltol", C.c_float), ("maxiters", C.c_int),
                 ("save_start", C.c_int), ("save_everystep", C.c_int), ("exact_pow", C.c_int)]
@@ -73,6 +79,11 @@ def lib():
         L.lro_mlp_param_count.argtypes = [C.c_int] * 3
         L.lro_mlp_rhs.restype = None
         L.lro_mlp_rhs.argtypes = [C.POINTER(Mlp), fp, C.c_float, C.c_int, fp]
+        L.lro_conv_param_count.argtypes = [C.c_int] * 2
+        L.lro_conv_rhs.restype = None
+        L.lro_conv_rhs.argtypes = [C.POINTER(Conv), fp, C.c_float, C.c_int, fp]
+        L.lro_conv_as_field.restype = None
+        L.lro_conv_as_field.argtypes = [C.POINTER(Conv), C.POINTER(Field)]
         L.lro_mlp_as_field.restype = None
         L.lro_mlp_as_field.argtypes = [C.POINTER(Mlp), C.POINTER(Field)]
         L.lro_tsit5_step.argtypes = [C.POINTER(Field), fp, fp, C.c_float, C.c_float, C.c_float,
@@ -140,6 +151,40 @@ class MlpField:
         du = np.empty_like(u)
         lib().lro_mlp_rhs(C.byref(self.m), _fp(u), float(t), B, _fp(du))
         return du
+
+
+class ConvField:
+    """TDChain(Chain(Conv3x3(C+1=>Hc), BN(Hc,act)), Chain(Conv(Hc+1=>Hc), BN(Hc,act)), Conv(Hc+1=>C))
+    on a (W,H,C) image state (experiments/src/construct.jl:213-218), flat Lux-ordered params."""
+
+    def __init__(self, W, H, Cch, Hc, params, act="gelu", bn_train=True, bn_state=None, eps=1e-5, nthreads=1):
+        self.W, self.H, self.C, self.Hc = int(W), int(H), int(Cch), int(Hc)
+        self.D = self.W * self.H * self.C
+        self.params = _f32(params)
+        assert self.params.size == lib().lro_conv_param_count(self.C, self.Hc), "param count"
+        self.bn_state = None if bn_state is None else _f32(bn_state)
+        self.m = Conv(self.W, self.H, self.C, self.Hc, ACT[act], int(bool(bn_train)), float(eps), _fp(self.params),
+                      _fp(self.bn_state) if self.bn_state is not None else None, int(nthreads))
+        self.field = Field()
+        lib().lro_conv_as_field(C.byref(self.m), C.byref(self.field))
+
+    def rhs(self, u, t):
+        u = _f32(u)
+        B = u.size // self.D
+        du = np.empty_like(u)
+        lib().lro_conv_rhs(C.byref(self.m), _fp(u), float(t), B, _fp(du))
+        return du
+
+
+def glorot_conv_params(Cch, Hc, seed=0):
+    """Lux Conv init: weight ~ glorot_uniform over (3,3,cin,cout) (fan_in = 9 cin, fan_out = 9 cout), no
+    bias; BatchNorm scale = 1, bias = 0.  numpy stream (the Julia RNG streams cannot be reproduced)."""
+    rng = np.random.default_rng(seed)
+    def glorot(cin, cout):
+        return ((rng.random(9 * cin * cout, dtype=np.float32) - np.float32(0.5)) *
+                np.float32(np.sqrt(24.0 / (9 * cin + 9 * cout)))).astype(np.float32)
+    one, zero = np.ones(Hc, np.float32), np.zeros(Hc, np.float32)
+    return np.concatenate([glorot(Cch + 1, Hc), one, zero, glorot(Hc + 1, Hc), one, zero, glorot(Hc + 1, Cch)])
 
 
 class PyField:
