@@ -162,6 +162,52 @@ int lrnde_sde_euler_heun_step(lrnde_sde* sde, const float* uprev, const float* d
                               float dt, float abstol, float reltol, float delta, float* u,
                               float* eest_host, float* reg_val_host);
 
+/* ---- conv vector field (experiments/src/construct.jl:213-218) ----
+ * node_core = TDChain(Chain(Conv3x3(C+1=>Hc, no bias), BatchNorm(Hc, act)),
+ *                     Chain(Conv3x3(Hc+1=>Hc), BatchNorm(Hc, act)), Conv3x3(Hc+1=>C))
+ * on a (W x H x C x B) image state in the reference's own (Julia WHCN, w fastest) order — the same
+ * (B, W*H*C) sample-major device array as everywhere else in this header.  Flat parameters in
+ * Lux/ComponentArray order: conv1.weight (3x3x(C+1)xHc, column-major), bn1.scale, bn1.bias,
+ * conv2.weight (3x3x(Hc+1)xHc), bn2.scale, bn2.bias, conv3.weight (3x3x(Hc+1)xC).
+ * The t plane is concatenated as the last channel before every conv (src/layers/common.jl:10-45) and
+ * is zero padded at the border like any other channel.  bn_train = 1: batch statistics (Lux training
+ * mode); 0: the running statistics given to lrnde_conv_set_bn_state (default mean 0 / var 1).
+ * compute_dtype LRNDE_F32: fp32 MFMA; LRNDE_BF16: bf16 MFMA operands, fp32 accumulation, fp32 state,
+ * stage combination and error norm (BASELINE.json config 4).
+ * The solver entry points have the meaning of their lrnde_* namesakes above (same reference lines);
+ * the adaptive loop's controller runs on the host for this field (an f-eval is 10^2..10^3 us). */
+enum { LRNDE_F32 = 0, LRNDE_BF16 = 1 };
+typedef struct {
+  int32_t width, height, channels; /* state image W, H, C (CIFAR block: 32, 32, 8) */
+  int32_t hidden;                  /* Hc (64) */
+  int32_t act;                     /* LRNDE_ACT_*: activation inside the BatchNorm layers (gelu) */
+  int32_t bn_train;
+  int32_t compute_dtype;
+  float bn_eps;                    /* Lux default 1e-5 */
+} lrnde_conv_desc;
+typedef struct lrnde_conv lrnde_conv;
+size_t lrnde_conv_param_count(const lrnde_conv_desc* d);
+int lrnde_conv_create(lrnde_conv** out, const lrnde_conv_desc* d, int device, void* stream);
+int lrnde_conv_destroy(lrnde_conv* c);
+const char* lrnde_conv_last_error(const lrnde_conv* c);
+int lrnde_conv_set_params(lrnde_conv* c, const float* p, size_t n);               /* device pointer */
+int lrnde_conv_set_bn_state(lrnde_conv* c, const float* mean_var, size_t n);      /* device, [mean1 var1 mean2 var2] */
+int lrnde_conv_rhs(lrnde_conv* c, const float* u, float t, int32_t B, float* du);
+int lrnde_conv_init_dt(lrnde_conv* c, const float* u0, int32_t B, float t0, float t1, float abstol,
+                       float reltol, float* k1, float* dt_host);
+int lrnde_conv_perform_step(lrnde_conv* c, const float* uprev, const float* k1, int32_t B, float t, float dt,
+                            float abstol, float reltol, float* u, float* k7, float* eest_host,
+                            float* reg_error_host, float* reg_stiff_host);
+int lrnde_conv_solve(lrnde_conv* c, const float* u0, int32_t B, float t0, float t1, const lrnde_solve_opts* o,
+                     const float* saveat_host, int32_t nsave, float* u_saved, float* t_saved_host,
+                     int32_t cap_saved, lrnde_stats* st, lrnde_trace_row* trace_host, int32_t cap_trace);
+int lrnde_conv_node_forward(lrnde_conv* c, const float* x, int32_t B, float t0, float t2,
+                            const lrnde_solve_opts* o, int32_t mode, int32_t reg_type, float t1_or_rand,
+                            float* u_end, float* reg_val_host, int32_t* nfe_host, lrnde_stats* st,
+                            float* t1_used_host);
+/* average microseconds of one f-eval (3 conv + 2 batch-norm statistics launches), HIP events */
+int lrnde_conv_bench_rhs(lrnde_conv* c, const float* u, float t, int32_t B, int32_t reps, float* us_host);
+
 /* ---- backward pass ----
  * lrnde_vjp: the vector-Jacobian product Zygote.pullback(dudt, y, p, t) computes inside the adjoint
  * RHS (SciMLSensitivity ZygoteVJP): dy = (df/dy)^T lam, gp = (df/dp)^T lam (flat Lux layout, may be

@@ -10,4 +10,5 @@ from .layers import (Chain, Dense, Handle, NeuralODE, ODESolution, TDChain,  # n
                      diffeqsol_to_array, diffeqsol_to_timeseries, flatten_params,
                      glorot_params)
 from .sde import NeuralDSDE, SdeHandle  # noqa: F401
+from .conv import BatchNorm, Conv, ConvHandle, glorot_conv_params  # noqa: F401
 from .sharding import shard_columns, init_comm  # noqa: F401

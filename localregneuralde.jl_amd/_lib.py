@@ -11,11 +11,17 @@ STATUS = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "DtNaN", 4: "BadAr
 ACT = {"identity": 0, "tanh": 1, "gelu": 2}
 REG_TYPE = {"error_estimate": 0, "stiffness_estimate": 1}
 MODE = {"none": 0, "unbiased": 1, "biased": 2}
+DTYPE = {"f32": 0, "bf16": 1}
 
 
 class ModelDesc(C.Structure):
     _fields_ = [("state_dim", C.c_int32), ("hidden_dim", C.c_int32), ("time_dep", C.c_int32),
                 ("act", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32), ("hidden", C.c_int32),
+                ("act", C.c_int32), ("bn_train", C.c_int32), ("compute_dtype", C.c_int32), ("bn_eps", C.c_float)]
 
 
 class SolveOpts(C.Structure):
@@ -65,6 +71,20 @@ SYMBOLS = [
     ("lrnde_step_reg_grad", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _vp, _fp]),
     ("lrnde_node_backward", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _i32, _i32, _f, _vp, _f, _vp, _vp,
                                       C.POINTER(Stats), C.POINTER(Stats)]),
+    ("lrnde_conv_param_count", C.c_size_t, [C.POINTER(ConvDesc)]),
+    ("lrnde_conv_create", C.c_int, [C.POINTER(_vp), C.POINTER(ConvDesc), C.c_int, _vp]),
+    ("lrnde_conv_destroy", C.c_int, [_vp]),
+    ("lrnde_conv_last_error", C.c_char_p, [_vp]),
+    ("lrnde_conv_set_params", C.c_int, [_vp, _vp, C.c_size_t]),
+    ("lrnde_conv_set_bn_state", C.c_int, [_vp, _vp, C.c_size_t]),
+    ("lrnde_conv_rhs", C.c_int, [_vp, _vp, _f, _i32, _vp]),
+    ("lrnde_conv_init_dt", C.c_int, [_vp, _vp, _i32, _f, _f, _f, _f, _vp, _fp]),
+    ("lrnde_conv_perform_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _vp, _vp, _fp, _fp, _fp]),
+    ("lrnde_conv_solve", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _fp, _i32, _vp, _fp, _i32,
+                                   C.POINTER(Stats), C.POINTER(TraceRow), _i32]),
+    ("lrnde_conv_node_forward", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _i32, _i32, _f, _vp,
+                                          _fp, C.POINTER(_i32), C.POINTER(Stats), _fp]),
+    ("lrnde_conv_bench_rhs", C.c_int, [_vp, _vp, _f, _i32, _i32, _fp]),
     ("lrnde_bench_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _fp]),
     ("lrnde_last_solve_kernel_ms", C.c_int, [_vp, _fp, C.POINTER(_i32)]),
 ]

@@ -1,0 +1,947 @@
+// lrnde_conv.hip — the conv vector field of the reference's CIFAR10 NeuralODE
+// (experiments/src/construct.jl:213-218) and the adaptive Tsit5 path around it, for gfx950.
+//
+//   node_core = TDChain(Chain(Conv3x3(C+1=>Hc, no bias), BatchNorm(Hc, act)),
+//                       Chain(Conv3x3(Hc+1=>Hc),         BatchNorm(Hc, act)),
+//                       Conv3x3(Hc+1=>C))
+//
+// One f-eval = three implicit-GEMM convolution launches + two tiny batch-statistics launches:
+//   k_conv_wide<CIN=C>   state (planar WHCN, the reference layout) -> y1 raw (NHWC, Hc channels)
+//                        + per-workgroup per-channel fp64 sum / sum of squares
+//   k_bn_finalize        fixed-order reduction of the partials -> mean, 1/sqrt(var+eps)
+//   k_conv_wide<CIN=Hc>  BatchNorm + activation applied while the halo tile is staged into LDS,
+//                        -> y2 raw + partials
+//   k_bn_finalize
+//   k_conv_out           BatchNorm + activation on load, Hc -> C, planar output (the k of the stage)
+// GEMM mapping (v_mfma_f32_16x16x4_f32 / v_mfma_f32_16x16x32_bf16): M = 16 consecutive pixels of a
+// TR-row image strip held with its halo in LDS as [row][col][channel], N = 16 output channels,
+// K = (tap, input channel); weights pre-packed in B-fragment order and streamed from L2 by
+// buffer loads (one 1-KiB wave-load = 16 k of one N tile).  In the wide kernels a wave owns one
+// N tile and all M tiles of the strip, so the four waves of a workgroup stream disjoint weights.
+// The t plane (src/layers/common.jl:10-45) is a channel that is zero outside the image: its
+// contribution is t * (sum of its in-image taps) — one of 9 border classes, precomputed per
+// parameter set.
+//
+// The Tsit5 loop around it (init dt, stages, embedded error, local regularisation values, PI
+// controller, saveat) mirrors src/perform_step.jl:3-47 / src/layers/neural_ode.jl:33-100 with the
+// controller on the host: an f-eval of this field is 10^2..10^3 us, a step is >= 1 ms, and one
+// stream synchronisation per attempted step is noise.  Elementwise work (stage combination, error
+// residual, reg residuals) runs in k_lincomb / k_sums_*.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lrnde.h"
+#include "lrnde_math.hpp"
+
+using namespace lrnde;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int CNT = 256;        // threads per conv workgroup (4 waves)
+constexpr int MAXMT = 8;        // M tiles (16 pixels) per strip
+constexpr int NSUMB = 256;      // blocks of the elementwise reduction kernels
+
+struct ConvArgs {
+  int W, H, B, TR, MT, TP;      // strip: TR rows, TP = TR*W pixels, MT = ceil(TP/16)
+  int CIN, CINP;                // real input channels, LDS channel stride (floats / bf16 pairs)
+  int COUT;
+  const float* in;              // planar state (B,CIN,H,W) or NHWC raw (B,H,W,CIN)
+  float* out;                   // NHWC raw (B,H,W,COUT) or planar (B,COUT,H,W)
+  const void* wpk;              // packed weights [NG][NT][64][4] f32 or [NG][NT][64][8] bf16
+  const float* tsum;            // [9 classes][NT*16]  sum of the in-image t-channel taps
+  float t;
+  // BatchNorm of the INPUT (y = act(((x-mean)*inv)*scale + bias)), NHWC inputs only
+  const float* mean; const float* inv; const float* scale; const float* bias;
+  int act;
+  double* part;                 // [nwg][COUT][2] sum, sum of squares of the raw output (or null)
+};
+
+__device__ __forceinline__ f32x4 wload4(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+
+// ---- parameter repack ---------------------------------------------------------------------
+// Wk[k][co] with k = tap*CIN + ci, tap = ky*3 + kx, from Julia (kx,ky,ci,co) column-major with
+// CIN+1 input channels (the last one is the t plane).  f32: [g][nt][lane][j] = Wk[16g+4(l>>4)+j][16nt+(l&15)];
+// bf16: [g][nt][lane][j] = Wk[32g+8(l>>4)+j][16nt+(l&15)].
+__global__ void k_pack_conv(const float* w, int CIN, int COUT, int NG, int NT, int bf16, void* out, float* tsum) {
+  const int KPG = bf16 ? 32 : 16, PL = bf16 ? 8 : 4;
+  const size_t total = (size_t)NG * NT * 64 * PL;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i % PL, l = (i / PL) % 64;
+    const size_t blk = i / (PL * 64);
+    const int nt = blk % NT, g = blk / NT;
+    const int k = g * KPG + PL * (l >> 4) + j, co = nt * 16 + (l & 15);
+    const int tap = k / CIN, ci = k % CIN;
+    float v = 0.f;
+    if (tap < 9 && co < COUT) { const int ky = tap / 3, kx = tap % 3; v = w[kx + 3 * (ky + 3 * (ci + (size_t)(CIN + 1) * co))]; }
+    if (bf16) reinterpret_cast<__hip_bfloat16*>(out)[i] = __float2bfloat16(v);
+    else reinterpret_cast<float*>(out)[i] = v;
+  }
+  // t-plane tap sums per border class: cls = rc*3 + cc; rc 0: first row, 1: interior, 2: last row
+  const int nco = NT * 16;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 9 * nco; i += gridDim.x * blockDim.x) {
+    const int co = i % nco, cls = i / nco, rc = cls / 3, cc = cls % 3;
+    float s = 0.f;
+    if (co < COUT)
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+          // input row y+1-ky: outside for (first row, ky=2) and (last row, ky=0); same for columns
+          if ((rc == 0 && ky == 2) || (rc == 2 && ky == 0) || (cc == 0 && kx == 2) || (cc == 2 && kx == 0)) continue;
+          s = s + w[kx + 3 * (ky + 3 * (CIN + (size_t)(CIN + 1) * co))];
+        }
+    tsum[i] = s;
+  }
+}
+
+__device__ __forceinline__ int border_class(int y, int x, int H, int W) {
+  const int rc = (y == 0) ? 0 : ((y == H - 1) ? 2 : 1);
+  const int cc = (x == 0) ? 0 : ((x == W - 1) ? 2 : 1);
+  return rc * 3 + cc;
+}
+
+// ---- halo tile staging ---------------------------------------------------------------------
+// LDS tile [(TR+2)][(W+2)][CINP], zero outside the image.  T = float or __hip_bfloat16.
+template <class T> __device__ __forceinline__ T cvt_to(float v);
+template <> __device__ __forceinline__ float cvt_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ __hip_bfloat16 cvt_to<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+
+template <class T>
+__device__ __forceinline__ void stage_planar(const ConvArgs& a, int n, int y0, T* tile) {
+  const int WP = a.W + 2, rows = a.TR + 2;
+  const int total = a.CIN * rows * WP;
+  const float* src = a.in + (size_t)n * a.CIN * a.H * a.W;
+  for (int i = threadIdx.x; i < total; i += CNT) {
+    const int cc = i % WP, rr = (i / WP) % rows, c = i / (WP * rows);
+    const int y = y0 - 1 + rr, x = cc - 1;
+    float v = 0.f;
+    if (y >= 0 && y < a.H && x >= 0 && x < a.W) v = src[((size_t)c * a.H + y) * a.W + x];
+    tile[(size_t)(rr * WP + cc) * a.CINP + c] = cvt_to<T>(v);
+  }
+}
+
+template <class T>
+__device__ __forceinline__ void stage_nhwc_bn(const ConvArgs& a, int n, int y0, T* tile) {
+  // CIN % 4 == 0; (CIN/4) threads per position, float4 each; BatchNorm + activation on the way in
+  const int WP = a.W + 2, rows = a.TR + 2, cq = a.CIN / 4;
+  const int total = rows * WP * cq;
+  const float* src = a.in + (size_t)n * a.H * a.W * a.CIN;
+  for (int i = threadIdx.x; i < total; i += CNT) {
+    const int q = i % cq, pos = i / cq;
+    const int cc = pos % WP, rr = pos / WP;
+    const int y = y0 - 1 + rr, x = cc - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
+      const f32x4 raw = *reinterpret_cast<const f32x4*>(src + ((size_t)y * a.W + x) * a.CIN + q * 4);
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + q * 4), iv = *reinterpret_cast<const f32x4*>(a.inv + q * 4);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4), bi = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const float xn = (raw[h] - mu[h]) * iv[h];
+        const float z = xn * sc[h] + bi[h];
+        v[h] = act_apply(a.act, z);
+      }
+    }
+    T* d = tile + (size_t)pos * a.CINP + q * 4;
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<f32x4*>(d) = v;
+    else {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) d[h] = cvt_to<T>(v[h]);
+    }
+  }
+}
+
+// per-lane LDS offsets (in elements) of the M tiles' pixels; pixels beyond the strip use pixel 0
+__device__ __forceinline__ void pixel_bases(const ConvArgs& a, int (&ab)[MAXMT]) {
+  const int li = threadIdx.x & 15, WP = a.W + 2;
+#pragma unroll
+  for (int mt = 0; mt < MAXMT; ++mt) {
+    int p = mt * 16 + li;
+    if (p >= a.TP) p = 0;
+    const int r = p / a.W, x = p % a.W;
+    ab[mt] = (r * WP + x) * a.CINP;
+  }
+}
+__device__ __forceinline__ int tap_off(const ConvArgs& a, int tap) {  // tap = ky*3+kx
+  const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+  return ((2 - ky) * (a.W + 2) + (2 - kx)) * a.CINP;
+}
+
+// ===== fp32 kernels ==========================================================================
+// wide: COUT = 64 (NT = 4): wave w owns output channels 16w..16w+15 for all M tiles of the strip.
+// CIN_T: 64 (NHWC + BatchNorm input) or 8 (planar state input).
+template <int CIN_T>
+__global__ __launch_bounds__(CNT) void k_conv_wide_f32(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int strips = a.H / a.TR;
+  const int n = blockIdx.x / strips, y0 = (blockIdx.x % strips) * a.TR;
+  const int NT = a.COUT / 16;
+  constexpr int NG = (9 * CIN_T + 15) / 16;
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * NT * 1024, 0x00020000);
+  const int wv = lane * 16;
+  if constexpr (CIN_T == 64) stage_nhwc_bn<float>(a, n, y0, tile);
+  else stage_planar<float>(a, n, y0, tile);
+  int ab[MAXMT];
+  pixel_bases(a, ab);
+  f32x4 acc[MAXMT];
+#pragma unroll
+  for (int mt = 0; mt < MAXMT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  if constexpr (CIN_T == 64) {
+    // 9 taps x 4 k-groups of 16 channels; the next tap's weights are in flight during this tap
+    f32x4 wc[4], wn[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wc[q] = wload4(rsW, wv, ((0 * 4 + q) * NT + wave) * 1024);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int tn = tap < 8 ? tap + 1 : 8;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wn[q] = wload4(rsW, wv, ((tn * 4 + q) * NT + wave) * 1024);
+      const int to = tap_off(a, tap) + 4 * kg;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int mt = 0; mt < MAXMT; ++mt) {
+          if (mt < a.MT) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(tile + ab[mt] + to + 16 * q);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wc[q].x, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wc[q].y, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wc[q].z, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wc[q].w, acc[mt], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wc[q] = wn[q];
+    }
+  } else {
+    // CIN = 8: a k-group of 16 = two taps x 8 channels; lane group kg reads tap 2g + (kg>>1), channels 4(kg&1)..
+    static_assert(CIN_T == 8, "planar input path is written for 8 state channels");
+    f32x4 wq[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wq[g] = wload4(rsW, wv, (g * NT + wave) * 1024);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      int tap = 2 * g + (kg >> 1);
+      if (tap > 8) tap = 8;  // zero weights there
+      const int to = tap_off(a, tap) + 4 * (kg & 1);
+#pragma unroll
+      for (int mt = 0; mt < MAXMT; ++mt) {
+        if (mt < a.MT) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(tile + ab[mt] + to);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wq[g].x, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wq[g].y, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wq[g].z, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wq[g].w, acc[mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // epilogue: + t * tsum[class], raw NHWC store, batch statistics
+  const int co = wave * 16 + li;
+  float ts[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) ts[c] = a.tsum[c * NT * 16 + co];
+  double s1 = 0.0, s2 = 0.0;
+  float* dst = a.out + (size_t)n * a.H * a.W * a.COUT;
+#pragma unroll
+  for (int mt = 0; mt < MAXMT; ++mt) {
+    if (mt < a.MT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = mt * 16 + kg * 4 + r;
+        if (p < a.TP) {
+          const int y = y0 + p / a.W, x = p % a.W;
+          const float v = fma_(ts[border_class(y, x, a.H, a.W)], a.t, acc[mt][r]);
+          dst[((size_t)y * a.W + x) * a.COUT + co] = v;
+          s1 += (double)v; s2 += (double)v * (double)v;
+        }
+      }
+    }
+  }
+  if (a.part) {
+    // lanes li share a channel across the 4 lane groups
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (kg == 0) { double* pp = a.part + ((size_t)blockIdx.x * a.COUT + co) * 2; pp[0] = s1; pp[1] = s2; }
+  }
+}
+
+// out: CIN = Hc (64) NHWC + BatchNorm input -> COUT <= 16 planar output; waves split the M tiles
+__global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int strips = a.H / a.TR;
+  const int n = blockIdx.x / strips, y0 = (blockIdx.x % strips) * a.TR;
+  constexpr int NG = 36;
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * 1024, 0x00020000);
+  const int wv = lane * 16;
+  stage_nhwc_bn<float>(a, n, y0, tile);
+  int ab[MAXMT];
+  pixel_bases(a, ab);
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int m0 = wave, m1 = wave + 4;
+  const int ab0 = (m0 == 0) ? ab[0] : (m0 == 1) ? ab[1] : (m0 == 2) ? ab[2] : ab[3];
+  const int ab1 = (m1 == 4) ? ab[4] : (m1 == 5) ? ab[5] : (m1 == 6) ? ab[6] : ab[7];
+  __syncthreads();
+  f32x4 wc[4], wn[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wc[q] = wload4(rsW, wv, q * 1024);
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int tn = tap < 8 ? tap + 1 : 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wn[q] = wload4(rsW, wv, (tn * 4 + q) * 1024);
+    const int to = tap_off(a, tap) + 4 * kg;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (m0 < a.MT) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(tile + ab0 + to + 16 * q);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wc[q].x, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wc[q].y, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wc[q].z, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wc[q].w, acc[0], 0, 0, 0);
+      }
+      if (m1 < a.MT) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(tile + ab1 + to + 16 * q);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wc[q].x, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wc[q].y, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wc[q].z, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wc[q].w, acc[1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wc[q] = wn[q];
+  }
+  // planar store: lane = channel li (< COUT), 4 consecutive pixels of one row (W % 4 == 0)
+  if (li < a.COUT) {
+    float ts[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) ts[c] = a.tsum[c * 16 + li];
+    float* dst = a.out + ((size_t)n * a.COUT + li) * a.H * a.W;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int mt = h == 0 ? m0 : m1;
+      const int p = mt * 16 + kg * 4;
+      if (mt < a.MT && p < a.TP) {
+        const int y = y0 + p / a.W, x = p % a.W;
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fma_(ts[border_class(y, x + r, a.H, a.W)], a.t, acc[h][r]);
+        *reinterpret_cast<f32x4*>(dst + (size_t)y * a.W + x) = v;
+      }
+    }
+  }
+}
+
+// ---- batch statistics: fixed-order reduction of the per-workgroup partials --------------------
+__global__ __launch_bounds__(64) void k_bn_finalize(const double* part, int nwg, int ch, double count, float eps,
+                                                    float* mean, float* inv) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int w = lane; w < nwg; w += 64) { const double* p = part + ((size_t)w * ch + c) * 2; s1 += p[0]; s2 += p[1]; }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  if (lane == 0) {
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    inv[c] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+__global__ void k_bn_from_state(const float* mean_var, int ch, float eps, float* mean, float* inv) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < ch) {
+    mean[c] = mean_var ? mean_var[c] : 0.f;
+    inv[c] = (float)(1.0 / sqrt((double)(mean_var ? mean_var[ch + c] : 1.0f) + (double)eps));
+  }
+}
+
+// ---- elementwise pieces of the Tsit5 step (src/perform_step.jl:11-27, same operation order) -----
+struct LinArgs {
+  float* out; const float* base; float dt; int nk; size_t n;
+  const float* k[7]; float c[7];
+};
+// nk == 1: out = base + c0*k0 (c0 = dt*a21 pre-multiplied, :11-12); else out = base + dt*(((c0 k0 + c1 k1) + c2 k2) ...)
+__global__ void k_lincomb(LinArgs a) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+    float r;
+    if (a.nk == 1) r = a.base[i] + a.c[0] * a.k[0][i];
+    else {
+      float s = a.c[0] * a.k[0][i] + a.c[1] * a.k[1][i];
+      for (int j = 2; j < a.nk; ++j) s = s + a.c[j] * a.k[j][i];
+      r = a.base ? a.base[i] + a.dt * s : a.dt * s;
+    }
+    a.out[i] = r;
+  }
+}
+
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* out3) {
+  __shared__ double red[3][4];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = a; red[1][wave] = b; red[2][wave] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out3[0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    out3[1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    out3[2] = ((red[2][0] + red[2][1]) + red[2][2]) + red[2][3];
+  }
+}
+// ode_determine_initdt sums: (u0/sk)^2, (f0/sk)^2, ((f1-f0)/sk)^2, sk = abstol + |u0| reltol
+__global__ __launch_bounds__(256) void k_sums_init(const float* u0, const float* f0, const float* f1, float abstol,
+                                                   float reltol, size_t n, double* part) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float sk = abstol + __builtin_fabsf(u0[i]) * reltol;
+    const float r0 = u0[i] / sk, r1 = f0[i] / sk;
+    const float q0 = r0 * r0, q1 = r1 * r1;
+    a0 += (double)q0; a1 += (double)q1;
+    if (f1) { const float r2 = (f1[i] - f0[i]) / sk; const float q2 = r2 * r2; a2 += (double)q2; }
+  }
+  block_sum3(a0, a1, a2, part + (size_t)blockIdx.x * 3);
+}
+// error residual (src/perform_step.jl:21-27, 210-212) and the two stiffness sums (:40-47)
+struct ErrArgs { const float* uprev; const float* u; const float* k[7]; const float* g6; float dt, abstol, reltol; size_t n; double* part; };
+__global__ __launch_bounds__(256) void k_sums_err(ErrArgs a) {
+  double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+  const float b0 = (float)Tsit5::BT[0], b1 = (float)Tsit5::BT[1], b2 = (float)Tsit5::BT[2], b3 = (float)Tsit5::BT[3],
+              b4 = (float)Tsit5::BT[4], b5 = (float)Tsit5::BT[5], b6 = (float)Tsit5::BT[6];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+    float s = b0 * a.k[0][i] + b1 * a.k[1][i];
+    s = s + b2 * a.k[2][i];
+    s = s + b3 * a.k[3][i];
+    s = s + b4 * a.k[4][i];
+    s = s + b5 * a.k[5][i];
+    s = s + b6 * a.k[6][i];
+    const float ut = a.dt * s;
+    const float sc = a.abstol + fmaxf_(__builtin_fabsf(a.uprev[i]), __builtin_fabsf(a.u[i])) * a.reltol;
+    const float r = ut / sc;
+    const float q = r * r;
+    e0 += (double)q;
+    const float d1 = a.k[6][i] - a.k[5][i], d2 = a.u[i] - a.g6[i];
+    const float q1 = d1 * d1, q2 = d2 * d2;
+    e1 += (double)q1; e2 += (double)q2;
+  }
+  block_sum3(e0, e1, e2, a.part + (size_t)blockIdx.x * 3);
+}
+
+}  // namespace
+
+// =============================================================================================
+// host side
+// =============================================================================================
+struct lrnde_conv {
+  lrnde_conv_desc d;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool have_params = false;
+  int NG1 = 0, NG2 = 0;
+  // parameters
+  void *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
+  float *ts1 = nullptr, *ts2 = nullptr, *ts3 = nullptr;
+  float *bn = nullptr;       // scale1 bias1 scale2 bias2 (4*Hc)
+  float *stat = nullptr;     // mean1 inv1 mean2 inv2 (4*Hc)
+  float *bn_state = nullptr; // running mean1 var1 mean2 var2 (test mode), or null
+  // workspace (per batch size)
+  int wsB = 0;
+  float *y1 = nullptr, *y2 = nullptr;
+  double* part = nullptr; int nwg = 0;
+  float* vec = nullptr;      // 11 state-sized vectors
+  double *sums = nullptr, *sums_host = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<float> last_ts;
+};
+
+namespace {
+
+int cfail(lrnde_conv* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+#define CHK(c, x)                                                                              \
+  do {                                                                                         \
+    hipError_t e_ = (x);                                                                       \
+    if (e_ != hipSuccess)                                                                      \
+      return cfail(c, LRNDE_HIP_ERROR, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+inline size_t state_n(const lrnde_conv* c, int B) { return (size_t)B * c->d.width * c->d.height * c->d.channels; }
+inline int strip_rows(const lrnde_conv* c) {
+  // largest TR dividing H with TR*W <= 128 pixels (8 M tiles)
+  int best = 0;
+  for (int tr = 1; tr <= c->d.height; ++tr)
+    if (c->d.height % tr == 0 && tr * c->d.width <= 16 * MAXMT) best = tr;
+  return best;
+}
+inline int cinp_of(int cin) { return cin == 8 ? 12 : cin + 4; }
+
+int ensure_ws(lrnde_conv* c, int B) {
+  if (B == c->wsB) return LRNDE_OK;
+  for (void* p : {(void*)c->y1, (void*)c->y2, (void*)c->part, (void*)c->vec}) if (p) CHK(c, hipFree(p));
+  c->y1 = c->y2 = nullptr; c->part = nullptr; c->vec = nullptr; c->wsB = 0;
+  const size_t px = (size_t)B * c->d.width * c->d.height;
+  c->nwg = B * (c->d.height / strip_rows(c));
+  CHK(c, hipMalloc(&c->y1, sizeof(float) * px * c->d.hidden));
+  CHK(c, hipMalloc(&c->y2, sizeof(float) * px * c->d.hidden));
+  CHK(c, hipMalloc(&c->part, sizeof(double) * (size_t)c->nwg * c->d.hidden * 2));
+  CHK(c, hipMalloc(&c->vec, sizeof(float) * 11 * state_n(c, B)));
+  c->wsB = B;
+  return LRNDE_OK;
+}
+
+int check_ready(lrnde_conv* c, int B) {
+  if (!c) return LRNDE_BADARG;
+  if (B <= 0) return cfail(c, LRNDE_BADARG, "batch must be positive");
+  if (!c->have_params) return cfail(c, LRNDE_BADARG, "lrnde_conv_set_params has not been called");
+  CHK(c, hipSetDevice(c->device));
+  return ensure_ws(c, B);
+}
+
+ConvArgs base_args(const lrnde_conv* c, int B) {
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.W = c->d.width; a.H = c->d.height; a.B = B; a.TR = strip_rows(c);
+  a.TP = a.TR * a.W; a.MT = (a.TP + 15) / 16;
+  a.act = c->d.act;
+  return a;
+}
+
+// du = f(u, t): the five launches
+int launch_rhs(lrnde_conv* c, const float* u, float t, int B, float* du) {
+  const int Hc = c->d.hidden, C = c->d.channels;
+  const bool train = c->d.bn_train != 0;
+  const double count = (double)B * c->d.width * c->d.height;
+  ConvArgs a = base_args(c, B);
+  const int rows = a.TR + 2, WP = a.W + 2;
+  // conv1: state -> y1
+  a.CIN = C; a.CINP = cinp_of(C); a.COUT = Hc; a.in = u; a.out = c->y1; a.wpk = c->w1; a.tsum = c->ts1; a.t = t;
+  a.part = train ? c->part : nullptr;
+  hipLaunchKernelGGL(k_conv_wide_f32<8>, dim3(c->nwg), dim3(CNT), sizeof(float) * rows * WP * a.CINP, c->stream, a);
+  CHK(c, hipGetLastError());
+  if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(64), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat, c->stat + Hc);
+  // conv2: BN1+act(y1) -> y2
+  a.CIN = Hc; a.CINP = cinp_of(Hc); a.in = c->y1; a.out = c->y2; a.wpk = c->w2; a.tsum = c->ts2;
+  a.mean = c->stat; a.inv = c->stat + Hc; a.scale = c->bn; a.bias = c->bn + Hc;
+  hipLaunchKernelGGL(k_conv_wide_f32<64>, dim3(c->nwg), dim3(CNT), sizeof(float) * rows * WP * a.CINP, c->stream, a);
+  CHK(c, hipGetLastError());
+  if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(64), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat + 2 * Hc, c->stat + 3 * Hc);
+  // conv3: BN2+act(y2) -> du (planar)
+  a.COUT = C; a.in = c->y2; a.out = du; a.wpk = c->w3; a.tsum = c->ts3; a.part = nullptr;
+  a.mean = c->stat + 2 * Hc; a.inv = c->stat + 3 * Hc; a.scale = c->bn + 2 * Hc; a.bias = c->bn + 3 * Hc;
+  hipLaunchKernelGGL(k_conv_out_f32, dim3(c->nwg), dim3(CNT), sizeof(float) * rows * WP * a.CINP, c->stream, a);
+  CHK(c, hipGetLastError());
+  return LRNDE_OK;
+}
+
+int lincomb(lrnde_conv* c, float* out, const float* base, float dt, int nk, const float* const* k, const float* coef, size_t n) {
+  LinArgs a;
+  a.out = out; a.base = base; a.dt = dt; a.nk = nk; a.n = n;
+  for (int j = 0; j < 7; ++j) { a.k[j] = j < nk ? k[j] : nullptr; a.c[j] = j < nk ? coef[j] : 0.f; }
+  int nb = (int)((n + 255) / 256); if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_lincomb, dim3(nb), dim3(256), 0, c->stream, a);
+  CHK(c, hipGetLastError());
+  return LRNDE_OK;
+}
+
+int fetch_sums(lrnde_conv* c, double* s3) {
+  CHK(c, hipMemcpyAsync(c->sums_host, c->sums, sizeof(double) * NSUMB * 3, hipMemcpyDeviceToHost, c->stream));
+  CHK(c, hipStreamSynchronize(c->stream));
+  s3[0] = s3[1] = s3[2] = 0.0;
+  for (int i = 0; i < NSUMB; ++i) { s3[0] += c->sums_host[3 * i]; s3[1] += c->sums_host[3 * i + 1]; s3[2] += c->sums_host[3 * i + 2]; }
+  return LRNDE_OK;
+}
+
+// ode_determine_initdt (OrdinaryDiffEq, un-vendored): f0 -> k1 (= fsalfirst)
+int init_dt(lrnde_conv* c, const float* u0, int B, float t0, float tend, float abstol, float reltol, float* f0,
+            float* tmp, float* f1, float* dt_out) {
+  const size_t n = state_n(c, B);
+  const float dtmax = tend - t0;
+  int rc;
+  double s[3];
+  if ((rc = launch_rhs(c, u0, t0, B, f0))) return rc;
+  hipLaunchKernelGGL(k_sums_init, dim3(NSUMB), dim3(256), 0, c->stream, u0, f0, (const float*)nullptr, abstol, reltol, n, c->sums);
+  if ((rc = fetch_sums(c, s))) return rc;
+  const float d0 = (float)sqrt(s[0] / (double)n), d1 = (float)sqrt(s[1] / (double)n);
+  float dt0 = ((double)d0 < 1e-5 || (double)d1 < 1e-5) ? 1e-6f : (d0 / d1) / 100.0f;
+  dt0 = fminf(dt0, dtmax);
+  const float* kk[1] = {f0};
+  if ((rc = lincomb(c, tmp, u0, 0.f, 1, kk, &dt0, n))) return rc;
+  if ((rc = launch_rhs(c, tmp, t0 + dt0, B, f1))) return rc;
+  hipLaunchKernelGGL(k_sums_init, dim3(NSUMB), dim3(256), 0, c->stream, u0, f0, (const float*)f1, abstol, reltol, n, c->sums);
+  if ((rc = fetch_sums(c, s))) return rc;
+  const float d2 = (float)sqrt(s[2] / (double)n) / dt0;
+  const float maxd = fmaxf(d1, d2);
+  float dt1;
+  if ((double)maxd <= 1e-15) dt1 = fmaxf(1e-6f, dt0 * 1e-3f);
+  else { const float l10 = (float)log10((double)maxd); const float e = (-(2.0f + l10)) / 5.0f; dt1 = (float)pow(10.0, (double)e); }
+  *dt_out = fminf(fminf(100.0f * dt0, dt1), dtmax);
+  return LRNDE_OK;
+}
+
+// one Tsit5 step (src/perform_step.jl:3-32): ks = k2..k6 (5 vectors), g6, tmp work vectors
+int tsit5_step(lrnde_conv* c, const float* uprev, const float* k1, int B, float t, float dt, float abstol, float reltol,
+               float* u, float* k7, float* ks, float* g6, float* tmp, double* sums3) {
+  const size_t n = state_n(c, B);
+  float A[21];
+  for (int i = 0; i < 21; ++i) A[i] = (float)Tsit5::A[i];
+  const float cs[6] = {(float)Tsit5::C[0], (float)Tsit5::C[1], (float)Tsit5::C[2], (float)Tsit5::C[3], 1.0f, 1.0f};
+  const float* K[7] = {k1, ks, ks + n, ks + 2 * n, ks + 3 * n, ks + 4 * n, k7};
+  float* Kw[7] = {nullptr, ks, ks + n, ks + 2 * n, ks + 3 * n, ks + 4 * n, k7};
+  int rc;
+  for (int s = 2; s <= 7; ++s) {
+    const int off = (s - 2) * (s - 1) / 2;
+    float* x = (s == 6) ? g6 : (s == 7) ? u : tmp;
+    if (s == 2) { const float a21 = dt * A[0]; if ((rc = lincomb(c, x, uprev, 0.f, 1, K, &a21, n))) return rc; }
+    else if ((rc = lincomb(c, x, uprev, dt, s - 1, K, A + off, n))) return rc;
+    if ((rc = launch_rhs(c, x, t + cs[s - 2] * dt, B, Kw[s - 1]))) return rc;
+  }
+  ErrArgs e;
+  e.uprev = uprev; e.u = u; for (int j = 0; j < 7; ++j) e.k[j] = K[j];
+  e.g6 = g6; e.dt = dt; e.abstol = abstol; e.reltol = reltol; e.n = n; e.part = c->sums;
+  hipLaunchKernelGGL(k_sums_err, dim3(NSUMB), dim3(256), 0, c->stream, e);
+  CHK(c, hipGetLastError());
+  return fetch_sums(c, sums3);
+}
+
+void reg_values(const double* s, size_t n, float dt, float* eest, float* re, float* rs) {
+  const float ee = (float)sqrt(s[0] / (double)n);
+  if (eest) *eest = ee;
+  if (re) *re = ee * dt;
+  if (rs) {
+    const float den = (float)sqrt(s[2] / (double)n);
+    if (den == 0.0f) *rs = 0.0f;
+    else { const float num = (float)sqrt(s[1] / (double)n); *rs = fabsf(num / (den + 1.1920929e-7f)) / 3.5068f; }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t lrnde_conv_param_count(const lrnde_conv_desc* d) {
+  if (!d) return 0;
+  const size_t C = d->channels, Hc = d->hidden;
+  return 9 * (C + 1) * Hc + 2 * Hc + 9 * (Hc + 1) * Hc + 2 * Hc + 9 * (Hc + 1) * C;
+}
+
+int lrnde_conv_create(lrnde_conv** out, const lrnde_conv_desc* d, int device, void* stream) {
+  if (!out || !d) return LRNDE_BADARG;
+  *out = nullptr;
+  // shapes the kernels are written for: 8 state channels, 64 hidden channels, W % 4 == 0, W <= 128
+  if (d->channels != 8 || d->hidden != 64 || d->width % 4 != 0 || d->width < 4 || d->width > 16 * MAXMT ||
+      d->height < 2 || d->act < 0 || d->act > 2)
+    return LRNDE_UNSUPPORTED;
+  if (d->compute_dtype != LRNDE_F32) return LRNDE_UNSUPPORTED;
+  lrnde_conv* c = new lrnde_conv();
+  c->d = *d;
+  if (!(c->d.bn_eps > 0.f)) c->d.bn_eps = 1e-5f;
+  c->device = device;
+  c->stream = (hipStream_t)stream;
+  if (hipSetDevice(device) != hipSuccess) { delete c; return LRNDE_HIP_ERROR; }
+  const int C = d->channels, Hc = d->hidden;
+  c->NG1 = (9 * C + 15) / 16; c->NG2 = (9 * Hc + 15) / 16;
+  bool ok = hipMalloc(&c->w1, (size_t)c->NG1 * 4 * 1024) == hipSuccess &&
+            hipMalloc(&c->w2, (size_t)c->NG2 * 4 * 1024) == hipSuccess &&
+            hipMalloc(&c->w3, (size_t)c->NG2 * 1 * 1024) == hipSuccess &&
+            hipMalloc(&c->ts1, sizeof(float) * 9 * 64) == hipSuccess && hipMalloc(&c->ts2, sizeof(float) * 9 * 64) == hipSuccess &&
+            hipMalloc(&c->ts3, sizeof(float) * 9 * 16) == hipSuccess &&
+            hipMalloc(&c->bn, sizeof(float) * 4 * Hc) == hipSuccess && hipMalloc(&c->stat, sizeof(float) * 4 * Hc) == hipSuccess &&
+            hipMalloc(&c->sums, sizeof(double) * NSUMB * 3) == hipSuccess &&
+            hipHostMalloc(&c->sums_host, sizeof(double) * NSUMB * 3) == hipSuccess &&
+            hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+  if (!ok) { lrnde_conv_destroy(c); return LRNDE_HIP_ERROR; }
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wide_f32<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wide_f32<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_out_f32), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  *out = c;
+  return LRNDE_OK;
+}
+
+int lrnde_conv_destroy(lrnde_conv* c) {
+  if (!c) return LRNDE_OK;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
+  void* ptrs[] = {c->w1, c->w2, c->w3, c->ts1, c->ts2, c->ts3, c->bn, c->stat, c->bn_state, c->y1, c->y2, c->part, c->vec, c->sums};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (c->sums_host) hipHostFree(c->sums_host);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  delete c;
+  return LRNDE_OK;
+}
+
+const char* lrnde_conv_last_error(const lrnde_conv* c) { return c ? c->err.c_str() : "null handle"; }
+
+int lrnde_conv_set_params(lrnde_conv* c, const float* p, size_t n) {
+  if (!c || !p) return LRNDE_BADARG;
+  if (n != lrnde_conv_param_count(&c->d)) return cfail(c, LRNDE_BADARG, "parameter count %zu != expected %zu", n, lrnde_conv_param_count(&c->d));
+  CHK(c, hipSetDevice(c->device));
+  const int C = c->d.channels, Hc = c->d.hidden;
+  const float* w1 = p; const float* g1 = w1 + 9 * (C + 1) * Hc;
+  const float* w2 = g1 + 2 * Hc; const float* g2 = w2 + 9 * (Hc + 1) * Hc;
+  const float* w3 = g2 + 2 * Hc;
+  hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w1, C, Hc, c->NG1, 4, 0, c->w1, c->ts1);
+  hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w2, Hc, Hc, c->NG2, 4, 0, c->w2, c->ts2);
+  hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w3, Hc, C, c->NG2, 1, 0, c->w3, c->ts3);
+  CHK(c, hipGetLastError());
+  CHK(c, hipMemcpyAsync(c->bn, g1, sizeof(float) * 2 * Hc, hipMemcpyDeviceToDevice, c->stream));
+  CHK(c, hipMemcpyAsync(c->bn + 2 * Hc, g2, sizeof(float) * 2 * Hc, hipMemcpyDeviceToDevice, c->stream));
+  if (!c->d.bn_train) {
+    const float* st = c->bn_state;
+    hipLaunchKernelGGL(k_bn_from_state, dim3(1), dim3(64), 0, c->stream, st, Hc, c->d.bn_eps, c->stat, c->stat + Hc);
+    hipLaunchKernelGGL(k_bn_from_state, dim3(1), dim3(64), 0, c->stream, st ? st + 2 * Hc : nullptr, Hc, c->d.bn_eps, c->stat + 2 * Hc, c->stat + 3 * Hc);
+    CHK(c, hipGetLastError());
+  }
+  c->have_params = true;
+  return LRNDE_OK;
+}
+
+int lrnde_conv_set_bn_state(lrnde_conv* c, const float* mean_var, size_t n) {
+  if (!c || !mean_var) return LRNDE_BADARG;
+  const int Hc = c->d.hidden;
+  if (n != (size_t)4 * Hc) return cfail(c, LRNDE_BADARG, "bn state has %zu entries, expected %d", n, 4 * Hc);
+  CHK(c, hipSetDevice(c->device));
+  if (!c->bn_state) CHK(c, hipMalloc(&c->bn_state, sizeof(float) * 4 * Hc));
+  CHK(c, hipMemcpyAsync(c->bn_state, mean_var, sizeof(float) * 4 * Hc, hipMemcpyDeviceToDevice, c->stream));
+  if (!c->d.bn_train) {
+    hipLaunchKernelGGL(k_bn_from_state, dim3(1), dim3(64), 0, c->stream, (const float*)c->bn_state, Hc, c->d.bn_eps, c->stat, c->stat + Hc);
+    hipLaunchKernelGGL(k_bn_from_state, dim3(1), dim3(64), 0, c->stream, (const float*)(c->bn_state + 2 * Hc), Hc, c->d.bn_eps, c->stat + 2 * Hc, c->stat + 3 * Hc);
+    CHK(c, hipGetLastError());
+  }
+  return LRNDE_OK;
+}
+
+int lrnde_conv_rhs(lrnde_conv* c, const float* u, float t, int32_t B, float* du) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!u || !du) return cfail(c, LRNDE_BADARG, "null pointer");
+  if ((rc = launch_rhs(c, u, t, B, du))) return rc;
+  CHK(c, hipStreamSynchronize(c->stream));
+  return LRNDE_OK;
+}
+
+int lrnde_conv_init_dt(lrnde_conv* c, const float* u0, int32_t B, float t0, float t1, float abstol, float reltol,
+                       float* k1, float* dt_host) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!u0 || !dt_host) return cfail(c, LRNDE_BADARG, "null pointer");
+  const size_t n = state_n(c, B);
+  float* f0 = k1 ? k1 : c->vec;
+  return init_dt(c, u0, B, t0, t1, abstol, reltol, f0, c->vec + n, c->vec + 2 * n, dt_host);
+}
+
+int lrnde_conv_perform_step(lrnde_conv* c, const float* uprev, const float* k1, int32_t B, float t, float dt,
+                            float abstol, float reltol, float* u, float* k7, float* eest_host,
+                            float* reg_error_host, float* reg_stiff_host) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!uprev || !k1) return cfail(c, LRNDE_BADARG, "null pointer");
+  const size_t n = state_n(c, B);
+  float* V = c->vec;
+  float* uo = u ? u : V; float* k7o = k7 ? k7 : V + n;
+  double s[3];
+  if ((rc = tsit5_step(c, uprev, k1, B, t, dt, abstol, reltol, uo, k7o, V + 2 * n, V + 7 * n, V + 8 * n, s))) return rc;
+  reg_values(s, n, dt, eest_host, reg_error_host, reg_stiff_host);
+  return LRNDE_OK;
+}
+
+int lrnde_conv_solve(lrnde_conv* c, const float* u0, int32_t B, float t0, float t1, const lrnde_solve_opts* o,
+                     const float* saveat, int32_t nsave, float* u_saved, float* t_saved, int32_t cap_saved,
+                     lrnde_stats* st, lrnde_trace_row* trace, int32_t cap_trace) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!u0 || !o || !st) return cfail(c, LRNDE_BADARG, "null pointer");
+  memset(st, 0, sizeof(*st));
+  if (!(t1 > t0)) return cfail(c, LRNDE_BADARG, "tspan must be increasing");
+  for (int i = 1; i < nsave; ++i) if (!(saveat[i] >= saveat[i - 1])) return cfail(c, LRNDE_BADARG, "saveat must be sorted");
+  const size_t n = state_n(c, B);
+  const float abstol = o->abstol, reltol = o->reltol;
+  const float gamma = 0.9f, qmin = 0.2f, qmax = 10.0f, qoldinit = 1e-4f;
+  const float beta1 = (float)(7.0 / 50.0), beta2 = (float)(2.0 / 25.0);
+  float* V = c->vec;
+  float *uprev = V, *u = V + n, *k1 = V + 2 * n, *ks = V + 3 * n, *k7 = V + 8 * n, *g6 = V + 9 * n, *tmp = V + 10 * n;
+  int nsaved = 0, isave = 0, ntrace = 0;
+  c->last_ts.clear();
+  auto push = [&](float tt, const float* uu) -> int {
+    if (nsaved >= cap_saved || !u_saved) return cfail(c, LRNDE_CAPACITY, "u_saved capacity %d exhausted", cap_saved);
+    CHK(c, hipMemcpyAsync(u_saved + (size_t)nsaved * n, uu, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+    if (t_saved) t_saved[nsaved] = tt;
+    c->last_ts.push_back(tt);
+    nsaved++;
+    return LRNDE_OK;
+  };
+  CHK(c, hipMemcpyAsync(uprev, u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  float t = t0;
+  const float dtmax = t1 - t0;
+  const float dtmin = fmaxf(eps_f(t1), eps_f(t0));
+  float dt;
+  if ((rc = init_dt(c, uprev, B, t0, t1, abstol, reltol, k1, tmp, g6, &dt))) return rc;
+  st->nf = 3; st->dt_init = dt;
+  float qold = qoldinit, q11 = 1.0f, dtpropose = dt;
+  int accept = 0, iter = 0;
+  if (o->save_start && (rc = push(t0, uprev))) return rc;
+  while (isave < nsave && saveat[isave] <= t0) isave++;
+  rc = LRNDE_OK;
+  while (t < t1) {
+    if (iter > 0) {
+      if (accept) { std::swap(uprev, u); std::swap(k1, k7); dt = dtpropose; }
+      else dt = dt / fminf(1.0f / qmin, q11 / gamma);
+    }
+    iter++;
+    dt = fminf(dtmax, dt); dt = fmaxf(dt, dtmin); dt = fminf(fabsf(dt), fabsf(t1 - t));
+    if (iter > o->maxiters) { rc = LRNDE_MAXITERS; break; }
+    if (dt != dt) { rc = LRNDE_DT_NAN; break; }
+    if (fabsf(dt) <= fabsf(dtmin)) { rc = LRNDE_DT_LESS_THAN_MIN; break; }
+    double s[3];
+    int r2;
+    if ((r2 = tsit5_step(c, uprev, k1, B, t, dt, abstol, reltol, u, k7, ks, g6, tmp, s))) return r2;
+    st->nf += 6;
+    const float eest = (float)sqrt(s[0] / (double)n);
+    st->eest_last = eest;
+    if (eest != eest) { rc = LRNDE_DT_NAN; break; }
+    const float ttmp = t + dt;
+    float q;
+    if (eest == 0.0f) q = 1.0f / qmax;
+    else {
+      if (o->exact_pow) { q11 = (float)pow((double)eest, (double)beta1); q = q11 / (float)pow((double)qold, (double)beta2); }
+      else { q11 = fastpow(eest, beta1); q = q11 / fastpow(qold, beta2); }
+      q = fmaxf(1.0f / qmax, fminf(1.0f / qmin, q / gamma));
+    }
+    accept = (eest <= 1.0f);
+    if (trace && ntrace < cap_trace) { trace[ntrace].t = t; trace[ntrace].dt = dt; trace[ntrace].eest = eest; trace[ntrace].accepted = accept; ntrace++; }
+    if (accept) {
+      st->naccept++;
+      const float dtnew = dt / q;
+      qold = fmaxf(eest, qoldinit);
+      const float tprev = t;
+      t = (fabsf(ttmp - t1) < 100.0f * eps_f(fmaxf(t, t1))) ? t1 : ttmp;
+      dtpropose = fmaxf(fminf(dtmax, dtnew), fmaxf(eps_f(t), dtmin));
+      while (isave < nsave && saveat[isave] <= t) {  // savevalues!
+        const float tsv = saveat[isave++];
+        if (tsv != t) {
+          const float theta = (tsv - tprev) / dt;
+          float bw[7];
+          tsit5_bweights(theta, bw);
+          const float* K[7] = {k1, ks, ks + n, ks + 2 * n, ks + 3 * n, ks + 4 * n, k7};
+          int r3;
+          if ((r3 = lincomb(c, tmp, uprev, dt, 7, K, bw, n))) return r3;
+          if ((r3 = push(tsv, tmp))) return r3;
+        } else { int r3; if ((r3 = push(t, u))) return r3; }
+      }
+      if (o->save_everystep) { int r3; if ((r3 = push(t, u))) return r3; }
+    } else st->nreject++;
+  }
+  CHK(c, hipStreamSynchronize(c->stream));
+  st->retcode = rc; st->iters = iter; st->nsaved = nsaved; st->t_final = t; st->dt_final = dt;
+  if (rc) return cfail(c, rc, "solve stopped with retcode %d at t=%g (dt=%g, %d iterations)", rc, (double)t, (double)dt, iter);
+  return LRNDE_OK;
+}
+
+int lrnde_conv_node_forward(lrnde_conv* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
+                            int32_t mode, int32_t reg_type, float t1_or_rand, float* u_end, float* reg_val,
+                            int32_t* nfe, lrnde_stats* st, float* t1_used) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!x || !o || !u_end || !reg_val || !nfe || !st) return cfail(c, LRNDE_BADARG, "null pointer");
+  if (mode < LRNDE_MODE_NONE || mode > LRNDE_MODE_BIASED) return cfail(c, LRNDE_BADARG, "unknown regularize mode %d", mode);
+  const size_t n = state_n(c, B);
+  lrnde_solve_opts oo = *o;
+  *reg_val = 0.0f;
+  if (t1_used) *t1_used = t2;
+  float* us = nullptr;
+  auto done = [&](int code) { if (us) hipFree(us); return code; };
+  if (mode == LRNDE_MODE_NONE) {  // src/layers/neural_ode.jl:56-60
+    oo.save_everystep = 0;
+    CHK(c, hipMalloc(&us, sizeof(float) * n * 2));
+    float sv[1] = {t2}, ts[2];
+    if ((rc = lrnde_conv_solve(c, x, B, t0, t2, &oo, sv, 1, us, ts, 2, st, nullptr, 0))) return done(rc);
+    CHK(c, hipMemcpy(u_end, us + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice));
+    *nfe = st->nf;
+    return done(LRNDE_OK);
+  }
+  float t1;
+  float* u1 = nullptr;
+  CHK(c, hipMalloc(&u1, sizeof(float) * n));
+  auto done2 = [&](int code) { hipFree(u1); return done(code); };
+  if (mode == LRNDE_MODE_UNBIASED) {  // :68-84, saveat = [t1, t2]
+    t1 = t1_or_rand;
+    oo.save_everystep = 0;
+    if (hipMalloc(&us, sizeof(float) * n * 3) != hipSuccess) return done2(cfail(c, LRNDE_HIP_ERROR, "allocation failed"));
+    float sv[2] = {t1, t2}, ts[3];
+    if ((rc = lrnde_conv_solve(c, x, B, t0, t2, &oo, sv, 2, us, ts, 3, st, nullptr, 0))) return done2(rc);
+    const int i1 = oo.save_start ? 1 : 0;
+    hipMemcpy(u1, us + (size_t)i1 * n, sizeof(float) * n, hipMemcpyDeviceToDevice);
+    hipMemcpy(u_end, us + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice);
+  } else {  // :88-100 biased, saveat = [] => every accepted step
+    oo.save_everystep = 1;
+    int cap = oo.maxiters + 2; if (cap > 512) cap = 512;
+    if (hipMalloc(&us, sizeof(float) * n * cap) != hipSuccess) return done2(cfail(c, LRNDE_HIP_ERROR, "allocation failed"));
+    std::vector<float> ts(cap);
+    if ((rc = lrnde_conv_solve(c, x, B, t0, t2, &oo, nullptr, 0, us, ts.data(), cap, st, nullptr, 0))) return done2(rc);
+    if (st->nsaved < 2) return done2(cfail(c, LRNDE_BADARG, "biased mode needs at least two saved steps"));
+    const int m = st->nsaved - 1;
+    int idx = (int)(t1_or_rand * (float)m);
+    if (idx >= m) idx = m - 1;
+    if (idx < 0) idx = 0;
+    t1 = ts[idx];
+    hipMemcpy(u1, us + (size_t)idx * n, sizeof(float) * n, hipMemcpyDeviceToDevice);
+    hipMemcpy(u_end, us + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice);
+  }
+  if (t1_used) *t1_used = t1;
+  // _get_ode_integrator :33-38 => init on (t1,t2); _perform_step :77
+  float* V = c->vec;
+  float dtl, ee, re, rs;
+  if ((rc = init_dt(c, u1, B, t1, t2, oo.abstol, oo.reltol, V + 2 * n, V + 10 * n, V + 9 * n, &dtl))) return done2(rc);
+  double s[3];
+  if ((rc = tsit5_step(c, u1, V + 2 * n, B, t1, dtl, oo.abstol, oo.reltol, V + n, V + 8 * n, V + 3 * n, V + 9 * n, V + 10 * n, s))) return done2(rc);
+  reg_values(s, n, dtl, &ee, &re, &rs);
+  *reg_val = (reg_type == LRNDE_REG_STIFFNESS_ESTIMATE) ? rs : re;
+  *nfe = st->nf + (6 + 3);
+  return done2(LRNDE_OK);
+}
+
+int lrnde_conv_bench_rhs(lrnde_conv* c, const float* u, float t, int32_t B, int32_t reps, float* us_host) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!u || !us_host || reps <= 0) return cfail(c, LRNDE_BADARG, "bad argument");
+  const size_t n = state_n(c, B);
+  for (int i = 0; i < 3; ++i) if ((rc = launch_rhs(c, u, t, B, c->vec + n))) return rc;
+  CHK(c, hipEventRecord(c->ev0, c->stream));
+  for (int i = 0; i < reps; ++i) if ((rc = launch_rhs(c, u, t, B, c->vec + n))) return rc;
+  CHK(c, hipEventRecord(c->ev1, c->stream));
+  CHK(c, hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  CHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *us_host = ms * 1000.0f / (float)reps;
+  return LRNDE_OK;
+}
+
+}  // extern "C"

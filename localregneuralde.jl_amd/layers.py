@@ -286,7 +286,9 @@ class NeuralODE:
         self.tspan = (np.float32(tspan[0]), np.float32(tspan[1]))
         self.maxiters, self.kwargs = int(maxiters), dict(kwargs)
         self.regularize, self.regularize_type = regularize, regularize_type
-        self.desc = _mlp_desc(model)
+        from .conv import conv_topology
+        self._conv = conv_topology(model)  # (C, Hc, act, eps) for the CIFAR node_core, else None
+        self.desc = None if self._conv else _mlp_desc(model)
         self._handle = None
         self._ps_key = None
 
@@ -295,13 +297,27 @@ class NeuralODE:
         rng.standard_normal()
         return dict(model={}, nfe=-1, reg_val=np.float32(0.0), rng=copy.deepcopy(rng), training=True)
 
-    def handle(self):
+    def handle(self, x=None):
+        if self._conv:  # the conv field's handle is per image size: x is (B, C, H, W)
+            from .conv import ConvHandle
+            if x is None and self._handle is None:
+                raise ValueError("the conv field needs the input to size its handle")
+            if x is not None:
+                if x.dim() != 4 or x.shape[1] != self._conv[0]:
+                    raise ValueError(f"conv field input must be (B, {self._conv[0]}, H, W), got {tuple(x.shape)}")
+                hw = (int(x.shape[3]), int(x.shape[2]))
+                if self._handle is None or self._hw != hw:
+                    Cst, Hc, act, eps = self._conv
+                    self._handle = ConvHandle(hw[0], hw[1], Cst, Hc, act=act, bn_train=True, bn_eps=eps,
+                                              compute_dtype=self.kwargs.get("compute_dtype", "f32"))
+                    self._hw, self._ps_key = hw, None
+            return self._handle
         if self._handle is None:
             self._handle = Handle(self.desc)
         return self._handle
 
-    def _bind(self, ps):
-        h = self.handle()
+    def _bind(self, ps, x=None):
+        h = self.handle(x)
         key = (ps.data_ptr(), ps._version) if isinstance(ps, torch.Tensor) else None
         if key is None or key != self._ps_key:
             h.set_params(ps)
@@ -309,7 +325,7 @@ class NeuralODE:
         return h
 
     def __call__(self, x, ps, st):
-        h = self._bind(ps)
+        h = self._bind(ps, x)
         t0, t2 = self.tspan
         kw = self.kwargs
         abstol, reltol = kw.get("abstol", 1e-6), kw.get("reltol", 1e-3)  # OrdinaryDiffEq defaults
@@ -355,6 +371,8 @@ class NeuralODE:
         """What `Zygote.pullback` returns for this layer in the reference's training step
         (experiments/src/utils.jl:104-115) for  loss = <du_end, sol.u[end]> + w_reg * reg_val:
         (dx, dps).  The forward is re-run with the same rng draw as `__call__` would make."""
+        if self._conv:
+            raise NotImplementedError("the conv field's backward pass is not built")
         h = self._bind(ps)
         t0, t2 = self.tspan
         kw = self.kwargs

@@ -1,0 +1,163 @@
+"""GPU parity of the conv vector field path (lrnde_conv_*) against the oracle (lro_conv_rhs and the
+field-agnostic Tsit5 machinery of oracle/lrnde_oracle.c).  Parity here is BY TOLERANCE — rtol 1e-5 of the
+output scale for fp32 (BASELINE.json north_star) — because train-mode batch statistics couple all samples
+through sums whose order the GPU does not reproduce; accepted/rejected step counts must still be equal."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5  # of the output scale, fp32 path
+
+
+def _mods():
+    import lrnde_amd as P
+    import oracle as O
+    return P, O
+
+
+def _case(W, H, B, seed, act="gelu", train=True, scale=1.0):
+    P, O = _mods()
+    C, Hc = 8, 64
+    rng = np.random.default_rng(seed)
+    p = O.glorot_conv_params(C, Hc, seed=seed) * np.float32(scale)
+    n1 = 9 * (C + 1) * Hc
+    p[n1:n1 + Hc] = rng.uniform(0.5, 1.5, Hc); p[n1 + Hc:n1 + 2 * Hc] = rng.uniform(-0.3, 0.3, Hc)
+    n2 = n1 + 2 * Hc + 9 * (Hc + 1) * Hc
+    p[n2:n2 + Hc] = rng.uniform(0.5, 1.5, Hc); p[n2 + Hc:n2 + 2 * Hc] = rng.uniform(-0.3, 0.3, Hc)
+    p = p.astype(np.float32)
+    u = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    st = None
+    if not train:
+        st = np.concatenate([rng.normal(0, 0.2, Hc), rng.uniform(0.5, 2, Hc), rng.normal(0, 0.2, Hc),
+                             rng.uniform(0.5, 2, Hc)]).astype(np.float32)
+    fld = O.ConvField(W, H, C, Hc, p, act=act, bn_train=train, bn_state=st, nthreads=8)
+    h = P.ConvHandle(W, H, C, Hc, act=act, bn_train=train)
+    if st is not None:
+        h.set_bn_state(st)
+    h.set_params(p)
+    return fld, h, p, u
+
+
+def _close(got, ref, rtol=RTOL):
+    got = got.cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = np.asarray(ref).reshape(got.shape)
+    sc = max(float(np.abs(ref).max()), 1e-30)
+    err = float(np.abs(got - ref).max())
+    assert err <= rtol * sc, f"max abs err {err:.3e} > {rtol:g} * scale {sc:.3e}"
+
+
+@pytest.mark.parametrize("W,H,B,train,act", [
+    (8, 8, 3, True, "gelu"),      # 2 strips of 4 rows? (TR=8: one strip of 64 px)
+    (16, 16, 2, True, "gelu"),    # 128-pixel strips, 2 per image
+    (28, 28, 2, False, "gelu"),   # MNIST-conv variant: 7 M tiles, test-mode BN
+    (32, 32, 2, True, "gelu"),    # CIFAR block shape
+    (12, 8, 5, True, "tanh"),     # ragged: 96-pixel strips, odd batch
+    (32, 32, 1, False, "identity"),
+])
+def test_conv_rhs_matches_oracle(W, H, B, train, act):
+    fld, h, p, u = _case(W, H, B, seed=W + B, act=act, train=train)
+    for t in (0.0, 0.613):
+        got = h.rhs(torch.from_numpy(u).cuda(), t)
+        _close(got, fld.rhs(u.reshape(B, -1), t))
+
+
+def test_conv_t_plane_border_classes():
+    """only the t channel of conv3 non-zero: du = t * (number of in-image taps)"""
+    P, O = _mods()
+    W = H = 8; C = 8; Hc = 64
+    p = np.zeros(O.lib().lro_conv_param_count(C, Hc), np.float32)
+    n3 = 9 * (C + 1) * Hc + 2 * Hc + 9 * (Hc + 1) * Hc + 2 * Hc
+    p[n3:].reshape(C, Hc + 1, 3, 3)[:, Hc, :, :] = 1.0
+    h = P.ConvHandle(W, H, C, Hc, bn_train=False)
+    h.set_params(p)
+    du = h.rhs(torch.zeros(1, C, H, W, device="cuda"), 2.0).cpu().numpy()[0]
+    cnt = np.full((H, W), 9.0); cnt[0, :] = 6; cnt[-1, :] = 6; cnt[:, 0] = 6; cnt[:, -1] = 6
+    cnt[0, 0] = cnt[0, -1] = cnt[-1, 0] = cnt[-1, -1] = 4
+    for c in range(C):
+        assert np.array_equal(du[c], 2.0 * cnt)
+
+
+def test_conv_init_dt_and_step_match_oracle():
+    P, O = _mods()
+    fld, h, p, u = _case(16, 16, 3, seed=11, scale=2.0)
+    B = 3
+    ud = torch.from_numpy(u).cuda()
+    dt_o, k1_o = O.init_dt(fld, u.reshape(B, -1), 0.1, 1.0, 1e-4, 1e-4)
+    dt_g, k1_g = h.init_dt(ud, 0.1, 1.0, 1e-4, 1e-4)
+    assert abs(float(dt_g) - float(dt_o)) <= 1e-4 * float(dt_o)
+    _close(k1_g, k1_o)
+    # a step large enough that the embedded error is truncation error, not fp32 cancellation noise
+    dt = 0.3
+    so = O.tsit5_step(fld, u.reshape(B, -1), k1_o, 0.1, dt, 1e-4, 1e-4)
+    sg = h.perform_step(ud, k1_g, 0.1, dt, 1e-4, 1e-4)
+    _close(sg["u"], so["u"]); _close(sg["k7"], so["k7"], rtol=5e-5)
+    assert float(so["eest"]) > 1e-2
+    for key in ("eest", "reg_error", "reg_stiff"):
+        assert abs(float(sg[key]) - float(so[key])) <= 5e-3 * abs(float(so[key])) + 1e-12, key
+
+
+@pytest.mark.parametrize("tol,scale", [(1e-3, 3.0), (1e-4, 1.5)])
+def test_conv_solve_matches_oracle_step_for_step(tol, scale):
+    P, O = _mods()
+    W = H = 16; B = 2
+    fld, h, p, u = _case(W, H, B, seed=5, scale=scale)
+    ro = O.solve(fld, u.reshape(B, -1), 0.0, 1.0, tol, tol, saveat=[0.37, 1.0])
+    rg = h.solve(torch.from_numpy(u).cuda(), 0.0, 1.0, tol, tol, saveat=[0.37, 1.0], trace=True)
+    so, sg = ro["stats"], rg["stats"]
+    assert (sg["naccept"], sg["nreject"], sg["nf"]) == (so["naccept"], so["nreject"], so["nf"])
+    assert so["naccept"] >= 3
+    np.testing.assert_allclose(rg["trace"]["dt"], ro["trace"]["dt"][:len(rg["trace"])], rtol=2e-3)
+    assert list(rg["t"]) == [np.float32(0.37), np.float32(1.0)]
+    for i in range(2):
+        _close(rg["u"][i], ro["u"][i], rtol=2e-5)
+
+
+@pytest.mark.parametrize("mode,reg_type", [("unbiased", "error_estimate"), ("biased", "stiffness_estimate"),
+                                           ("none", "error_estimate")])
+def test_conv_node_forward_matches_oracle(mode, reg_type):
+    P, O = _mods()
+    W = H = 8; B = 4
+    fld, h, p, u = _case(W, H, B, seed=21, scale=2.0)
+    ro = O.node_forward(fld, u.reshape(B, -1), 0.0, 1.0, 1e-3, 1e-3, mode=mode, reg_type=reg_type, t1_or_rand=0.41)
+    rg = h.node_forward(torch.from_numpy(u).cuda(), 0.0, 1.0, 1e-3, 1e-3, mode=mode, reg_type=reg_type,
+                        t1_or_rand=0.41)
+    assert rg["nfe"] == ro["nfe"]
+    assert rg["stats"]["naccept"] == ro["stats"]["naccept"] and rg["stats"]["nreject"] == ro["stats"]["nreject"]
+    _close(rg["u_end"], ro["u_end"], rtol=2e-5)
+    if mode == "none":
+        assert rg["reg_val"] == 0.0 and ro["reg_val"] == 0.0
+    else:
+        # the local step runs at the automatic initial dt, where utilde = dt*sum(btilde_j k_j) (sum btilde = 0)
+        # is a difference of nearly equal fp32 numbers: its rms carries a few % of rounding noise
+        assert abs(float(rg["reg_val"]) - float(ro["reg_val"])) <= 5e-2 * abs(float(ro["reg_val"]))
+        if mode == "unbiased":
+            assert rg["t1"] == ro["t1"] == np.float32(0.41)
+        else:  # an accepted step time: equal up to the dt differences
+            assert abs(float(rg["t1"]) - float(ro["t1"])) <= 2e-3
+
+
+def test_conv_layer_surface_runs_the_cifar_block():
+    """NeuralODE over the reference's node_core spec (experiments/src/construct.jl:213-218)"""
+    P, O = _mods()
+    core = P.TDChain(P.Chain(P.Chain(P.Conv((3, 3), 9, 64), P.BatchNorm(64, "gelu")),
+                             P.Chain(P.Conv((3, 3), 65, 64), P.BatchNorm(64, "gelu")),
+                             P.Conv((3, 3), 65, 8)))
+    node = P.NeuralODE(core, regularize="unbiased", abstol=1e-3, reltol=1e-3, save_start=False, maxiters=1000)
+    ps = torch.from_numpy(P.glorot_conv_params(8, 64, seed=0)).cuda()
+    x = torch.from_numpy(np.random.default_rng(0).standard_normal((2, 8, 16, 16)).astype(np.float32)).cuda()
+    st = node.initialstates(np.random.default_rng(0))
+    sol, st2 = node(x, ps, st)
+    assert st2["nfe"] == sol.destats.nf + 9 and st2["reg_val"] > 0 and len(sol.u) == 2
+    assert torch.isfinite(sol.u[-1]).all() and tuple(sol.u[-1].shape) == tuple(x.shape)
+    st_test = dict(st, training=False)
+    sol_t, st3 = node(x, ps, st_test)
+    assert st3["reg_val"] == 0.0 and st3["nfe"] == sol_t.destats.nf
