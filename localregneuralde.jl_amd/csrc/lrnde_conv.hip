@@ -66,6 +66,7 @@ struct ConvArgs {
   const float* mean; const float* inv; const float* scale; const float* bias;
   int act;
   double* part;                 // [nwg][COUT][2] sum, sum of squares of the raw output (or null)
+  int dbg;                      // LRNDE_CONV_DBG bits (timing experiments): 1 no MFMA loop, 2 no epilogue, 4 no staging
 };
 
 __device__ __forceinline__ f32x4 wload4(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
@@ -132,57 +133,97 @@ __device__ __forceinline__ void stage_planar(const ConvArgs& a, int n, int y0, T
   }
 }
 
-template <class T>
-__device__ __forceinline__ void stage_nhwc_bn(const ConvArgs& a, int n, int y0, T* tile) {
-  // CIN % 4 == 0; (CIN/4) threads per position, float4 each; BatchNorm + activation on the way in
-  const int WP = a.W + 2, rows = a.TR + 2, cq = a.CIN / 4;
-  const int total = rows * WP * cq;
-  const float* src = a.in + (size_t)n * a.H * a.W * a.CIN;
-  for (int i = threadIdx.x; i < total; i += CNT) {
-    const int q = i % cq, pos = i / cq;
-    const int cc = pos % WP, rr = pos / WP;
-    const int y = y0 - 1 + rr, x = cc - 1;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
-      const f32x4 raw = *reinterpret_cast<const f32x4*>(src + ((size_t)y * a.W + x) * a.CIN + q * 4);
-      const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + q * 4), iv = *reinterpret_cast<const f32x4*>(a.inv + q * 4);
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4), bi = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
+// NHWC raw input (CIN = 64) -> LDS tile [(TR+2)*(W+2) positions][64 channels], no padding: the channel
+// quad index is XOR-swizzled with the low 4 bits of the position (conflict-free ds_read_b128 /
+// ds_write_b128 for 16 consecutive positions).  BatchNorm + activation applied on the way in
+// (y = act(((x-mean)*inv)*scale + bias)); positions outside the image are zero (the conv's padding).
+__device__ __forceinline__ int swz_f32(int pos, int cq) { return pos * 64 + ((cq ^ (pos & 15)) << 2); }
+
+template <int ACT>
+__device__ __forceinline__ void stage_nhwc_bn_f32(const ConvArgs& a, int n, int y0, float* tile) {
+  constexpr int CQ = 16, PSTEP = CNT / CQ, UN = 4;
+  const int WP = a.W + 2, npos = (a.TR + 2) * WP;
+  const int q = threadIdx.x % CQ;
+  const float* src = a.in + (size_t)n * a.H * a.W * 64 + q * 4;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + q * 4), iv = *reinterpret_cast<const f32x4*>(a.inv + q * 4);
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4), bi = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
+  for (int pos0 = threadIdx.x / CQ; pos0 < npos; pos0 += UN * PSTEP) {
+    f32x4 raw[UN];
+    bool ok[UN];
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const float xn = (raw[h] - mu[h]) * iv[h];
-        const float z = xn * sc[h] + bi[h];
-        v[h] = act_apply(a.act, z);
-      }
+    for (int u = 0; u < UN; ++u) {
+      const int pos = pos0 + u * PSTEP;
+      const int cc = pos % WP, rr = pos / WP;
+      const int y = y0 - 1 + rr, x = cc - 1;
+      ok[u] = pos < npos && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      raw[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok[u]) raw[u] = *reinterpret_cast<const f32x4*>(src + ((size_t)y * a.W + x) * 64);
     }
-    T* d = tile + (size_t)pos * a.CINP + q * 4;
-    if constexpr (sizeof(T) == 4) *reinterpret_cast<f32x4*>(d) = v;
-    else {
 #pragma unroll
-      for (int h = 0; h < 4; ++h) d[h] = cvt_to<T>(v[h]);
+    for (int u = 0; u < UN; ++u) {
+      const int pos = pos0 + u * PSTEP;
+      if (pos >= npos) break;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok[u]) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const float xn = (raw[u][h] - mu[h]) * iv[h];
+          const float z = xn * sc[h] + bi[h];
+          v[h] = ACT == 2 ? geluf_c(z) : (ACT == 1 ? tanhf_c(z) : z);
+        }
+      }
+      *reinterpret_cast<f32x4*>(tile + swz_f32(pos, q)) = v;
     }
   }
 }
+__device__ __forceinline__ void stage_nhwc_bn_f32(const ConvArgs& a, int n, int y0, float* tile) {
+  if (a.act == 2) stage_nhwc_bn_f32<2>(a, n, y0, tile);
+  else if (a.act == 1) stage_nhwc_bn_f32<1>(a, n, y0, tile);
+  else stage_nhwc_bn_f32<0>(a, n, y0, tile);
+}
 
 // per-lane LDS offsets (in elements) of the M tiles' pixels; pixels beyond the strip use pixel 0
-__device__ __forceinline__ void pixel_bases(const ConvArgs& a, int (&ab)[MAXMT]) {
+__device__ __forceinline__ void pixel_bases(const ConvArgs& a, int (&ab)[MAXMT], int stride) {
   const int li = threadIdx.x & 15, WP = a.W + 2;
 #pragma unroll
   for (int mt = 0; mt < MAXMT; ++mt) {
     int p = mt * 16 + li;
     if (p >= a.TP) p = 0;
     const int r = p / a.W, x = p % a.W;
-    ab[mt] = (r * WP + x) * a.CINP;
+    ab[mt] = (r * WP + x) * stride;  // stride 1: tile position; CINP: element offset
   }
 }
-__device__ __forceinline__ int tap_off(const ConvArgs& a, int tap) {  // tap = ky*3+kx
+__device__ __forceinline__ int tap_pos(const ConvArgs& a, int tap) {  // tap = ky*3+kx -> position offset
   const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-  return ((2 - ky) * (a.W + 2) + (2 - kx)) * a.CINP;
+  return (2 - ky) * (a.W + 2) + (2 - kx);
+}
+
+// raw NHWC store (+ t * tsum[class]) of a wide kernel's accumulators, and the lane's share of the
+// batch statistics (from the fp32 values, before any bf16 rounding of the stored copy)
+template <int MT, bool OBF>
+__device__ __forceinline__ void wide_epilogue(const ConvArgs& a, const f32x4 (&acc)[MT], const float (&ts)[9], int n, int y0,
+                                              int co, int kg, double& s1, double& s2) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int p = mt * 16 + kg * 4;  // 4 consecutive pixels of one row (W % 4 == 0)
+    if (p < a.TP) {
+      const int y = y0 + p / a.W, x = p % a.W;
+      const size_t o = (((size_t)n * a.H + y) * a.W + x) * a.COUT + co;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = fma_(ts[border_class(y, x + r, a.H, a.W)], a.t, acc[mt][r]);
+        if constexpr (OBF) reinterpret_cast<__bf16*>(a.out)[o + (size_t)r * a.COUT] = (__bf16)v;
+        else a.out[o + (size_t)r * a.COUT] = v;
+        s1 += (double)v; s2 += (double)v * (double)v;
+      }
+    }
+  }
 }
 
 // ===== fp32 kernels ==========================================================================
 // wide: COUT = 64 (NT = 4): wave w owns output channels 16w..16w+15 for all M tiles of the strip.
 // CIN_T: 64 (NHWC + BatchNorm input) or 8 (planar state input).
-template <int CIN_T>
+template <int CIN_T, int MT, bool OBF>
 __global__ __launch_bounds__(CNT) void k_conv_wide_f32(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tile = reinterpret_cast<float*>(smem);
@@ -195,16 +236,20 @@ __global__ __launch_bounds__(CNT) void k_conv_wide_f32(ConvArgs a) {
   constexpr int NG = (9 * CIN_T + 15) / 16;
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * NT * 1024, 0x00020000);
   const int wv = lane * 16;
-  if constexpr (CIN_T == 64) stage_nhwc_bn<float>(a, n, y0, tile);
-  else stage_planar<float>(a, n, y0, tile);
+  if (!(a.dbg & 4)) {
+    if constexpr (CIN_T == 64) stage_nhwc_bn_f32(a, n, y0, tile);
+    else stage_planar<float>(a, n, y0, tile);
+  }
   int ab[MAXMT];
-  pixel_bases(a, ab);
-  f32x4 acc[MAXMT];
+  pixel_bases(a, ab, CIN_T == 64 ? 1 : a.CINP);
+  f32x4 acc[MT];
 #pragma unroll
-  for (int mt = 0; mt < MAXMT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  if constexpr (CIN_T == 64) {
-    // 9 taps x 4 k-groups of 16 channels; the next tap's weights are in flight during this tap
+  if (a.dbg & 1) {
+  } else if constexpr (CIN_T == 64) {
+    // 9 taps x 4 k-groups of 16 channels; the next tap's weights are in flight during this tap.
+    // Per k-group: MT A fragments (ds_read_b128), then 4 k-steps x MT independent accumulators.
     f32x4 wc[4], wn[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) wc[q] = wload4(rsW, wv, ((0 * 4 + q) * NT + wave) * 1024);
@@ -213,19 +258,27 @@ __global__ __launch_bounds__(CNT) void k_conv_wide_f32(ConvArgs a) {
       const int tn = tap < 8 ? tap + 1 : 8;
 #pragma unroll
       for (int q = 0; q < 4; ++q) wn[q] = wload4(rsW, wv, ((tn * 4 + q) * NT + wave) * 1024);
-      const int to = tap_off(a, tap) + 4 * kg;
+      const int tp = tap_pos(a, tap);
+      int pb[MT], hi[MT];  // swizzled base of this lane's channel quad kg, and the swizzle bits of 4q
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int pos = ab[mt] + tp;
+        pb[mt] = pos * 64 + ((kg ^ (pos & 3)) << 2);
+        hi[mt] = (pos & 12) << 2;
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        f32x4 av[MT];
 #pragma unroll
-        for (int mt = 0; mt < MAXMT; ++mt) {
-          if (mt < a.MT) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(tile + ab[mt] + to + 16 * q);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wc[q].x, acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wc[q].y, acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wc[q].z, acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wc[q].w, acc[mt], 0, 0, 0);
-          }
-        }
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(tile + pb[mt] + ((16 * q) ^ hi[mt]));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, wc[q].x, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, wc[q].y, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, wc[q].z, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, wc[q].w, acc[mt], 0, 0, 0);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) wc[q] = wn[q];
@@ -240,41 +293,28 @@ __global__ __launch_bounds__(CNT) void k_conv_wide_f32(ConvArgs a) {
     for (int g = 0; g < NG; ++g) {
       int tap = 2 * g + (kg >> 1);
       if (tap > 8) tap = 8;  // zero weights there
-      const int to = tap_off(a, tap) + 4 * (kg & 1);
+      const int to = tap_pos(a, tap) * a.CINP + 4 * (kg & 1);
+      f32x4 av[MT];
 #pragma unroll
-      for (int mt = 0; mt < MAXMT; ++mt) {
-        if (mt < a.MT) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(tile + ab[mt] + to);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wq[g].x, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wq[g].y, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wq[g].z, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wq[g].w, acc[mt], 0, 0, 0);
-        }
-      }
+      for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(tile + ab[mt] + to);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, wq[g].x, acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, wq[g].y, acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, wq[g].z, acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, wq[g].w, acc[mt], 0, 0, 0);
     }
   }
   // epilogue: + t * tsum[class], raw NHWC store, batch statistics
+  if (a.dbg & 2) { if (acc[0][0] == 123.f) a.out[0] = 1.f; return; }
   const int co = wave * 16 + li;
   float ts[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) ts[c] = a.tsum[c * NT * 16 + co];
   double s1 = 0.0, s2 = 0.0;
-  float* dst = a.out + (size_t)n * a.H * a.W * a.COUT;
-#pragma unroll
-  for (int mt = 0; mt < MAXMT; ++mt) {
-    if (mt < a.MT) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int p = mt * 16 + kg * 4 + r;
-        if (p < a.TP) {
-          const int y = y0 + p / a.W, x = p % a.W;
-          const float v = fma_(ts[border_class(y, x, a.H, a.W)], a.t, acc[mt][r]);
-          dst[((size_t)y * a.W + x) * a.COUT + co] = v;
-          s1 += (double)v; s2 += (double)v * (double)v;
-        }
-      }
-    }
-  }
+  wide_epilogue<MT, OBF>(a, acc, ts, n, y0, co, kg, s1, s2);
   if (a.part) {
     // lanes li share a channel across the 4 lane groups
     s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
@@ -284,6 +324,7 @@ __global__ __launch_bounds__(CNT) void k_conv_wide_f32(ConvArgs a) {
 }
 
 // out: CIN = Hc (64) NHWC + BatchNorm input -> COUT <= 16 planar output; waves split the M tiles
+template <int MT>
 __global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tile = reinterpret_cast<float*>(smem);
@@ -295,9 +336,9 @@ __global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
   constexpr int NG = 36;
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * 1024, 0x00020000);
   const int wv = lane * 16;
-  stage_nhwc_bn<float>(a, n, y0, tile);
+  stage_nhwc_bn_f32(a, n, y0, tile);
   int ab[MAXMT];
-  pixel_bases(a, ab);
+  pixel_bases(a, ab, 1);
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   const int m0 = wave, m1 = wave + 4;
   const int ab0 = (m0 == 0) ? ab[0] : (m0 == 1) ? ab[1] : (m0 == 2) ? ab[2] : ab[3];
@@ -311,18 +352,21 @@ __global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
     const int tn = tap < 8 ? tap + 1 : 8;
 #pragma unroll
     for (int q = 0; q < 4; ++q) wn[q] = wload4(rsW, wv, (tn * 4 + q) * 1024);
-    const int to = tap_off(a, tap) + 4 * kg;
+    const int tp = tap_pos(a, tap);
+    const int pos0 = ab0 + tp, pos1 = ab1 + tp;
+    const int pb0 = pos0 * 64 + ((kg ^ (pos0 & 3)) << 2), hi0 = (pos0 & 12) << 2;
+    const int pb1 = pos1 * 64 + ((kg ^ (pos1 & 3)) << 2), hi1 = (pos1 & 12) << 2;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (m0 < a.MT) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(tile + ab0 + to + 16 * q);
+      if (m0 < MT) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(tile + pb0 + ((16 * q) ^ hi0));
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wc[q].x, acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wc[q].y, acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wc[q].z, acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wc[q].w, acc[0], 0, 0, 0);
       }
-      if (m1 < a.MT) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(tile + ab1 + to + 16 * q);
+      if (MT > 4 && m1 < MT) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(tile + pb1 + ((16 * q) ^ hi1));
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wc[q].x, acc[1], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wc[q].y, acc[1], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wc[q].z, acc[1], 0, 0, 0);
@@ -342,7 +386,174 @@ __global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
     for (int h = 0; h < 2; ++h) {
       const int mt = h == 0 ? m0 : m1;
       const int p = mt * 16 + kg * 4;
-      if (mt < a.MT && p < a.TP) {
+      if (mt < MT && p < a.TP) {
+        const int y = y0 + p / a.W, x = p % a.W;
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fma_(ts[border_class(y, x + r, a.H, a.W)], a.t, acc[h][r]);
+        *reinterpret_cast<f32x4*>(dst + (size_t)y * a.W + x) = v;
+      }
+    }
+  }
+}
+
+// ===== bf16 kernels (compute_dtype LRNDE_BF16) ==================================================
+// Activations y1/y2 are stored as bf16 NHWC; the halo tile is bf16 [pos][64] (128 B per position) with the
+// 16-byte chunk index XOR-swizzled by (pos>>1)&7; v_mfma_f32_16x16x32_bf16 takes 8 consecutive k per lane,
+// so one tap of 64 channels is two k-groups.  Accumulation, the t-plane term, batch statistics: fp32/fp64.
+template <int ACT>
+__device__ __forceinline__ void stage_nhwc_bn_bf16(const ConvArgs& a, int n, int y0, __bf16* tile) {
+  constexpr int CQ = 8, PSTEP = CNT / CQ, UN = 4;
+  const int WP = a.W + 2, npos = (a.TR + 2) * WP;
+  const int q = threadIdx.x % CQ;
+  const __bf16* src = reinterpret_cast<const __bf16*>(a.in) + (size_t)n * a.H * a.W * 64 + q * 8;
+  float mu[8], iv[8], sc[8], bi[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) { mu[h] = a.mean[q * 8 + h]; iv[h] = a.inv[q * 8 + h]; sc[h] = a.scale[q * 8 + h]; bi[h] = a.bias[q * 8 + h]; }
+  for (int pos0 = threadIdx.x / CQ; pos0 < npos; pos0 += UN * PSTEP) {
+    bf16x8 raw[UN];
+    bool ok[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int pos = pos0 + u * PSTEP;
+      const int cc = pos % WP, rr = pos / WP;
+      const int y = y0 - 1 + rr, x = cc - 1;
+      ok[u] = pos < npos && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      if (ok[u]) raw[u] = *reinterpret_cast<const bf16x8*>(src + ((size_t)y * a.W + x) * 64);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int pos = pos0 + u * PSTEP;
+      if (pos >= npos) break;
+      bf16x8 v;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        float o = 0.f;
+        if (ok[u]) {
+          const float xn = ((float)raw[u][h] - mu[h]) * iv[h];
+          const float z = xn * sc[h] + bi[h];
+          o = ACT == 2 ? geluf_c(z) : (ACT == 1 ? tanhf_c(z) : z);
+        }
+        v[h] = (__bf16)o;
+      }
+      *reinterpret_cast<bf16x8*>(tile + pos * 64 + (((q ^ (pos >> 1)) & 7) << 3)) = v;
+    }
+  }
+}
+__device__ __forceinline__ void stage_nhwc_bn_bf16(const ConvArgs& a, int n, int y0, __bf16* tile) {
+  if (a.act == 2) stage_nhwc_bn_bf16<2>(a, n, y0, tile);
+  else if (a.act == 1) stage_nhwc_bn_bf16<1>(a, n, y0, tile);
+  else stage_nhwc_bn_bf16<0>(a, n, y0, tile);
+}
+__device__ __forceinline__ bf16x8 wload8(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+
+// conv2 in bf16: 64 -> 64 channels, wave w owns output channels 16w..16w+15
+template <int MT>
+__global__ __launch_bounds__(CNT) void k_conv_wide_bf16(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* tile = reinterpret_cast<__bf16*>(smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int strips = a.H / a.TR;
+  const int n = blockIdx.x / strips, y0 = (blockIdx.x % strips) * a.TR;
+  constexpr int NT = 4, NG = 18;
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * NT * 1024, 0x00020000);
+  const int wv = lane * 16;
+  stage_nhwc_bn_bf16(a, n, y0, tile);
+  int ab[MAXMT];
+  pixel_bases(a, ab, 1);
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  bf16x8 wc[2], wn[2];
+  wc[0] = wload8(rsW, wv, (0 * NT + wave) * 1024);
+  wc[1] = wload8(rsW, wv, (1 * NT + wave) * 1024);
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int tn = tap < 8 ? tap + 1 : 8;
+    wn[0] = wload8(rsW, wv, ((tn * 2 + 0) * NT + wave) * 1024);
+    wn[1] = wload8(rsW, wv, ((tn * 2 + 1) * NT + wave) * 1024);
+    const int tp = tap_pos(a, tap);
+    int pb[MT], hi[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int pos = ab[mt] + tp, sw = pos >> 1;
+      pb[mt] = pos * 64 + (((kg ^ sw) & 3) << 3);
+      hi[mt] = (sw & 4) << 3;
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      bf16x8 av[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const bf16x8*>(tile + pb[mt] + ((32 * g2) ^ hi[mt]));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mt], wc[g2], acc[mt], 0, 0, 0);
+    }
+    wc[0] = wn[0]; wc[1] = wn[1];
+  }
+  const int co = wave * 16 + li;
+  float ts[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) ts[c] = a.tsum[c * NT * 16 + co];
+  double s1 = 0.0, s2 = 0.0;
+  wide_epilogue<MT, true>(a, acc, ts, n, y0, co, kg, s1, s2);
+  if (a.part) {
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (kg == 0) { double* pp = a.part + ((size_t)blockIdx.x * a.COUT + co) * 2; pp[0] = s1; pp[1] = s2; }
+  }
+}
+
+// conv3 in bf16: 64 -> COUT <= 16 channels, planar fp32 output; waves split the M tiles
+template <int MT>
+__global__ __launch_bounds__(CNT) void k_conv_out_bf16(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* tile = reinterpret_cast<__bf16*>(smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int strips = a.H / a.TR;
+  const int n = blockIdx.x / strips, y0 = (blockIdx.x % strips) * a.TR;
+  constexpr int NG = 18;
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * 1024, 0x00020000);
+  const int wv = lane * 16;
+  stage_nhwc_bn_bf16(a, n, y0, tile);
+  int ab[MAXMT];
+  pixel_bases(a, ab, 1);
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int m0 = wave, m1 = wave + 4;
+  const int ab0 = (m0 == 0) ? ab[0] : (m0 == 1) ? ab[1] : (m0 == 2) ? ab[2] : ab[3];
+  const int ab1 = (m1 == 4) ? ab[4] : (m1 == 5) ? ab[5] : (m1 == 6) ? ab[6] : ab[7];
+  __syncthreads();
+  bf16x8 wq[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) wq[g] = wload8(rsW, wv, g * 1024);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int tp = tap_pos(a, tap);
+    const int pos0 = ab0 + tp, pos1 = ab1 + tp;
+    const int pb0 = pos0 * 64 + (((kg ^ (pos0 >> 1)) & 3) << 3), hi0 = ((pos0 >> 1) & 4) << 3;
+    const int pb1 = pos1 * 64 + (((kg ^ (pos1 >> 1)) & 3) << 3), hi1 = ((pos1 >> 1) & 4) << 3;
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      if (m0 < MT) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(tile + pb0 + ((32 * g2) ^ hi0)), wq[tap * 2 + g2], acc[0], 0, 0, 0);
+      if (MT > 4 && m1 < MT) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(tile + pb1 + ((32 * g2) ^ hi1)), wq[tap * 2 + g2], acc[1], 0, 0, 0);
+    }
+  }
+  if (li < a.COUT) {
+    float ts[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) ts[c] = a.tsum[c * 16 + li];
+    float* dst = a.out + ((size_t)n * a.COUT + li) * a.H * a.W;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int mt = h == 0 ? m0 : m1;
+      const int p = mt * 16 + kg * 4;
+      if (mt < MT && p < a.TP) {
         const int y = y0 + p / a.W, x = p % a.W;
         f32x4 v;
 #pragma unroll
@@ -354,16 +565,22 @@ __global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
 }
 
 // ---- batch statistics: fixed-order reduction of the per-workgroup partials --------------------
-__global__ __launch_bounds__(64) void k_bn_finalize(const double* part, int nwg, int ch, double count, float eps,
-                                                    float* mean, float* inv) {
-  const int c = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_bn_finalize(const double* part, int nwg, int ch, double count, float eps,
+                                                     float* mean, float* inv) {
+  // one block per channel; thread i sums partials i, i+256, ... (independent loads), then a fixed tree
+  __shared__ double r1[256], r2[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int w = lane; w < nwg; w += 64) { const double* p = part + ((size_t)w * ch + c) * 2; s1 += p[0]; s2 += p[1]; }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-  if (lane == 0) {
-    const double mu = s1 / count;
-    double var = s2 / count - mu * mu;
+  for (int w = tid; w < nwg; w += 256) { const double* p = part + ((size_t)w * ch + c) * 2; s1 += p[0]; s2 += p[1]; }
+  r1[tid] = s1; r2[tid] = s2;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) { r1[tid] += r1[tid + o]; r2[tid] += r2[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double mu = r1[0] / count;
+    double var = r2[0] / count - mu * mu;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)mu;
     inv[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -501,7 +718,7 @@ inline int strip_rows(const lrnde_conv* c) {
     if (c->d.height % tr == 0 && tr * c->d.width <= 16 * MAXMT) best = tr;
   return best;
 }
-inline int cinp_of(int cin) { return cin == 8 ? 12 : cin + 4; }
+inline int cinp_of(int cin) { return cin == 8 ? 12 : cin; }  // 64-channel tiles are swizzled, not padded
 
 int ensure_ws(lrnde_conv* c, int B) {
   if (B == c->wsB) return LRNDE_OK;
@@ -534,29 +751,56 @@ ConvArgs base_args(const lrnde_conv* c, int B) {
   return a;
 }
 
+// the conv kernels are instantiated per number of M tiles of the strip (1..8)
+template <int MT> void launch_one(lrnde_conv* c, int which, const ConvArgs& a, size_t sm) {
+  if (c->d.compute_dtype == LRNDE_BF16) {
+    if (which == 0) hipLaunchKernelGGL((k_conv_wide_f32<8, MT, true>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+    else if (which == 1) hipLaunchKernelGGL(k_conv_wide_bf16<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+    else hipLaunchKernelGGL(k_conv_out_bf16<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+    return;
+  }
+  if (which == 0) hipLaunchKernelGGL((k_conv_wide_f32<8, MT, false>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+  else if (which == 1) hipLaunchKernelGGL((k_conv_wide_f32<64, MT, false>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+  else hipLaunchKernelGGL(k_conv_out_f32<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+}
+void launch_mt(lrnde_conv* c, int which, const ConvArgs& a, size_t sm) {
+  switch (a.MT) {
+    case 1: launch_one<1>(c, which, a, sm); break;
+    case 2: launch_one<2>(c, which, a, sm); break;
+    case 3: launch_one<3>(c, which, a, sm); break;
+    case 4: launch_one<4>(c, which, a, sm); break;
+    case 5: launch_one<5>(c, which, a, sm); break;
+    case 6: launch_one<6>(c, which, a, sm); break;
+    case 7: launch_one<7>(c, which, a, sm); break;
+    default: launch_one<8>(c, which, a, sm); break;
+  }
+}
+
 // du = f(u, t): the five launches
 int launch_rhs(lrnde_conv* c, const float* u, float t, int B, float* du) {
   const int Hc = c->d.hidden, C = c->d.channels;
   const bool train = c->d.bn_train != 0;
   const double count = (double)B * c->d.width * c->d.height;
   ConvArgs a = base_args(c, B);
+  a.dbg = getenv("LRNDE_CONV_DBG") ? atoi(getenv("LRNDE_CONV_DBG")) : 0;
   const int rows = a.TR + 2, WP = a.W + 2;
   // conv1: state -> y1
   a.CIN = C; a.CINP = cinp_of(C); a.COUT = Hc; a.in = u; a.out = c->y1; a.wpk = c->w1; a.tsum = c->ts1; a.t = t;
   a.part = train ? c->part : nullptr;
-  hipLaunchKernelGGL(k_conv_wide_f32<8>, dim3(c->nwg), dim3(CNT), sizeof(float) * rows * WP * a.CINP, c->stream, a);
+  launch_mt(c, 0, a, sizeof(float) * rows * WP * a.CINP);
   CHK(c, hipGetLastError());
-  if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(64), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat, c->stat + Hc);
+  if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(256), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat, c->stat + Hc);
   // conv2: BN1+act(y1) -> y2
   a.CIN = Hc; a.CINP = cinp_of(Hc); a.in = c->y1; a.out = c->y2; a.wpk = c->w2; a.tsum = c->ts2;
   a.mean = c->stat; a.inv = c->stat + Hc; a.scale = c->bn; a.bias = c->bn + Hc;
-  hipLaunchKernelGGL(k_conv_wide_f32<64>, dim3(c->nwg), dim3(CNT), sizeof(float) * rows * WP * a.CINP, c->stream, a);
+  const size_t esz = c->d.compute_dtype == LRNDE_BF16 ? 2 : 4;
+  launch_mt(c, 1, a, esz * rows * WP * a.CINP);
   CHK(c, hipGetLastError());
-  if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(64), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat + 2 * Hc, c->stat + 3 * Hc);
+  if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(256), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat + 2 * Hc, c->stat + 3 * Hc);
   // conv3: BN2+act(y2) -> du (planar)
   a.COUT = C; a.in = c->y2; a.out = du; a.wpk = c->w3; a.tsum = c->ts3; a.part = nullptr;
   a.mean = c->stat + 2 * Hc; a.inv = c->stat + 3 * Hc; a.scale = c->bn + 2 * Hc; a.bias = c->bn + 3 * Hc;
-  hipLaunchKernelGGL(k_conv_out_f32, dim3(c->nwg), dim3(CNT), sizeof(float) * rows * WP * a.CINP, c->stream, a);
+  launch_mt(c, 2, a, esz * rows * WP * a.CINP);
   CHK(c, hipGetLastError());
   return LRNDE_OK;
 }
@@ -659,7 +903,7 @@ int lrnde_conv_create(lrnde_conv** out, const lrnde_conv_desc* d, int device, vo
   if (d->channels != 8 || d->hidden != 64 || d->width % 4 != 0 || d->width < 4 || d->width > 16 * MAXMT ||
       d->height < 2 || d->act < 0 || d->act > 2)
     return LRNDE_UNSUPPORTED;
-  if (d->compute_dtype != LRNDE_F32) return LRNDE_UNSUPPORTED;
+  if (d->compute_dtype != LRNDE_F32 && d->compute_dtype != LRNDE_BF16) return LRNDE_UNSUPPORTED;
   lrnde_conv* c = new lrnde_conv();
   c->d = *d;
   if (!(c->d.bn_eps > 0.f)) c->d.bn_eps = 1e-5f;
@@ -667,7 +911,8 @@ int lrnde_conv_create(lrnde_conv** out, const lrnde_conv_desc* d, int device, vo
   c->stream = (hipStream_t)stream;
   if (hipSetDevice(device) != hipSuccess) { delete c; return LRNDE_HIP_ERROR; }
   const int C = d->channels, Hc = d->hidden;
-  c->NG1 = (9 * C + 15) / 16; c->NG2 = (9 * Hc + 15) / 16;
+  c->NG1 = (9 * C + 15) / 16;
+  c->NG2 = d->compute_dtype == LRNDE_BF16 ? (9 * Hc + 31) / 32 : (9 * Hc + 15) / 16;
   bool ok = hipMalloc(&c->w1, (size_t)c->NG1 * 4 * 1024) == hipSuccess &&
             hipMalloc(&c->w2, (size_t)c->NG2 * 4 * 1024) == hipSuccess &&
             hipMalloc(&c->w3, (size_t)c->NG2 * 1 * 1024) == hipSuccess &&
@@ -678,9 +923,6 @@ int lrnde_conv_create(lrnde_conv** out, const lrnde_conv_desc* d, int device, vo
             hipHostMalloc(&c->sums_host, sizeof(double) * NSUMB * 3) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
   if (!ok) { lrnde_conv_destroy(c); return LRNDE_HIP_ERROR; }
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wide_f32<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wide_f32<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_out_f32), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   *out = c;
   return LRNDE_OK;
 }
@@ -709,8 +951,9 @@ int lrnde_conv_set_params(lrnde_conv* c, const float* p, size_t n) {
   const float* w2 = g1 + 2 * Hc; const float* g2 = w2 + 9 * (Hc + 1) * Hc;
   const float* w3 = g2 + 2 * Hc;
   hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w1, C, Hc, c->NG1, 4, 0, c->w1, c->ts1);
-  hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w2, Hc, Hc, c->NG2, 4, 0, c->w2, c->ts2);
-  hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w3, Hc, C, c->NG2, 1, 0, c->w3, c->ts3);
+  const int bf = c->d.compute_dtype == LRNDE_BF16 ? 1 : 0;
+  hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w2, Hc, Hc, c->NG2, 4, bf, c->w2, c->ts2);
+  hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w3, Hc, C, c->NG2, 1, bf, c->w3, c->ts3);
   CHK(c, hipGetLastError());
   CHK(c, hipMemcpyAsync(c->bn, g1, sizeof(float) * 2 * Hc, hipMemcpyDeviceToDevice, c->stream));
   CHK(c, hipMemcpyAsync(c->bn + 2 * Hc, g2, sizeof(float) * 2 * Hc, hipMemcpyDeviceToDevice, c->stream));

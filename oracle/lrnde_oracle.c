@@ -258,6 +258,7 @@ void lro_mlp_as_field(const lro_mlp* m, lro_field* out) {
 /* ------------------------------------------------------------------------- */
 /* conv vector field (experiments/src/construct.jl:213-218)                   */
 /* ------------------------------------------------------------------------- */
+static float bf16_round(float x);
 int lro_conv_param_count(int C, int Hc) {
   return 9 * (C + 1) * Hc + 2 * Hc + 9 * (Hc + 1) * Hc + 2 * Hc + 9 * (Hc + 1) * C;
 }
@@ -298,8 +299,8 @@ static void conv3x3_t(const float* in, int B, int cin, int cout, int H, int W, c
 }
 
 /* Lux BatchNorm(ch, act) over (W,H,N) per channel, in place on (B, ch, H, W) */
-static void batchnorm_act(float* x, int B, int ch, long plane, const float* scale, const float* bias,
-                          int train, const float* rmean, const float* rvar, float eps, int act, int nth) {
+static void batchnorm_act_ex(float* x, int B, int ch, long plane, const float* scale, const float* bias,
+                             int train, const float* rmean, const float* rvar, float eps, int act, int nth, int round_raw) {
 #pragma omp parallel for schedule(static) num_threads(nth)
   for (int c = 0; c < ch; ++c) {
     float mean, inv;
@@ -319,12 +320,32 @@ static void batchnorm_act(float* x, int B, int ch, long plane, const float* scal
     for (int b = 0; b < B; ++b) {
       float* p = x + ((long)b * ch + c) * plane;
       for (long i = 0; i < plane; ++i) {
-        const float xn = (p[i] - mean) * inv;
+        const float raw = round_raw ? bf16_round(p[i]) : p[i];
+        const float xn = (raw - mean) * inv;
         const float y = xn * scale[c] + bias[c];
         p[i] = act_apply(act, y);
       }
     }
   }
+}
+static void batchnorm_act(float* x, int B, int ch, long plane, const float* scale, const float* bias,
+                          int train, const float* rmean, const float* rvar, float eps, int act, int nth) {
+  batchnorm_act_ex(x, B, ch, plane, scale, bias, train, rmean, rvar, eps, act, nth, 0);
+}
+
+static float bf16_round(float x) { /* round to nearest even on the top 16 bits */
+  uint32_t u; memcpy(&u, &x, 4);
+  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+  float r; memcpy(&r, &u, 4);
+  return r;
+}
+static void bf16_round_array(float* x, long n) { for (long i = 0; i < n; ++i) x[i] = bf16_round(x[i]); }
+/* copy of a conv weight (3x3x(cin+1)xcout) with the real input channels rounded to bf16 */
+static float* bf16_weights(const float* w, int cin, int cout) {
+  const long n = 9L * (cin + 1) * cout;
+  float* r = (float*)malloc(sizeof(float) * (size_t)n);
+  for (long i = 0; i < n; ++i) { const int ci = (int)((i / 9) % (cin + 1)); r[i] = ci < cin ? bf16_round(w[i]) : w[i]; }
+  return r;
 }
 
 void lro_conv_rhs(const lro_conv* m, const float* u, float t, int B, float* du) {
@@ -339,11 +360,26 @@ void lro_conv_rhs(const lro_conv* m, const float* u, float t, int B, float* du) 
   float* y1 = (float*)malloc(sizeof(float) * (size_t)B * Hc * plane);
   float* y2 = (float*)malloc(sizeof(float) * (size_t)B * Hc * plane);
   const float* st = m->bn_state;
-  conv3x3_t(u, B, C, Hc, H, W, w1, t, y1, nth);
-  batchnorm_act(y1, B, Hc, plane, g1, b1, m->bn_train, st ? st : NULL, st ? st + Hc : NULL, m->eps, m->act, nth);
-  conv3x3_t(y1, B, Hc, Hc, H, W, w2, t, y2, nth);
-  batchnorm_act(y2, B, Hc, plane, g2, b2, m->bn_train, st ? st + 2 * Hc : NULL, st ? st + 3 * Hc : NULL, m->eps, m->act, nth);
-  conv3x3_t(y2, B, Hc, C, H, W, w3, t, du, nth);
+  const long ny = (long)B * Hc * plane;
+  if (m->bf16) {
+    /* statistics come from the fp32 conv output, the normalised copy is the bf16-rounded one */
+    float* w2r = bf16_weights(w2, Hc, Hc);
+    float* w3r = bf16_weights(w3, Hc, C);
+    conv3x3_t(u, B, C, Hc, H, W, w1, t, y1, nth);
+    batchnorm_act_ex(y1, B, Hc, plane, g1, b1, m->bn_train, st ? st : NULL, st ? st + Hc : NULL, m->eps, m->act, nth, 1);
+    bf16_round_array(y1, ny);
+    conv3x3_t(y1, B, Hc, Hc, H, W, w2r, t, y2, nth);
+    batchnorm_act_ex(y2, B, Hc, plane, g2, b2, m->bn_train, st ? st + 2 * Hc : NULL, st ? st + 3 * Hc : NULL, m->eps, m->act, nth, 1);
+    bf16_round_array(y2, ny);
+    conv3x3_t(y2, B, Hc, C, H, W, w3r, t, du, nth);
+    free(w2r); free(w3r);
+  } else {
+    conv3x3_t(u, B, C, Hc, H, W, w1, t, y1, nth);
+    batchnorm_act(y1, B, Hc, plane, g1, b1, m->bn_train, st ? st : NULL, st ? st + Hc : NULL, m->eps, m->act, nth);
+    conv3x3_t(y1, B, Hc, Hc, H, W, w2, t, y2, nth);
+    batchnorm_act(y2, B, Hc, plane, g2, b2, m->bn_train, st ? st + 2 * Hc : NULL, st ? st + 3 * Hc : NULL, m->eps, m->act, nth);
+    conv3x3_t(y2, B, Hc, C, H, W, w3, t, du, nth);
+  }
   free(y1); free(y2);
 }
 

@@ -100,6 +100,9 @@ typedef struct {
   const float* p;
   const float* bn_state; /* may be NULL in test mode: mean 0, var 1 */
   int nthreads;
+  int bf16;              /* 1: emulate the bf16 compute mode of the HIP path: y1, y2 and the activated
+                            conv2/conv3 inputs rounded to bf16 (RNE), conv2/conv3 weights (not the t
+                            plane's) rounded to bf16, fp32 accumulation; conv1 stays fp32 */
 } lro_conv;
 
 typedef struct {

@@ -34,7 +34,7 @@ class Mlp(C.Structure):
 class Conv(C.Structure):
     _fields_ = [("W", C.c_int), ("H", C.c_int), ("C", C.c_int), ("Hc", C.c_int), ("act", C.c_int),
                 ("bn_train", C.c_int), ("eps", C.c_float), ("p", C.POINTER(C.c_float)),
-                ("bn_state", C.POINTER(C.c_float)), ("nthreads", C.c_int)]
+                ("bn_state", C.POINTER(C.c_float)), ("nthreads", C.c_int), ("bf16", C.c_int)]
 
 
 class Opts(C.Structure):
@@ -157,14 +157,15 @@ class ConvField:
     """TDChain(Chain(Conv3x3(C+1=>Hc), BN(Hc,act)), Chain(Conv(Hc+1=>Hc), BN(Hc,act)), Conv(Hc+1=>C))
     on a (W,H,C) image state (experiments/src/construct.jl:213-218), flat Lux-ordered params."""
 
-    def __init__(self, W, H, Cch, Hc, params, act="gelu", bn_train=True, bn_state=None, eps=1e-5, nthreads=1):
+    def __init__(self, W, H, Cch, Hc, params, act="gelu", bn_train=True, bn_state=None, eps=1e-5, nthreads=1,
+                 bf16=False):
         self.W, self.H, self.C, self.Hc = int(W), int(H), int(Cch), int(Hc)
         self.D = self.W * self.H * self.C
         self.params = _f32(params)
         assert self.params.size == lib().lro_conv_param_count(self.C, self.Hc), "param count"
         self.bn_state = None if bn_state is None else _f32(bn_state)
         self.m = Conv(self.W, self.H, self.C, self.Hc, ACT[act], int(bool(bn_train)), float(eps), _fp(self.params),
-                      _fp(self.bn_state) if self.bn_state is not None else None, int(nthreads))
+                      _fp(self.bn_state) if self.bn_state is not None else None, int(nthreads), int(bool(bf16)))
         self.field = Field()
         lib().lro_conv_as_field(C.byref(self.m), C.byref(self.field))
 

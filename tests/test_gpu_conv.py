@@ -161,3 +161,38 @@ def test_conv_layer_surface_runs_the_cifar_block():
     st_test = dict(st, training=False)
     sol_t, st3 = node(x, ps, st_test)
     assert st3["reg_val"] == 0.0 and st3["nfe"] == sol_t.destats.nf
+
+
+# ---- bf16 compute mode (BASELINE.json config 4: CIFAR10 block, bf16 MFMA, fp32 accumulate / state / norms) ----
+# Tolerances are bf16-appropriate and stated against the OUTPUT SCALE: against the oracle's bf16 emulation
+# (same roundings, different summation order: a value near a bf16 rounding boundary can flip, 2^-9 relative on
+# that activation) 5e-3; against the plain fp32 oracle 3e-2.
+def _bf16_case(W, H, B, seed, train=True):
+    P, O = _mods()
+    fld32, h32, p, u = _case(W, H, B, seed=seed, train=train)
+    st = fld32.bn_state
+    fldbf = O.ConvField(W, H, 8, 64, p, act="gelu", bn_train=train, bn_state=st, nthreads=8, bf16=True)
+    hbf = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=train, compute_dtype="bf16")
+    if st is not None:
+        hbf.set_bn_state(st)
+    hbf.set_params(p)
+    return fld32, fldbf, hbf, u
+
+
+@pytest.mark.parametrize("W,H,B,train", [(16, 16, 2, True), (32, 32, 2, True), (28, 28, 2, False), (12, 8, 3, True)])
+def test_conv_bf16_rhs(W, H, B, train):
+    fld32, fldbf, hbf, u = _bf16_case(W, H, B, seed=W + 7, train=train)
+    got = hbf.rhs(torch.from_numpy(u).cuda(), 0.3)
+    _close(got, fldbf.rhs(u.reshape(B, -1), 0.3), rtol=5e-3)
+    _close(got, fld32.rhs(u.reshape(B, -1), 0.3), rtol=3e-2)
+
+
+def test_conv_bf16_node_forward():
+    P, O = _mods()
+    W = H = 16; B = 2
+    fld32, fldbf, hbf, u = _bf16_case(W, H, B, seed=9)
+    ro = O.node_forward(fldbf, u.reshape(B, -1), 0.0, 1.0, 1e-2, 1e-2, mode="unbiased", t1_or_rand=0.41)
+    rg = hbf.node_forward(torch.from_numpy(u).cuda(), 0.0, 1.0, 1e-2, 1e-2, mode="unbiased", t1_or_rand=0.41)
+    assert rg["stats"]["retcode"] == 0 and abs(rg["stats"]["naccept"] - ro["stats"]["naccept"]) <= 1
+    _close(rg["u_end"], ro["u_end"], rtol=2e-2)
+    assert rg["reg_val"] > 0
