@@ -54,7 +54,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=512)
     ap.add_argument("--adjoint-steps", type=int, default=5, help="timed forward+adjoint passes (single GPU)")
+    ap.add_argument("--workload", default="mlp", choices=["mlp", "cifar_conv_bf16", "cifar_conv_f32", "mnist_conv_f32"],
+                    help="mlp: the headline MNIST-ODE MLP field (default).  The conv workloads time the CIFAR10 node_core "
+                         "(BASELINE.json configs 4 and 2-ii); single GPU.")
     args = ap.parse_args()
+    if args.workload != "mlp":
+        return conv_main(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -181,6 +186,81 @@ def main():
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()
+
+
+# ---- conv vector field workloads (BASELINE.json config 4: CIFAR10 block B=256 bf16; config 2-ii: 28x28 conv field) ----
+CONV_FLOP_PER_PIXEL = 2 * (81 * 64 + 585 * 64 + 585 * 8)  # 94 608 (96 878 592 per 32x32 sample)
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md dense bf16
+
+
+def conv_main(args):
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("the conv workloads are single-GPU (train-mode BatchNorm couples the batch: replicas only)")
+    torch.cuda.set_device(0)
+    import lrnde_amd as P
+    W, H, B, dt, tol, train = {"cifar_conv_bf16": (32, 32, 256, "bf16", 1e-4, True),
+                               "cifar_conv_f32": (32, 32, 256, "f32", 1e-4, True),
+                               "mnist_conv_f32": (28, 28, 512, "f32", 1e-4, False)}[args.workload]
+    if args.batch != 512:
+        B = args.batch
+    steps, warmup = min(args.steps, 10), min(args.warmup, 2)
+    params = P.glorot_conv_params(8, 64, seed=0)
+    xh = np.random.default_rng(0).standard_normal((B, 8, H, W)).astype(np.float32)  # u0 ~ N(0,1)
+    x = torch.from_numpy(xh).cuda()
+    h = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=train, compute_dtype=dt)
+    h.set_params(params)
+    t1s = np.random.default_rng(1).random(steps + warmup, dtype=np.float32)
+
+    def one_pass(i):
+        return h.node_forward(x, 0.0, 1.0, tol, tol, mode="unbiased", reg_type="error_estimate",
+                              t1_or_rand=float(t1s[i]), maxiters=10000)
+
+    for i in range(warmup):
+        one_pass(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nfe_total, steps_total = 0, 0
+    for i in range(steps):
+        r = one_pass(warmup + i)
+        nfe_total += r["nfe"]
+        steps_total += r["stats"]["naccept"] + r["stats"]["nreject"] + 1
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    us = h.bench_rhs(x, 0.3, reps=20)  # HIP events on the handle's stream around 20 f-evals
+    flop = CONV_FLOP_PER_PIXEL * W * H * B
+    peak = PEAK_BF16_MFMA_TFLOPS if dt == "bf16" else PEAK_F32_MFMA_TFLOPS
+    achieved = flop / (us * 1e-6) / 1e12
+    out = {
+        "metric": f"NFE/s (vector-field evals/s inside the adaptive Tsit5 NeuralODE forward, conv field {W}x{W}x8, B={B})",
+        "value": nfe_total / el, "unit": "NFE/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dt, "data": "synthetic",
+        "config": {"workload": f"{args.workload}: TDChain(Conv3x3(9=>64)+BN+gelu, Conv3x3(65=>64)+BN+gelu, Conv3x3(65=>8)) on "
+                               f"{W}x{H}x8xB={B}, BatchNorm {'batch' if train else 'running'} statistics, Tsit5 adaptive "
+                               f"abstol=reltol={tol:g}, tspan=(0,1), regularize=unbiased/error_estimate, forward pass",
+                   "global_batch": B, "parallelism": "single GPU", "nfe_per_pass": nfe_total / steps,
+                   "rk_steps_per_sec": steps_total / el, "fwd_ms_per_batch": el / steps * 1e3},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": None, "kernel": "one f-eval = k_conv_wide(conv1) + k_bn_finalize + k_conv_wide(conv2) + "
+                                                "k_bn_finalize + k_conv_out(conv3)",
+                     "us_per_launch": us, "flop_per_launch": flop},
+    }
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O
+        cores = int(os.environ.get("LRNDE_CPU_CORES", min(len(os.sched_getaffinity(0)), 16)))
+        cb = min(B, 16)  # bounded sample: f-evals of a 16-sample slice (batch statistics of the slice)
+        fld = O.ConvField(W, H, 8, 64, params, act="gelu", bn_train=train, nthreads=cores, bf16=(dt == "bf16"))
+        tc = time.time()
+        n = 0
+        while time.time() - tc < 10.0:
+            fld.rhs(xh[:cb].reshape(cb, -1), 0.3)
+            n += 1
+        cel = time.time() - tc
+        out["cpu_baseline"] = {"value": n / cel * (cb / B), "unit": "NFE/s", "cores": cores, "kind": "port",
+                               "sample": f"{n} f-evals of the C oracle (OpenMP, {cores} threads) on a {cb}-sample slice in "
+                                         f"{cel:.1f} s, scaled by {cb}/{B} to whole-batch f-evals per second"}
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
