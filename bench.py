@@ -111,27 +111,35 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
 
-    # forward + adjoint ms/batch (the second half of BASELINE.json's metric): pullback of
-    # ce-like loss + w_reg*reg_val through the layer, as experiments/src/utils.jl:104-115 times it.
-    # Single GPU only in this build (the adjoint's parameter cotangent is not sharded yet).
+    # forward + adjoint ms/batch (the second half of BASELINE.json's metric): the reference's training step
+    # (experiments/src/utils.jl:104-123) = pullback of  logitcrossentropy(classifier(sol.u[end]), y) + w_reg*reg_val
+    # through Chain(neural_ode, classifier Dense(784=>10)); fwd/bwd split timed as there.  Single GPU only in this
+    # build (the adjoint's parameter cotangent is not sharded yet).
     fwd_adj_ms, bwd_stats = None, None
     if world == 1 and args.adjoint_steps > 0:
-        g = torch.from_numpy(np.random.default_rng(2).standard_normal((args.batch, D)).astype(np.float32)).cuda()
-        tol_b = args.tol
-
-        def one_bwd(i):
-            return h.node_backward(x, 0.0, 1.0, tol_b, tol_b, g, mode="unbiased", reg_type="error_estimate",
-                                   t1_or_rand=float(t1s[i % len(t1s)]), w_reg=2.5, maxiters=10000)
-
-        one_bwd(0)
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
+        node = P.NeuralODE(model, regularize="unbiased", regularize_type="error_estimate", abstol=args.tol, reltol=args.tol,
+                           save_start=False, maxiters=10000)
+        node._handle = h  # reuse the bench handle (parameters already bound)
+        ps_d = torch.from_numpy(params).cuda()
+        node._ps_key = (ps_d.data_ptr(), ps_d._version)
+        h.set_params(ps_d)
+        rngc = np.random.default_rng(2)
+        pc = torch.from_numpy((rngc.random(10 * (D + 1), dtype=np.float32) - np.float32(0.5)) *
+                              np.float32(np.sqrt(24.0 / (D + 10)))).cuda()
+        labels = torch.from_numpy(rngc.integers(0, 10, args.batch).astype(np.int32)).cuda()
+        st0 = node.initialstates(np.random.default_rng(3))
+        P.run_training_step(node, ps_d, pc, st0, x, labels, 2.5)
+        fw_t, bw_t = [], []
         for i in range(args.adjoint_steps):
-            rb = one_bwd(i)
-        torch.cuda.synchronize()
-        fwd_adj_ms = (time.perf_counter() - tb) / args.adjoint_steps * 1e3
-        bwd_stats = {"adjoint_naccept": rb["stats_bwd"]["naccept"], "adjoint_nreject": rb["stats_bwd"]["nreject"],
-                     "adjoint_nf": rb["stats_bwd"]["nf"]}
+            st_i = dict(st0, rng=np.random.default_rng(100 + i))
+            loss, _, tstats, grads, times = P.run_training_step(node, ps_d, pc, st_i, x, labels, 2.5)
+            fw_t.append(times["fwd_time"]); bw_t.append(times["bwd_time"])
+        fwd_adj_ms = (sum(fw_t) + sum(bw_t)) / args.adjoint_steps * 1e3
+        bwd_stats = {"train_fwd_ms": sum(fw_t) / len(fw_t) * 1e3, "train_bwd_ms": sum(bw_t) / len(bw_t) * 1e3,
+                     "adjoint_naccept": times["adjoint"]["naccept"], "adjoint_nreject": times["adjoint"]["nreject"],
+                     "adjoint_nf": times["adjoint"]["nf"], "loss": float(loss), "w_reg": 2.5,
+                     "what": "run_training_step: node forward with dense record + Dense(784=>10) + logitcrossentropy, "
+                             "then continuous adjoint + regulariser sweep + classifier cotangents"}
 
     # roofline leg: the dominant kernel (one full Tsit5 step per launch), HIP events on its stream
     k1 = h.rhs(x, 0.0)

@@ -162,6 +162,24 @@ int lrnde_sde_euler_heun_step(lrnde_sde* sde, const float* uprev, const float* d
                               float dt, float abstol, float reltol, float delta, float* u,
                               float* eest_host, float* reg_val_host);
 
+/* The same in two halves, for a training step that needs sol.u[end] before it can form du_end
+ * (experiments/src/utils.jl:104-115: Zygote.pullback forward, then back(...)): the forward keeps the dense
+ * record, the backward consumes it (one backward per record). */
+int lrnde_node_forward_record(lrnde_ctx* ctx, const float* x, int32_t B, float t0, float t2,
+                              const lrnde_solve_opts* opts, int32_t mode, int32_t reg_type, float t1_or_rand,
+                              float* u_end, float* reg_val_host, int32_t* nfe_host, lrnde_stats* stats_host,
+                              float* t1_used_host);
+int lrnde_node_backward_recorded(lrnde_ctx* ctx, int32_t B, const float* du_end, float w_reg, float* dx, float* dp,
+                                 lrnde_stats* stats_bwd_host);
+
+/* Classifier head + loss of the MNIST experiments: logits = Dense(D => K)(u) with flat Lux
+ * parameters pc = [vec(W) (K x D, column-major); b] (experiments/src/construct.jl:199), loss =
+ * logitcrossentropy(logits, onehot(labels)) = mean over the batch (experiments/src/utils.jl:88).  Returns the
+ * loss on the host and, where the pointers are non-NULL, logits (B,K), du = d loss / d u (B,D) and
+ * dpc = d loss / d pc (device).  labels: device int32 (B), 0-based.  D is the handle's state_dim. */
+int lrnde_classifier_ce(lrnde_ctx* ctx, const float* u, int32_t B, const float* pc, int32_t K, const int32_t* labels,
+                        float* loss_host, float* logits, float* du, float* dpc);
+
 /* ---- conv vector field (experiments/src/construct.jl:213-218) ----
  * node_core = TDChain(Chain(Conv3x3(C+1=>Hc, no bias), BatchNorm(Hc, act)),
  *                     Chain(Conv3x3(Hc+1=>Hc), BatchNorm(Hc, act)), Conv3x3(Hc+1=>C))

@@ -1425,6 +1425,9 @@ struct lrnde_ctx {
   double* adj_part = nullptr; double* adj_part_host = nullptr;
   std::vector<float> last_ts;  // sol.t of the last node_forward (cotangent times of the adjoint)
   float last_t1 = 0.f; int last_i1 = 0;
+  // arguments of the last lrnde_node_forward_record (what lrnde_node_backward_recorded differentiates)
+  bool rec_valid = false; int rec_B = 0, rec_mode = 0, rec_reg_type = 0, rec_naccept = 0;
+  float rec_t0 = 0.f, rec_t2 = 0.f, rec_t1 = 0.f; lrnde_solve_opts rec_opts{};
   int wsNB = 0;  // tile width the workspace (partial-sum vectors) was sized for
   // workspace
   int wsB = 0;
@@ -2465,45 +2468,60 @@ int lrnde_step_reg_grad(lrnde_ctx* c, const float* uprev, const float* k1, int32
   return LRNDE_OK;
 }
 
-// backward of  loss = <du_end, sol.u[end]> + w_reg * reg_val  through the NeuralODE layer:
-// forward re-solve with a dense record, continuous adjoint (InterpolatingAdjoint restatement), and
-// the regulariser's reverse sweep.  dx (B,D), dp (P): device.
-int lrnde_node_backward(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
-                        int32_t mode, int32_t reg_type, float t1_or_rand, const float* du_end, float w_reg,
-                        float* dx, float* dp, lrnde_stats* st_fwd, lrnde_stats* st_bwd) {
+// node_forward that also keeps what the backward pass needs: the dense record of every accepted
+// step (retry with a larger record if it overflows) and the solve's arguments.
+int lrnde_node_forward_record(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
+                              int32_t mode, int32_t reg_type, float t1_or_rand, float* u_end, float* reg_val_host,
+                              int32_t* nfe_host, lrnde_stats* st, float* t1_used_host) {
   int rc = check_ready(c, B);
   if (rc) return rc;
-  if (!x || !o || !du_end || !dx || !dp || !st_fwd || !st_bwd) return fail(c, LRNDE_BADARG, "null pointer");
+  if (!x || !o || !u_end || !reg_val_host || !nfe_host || !st) return fail(c, LRNDE_BADARG, "null pointer");
   if (c->nranks > 1) return fail(c, LRNDE_UNSUPPORTED, "the adjoint is single-GPU in this build");
   const size_t n = (size_t)B * c->desc.state_dim;
-  const size_t P = lrnde_param_count(&c->desc);
-  // 1. forward with dense record (retry with a larger record if it overflows)
-  std::vector<float> u_end_dummy;
-  float* u_end = nullptr;
-  HIPCHK(c, hipMalloc(&u_end, sizeof(float) * n));
-  float regv = 0.f, t1 = t2; int nfe = 0;
+  c->rec_valid = false;
+  float t1 = t2;
   for (int attempt = 0;; ++attempt) {
     if (c->dense_cap == 0 || c->dense_n != n) {
       if (c->dense) { hipFree(c->dense); hipFree(c->dense_t); hipFree(c->dense_dt); c->dense = nullptr; }
       if (c->dense_cap == 0) c->dense_cap = 64;
       if (hipMalloc(&c->dense, sizeof(float) * (size_t)c->dense_cap * 8 * n) != hipSuccess ||
           hipMalloc(&c->dense_t, sizeof(float) * c->dense_cap) != hipSuccess ||
-          hipMalloc(&c->dense_dt, sizeof(float) * c->dense_cap) != hipSuccess) { hipFree(u_end); return fail(c, LRNDE_HIP_ERROR, "dense record allocation failed"); }
+          hipMalloc(&c->dense_dt, sizeof(float) * c->dense_cap) != hipSuccess)
+        return fail(c, LRNDE_HIP_ERROR, "dense record allocation failed");
       c->dense_n = n;
     }
     c->dense_on = true;
-    rc = lrnde_node_forward(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, u_end, &regv, &nfe, st_fwd, &t1);
+    rc = lrnde_node_forward(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, u_end, reg_val_host, nfe_host, st, &t1);
     c->dense_on = false;
     if (rc == LRNDE_CAPACITY && attempt < 8) { c->dense_cap *= 2; c->dense_n = 0; continue; }
     break;
   }
-  hipFree(u_end);
   if (rc) return rc;
-  const int nsteps = st_fwd->naccept;
+  if (t1_used_host) *t1_used_host = t1;
+  c->rec_valid = true; c->rec_B = B; c->rec_t0 = t0; c->rec_t2 = t2; c->rec_opts = *o; c->rec_mode = mode;
+  c->rec_reg_type = reg_type; c->rec_t1 = t1; c->rec_naccept = st->naccept;
+  return LRNDE_OK;
+}
+
+// backward of  loss = <du_end, sol.u[end]> + w_reg * reg_val  from the record of the last
+// lrnde_node_forward_record: continuous adjoint (InterpolatingAdjoint restatement) + the regulariser's
+// reverse sweep.  dx (B,D), dp (P): device.
+int lrnde_node_backward_recorded(lrnde_ctx* c, int32_t B, const float* du_end, float w_reg, float* dx, float* dp,
+                                 lrnde_stats* st_bwd) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!du_end || !dx || !dp || !st_bwd) return fail(c, LRNDE_BADARG, "null pointer");
+  if (!c->rec_valid || c->rec_B != B) return fail(c, LRNDE_BADARG, "no forward record for this batch (call lrnde_node_forward_record first)");
+  const lrnde_solve_opts* o = &c->rec_opts;
+  const float t0 = c->rec_t0, t2 = c->rec_t2, t1 = c->rec_t1;
+  const int mode = c->rec_mode, reg_type = c->rec_reg_type;
+  const size_t n = (size_t)B * c->desc.state_dim;
+  const size_t P = lrnde_param_count(&c->desc);
+  const int nsteps = c->rec_naccept;
   std::vector<float> dts(nsteps), dds(nsteps);
   HIPCHK(c, hipMemcpy(dts.data(), c->dense_t, sizeof(float) * nsteps, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(dds.data(), c->dense_dt, sizeof(float) * nsteps, hipMemcpyDeviceToHost));
-  // 2. adjoint solve on z = [lambda; mu] in s = -t from -t2 to -t0, tstops at the saved times
+  // adjoint solve on z = [lambda; mu] in s = -t from -t2 to -t0, tstops at the saved times
   const size_t N = n + P;
   AdjVec v;
   if ((rc = adj_alloc(c, N, v))) return rc;
@@ -2521,7 +2539,7 @@ int lrnde_node_backward(lrnde_ctx* c, const float* x, int32_t B, float t0, float
   HIPCHK(c, hipMemcpyAsync(dx, v.z, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dp, v.z + n, sizeof(float) * P, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  // 3. regulariser: dp += w_reg * d reg_val / d p   (no gradient w.r.t. x: test/runtests.jl:129)
+  // regulariser: dp += w_reg * d reg_val / d p   (no gradient w.r.t. x: test/runtests.jl:129)
   if (mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
     float *k1 = nullptr, *gr = nullptr, *u1 = nullptr;
     HIPCHK(c, hipMalloc(&k1, sizeof(float) * n));
@@ -2536,6 +2554,109 @@ int lrnde_node_backward(lrnde_ctx* c, const float* x, int32_t B, float t0, float
     hipFree(k1); hipFree(gr); hipFree(u1);
     if (rc) return rc;
   }
+  c->rec_valid = false;  // the regulariser sweep reused the state workspace
+  return LRNDE_OK;
+}
+
+// forward (with record) + backward in one call
+int lrnde_node_backward(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
+                        int32_t mode, int32_t reg_type, float t1_or_rand, const float* du_end, float w_reg,
+                        float* dx, float* dp, lrnde_stats* st_fwd, lrnde_stats* st_bwd) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!x || !o || !du_end || !dx || !dp || !st_fwd || !st_bwd) return fail(c, LRNDE_BADARG, "null pointer");
+  const size_t n = (size_t)B * c->desc.state_dim;
+  float* u_end = nullptr;
+  HIPCHK(c, hipMalloc(&u_end, sizeof(float) * n));
+  float regv = 0.f; int nfe = 0;
+  rc = lrnde_node_forward_record(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, u_end, &regv, &nfe, st_fwd, nullptr);
+  hipFree(u_end);
+  if (rc) return rc;
+  return lrnde_node_backward_recorded(c, B, du_end, w_reg, dx, dp, st_bwd);
+}
+
+// ---- classifier head + loss of the MNIST experiment (experiments/src/construct.jl:199 Dense(D => K),
+// experiments/src/utils.jl:88 logitcrossentropy = mean(-sum(y .* logsoftmax(logits)))): forward value
+// and the cotangents the pullback of `ce` sends to sol.u[end] and to the classifier parameters.
+}  // extern "C"
+namespace {
+// one wave per sample: logits[c] = sum_k W[c][k] u[k] + b[c] (fixed lane-strided order, butterfly reduce)
+__global__ __launch_bounds__(256) void k_cls_fwd(const float* u, const float* pc, const int32_t* labels, int B, int D, int K,
+                                                 float* logits, float* dl, float* loss_b) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* ub = u + (size_t)b * D;
+  float lg[16];
+  for (int c = 0; c < K; ++c) {
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) s = fma_(pc[(size_t)c + (size_t)K * k], ub[k], s);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    lg[c] = s + pc[(size_t)K * D + c];
+  }
+  float mx = lg[0];
+  for (int c = 1; c < K; ++c) mx = fmaxf_(mx, lg[c]);
+  float se = 0.f;
+  for (int c = 0; c < K; ++c) se += expf_c(lg[c] - mx);
+  const float lse = mx + logf(se);
+  const int y = labels[b];
+  if (lane == 0) {
+    for (int c = 0; c < K; ++c) {
+      if (logits) logits[(size_t)b * K + c] = lg[c];
+      const float sm = expf_c(lg[c] - lse);
+      dl[(size_t)b * K + c] = (sm - (c == y ? 1.f : 0.f)) / (float)B;
+    }
+    loss_b[b] = lse - lg[y];
+  }
+}
+// du[b][k] = sum_c dl[b][c] W[c][k]
+__global__ void k_cls_bwd_x(const float* dl, const float* pc, int B, int D, int K, float* du) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * D) return;
+  const int b = i / D, k = i % D;
+  float s = 0.f;
+  for (int c = 0; c < K; ++c) s = fma_(dl[(size_t)b * K + c], pc[(size_t)c + (size_t)K * k], s);
+  du[i] = s;
+}
+// dW[c][k] = sum_b dl[b][c] u[b][k] ; db[c] = sum_b dl[b][c]   (thread per (c,k); k == D is the bias)
+__global__ void k_cls_bwd_w(const float* dl, const float* u, int B, int D, int K, float* dpc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * (D + 1)) return;
+  const int c = i % K, k = i / K;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 4 <= B; b += 4) {
+    s0 = fma_(dl[(size_t)(b + 0) * K + c], k < D ? u[(size_t)(b + 0) * D + k] : 1.f, s0);
+    s1 = fma_(dl[(size_t)(b + 1) * K + c], k < D ? u[(size_t)(b + 1) * D + k] : 1.f, s1);
+    s2 = fma_(dl[(size_t)(b + 2) * K + c], k < D ? u[(size_t)(b + 2) * D + k] : 1.f, s2);
+    s3 = fma_(dl[(size_t)(b + 3) * K + c], k < D ? u[(size_t)(b + 3) * D + k] : 1.f, s3);
+  }
+  for (; b < B; ++b) s0 = fma_(dl[(size_t)b * K + c], k < D ? u[(size_t)b * D + k] : 1.f, s0);
+  dpc[(size_t)c + (size_t)K * k] = (s0 + s1) + (s2 + s3);
+}
+}  // namespace
+extern "C" {
+
+int lrnde_classifier_ce(lrnde_ctx* c, const float* u, int32_t B, const float* pc, int32_t K, const int32_t* labels,
+                        float* loss_host, float* logits, float* du, float* dpc) {
+  if (!c) return LRNDE_BADARG;
+  if (!u || !pc || !labels || !loss_host || B <= 0 || K <= 0 || K > 16) return fail(c, LRNDE_BADARG, "bad argument (1 <= K <= 16)");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int D = c->desc.state_dim;
+  float *dl = nullptr, *lb = nullptr;
+  HIPCHK(c, hipMalloc(&dl, sizeof(float) * (size_t)B * K));
+  HIPCHK(c, hipMalloc(&lb, sizeof(float) * (size_t)B));
+  hipLaunchKernelGGL(k_cls_fwd, dim3((B + 3) / 4), dim3(256), 0, c->stream, u, pc, labels, B, D, K, logits, dl, lb);
+  if (du) hipLaunchKernelGGL(k_cls_bwd_x, dim3((unsigned)(((size_t)B * D + 255) / 256)), dim3(256), 0, c->stream, (const float*)dl, pc, B, D, K, du);
+  if (dpc) hipLaunchKernelGGL(k_cls_bwd_w, dim3((K * (D + 1) + 255) / 256), dim3(256), 0, c->stream, (const float*)dl, u, B, D, K, dpc);
+  std::vector<float> h(B);
+  hipError_t e = hipMemcpyAsync(h.data(), lb, sizeof(float) * B, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(dl); hipFree(lb);
+  if (e != hipSuccess) return fail(c, LRNDE_HIP_ERROR, "classifier kernels failed: %s", hipGetErrorString(e));
+  double acc = 0.0;
+  for (int b = 0; b < B; ++b) acc += (double)h[b];
+  *loss_host = (float)(acc / (double)B);
   return LRNDE_OK;
 }
 

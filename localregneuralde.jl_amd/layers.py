@@ -232,6 +232,46 @@ class Handle:
                                             C.c_void_p(dp.data_ptr()), C.byref(sf), C.byref(sb)))
         return dict(dx=dx, dp=dp, stats_fwd=sf.asdict(), stats_bwd=sb.asdict())
 
+    def node_forward_record(self, x, t0, t2, abstol, reltol, mode="unbiased", reg_type="error_estimate",
+                            t1_or_rand=0.5, maxiters=1000, save_start=False, exact_pow=False):
+        """node_forward that keeps the dense record for one `node_backward_recorded`."""
+        B = x.numel() // self.D
+        o = L.SolveOpts(float(abstol), float(reltol), int(maxiters), int(save_start), 0, int(exact_pow))
+        u_end = torch.empty_like(x)
+        reg, nfe, st, t1u = C.c_float(), C.c_int32(), L.Stats(), C.c_float()
+        self._chk(L.lib.lrnde_node_forward_record(self._ctx, _dev_ptr(x, "x", self.D), B, float(t0), float(t2),
+                                                  C.byref(o), L.MODE[mode], L.REG_TYPE[reg_type], float(t1_or_rand),
+                                                  _dev_ptr(u_end, "u_end"), C.byref(reg), C.byref(nfe), C.byref(st),
+                                                  C.byref(t1u)))
+        return dict(u_end=u_end, reg_val=np.float32(reg.value), nfe=int(nfe.value), stats=st.asdict(),
+                    t1=np.float32(t1u.value))
+
+    def node_backward_recorded(self, du_end, w_reg=0.0):
+        B = du_end.numel() // self.D
+        dx = torch.empty_like(du_end)
+        dp = torch.empty(int(L.lib.lrnde_param_count(C.byref(self.desc))), dtype=torch.float32, device=du_end.device)
+        sb = L.Stats()
+        self._chk(L.lib.lrnde_node_backward_recorded(self._ctx, B, _dev_ptr(du_end, "du_end", self.D), float(w_reg),
+                                                     _dev_ptr(dx, "dx"), C.c_void_p(dp.data_ptr()), C.byref(sb)))
+        return dict(dx=dx, dp=dp, stats_bwd=sb.asdict())
+
+    def classifier_ce(self, u, pc, K, labels, want_grads=True):
+        """Dense(D => K) + logitcrossentropy on device: dict(loss, logits, du, dpc)."""
+        B = u.numel() // self.D
+        if pc.numel() != K * (self.D + 1):
+            raise ValueError(f"classifier parameters must have {K * (self.D + 1)} entries")
+        if not (labels.is_cuda and labels.dtype == torch.int32 and labels.numel() == B):
+            raise ValueError("labels must be a CUDA int32 tensor of length B")
+        logits = torch.empty((B, K), dtype=torch.float32, device=u.device)
+        du = torch.empty_like(u) if want_grads else None
+        dpc = torch.empty_like(pc) if want_grads else None
+        loss = C.c_float()
+        self._chk(L.lib.lrnde_classifier_ce(self._ctx, _dev_ptr(u, "u", self.D), B, _dev_ptr(pc, "pc"), int(K),
+                                            C.c_void_p(labels.data_ptr()), C.byref(loss), C.c_void_p(logits.data_ptr()),
+                                            C.c_void_p(du.data_ptr()) if want_grads else None,
+                                            C.c_void_p(dpc.data_ptr()) if want_grads else None))
+        return dict(loss=np.float32(loss.value), logits=logits, du=du, dpc=dpc)
+
     def bench_step(self, uprev, k1, t, dt, abstol, reltol, reps=50):
         """microseconds per launch of the full-step kernel (HIP events on the handle's stream)."""
         B = uprev.numel() // self.D

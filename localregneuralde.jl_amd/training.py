@@ -1,0 +1,41 @@
+"""The reference's training step around the NeuralODE layer:
+`Chain(flatten, neural_ode, sol_to_arr, classifier=Dense(D => K))` with
+`loss = logitcrossentropy(y_pred, y) + w_reg * reg_val` (experiments/src/construct.jl:20-35,180-200) and the
+fwd / bwd timing split of `run_training_step` (experiments/src/utils.jl:104-123).  The optimiser update is the
+caller's (out of scope)."""
+import copy
+import time
+
+import numpy as np
+import torch
+
+
+def run_training_step(node, ps, pc, st, x, labels, w_reg, num_classes=10):
+    """One forward + pullback.  ps: flat NeuralODE parameters, pc: flat classifier parameters [vec(W) K x D; b]
+    (CUDA float32), labels: CUDA int32 (B).  Returns (loss, st_, stats, grads, times) like the reference:
+    stats = (y_pred, nfe, ce_loss, reg_val), grads = dict(neural_ode=dps, classifier=dpc, x=dx),
+    times = dict(fwd_time, bwd_time) in seconds (wall, synchronised)."""
+    h = node._bind(ps)
+    t0, t2 = node.tspan
+    kw = node.kwargs
+    abstol, reltol = kw.get("abstol", 1e-6), kw.get("reltol", 1e-3)
+    mode = node.regularize if st["training"] else "none"
+    rng = copy.deepcopy(st["rng"])
+    r01 = np.float32(rng.random(dtype=np.float32))
+    t1_or_rand = np.float32(r01 * (t2 - t0) + t0) if mode == "unbiased" else r01
+    torch.cuda.synchronize()
+    tic = time.perf_counter()
+    fw = h.node_forward_record(x, t0, t2, abstol, reltol, mode=mode, reg_type=node.regularize_type,
+                               t1_or_rand=t1_or_rand, maxiters=node.maxiters, save_start=kw.get("save_start", True))
+    head = h.classifier_ce(fw["u_end"], pc, num_classes, labels)
+    loss = np.float32(head["loss"] + np.float32(w_reg) * fw["reg_val"])
+    torch.cuda.synchronize()
+    fwd_time = time.perf_counter() - tic
+    tic = time.perf_counter()
+    bw = h.node_backward_recorded(head["du"], w_reg=w_reg)
+    torch.cuda.synchronize()
+    bwd_time = time.perf_counter() - tic
+    st_ = dict(model=st["model"], nfe=fw["nfe"], reg_val=fw["reg_val"], rng=rng, training=st["training"])
+    stats = dict(y_pred=head["logits"], nfe=fw["nfe"], ce_loss=head["loss"], reg_val=fw["reg_val"])
+    grads = dict(neural_ode=bw["dp"], classifier=head["dpc"], x=bw["dx"])
+    return loss, st_, stats, grads, dict(fwd_time=fwd_time, bwd_time=bwd_time, adjoint=bw["stats_bwd"], forward=fw["stats"])

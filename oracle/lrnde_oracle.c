@@ -1179,3 +1179,44 @@ int lro_node_backward(const lro_mlp* m, const float* x, int B, float t0, float t
   lro_dense_free(&dense);
   return rc;
 }
+
+/* ------------------------------------------------------------------------- */
+/* classifier head + loss (experiments/src/construct.jl:199, utils.jl:88)      */
+/* ------------------------------------------------------------------------- */
+float lro_classifier_ce(const float* u, int B, int D, const float* pc, int K, const int* labels, float* logits,
+                        float* du, float* dpc) {
+  double total = 0.0;
+  double* dl = (double*)malloc(sizeof(double) * (size_t)B * K);
+  for (int b = 0; b < B; ++b) {
+    double lg[64];
+    double mx = -1e300;
+    for (int c = 0; c < K; ++c) {
+      double s = (double)pc[(size_t)K * D + c];
+      for (int k = 0; k < D; ++k) s += (double)pc[(size_t)c + (size_t)K * k] * (double)u[(size_t)b * D + k];
+      lg[c] = s;
+      if (s > mx) mx = s;
+      if (logits) logits[(size_t)b * K + c] = (float)s;
+    }
+    double se = 0.0;
+    for (int c = 0; c < K; ++c) se += exp(lg[c] - mx);
+    const double lse = mx + log(se);
+    total += lse - lg[labels[b]];
+    for (int c = 0; c < K; ++c) dl[(size_t)b * K + c] = (exp(lg[c] - lse) - (c == labels[b] ? 1.0 : 0.0)) / (double)B;
+  }
+  if (du)
+    for (int b = 0; b < B; ++b)
+      for (int k = 0; k < D; ++k) {
+        double s = 0.0;
+        for (int c = 0; c < K; ++c) s += dl[(size_t)b * K + c] * (double)pc[(size_t)c + (size_t)K * k];
+        du[(size_t)b * D + k] = (float)s;
+      }
+  if (dpc)
+    for (int k = 0; k <= D; ++k)
+      for (int c = 0; c < K; ++c) {
+        double s = 0.0;
+        for (int b = 0; b < B; ++b) s += dl[(size_t)b * K + c] * (k < D ? (double)u[(size_t)b * D + k] : 1.0);
+        dpc[(size_t)c + (size_t)K * k] = (float)s;
+      }
+  free(dl);
+  return (float)(total / (double)B);
+}

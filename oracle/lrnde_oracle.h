@@ -189,6 +189,10 @@ int lro_node_backward(const lro_mlp* m, const float* x, int B, float t0, float t
                       lro_stats* st_fwd, lro_stats* st_bwd);
 
 /* ---- SDE: adaptive Euler-Heun local step with supplied dW (src/perform_step.jl:172-206) ---- */
+/* classifier head + logitcrossentropy (experiments/src/construct.jl:199, experiments/src/utils.jl:88):
+ * pc = [vec(W) (K x D column-major); b]; returns mean CE; optional logits (B,K), du (B,D), dpc (K*(D+1)) */
+float lro_classifier_ce(const float* u, int B, int D, const float* pc, int K, const int* labels, float* logits,
+                        float* du, float* dpc);
 int lro_euler_heun_step(const lro_field* drift, const lro_field* diffusion, const float* uprev,
                         const float* dW, float t, float dt, float abstol, float reltol, float delta,
                         int B, float* u, float* eest, float* reg_val);

@@ -79,6 +79,8 @@ def lib():
         L.lro_mlp_param_count.argtypes = [C.c_int] * 3
         L.lro_mlp_rhs.restype = None
         L.lro_mlp_rhs.argtypes = [C.POINTER(Mlp), fp, C.c_float, C.c_int, fp]
+        L.lro_classifier_ce.restype = C.c_float
+        L.lro_classifier_ce.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_int), fp, fp, fp]
         L.lro_conv_param_count.argtypes = [C.c_int] * 2
         L.lro_conv_rhs.restype = None
         L.lro_conv_rhs.argtypes = [C.POINTER(Conv), fp, C.c_float, C.c_int, fp]
@@ -352,3 +354,14 @@ def node_backward(fld, x, t0, t2, abstol, reltol, du_end, mode="unbiased", reg_t
                                  REG[reg_type], float(t1_or_rand), _fp(du_end), float(w_reg), _fp(dx), _fp(dp),
                                  C.byref(sf), C.byref(sb))
     return dict(retcode=rc, dx=dx, dp=dp, stats_fwd=sf.asdict(), stats_bwd=sb.asdict())
+
+
+def classifier_ce(u, pc, K, labels):
+    """Dense(D => K) + logitcrossentropy: (loss, logits, du, dpc)."""
+    u = _f32(u); pc = _f32(pc)
+    B, D = u.shape
+    lab = np.ascontiguousarray(labels, dtype=np.int32)
+    logits = np.empty((B, K), np.float32); du = np.empty_like(u); dpc = np.empty_like(pc)
+    loss = lib().lro_classifier_ce(_fp(u), B, D, _fp(pc), K, lab.ctypes.data_as(C.POINTER(C.c_int)), _fp(logits),
+                                   _fp(du), _fp(dpc))
+    return np.float32(loss), logits, du, dpc

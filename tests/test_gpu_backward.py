@@ -70,3 +70,61 @@ def test_node_backward_matches_oracle(oracle, gpu_pkg, mode, w_reg):
     # test/runtests.jl:24-29: gradients finite and non-zero
     assert np.isfinite(dx).all() and np.isfinite(dp).all() and np.all(dx != 0) and np.mean(dp != 0) > 0.99
     print(mode, w_reg, "bwd steps gpu/oracle:", got["stats_bwd"]["naccept"], ref["stats_bwd"]["naccept"])
+
+
+def test_classifier_ce_matches_oracle(oracle, gpu_pkg):
+    import torch
+    P, O = gpu_pkg, oracle
+    D, H, B, K = 784, 100, 64, 10
+    model = P.TDChain(P.Chain(P.Dense(D + 1, H, "tanh"), P.Dense(H + 1, D)))
+    from localregneuralde_jl_amd.layers import Handle, _mlp_desc
+    h = Handle(_mlp_desc(model))
+    rng = np.random.default_rng(4)
+    u = rng.standard_normal((B, D)).astype(np.float32)
+    pc = (rng.standard_normal(K * (D + 1)) * 0.05).astype(np.float32)
+    lab = rng.integers(0, K, B).astype(np.int32)
+    lo, lg, du, dpc = O.classifier_ce(u, pc, K, lab)
+    r = h.classifier_ce(torch.from_numpy(u).cuda(), torch.from_numpy(pc).cuda(), K, torch.from_numpy(lab).cuda())
+    assert abs(float(r["loss"]) - float(lo)) <= 2e-6 * max(1.0, abs(float(lo)))
+    np.testing.assert_allclose(r["logits"].cpu().numpy(), lg, rtol=0, atol=2e-5 * np.abs(lg).max())
+    np.testing.assert_allclose(r["du"].cpu().numpy(), du, rtol=0, atol=2e-5 * np.abs(du).max())
+    np.testing.assert_allclose(r["dpc"].cpu().numpy(), dpc, rtol=0, atol=2e-5 * np.abs(dpc).max())
+
+
+def test_training_step_matches_oracle_and_one_call_backward(oracle, gpu_pkg):
+    """run_training_step (experiments/src/utils.jl:104-123): forward with record, classifier + CE, recorded backward
+    == the one-call lrnde_node_backward with the same du_end, and == the oracle's gradients."""
+    import torch
+    P, O = gpu_pkg, oracle
+    D, H, B, K = 40, 24, 16, 10
+    model = P.TDChain(P.Chain(P.Dense(D + 1, H, "tanh"), P.Dense(H + 1, D)))
+    node = P.NeuralODE(model, regularize="unbiased", abstol=1e-5, reltol=1e-5, save_start=False, maxiters=2000)
+    rng = np.random.default_rng(8)
+    ps = (P.glorot_params(model, seed=2) * np.float32(2.0)).astype(np.float32)
+    pc = (rng.standard_normal(K * (D + 1)) * 0.2).astype(np.float32)
+    x = rng.standard_normal((B, D)).astype(np.float32)
+    lab = rng.integers(0, K, B).astype(np.int32)
+    st = node.initialstates(np.random.default_rng(0))
+    w_reg = 2.5
+    loss, st_, stats, grads, times = P.run_training_step(node, torch.from_numpy(ps).cuda(), torch.from_numpy(pc).cuda(), st,
+                                                         torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda(), w_reg)
+    assert times["fwd_time"] > 0 and times["bwd_time"] > 0 and st_["nfe"] == stats["nfe"]
+    # oracle: same t1 draw
+    import copy
+    r01 = np.float32(copy.deepcopy(st["rng"]).random(dtype=np.float32))
+    t1 = np.float32(r01 * 1.0 + 0.0)
+    fld = O.MlpField(D, H, ps, nthreads=4)
+    fo = O.node_forward(fld, x, 0.0, 1.0, 1e-5, 1e-5, mode="unbiased", t1_or_rand=t1, maxiters=2000)
+    lo, lg, du, dpc = O.classifier_ce(fo["u_end"], pc, K, lab)
+    assert abs(float(stats["ce_loss"]) - float(lo)) <= 1e-5 * abs(float(lo))
+    assert abs(float(loss) - (float(lo) + w_reg * float(fo["reg_val"]))) <= 1e-5 * abs(float(loss))
+    bo = O.node_backward(fld, x, 0.0, 1.0, 1e-5, 1e-5, du, mode="unbiased", t1_or_rand=t1, w_reg=w_reg, maxiters=2000)
+    gp, gx = grads["neural_ode"].cpu().numpy(), grads["x"].cpu().numpy()
+    assert np.abs(gp - bo["dp"]).max() <= 2e-3 * np.abs(bo["dp"]).max()
+    assert np.abs(gx - bo["dx"]).max() <= 2e-3 * np.abs(bo["dx"]).max()
+    np.testing.assert_allclose(grads["classifier"].cpu().numpy(), dpc, rtol=0, atol=1e-4 * np.abs(dpc).max())
+    # the one-call entry point gives the same numbers
+    h = node.handle()
+    one = h.node_backward(torch.from_numpy(x).cuda(), 0.0, 1.0, 1e-5, 1e-5, torch.from_numpy(du).cuda(), mode="unbiased",
+                          t1_or_rand=float(t1), w_reg=w_reg, maxiters=2000)
+    assert np.abs(one["dp"].cpu().numpy() - gp).max() <= 1e-4 * np.abs(gp).max()

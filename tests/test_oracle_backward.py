@@ -129,3 +129,24 @@ def test_backward_modes_and_reg_weight(oracle):
     assert _rel(bia["dp"], none["dp"].astype(np.float64)) < 1e-3
     # reg_val has no gradient w.r.t. x (runtests.jl:129): dx is unchanged by w_reg, dp is not
     assert np.array_equal(unb0["dx"], unb1["dx"]) and not np.array_equal(unb0["dp"], unb1["dp"])
+
+
+def test_classifier_ce_matches_torch_float64(oracle):
+    O = oracle
+    """Dense(D => K) + logitcrossentropy (experiments/src/construct.jl:199, utils.jl:88) and its cotangents"""
+    rng = np.random.default_rng(3)
+    B, D, K = 9, 33, 10
+    u = rng.standard_normal((B, D)).astype(np.float32)
+    pc = (rng.standard_normal(K * (D + 1)) * 0.3).astype(np.float32)
+    lab = rng.integers(0, K, B)
+    loss, lg, du, dpc = O.classifier_ce(u, pc, K, lab)
+    ut = torch.tensor(u, dtype=torch.float64, requires_grad=True)
+    pt = torch.tensor(pc, dtype=torch.float64, requires_grad=True)
+    W = pt[:K * D].reshape(D, K).t()  # flat = vec(W) column-major (K x D)
+    logits = ut @ W.t() + pt[K * D:]
+    ce = torch.nn.functional.cross_entropy(logits, torch.tensor(lab))
+    ce.backward()
+    assert abs(float(loss) - ce.item()) < 1e-6
+    np.testing.assert_allclose(lg, logits.detach().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(du, ut.grad.numpy(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(dpc, pt.grad.numpy(), rtol=0, atol=1e-7)
