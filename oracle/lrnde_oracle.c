@@ -920,6 +920,143 @@ static float act_deriv(int act, float pre, float h) {
   return 1.0f;
 }
 
+/* ------------------------------------------------------------------------- */
+/* conv field: vector-Jacobian product (ZygoteVJP of the dudt closure)          */
+/* ------------------------------------------------------------------------- */
+/* din[b][ci][y][x] += sum_{co,ky,kx} w[kx,ky,ci,co] * g[b][co][y-1+ky][x-1+kx]   (real channels only);
+ * dw[kx,ky,ci,co] += sum_{b,y',x'} g[b][co][y'][x'] * in[b][ci][y'+1-ky][x'+1-kx]  (t channel: in = t inside) */
+static void conv3x3_t_bwd(const float* in, const float* g, int B, int cin, int cout, int H, int W, const float* w,
+                          float t, float* din, double* dw, int nth) {
+  const int cint = cin + 1;
+  const long plane = (long)H * W;
+  if (din) {
+#pragma omp parallel for collapse(2) schedule(static) num_threads(nth)
+    for (int b = 0; b < B; ++b)
+      for (int ci = 0; ci < cin; ++ci) {
+        float* d = din + ((long)b * cin + ci) * plane;
+        for (long i = 0; i < plane; ++i) d[i] = 0.0f;
+        for (int co = 0; co < cout; ++co) {
+          const float* gp = g + ((long)b * cout + co) * plane;
+          for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+              const float wv = w[kx + 3 * (ky + 3 * (ci + (long)cint * co))];
+              /* y' = y - 1 + ky in [0,H) */
+              const int dy = ky - 1, dx = kx - 1;
+              const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? H - dy : H;
+              const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? W - dx : W;
+              for (int y = y0; y < y1; ++y) {
+                float* drow = d + (long)y * W;
+                const float* grow = gp + (long)(y + dy) * W + dx;
+                for (int x = x0; x < x1; ++x) drow[x] = fmaf(wv, grow[x], drow[x]);
+              }
+            }
+        }
+      }
+  }
+  if (dw) {
+#pragma omp parallel for collapse(2) schedule(static) num_threads(nth)
+    for (int co = 0; co < cout; ++co)
+      for (int ci = 0; ci < cint; ++ci)
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx) {
+            const int dy = 1 - ky, dx = 1 - kx; /* in[y'+dy][x'+dx] */
+            const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? H - dy : H;
+            const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? W - dx : W;
+            double acc = 0.0;
+            for (int b = 0; b < B; ++b) {
+              const float* gp = g + ((long)b * cout + co) * plane;
+              const float* ip = ci < cin ? in + ((long)b * cin + ci) * plane : NULL;
+              for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x)
+                  acc += (double)gp[(long)y * W + x] * (ip ? (double)ip[(long)(y + dy) * W + x + dx] : (double)t);
+            }
+            dw[kx + 3 * (ky + 3 * (ci + (long)cint * co))] += acc;
+          }
+  }
+}
+
+/* BatchNorm(ch, act) backward.  a: raw conv output (B,ch,plane), dh: cotangent of the activated output (in/out:
+ * replaced by the cotangent of a).  dscale/dbias accumulate. */
+static void batchnorm_act_bwd(const float* a, float* dh, int B, int ch, long plane, const float* scale, const float* bias,
+                              int train, const float* rmean, const float* rvar, float eps, int act, double* dscale,
+                              double* dbias, int nth) {
+  const double N = (double)B * (double)plane;
+#pragma omp parallel for schedule(static) num_threads(nth)
+  for (int c = 0; c < ch; ++c) {
+    float mean, inv;
+    if (train) {
+      double s = 0.0;
+      for (int b = 0; b < B; ++b) { const float* p = a + ((long)b * ch + c) * plane; for (long i = 0; i < plane; ++i) s += (double)p[i]; }
+      const double mu = s / N;
+      double v = 0.0;
+      for (int b = 0; b < B; ++b) { const float* p = a + ((long)b * ch + c) * plane; for (long i = 0; i < plane; ++i) { const double d = (double)p[i] - mu; v += d * d; } }
+      v /= N;
+      mean = (float)mu; inv = (float)(1.0 / sqrt(v + (double)eps));
+    } else {
+      mean = rmean ? rmean[c] : 0.0f;
+      inv = (float)(1.0 / sqrt((double)(rvar ? rvar[c] : 1.0f) + (double)eps));
+    }
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < B; ++b) {
+      const float* p = a + ((long)b * ch + c) * plane;
+      float* d = dh + ((long)b * ch + c) * plane;
+      for (long i = 0; i < plane; ++i) {
+        const float xn = (p[i] - mean) * inv;
+        const float z = xn * scale[c] + bias[c];
+        const float hh = act_apply(act, z);
+        const float dz = d[i] * act_deriv(act, z, hh);
+        d[i] = dz;
+        s1 += (double)dz; s2 += (double)dz * (double)xn;
+      }
+    }
+    if (dscale) dscale[c] += s2;
+    if (dbias) dbias[c] += s1;
+    const float g = scale[c];
+    const float m1 = (float)(s1 / N), m2 = (float)(s2 / N);
+    for (int b = 0; b < B; ++b) {
+      const float* p = a + ((long)b * ch + c) * plane;
+      float* d = dh + ((long)b * ch + c) * plane;
+      for (long i = 0; i < plane; ++i) {
+        if (train) { const float xn = (p[i] - mean) * inv; d[i] = (inv * g) * ((d[i] - m1) - xn * m2); }
+        else d[i] = d[i] * (g * inv);
+      }
+    }
+  }
+}
+
+void lro_conv_vjp(const lro_conv* m, const float* y, float t, const float* lam, int B, float* dy, float* gp) {
+  const int C = m->C, Hc = m->Hc, H = m->H, W = m->W;
+  const long plane = (long)H * W;
+  const int nth = m->nthreads > 0 ? m->nthreads : 1;
+  const int P = lro_conv_param_count(C, Hc);
+  const long o_w1 = 0, o_g1 = o_w1 + 9L * (C + 1) * Hc, o_b1 = o_g1 + Hc, o_w2 = o_b1 + Hc,
+             o_g2 = o_w2 + 9L * (Hc + 1) * Hc, o_b2 = o_g2 + Hc, o_w3 = o_b2 + Hc;
+  const float* p = m->p;
+  const float* st = m->bn_state;
+  const size_t ny = (size_t)B * Hc * plane;
+  float* a1 = (float*)malloc(sizeof(float) * ny); float* h1 = (float*)malloc(sizeof(float) * ny);
+  float* a2 = (float*)malloc(sizeof(float) * ny); float* h2 = (float*)malloc(sizeof(float) * ny);
+  float* d2 = (float*)malloc(sizeof(float) * ny); float* d1 = (float*)malloc(sizeof(float) * ny);
+  double* g = gp ? (double*)calloc((size_t)P, sizeof(double)) : NULL;
+  /* forward, keeping raw and activated hidden tensors */
+  conv3x3_t(y, B, C, Hc, H, W, p + o_w1, t, a1, nth);
+  memcpy(h1, a1, sizeof(float) * ny);
+  batchnorm_act(h1, B, Hc, plane, p + o_g1, p + o_b1, m->bn_train, st ? st : NULL, st ? st + Hc : NULL, m->eps, m->act, nth);
+  conv3x3_t(h1, B, Hc, Hc, H, W, p + o_w2, t, a2, nth);
+  memcpy(h2, a2, sizeof(float) * ny);
+  batchnorm_act(h2, B, Hc, plane, p + o_g2, p + o_b2, m->bn_train, st ? st + 2 * Hc : NULL, st ? st + 3 * Hc : NULL, m->eps, m->act, nth);
+  /* backward */
+  conv3x3_t_bwd(h2, lam, B, Hc, C, H, W, p + o_w3, t, d2, g ? g + o_w3 : NULL, nth);
+  batchnorm_act_bwd(a2, d2, B, Hc, plane, p + o_g2, p + o_b2, m->bn_train, st ? st + 2 * Hc : NULL, st ? st + 3 * Hc : NULL,
+                    m->eps, m->act, g ? g + o_g2 : NULL, g ? g + o_b2 : NULL, nth);
+  conv3x3_t_bwd(h1, d2, B, Hc, Hc, H, W, p + o_w2, t, d1, g ? g + o_w2 : NULL, nth);
+  batchnorm_act_bwd(a1, d1, B, Hc, plane, p + o_g1, p + o_b1, m->bn_train, st ? st : NULL, st ? st + Hc : NULL, m->eps,
+                    m->act, g ? g + o_g1 : NULL, g ? g + o_b1 : NULL, nth);
+  conv3x3_t_bwd(y, d1, B, C, Hc, H, W, p + o_w1, t, dy, g ? g + o_w1 : NULL, nth);
+  if (gp) { for (int i = 0; i < P; ++i) gp[i] = (float)g[i]; free(g); }
+  free(a1); free(h1); free(a2); free(h2); free(d2); free(d1);
+}
+
 /* hidden pre-activation with the canonical dot product (same as lro_mlp_rhs layer 1) */
 static void mlp_hidden_pre(const lro_mlp* m, const float* x, float t, float* pre, float* tmp) {
   const int D = m->D, H = m->H, td = m->time_dep ? 1 : 0;

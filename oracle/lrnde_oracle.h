@@ -141,6 +141,10 @@ void lro_mlp_as_field(const lro_mlp* m, lro_field* out);
 int lro_conv_param_count(int C, int Hc);
 void lro_conv_rhs(const lro_conv* m, const float* u, float t, int B, float* du);
 void lro_conv_as_field(const lro_conv* m, lro_field* out);
+/* vector-Jacobian product of the conv field at (y, t): dy = (df/dy)^T lam, gp (may be NULL) = (df/dp)^T lam in
+ * the flat parameter layout (train-mode BatchNorm differentiated through its batch statistics, as Zygote does
+ * through Lux's batchnorm).  fp32 mode only. */
+void lro_conv_vjp(const lro_conv* m, const float* y, float t, const float* lam, int B, float* dy, float* gp);
 
 /* ---- step kernels ---- */
 /* ks: optional (5*D*B) k2..k6; g6: optional (D*B) */

@@ -84,6 +84,8 @@ def lib():
         L.lro_conv_param_count.argtypes = [C.c_int] * 2
         L.lro_conv_rhs.restype = None
         L.lro_conv_rhs.argtypes = [C.POINTER(Conv), fp, C.c_float, C.c_int, fp]
+        L.lro_conv_vjp.restype = None
+        L.lro_conv_vjp.argtypes = [C.POINTER(Conv), fp, C.c_float, fp, C.c_int, fp, fp]
         L.lro_conv_as_field.restype = None
         L.lro_conv_as_field.argtypes = [C.POINTER(Conv), C.POINTER(Field)]
         L.lro_mlp_as_field.restype = None
@@ -177,6 +179,15 @@ class ConvField:
         du = np.empty_like(u)
         lib().lro_conv_rhs(C.byref(self.m), _fp(u), float(t), B, _fp(du))
         return du
+
+
+def conv_vjp(fld, y, t, lam, want_gp=True):
+    y = _f32(y); lam = _f32(lam)
+    B = y.size // fld.D
+    dy = np.empty_like(y)
+    gp = np.zeros(fld.params.size, np.float32) if want_gp else None
+    lib().lro_conv_vjp(C.byref(fld.m), _fp(y), float(t), _fp(lam), B, _fp(dy), _fp(gp))
+    return dy, gp
 
 
 def glorot_conv_params(Cch, Hc, seed=0):

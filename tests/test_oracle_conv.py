@@ -125,3 +125,60 @@ def test_conv_field_drives_the_generic_solver():
     assert b["stats"]["naccept"] > a["stats"]["naccept"]
     ua, ub = a["u"][-1], b["u"][-1]
     assert np.abs(ua - ub).max() < 5e-3 * max(1.0, np.abs(ub).max())
+
+
+@pytest.mark.parametrize("W,H,C,Hc,B,train,act", [(8, 8, 8, 16, 3, True, "gelu"), (8, 6, 4, 8, 2, False, "gelu"),
+                                                  (6, 6, 8, 64, 2, True, "tanh")])
+def test_conv_vjp_matches_torch_autograd(W, H, C, Hc, B, train, act):
+    """lro_conv_vjp = what Zygote.pullback(dudt, y, p, t) returns (dy, dp), batch statistics differentiated"""
+    p, u = _case(W, H, C, Hc, B, seed=W + Hc + 1)
+    st = None
+    if not train:
+        rng = np.random.default_rng(5)
+        st = np.concatenate([rng.normal(0, 0.2, Hc), rng.uniform(0.5, 2, Hc), rng.normal(0, 0.2, Hc),
+                             rng.uniform(0.5, 2, Hc)]).astype(np.float32)
+    lam = np.random.default_rng(2).standard_normal(u.shape).astype(np.float32)
+    fld = O.ConvField(W, H, C, Hc, p, act=act, bn_train=train, bn_state=st, nthreads=4)
+    dy, gp = O.conv_vjp(fld, u, 0.37, lam)
+
+    # float64 autograd through the same restatement
+    ut = torch.tensor(u.astype(np.float64), requires_grad=True)
+    pt = torch.tensor(p.astype(np.float64), requires_grad=True)
+
+    def field(uu, pp):
+        x = uu.reshape(B, C, H, W)
+        off = [0]
+
+        def take(n):
+            v = pp[off[0]:off[0] + n]; off[0] += n
+            return v
+
+        def weight(cin, cout):
+            return torch.flip(take(9 * cin * cout).reshape(cout, cin, 3, 3), dims=(2, 3))
+
+        def tcat(z):
+            return torch.cat([z, torch.full((B, 1, H, W), 0.37, dtype=torch.float64)], dim=1)
+
+        def fact(z):
+            if act == "gelu":
+                return 0.5 * z * (1.0 + torch.tanh(np.sqrt(2.0 / np.pi) * (z + 0.044715 * z ** 3)))
+            return torch.tanh(z)
+
+        def bn(z, k):
+            g, b = take(Hc), take(Hc)
+            if train:
+                mu = z.mean(dim=(0, 2, 3), keepdim=True); var = z.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+            else:
+                s64 = torch.tensor(st.astype(np.float64))
+                mu = s64[2 * k * Hc:(2 * k + 1) * Hc].reshape(1, Hc, 1, 1); var = s64[(2 * k + 1) * Hc:(2 * k + 2) * Hc].reshape(1, Hc, 1, 1)
+            return fact((z - mu) / torch.sqrt(var + 1e-5) * g.reshape(1, Hc, 1, 1) + b.reshape(1, Hc, 1, 1))
+
+        z = bn(torch.nn.functional.conv2d(tcat(x), weight(C + 1, Hc), padding=1), 0)
+        z = bn(torch.nn.functional.conv2d(tcat(z), weight(Hc + 1, Hc), padding=1), 1)
+        return torch.nn.functional.conv2d(tcat(z), weight(Hc + 1, C), padding=1).reshape(B, -1)
+
+    out = field(ut, pt)
+    (out * torch.tensor(lam.astype(np.float64))).sum().backward()
+    dy_ref, gp_ref = ut.grad.numpy(), pt.grad.numpy()
+    assert np.abs(dy - dy_ref).max() <= 3e-5 * np.abs(dy_ref).max()
+    assert np.abs(gp - gp_ref).max() <= 3e-5 * np.abs(gp_ref).max()
