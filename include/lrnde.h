@@ -223,6 +223,10 @@ int lrnde_conv_node_forward(lrnde_conv* c, const float* x, int32_t B, float t0, 
                             const lrnde_solve_opts* o, int32_t mode, int32_t reg_type, float t1_or_rand,
                             float* u_end, float* reg_val_host, int32_t* nfe_host, lrnde_stats* st,
                             float* t1_used_host);
+/* Zygote.pullback(dudt, y, p, t) of the conv field (the adjoint RHS building block, as lrnde_vjp): dy = (df/dy)^T lam,
+ * gp (device, flat parameter layout, may be NULL) = (df/dp)^T lam; train-mode BatchNorm is differentiated through its
+ * batch statistics.  fp32 compute only. */
+int lrnde_conv_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int32_t B, float* dy, float* gp);
 /* average microseconds of one f-eval (3 conv + 2 batch-norm statistics launches), HIP events */
 int lrnde_conv_bench_rhs(lrnde_conv* c, const float* u, float t, int32_t B, int32_t reps, float* us_host);
 

@@ -181,6 +181,14 @@ class ConvHandle:
         return dict(u_end=u_end, reg_val=np.float32(reg.value), nfe=int(nfe.value), stats=st.asdict(),
                     t1=np.float32(t1u.value))
 
+    def vjp(self, y, t, lam, want_gp=True):
+        """(J^T lam, (df/dp)^T lam) of the conv field at (y, t) — the adjoint RHS building block."""
+        dy = torch.empty_like(y)
+        gp = torch.zeros(self.param_count(), dtype=torch.float32, device=y.device) if want_gp else None
+        self._chk(L.lib.lrnde_conv_vjp(self._ctx, _ptr(y, "y"), float(t), _ptr(lam, "lam"), self._B(y), _ptr(dy, "dy"),
+                                       C.c_void_p(gp.data_ptr()) if want_gp else None))
+        return dy, gp
+
     def bench_rhs(self, u, t, reps=20):
         """average microseconds of one f-eval (HIP events on the handle's stream)."""
         us = C.c_float()

@@ -66,6 +66,9 @@ struct ConvArgs {
   const float* mean; const float* inv; const float* scale; const float* bias;
   int act;
   double* part;                 // [nwg][COUT][2] sum, sum of squares of the raw output (or null)
+  // backward staging (smode 1): in = dz (cotangent after act'), in2 = raw forward activation of the same layer;
+  // the staged value is the cotangent of that raw activation, (inv*scale)*((dz - m1) - xn*m2)
+  int smode; const float* in2; const float* m1; const float* m2;
   int dbg;                      // LRNDE_CONV_DBG bits (timing experiments): 1 no MFMA loop, 2 no epilogue, 4 no staging
 };
 
@@ -107,6 +110,23 @@ __global__ void k_pack_conv(const float* w, int CIN, int COUT, int NG, int NT, i
   }
 }
 
+// Weights of the transposed convolution (cotangent of the conv input): a forward-shaped conv from the conv's
+// COUT channels to its CIN real channels with Wk'[tap' * COUT + co][ci] = w[2-kx', 2-ky', ci, co]
+// (d in[ci][y][x] = sum w[kx,ky,ci,co] g[co][y-1+ky][x-1+kx]).  Same fragment layout as k_pack_conv (f32).
+__global__ void k_pack_conv_t(const float* w, int CIN, int COUT, int NG, int NT, float* out) {
+  const size_t total = (size_t)NG * NT * 64 * 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i % 4, l = (i / 4) % 64;
+    const size_t blk = i / 256;
+    const int nt = blk % NT, g = blk / NT;
+    const int k = g * 16 + 4 * (l >> 4) + j, ci = nt * 16 + (l & 15);  // k indexes (tap', co), output channel = ci
+    const int tap = k / COUT, co = k % COUT;
+    float v = 0.f;
+    if (tap < 9 && ci < CIN) { const int ky = 2 - tap / 3, kx = 2 - tap % 3; v = w[kx + 3 * (ky + 3 * (ci + (size_t)(CIN + 1) * co))]; }
+    out[i] = v;
+  }
+}
+
 __device__ __forceinline__ int border_class(int y, int x, int H, int W) {
   const int rc = (y == 0) ? 0 : ((y == H - 1) ? 2 : 1);
   const int cc = (x == 0) ? 0 : ((x == W - 1) ? 2 : 1);
@@ -139,6 +159,47 @@ __device__ __forceinline__ void stage_planar(const ConvArgs& a, int n, int y0, T
 // (y = act(((x-mean)*inv)*scale + bias)); positions outside the image are zero (the conv's padding).
 __device__ __forceinline__ int swz_f32(int pos, int cq) { return pos * 64 + ((cq ^ (pos & 15)) << 2); }
 
+// backward staging: the cotangent of the raw activation from dz (a.in) and the raw activation itself (a.in2)
+__device__ __forceinline__ void stage_nhwc_bnbwd_f32(const ConvArgs& a, int n, int y0, float* tile) {
+  constexpr int CQ = 16, PSTEP = CNT / CQ, UN = 4;
+  const int WP = a.W + 2, npos = (a.TR + 2) * WP;
+  const int q = threadIdx.x % CQ;
+  const size_t base = (size_t)n * a.H * a.W * 64 + q * 4;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + q * 4), iv = *reinterpret_cast<const f32x4*>(a.inv + q * 4);
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4);
+  const f32x4 m1 = *reinterpret_cast<const f32x4*>(a.m1 + q * 4), m2 = *reinterpret_cast<const f32x4*>(a.m2 + q * 4);
+  for (int pos0 = threadIdx.x / CQ; pos0 < npos; pos0 += UN * PSTEP) {
+    f32x4 dz[UN], ar[UN];
+    bool ok[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int pos = pos0 + u * PSTEP;
+      const int cc = pos % WP, rr = pos / WP;
+      const int y = y0 - 1 + rr, x = cc - 1;
+      ok[u] = pos < npos && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      dz[u] = ar[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok[u]) {
+        const size_t o = base + ((size_t)y * a.W + x) * 64;
+        dz[u] = *reinterpret_cast<const f32x4*>(a.in + o);
+        ar[u] = *reinterpret_cast<const f32x4*>(a.in2 + o);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int pos = pos0 + u * PSTEP;
+      if (pos >= npos) break;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok[u]) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const float xn = (ar[u][h] - mu[h]) * iv[h];
+          v[h] = (iv[h] * sc[h]) * ((dz[u][h] - m1[h]) - xn * m2[h]);
+        }
+      }
+      *reinterpret_cast<f32x4*>(tile + swz_f32(pos, q)) = v;
+    }
+  }
+}
 template <int ACT>
 __device__ __forceinline__ void stage_nhwc_bn_f32(const ConvArgs& a, int n, int y0, float* tile) {
   constexpr int CQ = 16, PSTEP = CNT / CQ, UN = 4;
@@ -177,6 +238,7 @@ __device__ __forceinline__ void stage_nhwc_bn_f32(const ConvArgs& a, int n, int 
   }
 }
 __device__ __forceinline__ void stage_nhwc_bn_f32(const ConvArgs& a, int n, int y0, float* tile) {
+  if (a.smode == 1) { stage_nhwc_bnbwd_f32(a, n, y0, tile); return; }
   if (a.act == 2) stage_nhwc_bn_f32<2>(a, n, y0, tile);
   else if (a.act == 1) stage_nhwc_bn_f32<1>(a, n, y0, tile);
   else stage_nhwc_bn_f32<0>(a, n, y0, tile);
@@ -594,6 +656,241 @@ __global__ void k_bn_from_state(const float* mean_var, int ch, float eps, float*
   }
 }
 
+// ---- backward of BatchNorm(ch, act): dz = dh * act'(z) in place, per-block partial sums of dz and dz*xn ----
+struct BnBwdArgs {
+  float* g; const float* a; size_t npix;  // g: (npix, 64) cotangent in/out; a: raw forward activation
+  const float* mean; const float* inv; const float* scale; const float* bias; int act;
+  double* part;  // [gridDim.x][64][2]
+};
+__device__ __forceinline__ float act_deriv_c(int act, float pre, float h) {
+  if (act == 1) return 1.0f - h * h;
+  if (act == 2) {
+    const float two_lambda = 1.5957691216057308f;
+    const float x2 = pre * pre;
+    const float aa = (two_lambda * pre) * fma_(x2, 0.044715f, 1.0f);
+    const float sg = 1.0f / (1.0f + expf_c(-aa));
+    const float da = two_lambda * fma_(x2, 3.0f * 0.044715f, 1.0f);
+    return sg + pre * sg * (1.0f - sg) * da;
+  }
+  return 1.0f;
+}
+__global__ __launch_bounds__(256) void k_bn_bwd1(BnBwdArgs a) {
+  __shared__ double red[16][64][2];
+  const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;  // channel quad, position lane
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + q * 4), iv = *reinterpret_cast<const f32x4*>(a.inv + q * 4);
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4), bi = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  for (size_t p = (size_t)blockIdx.x * 16 + pl; p < a.npix; p += (size_t)gridDim.x * 16) {
+    const size_t o = p * 64 + q * 4;
+    const f32x4 dh = *reinterpret_cast<const f32x4*>(a.g + o), ar = *reinterpret_cast<const f32x4*>(a.a + o);
+    f32x4 dz;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const float xn = (ar[h] - mu[h]) * iv[h];
+      const float z = xn * sc[h] + bi[h];
+      const float hh = act_apply(a.act, z);
+      dz[h] = dh[h] * act_deriv_c(a.act, z, hh);
+      s1[h] += (double)dz[h]; s2[h] += (double)dz[h] * (double)xn;
+    }
+    *reinterpret_cast<f32x4*>(a.g + o) = dz;
+  }
+#pragma unroll
+  for (int h = 0; h < 4; ++h) { red[pl][q * 4 + h][0] = s1[h]; red[pl][q * 4 + h][1] = s2[h]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x >> 1, w = threadIdx.x & 1;
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += red[i][c][w];
+    a.part[((size_t)blockIdx.x * 64 + c) * 2 + w] = t;
+  }
+}
+// fixed-order reduction of the partials: m1 = S1/N, m2 = S2/N (zero in test mode), dscale = S2, dbias = S1
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const double* part, int nblk, double count, int train, float* m1, float* m2,
+                                                         float* dscale, float* dbias) {
+  __shared__ double r1[256], r2[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int w = tid; w < nblk; w += 256) { const double* p = part + ((size_t)w * 64 + c) * 2; s1 += p[0]; s2 += p[1]; }
+  r1[tid] = s1; r2[tid] = s2;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) { r1[tid] += r1[tid + o]; r2[tid] += r2[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    m1[c] = train ? (float)(r1[0] / count) : 0.f;
+    m2[c] = train ? (float)(r2[0] / count) : 0.f;
+    if (dscale) dscale[c] = (float)r2[0];
+    if (dbias) dbias[c] = (float)r1[0];
+  }
+}
+
+// ---- weight gradient: dw[co][tap][ci] = sum_pixels G[p][co] * IN[p + shift(tap)][ci]  (K = pixels) ----------
+// G: cotangent of the conv output (GM 0: planar 8 channels, GM 1: NHWC 64 via the BatchNorm-backward combine);
+// IN: the conv input (IM 0: planar 8 channels, IM 1: NHWC 64 with BatchNorm + activation on load).
+// One workgroup walks strips blockIdx.x, +gridDim.x, ...; LDS: G tile [pixel][GS], IN halo tile [pos][IS]
+// (strides 80 / 16 floats: conflict-free scalar reads for 16 channels x 4 consecutive pixels).
+// MFMA 16x16x4: A[i = co][k = pixel] = G, B[k = pixel][n = ci] = IN shifted by the tap.  Wave w owns output
+// channel tile w (GM 1) or input channel tile w (GM 0); accumulators [tap][ci tile].
+// Partials: pw[wg][tap][64 or 16 co][64 or 16 ci] floats, pt[wg][9 classes][co] (sums of G per border class,
+// for the t plane's weights); reduced in fixed order by k_wgrad_reduce.
+struct WgradArgs {
+  int W, H, B, TR, TP, nstrips;
+  const float* g; const float* g2;   // GM 0: planar cotangent; GM 1: dz (NHWC) and the raw activation of that layer
+  const float* gmean; const float* ginv; const float* gscale; const float* gm1; const float* gm2;
+  const float* in;                   // IM 0: planar input; IM 1: raw NHWC activation of the previous layer
+  const float* mean; const float* inv; const float* scale; const float* bias; int act;
+  float* pw; float* pt;
+};
+template <int GM, int IM>
+__global__ __launch_bounds__(CNT) void k_conv_wgrad(WgradArgs a) {
+  constexpr int GC = GM ? 64 : 16, GS = GM ? 80 : 16;   // channels held / stride of the G tile
+  constexpr int IC = IM ? 64 : 16, IS = IM ? 80 : 16;
+  constexpr int NCIT = (GM && IM) ? 4 : 1;               // ci tiles per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* gt = reinterpret_cast<float*>(smem);
+  float* it = gt + (size_t)a.TP * GS;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int WP = a.W + 2, npos = (a.TR + 2) * WP;
+  const int strips = a.H / a.TR;
+  const int cot = GM ? wave : 0;                 // output-channel tile of this wave
+  const int cit0 = (GM && IM) ? 0 : (GM ? 0 : wave);
+  f32x4 acc[9][NCIT];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int c = 0; c < NCIT; ++c) acc[tp][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float cls[9];  // thread (co = tid % GC, group = tid / GC): class sums of G over its pixels
+#pragma unroll
+  for (int c = 0; c < 9; ++c) cls[c] = 0.f;
+  int toff[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) { const int ky = tp / 3, kx = tp % 3; toff[tp] = ((2 - ky) * WP + (2 - kx)) * IS; }
+
+  for (int strip = blockIdx.x; strip < a.nstrips; strip += gridDim.x) {
+    const int n = strip / strips, y0 = (strip % strips) * a.TR;
+    __syncthreads();  // previous strip's tiles are no longer read
+    // ---- stage G (no halo) ----
+    if constexpr (GM == 0) {
+      for (int i = threadIdx.x; i < a.TP * 16; i += CNT) {
+        const int p = i % a.TP, c = i / a.TP;
+        float v = 0.f;
+        if (c < 8) v = a.g[((size_t)n * 8 + c) * a.H * a.W + (size_t)y0 * a.W + p];
+        gt[p * GS + c] = v;
+      }
+    } else {
+      const int q = threadIdx.x & 15;
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(a.gmean + q * 4), iv = *reinterpret_cast<const f32x4*>(a.ginv + q * 4);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.gscale + q * 4);
+      const f32x4 m1 = *reinterpret_cast<const f32x4*>(a.gm1 + q * 4), m2 = *reinterpret_cast<const f32x4*>(a.gm2 + q * 4);
+      for (int p = threadIdx.x >> 4; p < a.TP; p += CNT / 16) {
+        const size_t o = ((size_t)n * a.H * a.W + (size_t)y0 * a.W + p) * 64 + q * 4;
+        const f32x4 dz = *reinterpret_cast<const f32x4*>(a.g + o), ar = *reinterpret_cast<const f32x4*>(a.g2 + o);
+        f32x4 v;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { const float xn = (ar[h] - mu[h]) * iv[h]; v[h] = (iv[h] * sc[h]) * ((dz[h] - m1[h]) - xn * m2[h]); }
+        *reinterpret_cast<f32x4*>(gt + p * GS + q * 4) = v;
+      }
+    }
+    // ---- stage IN (halo, zero outside the image) ----
+    if constexpr (IM == 0) {
+      for (int i = threadIdx.x; i < npos * 16; i += CNT) {
+        const int pos = i % npos, c = i / npos;
+        const int cc = pos % WP, rr = pos / WP;
+        const int y = y0 - 1 + rr, x = cc - 1;
+        float v = 0.f;
+        if (c < 8 && y >= 0 && y < a.H && x >= 0 && x < a.W) v = a.in[((size_t)n * 8 + c) * a.H * a.W + (size_t)y * a.W + x];
+        it[pos * IS + c] = v;
+      }
+    } else {
+      const int q = threadIdx.x & 15;
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + q * 4), iv = *reinterpret_cast<const f32x4*>(a.inv + q * 4);
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4), bi = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
+      for (int pos = threadIdx.x >> 4; pos < npos; pos += CNT / 16) {
+        const int cc = pos % WP, rr = pos / WP;
+        const int y = y0 - 1 + rr, x = cc - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
+          const f32x4 raw = *reinterpret_cast<const f32x4*>(a.in + ((size_t)n * a.H * a.W + (size_t)y * a.W + x) * 64 + q * 4);
+#pragma unroll
+          for (int h = 0; h < 4; ++h) { const float xn = (raw[h] - mu[h]) * iv[h]; v[h] = act_apply(a.act, xn * sc[h] + bi[h]); }
+        }
+        *reinterpret_cast<f32x4*>(it + pos * IS + q * 4) = v;
+      }
+    }
+    __syncthreads();
+    // ---- border-class sums of G (t plane weights) ----
+    {
+      const int co = threadIdx.x % GC, grp = threadIdx.x / GC, ngrp = CNT / GC;
+      for (int p = grp; p < a.TP; p += ngrp) {
+        const int y = y0 + p / a.W, x = p % a.W;
+        const float v = gt[p * GS + co];
+        const int k = border_class(y, x, a.H, a.W);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) cls[c] += (c == k) ? v : 0.f;
+      }
+    }
+    // ---- MFMA over the strip's pixels, 4 per k-step ----
+    for (int r = 0; r < a.TR; ++r) {
+      for (int x4 = 0; x4 < a.W; x4 += 4) {
+        const int p = r * a.W + x4 + kg;
+        const float av = gt[p * GS + cot * 16 + li];
+        const int ib = (r * WP + x4 + kg) * IS + cit0 * 16 + li;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+#pragma unroll
+          for (int c = 0; c < NCIT; ++c)
+            acc[tp][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, it[ib + toff[tp] + c * 16], acc[tp][c], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- partials: pw[wg][tap][GC co][IC ci] ; D fragment row = co 4kg+r, col = ci li ----
+  float* pw = a.pw + (size_t)blockIdx.x * 9 * GC * IC;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int c = 0; c < NCIT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pw[((size_t)tp * GC + cot * 16 + kg * 4 + r) * IC + (cit0 + c) * 16 + li] = acc[tp][c][r];
+  // class sums: reduce the thread groups through LDS
+  __syncthreads();
+  float* red = gt;  // [CNT][9]
+#pragma unroll
+  for (int c = 0; c < 9; ++c) red[threadIdx.x * 9 + c] = cls[c];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * GC; i += CNT) {
+    const int co = i % GC, c = i / GC;
+    float t = 0.f;
+    for (int grp = 0; grp < CNT / GC; ++grp) t += red[(grp * GC + co) * 9 + c];
+    a.pt[((size_t)blockIdx.x * 9 + c) * GC + co] = t;
+  }
+}
+// gp[kx + 3(ky + 3(ci + (CIN+1) co))] = sum over workgroups (fixed order); the t plane's weights from the class sums
+__global__ void k_wgrad_reduce(const float* pw, const float* pt, int nwg, int GC, int IC, int CIN, int COUT, float t, float* gw) {
+  const int total = 9 * (CIN + 1) * COUT;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int kx = i % 3, ky = (i / 3) % 3, ci = (i / 9) % (CIN + 1), co = i / (9 * (CIN + 1));
+    const int tp = ky * 3 + kx;
+    double s = 0.0;
+    if (ci < CIN) {
+      for (int w = 0; w < nwg; ++w) s += (double)pw[(((size_t)w * 9 + tp) * GC + co) * IC + ci];
+    } else {
+      for (int cls = 0; cls < 9; ++cls) {
+        const int rc = cls / 3, cc = cls % 3;
+        if ((rc == 0 && ky == 2) || (rc == 2 && ky == 0) || (cc == 0 && kx == 2) || (cc == 2 && kx == 0)) continue;
+        double d = 0.0;
+        for (int w = 0; w < nwg; ++w) d += (double)pt[((size_t)w * 9 + cls) * GC + co];
+        s += d;
+      }
+      s *= (double)t;
+    }
+    gw[i] = (float)s;
+  }
+}
+
 // ---- elementwise pieces of the Tsit5 step (src/perform_step.jl:11-27, same operation order) -----
 struct LinArgs {
   float* out; const float* base; float dt; int nk; size_t n;
@@ -690,6 +987,13 @@ struct lrnde_conv {
   double *sums = nullptr, *sums_host = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<float> last_ts;
+  // backward pass
+  float *w1t = nullptr, *w2t = nullptr, *w3t = nullptr;  // transposed-conv weight packs
+  float* params = nullptr; bool w_t_valid = false;        // device copy of the flat parameters
+  float *zeros = nullptr;                                  // 9*64 zeros (no t-plane term in a cotangent)
+  float *bwm = nullptr;                                    // m1_2 m2_2 m1_1 m2_1 (4*Hc)
+  float *g1 = nullptr, *g2 = nullptr;                      // NHWC cotangents of the hidden layers
+  double* part_bw = nullptr; float *pw = nullptr, *pt = nullptr; int bwB = 0;
 };
 
 namespace {
@@ -776,8 +1080,11 @@ void launch_mt(lrnde_conv* c, int which, const ConvArgs& a, size_t sm) {
   }
 }
 
+int launch_rhs_ex(lrnde_conv* c, const float* u, float t, int B, float* du, bool last);
 // du = f(u, t): the five launches
-int launch_rhs(lrnde_conv* c, const float* u, float t, int B, float* du) {
+int launch_rhs(lrnde_conv* c, const float* u, float t, int B, float* du) { return launch_rhs_ex(c, u, t, B, du, true); }
+// last = false: stop after the second BatchNorm statistics (y1, y2 and the statistics stay for the backward pass)
+int launch_rhs_ex(lrnde_conv* c, const float* u, float t, int B, float* du, bool last) {
   const int Hc = c->d.hidden, C = c->d.channels;
   const bool train = c->d.bn_train != 0;
   const double count = (double)B * c->d.width * c->d.height;
@@ -797,10 +1104,121 @@ int launch_rhs(lrnde_conv* c, const float* u, float t, int B, float* du) {
   launch_mt(c, 1, a, esz * rows * WP * a.CINP);
   CHK(c, hipGetLastError());
   if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(256), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat + 2 * Hc, c->stat + 3 * Hc);
+  if (!last) return LRNDE_OK;
   // conv3: BN2+act(y2) -> du (planar)
   a.COUT = C; a.in = c->y2; a.out = du; a.wpk = c->w3; a.tsum = c->ts3; a.part = nullptr;
   a.mean = c->stat + 2 * Hc; a.inv = c->stat + 3 * Hc; a.scale = c->bn + 2 * Hc; a.bias = c->bn + 3 * Hc;
   launch_mt(c, 2, a, esz * rows * WP * a.CINP);
+  CHK(c, hipGetLastError());
+  return LRNDE_OK;
+}
+
+constexpr int NBW1 = 1024;   // blocks of k_bn_bwd1
+constexpr int NWGW = 256;    // workgroups of the weight-gradient kernels
+
+int ensure_bw(lrnde_conv* c, int B) {
+  const int Hc = c->d.hidden, C = c->d.channels;
+  if (!c->w2t) {
+    CHK(c, hipMalloc(&c->w3t, (size_t)((9 * C + 15) / 16) * 4 * 1024));
+    CHK(c, hipMalloc(&c->w2t, (size_t)((9 * Hc + 15) / 16) * 4 * 1024));
+    CHK(c, hipMalloc(&c->w1t, (size_t)((9 * Hc + 15) / 16) * 1 * 1024));
+    CHK(c, hipMalloc(&c->zeros, sizeof(float) * 9 * 64));
+    CHK(c, hipMemsetAsync(c->zeros, 0, sizeof(float) * 9 * 64, c->stream));
+    CHK(c, hipMalloc(&c->bwm, sizeof(float) * 4 * Hc));
+    CHK(c, hipMalloc(&c->part_bw, sizeof(double) * NBW1 * 64 * 2));
+    CHK(c, hipMalloc(&c->pw, sizeof(float) * (size_t)NWGW * 9 * 64 * 64));
+    CHK(c, hipMalloc(&c->pt, sizeof(float) * (size_t)NWGW * 9 * 64));
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    c->w_t_valid = false;
+  }
+  if (!c->w_t_valid) {  // transposed packs of the current parameters
+    const float* p = c->params;
+    const float* w1 = p; const float* w2 = w1 + 9 * (C + 1) * Hc + 2 * Hc; const float* w3 = w2 + 9 * (Hc + 1) * Hc + 2 * Hc;
+    // conv3^T: C -> Hc (NT 4), conv2^T: Hc -> Hc (NT 4), conv1^T: Hc -> C (NT 1)
+    hipLaunchKernelGGL(k_pack_conv_t, dim3(64), dim3(256), 0, c->stream, w3, Hc, C, (9 * C + 15) / 16, 4, c->w3t);
+    hipLaunchKernelGGL(k_pack_conv_t, dim3(64), dim3(256), 0, c->stream, w2, Hc, Hc, (9 * Hc + 15) / 16, 4, c->w2t);
+    hipLaunchKernelGGL(k_pack_conv_t, dim3(64), dim3(256), 0, c->stream, w1, C, Hc, (9 * Hc + 15) / 16, 1, c->w1t);
+    CHK(c, hipGetLastError());
+    c->w_t_valid = true;
+  }
+  if (c->bwB != B) {
+    if (c->g1) CHK(c, hipFree(c->g1));
+    if (c->g2) CHK(c, hipFree(c->g2));
+    c->g1 = c->g2 = nullptr; c->bwB = 0;
+    const size_t px = (size_t)B * c->d.width * c->d.height;
+    CHK(c, hipMalloc(&c->g1, sizeof(float) * px * Hc));
+    CHK(c, hipMalloc(&c->g2, sizeof(float) * px * Hc));
+    c->bwB = B;
+  }
+  return LRNDE_OK;
+}
+
+// dy = (df/dy)^T lam, gp (optional, device, flat layout) = (df/dp)^T lam at (y, t)
+int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, float* dy, float* gp) {
+  if (c->d.compute_dtype != LRNDE_F32) return cfail(c, LRNDE_UNSUPPORTED, "the conv backward pass is fp32 only");
+  int rc;
+  if ((rc = ensure_bw(c, B))) return rc;
+  const int Hc = c->d.hidden, C = c->d.channels, W = c->d.width, H = c->d.height;
+  const int train = c->d.bn_train ? 1 : 0;
+  const double count = (double)B * W * H;
+  const size_t npix = (size_t)B * W * H;
+  if ((rc = launch_rhs_ex(c, y, t, B, nullptr, false))) return rc;   // y1, y2, statistics
+  const size_t o_g1 = (size_t)9 * (C + 1) * Hc, o_w2 = o_g1 + 2 * Hc, o_g2 = o_w2 + (size_t)9 * (Hc + 1) * Hc, o_w3 = o_g2 + 2 * Hc;
+  ConvArgs a = base_args(c, B);
+  const int rows = a.TR + 2, WP = a.W + 2;
+  const int nstrips = c->nwg, nwgw = nstrips < NWGW ? nstrips : NWGW;
+  auto bn_bwd = [&](float* g, const float* araw, int layer) -> int {
+    BnBwdArgs b;
+    b.g = g; b.a = araw; b.npix = npix; b.mean = c->stat + 2 * layer * Hc; b.inv = c->stat + (2 * layer + 1) * Hc;
+    b.scale = c->bn + 2 * layer * Hc; b.bias = c->bn + (2 * layer + 1) * Hc; b.act = c->d.act; b.part = c->part_bw;
+    hipLaunchKernelGGL(k_bn_bwd1, dim3(NBW1), dim3(256), 0, c->stream, b);
+    const size_t og = layer == 0 ? o_g1 : o_g2;
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(Hc), dim3(256), 0, c->stream, (const double*)c->part_bw, NBW1, count, train,
+                       c->bwm + 2 * layer * Hc, c->bwm + (2 * layer + 1) * Hc, gp ? gp + og : nullptr, gp ? gp + og + Hc : nullptr);
+    CHK(c, hipGetLastError());
+    return LRNDE_OK;
+  };
+  auto wgrad = [&](int GM, int IM, const float* g, const float* graw, int glayer, const float* in, int ilayer, int CINr, int COUTr,
+                   float* gw) -> int {
+    WgradArgs w;
+    memset(&w, 0, sizeof(w));
+    w.W = W; w.H = H; w.B = B; w.TR = a.TR; w.TP = a.TP; w.nstrips = nstrips;
+    w.g = g; w.g2 = graw;
+    if (GM) { w.gmean = c->stat + 2 * glayer * Hc; w.ginv = c->stat + (2 * glayer + 1) * Hc; w.gscale = c->bn + 2 * glayer * Hc;
+              w.gm1 = c->bwm + 2 * glayer * Hc; w.gm2 = c->bwm + (2 * glayer + 1) * Hc; }
+    w.in = in;
+    if (IM) { w.mean = c->stat + 2 * ilayer * Hc; w.inv = c->stat + (2 * ilayer + 1) * Hc; w.scale = c->bn + 2 * ilayer * Hc;
+              w.bias = c->bn + (2 * ilayer + 1) * Hc; }
+    w.act = c->d.act; w.pw = c->pw; w.pt = c->pt;
+    const int GS = GM ? 80 : 16, IS = IM ? 80 : 16, GC = GM ? 64 : 16, IC = IM ? 64 : 16;
+    size_t sm = sizeof(float) * ((size_t)a.TP * GS + (size_t)rows * WP * IS);
+    if (sm < sizeof(float) * CNT * 9) sm = sizeof(float) * CNT * 9;
+    if (GM && IM) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
+    else if (GM) hipLaunchKernelGGL((k_conv_wgrad<1, 0>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
+    else hipLaunchKernelGGL((k_conv_wgrad<0, 1>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(64), dim3(256), 0, c->stream, (const float*)c->pw, (const float*)c->pt, nwgw, GC, IC, CINr, COUTr, t, gw);
+    CHK(c, hipGetLastError());
+    return LRNDE_OK;
+  };
+  // conv3^T: lam (planar) -> g2 = d h2
+  a.CIN = C; a.CINP = cinp_of(C); a.COUT = Hc; a.in = lam; a.out = c->g2; a.wpk = c->w3t; a.tsum = c->zeros; a.t = 0.f; a.part = nullptr;
+  launch_mt(c, 0, a, sizeof(float) * rows * WP * a.CINP);
+  if ((rc = bn_bwd(c->g2, c->y2, 1))) return rc;                        // g2 = dz2 ; m(2) ; d scale2, d bias2
+  if (gp && (rc = wgrad(0, 1, lam, nullptr, 0, c->y2, 1, Hc, C, gp + o_w3))) return rc;
+  // conv2^T: d a2 (from dz2, y2) -> g1 = d h1
+  a.CIN = Hc; a.CINP = cinp_of(Hc); a.COUT = Hc; a.in = c->g2; a.in2 = c->y2; a.smode = 1; a.out = c->g1; a.wpk = c->w2t;
+  a.mean = c->stat + 2 * Hc; a.inv = c->stat + 3 * Hc; a.scale = c->bn + 2 * Hc; a.bias = c->bn + 3 * Hc;
+  a.m1 = c->bwm + 2 * Hc; a.m2 = c->bwm + 3 * Hc;
+  launch_mt(c, 1, a, sizeof(float) * rows * WP * a.CINP);
+  if ((rc = bn_bwd(c->g1, c->y1, 0))) return rc;                        // g1 = dz1 ; m(1) ; d scale1, d bias1
+  if (gp && (rc = wgrad(1, 1, c->g2, c->y2, 1, c->y1, 0, Hc, Hc, gp + o_w2))) return rc;
+  // conv1^T: d a1 (from dz1, y1) -> dy (planar)
+  a.COUT = C; a.in = c->g1; a.in2 = c->y1; a.out = dy; a.wpk = c->w1t;
+  a.mean = c->stat; a.inv = c->stat + Hc; a.scale = c->bn; a.bias = c->bn + Hc; a.m1 = c->bwm; a.m2 = c->bwm + Hc;
+  launch_mt(c, 2, a, sizeof(float) * rows * WP * a.CINP);
+  if (gp && (rc = wgrad(1, 0, c->g1, c->y1, 0, y, 0, C, Hc, gp))) return rc;
   CHK(c, hipGetLastError());
   return LRNDE_OK;
 }
@@ -931,7 +1349,7 @@ int lrnde_conv_destroy(lrnde_conv* c) {
   if (!c) return LRNDE_OK;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
-  void* ptrs[] = {c->w1, c->w2, c->w3, c->ts1, c->ts2, c->ts3, c->bn, c->stat, c->bn_state, c->y1, c->y2, c->part, c->vec, c->sums};
+  void* ptrs[] = {c->params, c->w1t, c->w2t, c->w3t, c->zeros, c->bwm, c->g1, c->g2, c->part_bw, c->pw, c->pt, c->w1, c->w2, c->w3, c->ts1, c->ts2, c->ts3, c->bn, c->stat, c->bn_state, c->y1, c->y2, c->part, c->vec, c->sums};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->sums_host) hipHostFree(c->sums_host);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -963,6 +1381,9 @@ int lrnde_conv_set_params(lrnde_conv* c, const float* p, size_t n) {
     hipLaunchKernelGGL(k_bn_from_state, dim3(1), dim3(64), 0, c->stream, st ? st + 2 * Hc : nullptr, Hc, c->d.bn_eps, c->stat + 2 * Hc, c->stat + 3 * Hc);
     CHK(c, hipGetLastError());
   }
+  if (!c->params) CHK(c, hipMalloc(&c->params, sizeof(float) * n));
+  CHK(c, hipMemcpyAsync(c->params, p, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  c->w_t_valid = false;
   c->have_params = true;
   return LRNDE_OK;
 }
@@ -987,6 +1408,15 @@ int lrnde_conv_rhs(lrnde_conv* c, const float* u, float t, int32_t B, float* du)
   if (rc) return rc;
   if (!u || !du) return cfail(c, LRNDE_BADARG, "null pointer");
   if ((rc = launch_rhs(c, u, t, B, du))) return rc;
+  CHK(c, hipStreamSynchronize(c->stream));
+  return LRNDE_OK;
+}
+
+int lrnde_conv_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int32_t B, float* dy, float* gp) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!y || !lam || !dy) return cfail(c, LRNDE_BADARG, "null pointer");
+  if ((rc = launch_vjp(c, y, t, lam, B, dy, gp))) return rc;
   CHK(c, hipStreamSynchronize(c->stream));
   return LRNDE_OK;
 }

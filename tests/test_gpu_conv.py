@@ -196,3 +196,24 @@ def test_conv_bf16_node_forward():
     assert rg["stats"]["retcode"] == 0 and abs(rg["stats"]["naccept"] - ro["stats"]["naccept"]) <= 1
     _close(rg["u_end"], ro["u_end"], rtol=2e-2)
     assert rg["reg_val"] > 0
+
+
+# ---- backward building block: Zygote.pullback(dudt, y, p, t) of the conv field ----
+@pytest.mark.parametrize("W,H,B,train,act", [(8, 8, 3, True, "gelu"), (16, 16, 2, True, "gelu"), (32, 32, 2, True, "gelu"),
+                                             (28, 28, 2, False, "gelu"), (12, 8, 3, True, "tanh")])
+def test_conv_vjp_matches_oracle(W, H, B, train, act):
+    """rtol 5e-5 of each output's scale (fp32 MFMA sums vs the oracle's fp64 accumulations)"""
+    P, O = _mods()
+    fld, h, p, u = _case(W, H, B, seed=W + B + 3, act=act, train=train)
+    lam = np.random.default_rng(17).standard_normal(u.shape).astype(np.float32)
+    dy_ref, gp_ref = O.conv_vjp(fld, u.reshape(B, -1), 0.41, lam.reshape(B, -1))
+    dy, gp = h.vjp(torch.from_numpy(u).cuda(), 0.41, torch.from_numpy(lam).cuda())
+    _close(dy, dy_ref, rtol=5e-5)
+    gp = gp.cpu().numpy()
+    C, Hc = 8, 64
+    n1 = 9 * (C + 1) * Hc; n2 = n1 + 2 * Hc; n3 = n2 + 9 * (Hc + 1) * Hc; n4 = n3 + 2 * Hc
+    for name, sl in (("w1", slice(0, n1)), ("bn1", slice(n1, n2)), ("w2", slice(n2, n3)), ("bn2", slice(n3, n4)),
+                     ("w3", slice(n4, None))):
+        sc = np.abs(gp_ref[sl]).max()
+        err = np.abs(gp[sl] - gp_ref[sl]).max()
+        assert err <= 5e-5 * sc, f"{name}: {err:.3e} vs scale {sc:.3e}"
