@@ -1137,23 +1137,38 @@ void lro_mlp_vjp(const lro_mlp* m, const float* y, float t, const float* lam, in
 }
 
 /* adjoint field in reversed time s = -t:  z = [lambda (n); mu (P)],  dz/ds = [J^T lambda; (df/dp)^T lambda] at y(t) */
-typedef struct { const lro_mlp* m; const lro_dense* dense; int B; long n; int P; float* y; } adj_ctx;
+/* a vector field with its vector-Jacobian product (the backward drivers are field-agnostic) */
+typedef void (*lro_vjp_fn)(const void* ctx, const float* y, float t, const float* lam, int B, float* dy, float* gp);
+typedef struct { lro_field field; lro_vjp_fn vjp; const void* ctx; int P; } lro_diff_field;
+static void mlp_vjp_tramp(const void* ctx, const float* y, float t, const float* lam, int B, float* dy, float* gp) {
+  lro_mlp_vjp((const lro_mlp*)ctx, y, t, lam, B, dy, gp);
+}
+static void conv_vjp_tramp(const void* ctx, const float* y, float t, const float* lam, int B, float* dy, float* gp) {
+  lro_conv_vjp((const lro_conv*)ctx, y, t, lam, B, dy, gp);
+}
+static void diff_from_mlp(const lro_mlp* m, lro_diff_field* d) {
+  lro_mlp_as_field(m, &d->field); d->vjp = mlp_vjp_tramp; d->ctx = m; d->P = lro_mlp_param_count(m->D, m->H, m->time_dep ? 1 : 0);
+}
+static void diff_from_conv(const lro_conv* m, lro_diff_field* d) {
+  lro_conv_as_field(m, &d->field); d->vjp = conv_vjp_tramp; d->ctx = m; d->P = lro_conv_param_count(m->C, m->Hc);
+}
+typedef struct { const lro_diff_field* df; const lro_dense* dense; int B; long n; int P; float* y; } adj_ctx;
 static void adjoint_field(void* vctx, const float* z, float s, int B1, float* dz) {
   (void)B1;
   adj_ctx* c = (adj_ctx*)vctx;
   const float t = -s;
   lro_dense_eval(c->dense, t, c->y);
   memset(dz + c->n, 0, sizeof(float) * (size_t)c->P);
-  lro_mlp_vjp(c->m, c->y, t, z, c->B, dz, dz + c->n);
+  c->df->vjp(c->df->ctx, c->y, t, z, c->B, dz, dz + c->n);
 }
 
 /* gradient of the local regularisation value w.r.t. p (reverse sweep through one Tsit5 step) */
-int lro_tsit5_step_reg_grad(const lro_mlp* m, const float* uprev, const float* k1, float t, float dt,
-                            float abstol, float reltol, int B, int reg_type, float* gp, float* reg_val) {
-  const int D = m->D;
+static int step_reg_grad_generic(const lro_diff_field* df, const float* uprev, const float* k1, float t, float dt,
+                                 float abstol, float reltol, int B, int reg_type, float* gp, float* reg_val) {
+  const int D = df->field.D;
   const long n = (long)D * B;
-  const int P = lro_mlp_param_count(m->D, m->H, m->time_dep ? 1 : 0);
-  lro_field f; lro_mlp_as_field(m, &f);
+  const int P = df->P;
+  lro_field f = df->field;
   float A[21], BT[7];
   for (int i = 0; i < 21; ++i) A[i] = (float)TS_A[i];
   for (int i = 0; i < 7; ++i) BT[i] = (float)TS_BT[i];
@@ -1229,7 +1244,7 @@ int lro_tsit5_step_reg_grad(const lro_mlp* m, const float* uprev, const float* k
   /* reverse through stages 7..2: k_s = f(x_s); x_s = uprev + dt * sum_{j<s} a_sj k_j */
   for (int s = 7; s >= 2; --s) {
     const float* x = xs + (size_t)(s - 2) * n;
-    lro_mlp_vjp(m, x, t + cs[s - 2] * dt, kb + (size_t)(s - 1) * n, B, xb, gp);
+    df->vjp(df->ctx, x, t + cs[s - 2] * dt, kb + (size_t)(s - 1) * n, B, xb, gp);
     if (s == 7) for (long i = 0; i < n; ++i) xb[i] += ub[i];
     if (s == 6) for (long i = 0; i < n; ++i) xb[i] += g6b[i];
     const int off = (s - 2) * (s - 1) / 2;
@@ -1243,13 +1258,13 @@ int lro_tsit5_step_reg_grad(const lro_mlp* m, const float* uprev, const float* k
 }
 
 /* full backward of `loss = <du_end, sol.u[end]> + w_reg * reg_val` for the NeuralODE layer */
-int lro_node_backward(const lro_mlp* m, const float* x, int B, float t0, float t2, const lro_opts* o, int mode,
-                      int reg_type, float t1_or_rand, const float* du_end, float w_reg, float* dx, float* dp,
-                      lro_stats* st_fwd, lro_stats* st_bwd) {
-  const int D = m->D;
+static int node_backward_generic(const lro_diff_field* df, const float* x, int B, float t0, float t2, const lro_opts* o, int mode,
+                                 int reg_type, float t1_or_rand, const float* du_end, float w_reg, float* dx, float* dp,
+                                 lro_stats* st_fwd, lro_stats* st_bwd) {
+  const int D = df->field.D;
   const long n = (long)D * B;
-  const int P = lro_mlp_param_count(m->D, m->H, m->time_dep ? 1 : 0);
-  lro_field f; lro_mlp_as_field(m, &f);
+  const int P = df->P;
+  lro_field f = df->field;
   lro_opts oo = *o;
   lro_dense dense; memset(&dense, 0, sizeof(dense));
   int rc;
@@ -1290,7 +1305,7 @@ int lro_node_backward(const lro_mlp* m, const float* x, int B, float t0, float t
   const long N = n + P;
   float* z0 = (float*)calloc((size_t)N, sizeof(float));
   memcpy(z0, du_end, sizeof(float) * n);
-  adj_ctx ac; ac.m = m; ac.dense = &dense; ac.B = B; ac.n = n; ac.P = P; ac.y = (float*)malloc(sizeof(float) * (size_t)n);
+  adj_ctx ac; ac.df = df; ac.dense = &dense; ac.B = B; ac.n = n; ac.P = P; ac.y = (float*)malloc(sizeof(float) * (size_t)n);
   lro_field af; af.fn = adjoint_field; af.ctx = &ac; af.D = (int)N;
   float* stops = (float*)malloc(sizeof(float) * (size_t)(ntst > 0 ? ntst : 1));
   for (int i = 0; i < ntst; ++i) stops[i] = -tst[ntst - 1 - i];   /* ascending in s */
@@ -1307,7 +1322,7 @@ int lro_node_backward(const lro_mlp* m, const float* x, int B, float t0, float t
       float* gr = (float*)malloc(sizeof(float) * (size_t)P);
       float dtl, rv;
       lro_init_dt(&f, u1, t1, t2, oo.abstol, oo.reltol, B, k1, &dtl);
-      lro_tsit5_step_reg_grad(m, u1, k1, t1, dtl, oo.abstol, oo.reltol, B, reg_type, gr, &rv);
+      step_reg_grad_generic(df, u1, k1, t1, dtl, oo.abstol, oo.reltol, B, reg_type, gr, &rv);
       for (int i = 0; i < P; ++i) dp[i] += w_reg * gr[i];
       free(gr); free(k1);
     }
@@ -1356,4 +1371,28 @@ float lro_classifier_ce(const float* u, int B, int D, const float* pc, int K, co
       }
   free(dl);
   return (float)(total / (double)B);
+}
+
+/* public wrappers of the field-agnostic backward drivers */
+int lro_tsit5_step_reg_grad(const lro_mlp* m, const float* uprev, const float* k1, float t, float dt,
+                            float abstol, float reltol, int B, int reg_type, float* gp, float* reg_val) {
+  lro_diff_field d; diff_from_mlp(m, &d);
+  return step_reg_grad_generic(&d, uprev, k1, t, dt, abstol, reltol, B, reg_type, gp, reg_val);
+}
+int lro_node_backward(const lro_mlp* m, const float* x, int B, float t0, float t2, const lro_opts* o, int mode,
+                      int reg_type, float t1_or_rand, const float* du_end, float w_reg, float* dx, float* dp,
+                      lro_stats* st_fwd, lro_stats* st_bwd) {
+  lro_diff_field d; diff_from_mlp(m, &d);
+  return node_backward_generic(&d, x, B, t0, t2, o, mode, reg_type, t1_or_rand, du_end, w_reg, dx, dp, st_fwd, st_bwd);
+}
+int lro_conv_step_reg_grad(const lro_conv* m, const float* uprev, const float* k1, float t, float dt,
+                           float abstol, float reltol, int B, int reg_type, float* gp, float* reg_val) {
+  lro_diff_field d; diff_from_conv(m, &d);
+  return step_reg_grad_generic(&d, uprev, k1, t, dt, abstol, reltol, B, reg_type, gp, reg_val);
+}
+int lro_conv_node_backward(const lro_conv* m, const float* x, int B, float t0, float t2, const lro_opts* o, int mode,
+                           int reg_type, float t1_or_rand, const float* du_end, float w_reg, float* dx, float* dp,
+                           lro_stats* st_fwd, lro_stats* st_bwd) {
+  lro_diff_field d; diff_from_conv(m, &d);
+  return node_backward_generic(&d, x, B, t0, t2, o, mode, reg_type, t1_or_rand, du_end, w_reg, dx, dp, st_fwd, st_bwd);
 }

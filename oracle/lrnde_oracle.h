@@ -145,6 +145,12 @@ void lro_conv_as_field(const lro_conv* m, lro_field* out);
  * the flat parameter layout (train-mode BatchNorm differentiated through its batch statistics, as Zygote does
  * through Lux's batchnorm).  fp32 mode only. */
 void lro_conv_vjp(const lro_conv* m, const float* y, float t, const float* lam, int B, float* dy, float* gp);
+/* the conv-field instances of lro_tsit5_step_reg_grad / lro_node_backward (same drivers, field-agnostic) */
+int lro_conv_step_reg_grad(const lro_conv* m, const float* uprev, const float* k1, float t, float dt,
+                           float abstol, float reltol, int B, int reg_type, float* gp, float* reg_val);
+int lro_conv_node_backward(const lro_conv* m, const float* x, int B, float t0, float t2, const lro_opts* o, int mode,
+                           int reg_type, float t1_or_rand, const float* du_end, float w_reg, float* dx, float* dp,
+                           lro_stats* st_fwd, lro_stats* st_bwd);
 
 /* ---- step kernels ---- */
 /* ks: optional (5*D*B) k2..k6; g6: optional (D*B) */

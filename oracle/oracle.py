@@ -86,6 +86,10 @@ def lib():
         L.lro_conv_rhs.argtypes = [C.POINTER(Conv), fp, C.c_float, C.c_int, fp]
         L.lro_conv_vjp.restype = None
         L.lro_conv_vjp.argtypes = [C.POINTER(Conv), fp, C.c_float, fp, C.c_int, fp, fp]
+        L.lro_conv_step_reg_grad.argtypes = [C.POINTER(Conv), fp, fp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                             C.c_int, C.c_int, fp, C.POINTER(C.c_float)]
+        L.lro_conv_node_backward.argtypes = [C.POINTER(Conv), fp, C.c_int, C.c_float, C.c_float, C.POINTER(Opts), C.c_int,
+                                             C.c_int, C.c_float, fp, C.c_float, fp, fp, C.POINTER(Stats), C.POINTER(Stats)]
         L.lro_conv_as_field.restype = None
         L.lro_conv_as_field.argtypes = [C.POINTER(Conv), C.POINTER(Field)]
         L.lro_mlp_as_field.restype = None
@@ -347,8 +351,9 @@ def step_reg_grad(fld, uprev, k1, t, dt, abstol, reltol, reg_type="error_estimat
     B = uprev.size // fld.D
     gp = np.zeros(fld.params.size, np.float32)
     rv = C.c_float()
-    rc = lib().lro_tsit5_step_reg_grad(C.byref(fld.m), _fp(uprev), _fp(k1), float(t), float(dt), float(abstol),
-                                       float(reltol), B, REG[reg_type], _fp(gp), C.byref(rv))
+    fn = lib().lro_conv_step_reg_grad if isinstance(fld, ConvField) else lib().lro_tsit5_step_reg_grad
+    rc = fn(C.byref(fld.m), _fp(uprev), _fp(k1), float(t), float(dt), float(abstol),
+            float(reltol), B, REG[reg_type], _fp(gp), C.byref(rv))
     assert rc == 0
     return gp, np.float32(rv.value)
 
@@ -361,7 +366,8 @@ def node_backward(fld, x, t0, t2, abstol, reltol, du_end, mode="unbiased", reg_t
     dx = np.empty_like(x)
     dp = np.zeros(fld.params.size, np.float32)
     sf, sb = Stats(), Stats()
-    rc = lib().lro_node_backward(C.byref(fld.m), _fp(x), B, float(t0), float(t2), C.byref(o), MODE[mode],
+    fn = lib().lro_conv_node_backward if isinstance(fld, ConvField) else lib().lro_node_backward
+    rc = fn(C.byref(fld.m), _fp(x), B, float(t0), float(t2), C.byref(o), MODE[mode],
                                  REG[reg_type], float(t1_or_rand), _fp(du_end), float(w_reg), _fp(dx), _fp(dp),
                                  C.byref(sf), C.byref(sb))
     return dict(retcode=rc, dx=dx, dp=dp, stats_fwd=sf.asdict(), stats_bwd=sb.asdict())

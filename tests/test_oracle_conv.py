@@ -182,3 +182,28 @@ def test_conv_vjp_matches_torch_autograd(W, H, C, Hc, B, train, act):
     dy_ref, gp_ref = ut.grad.numpy(), pt.grad.numpy()
     assert np.abs(dy - dy_ref).max() <= 3e-5 * np.abs(dy_ref).max()
     assert np.abs(gp - gp_ref).max() <= 3e-5 * np.abs(gp_ref).max()
+
+
+def test_conv_node_backward_matches_finite_differences():
+    """the field-agnostic backward drivers with the conv field: directional derivative of
+    L = <w, sol.u[end]> + w_reg * reg_val along a random parameter direction vs central differences (fp32 solve,
+    so only a loose agreement is asked; the drivers themselves are pinned by the MLP autograd tests)"""
+    W = H = 6; C = 4; Hc = 8; B = 2
+    p, u = _case(W, H, C, Hc, B, seed=4)
+    rng = np.random.default_rng(0)
+    wv = rng.standard_normal(u.shape).astype(np.float32)
+    d = rng.standard_normal(p.shape).astype(np.float32)
+    tol, w_reg, t1 = 1e-6, 0.0, 0.4
+
+    def loss(pp):
+        fld = O.ConvField(W, H, C, Hc, pp.astype(np.float32), nthreads=2)
+        r = O.node_forward(fld, u, 0.0, 1.0, tol, tol, mode="unbiased", t1_or_rand=t1, maxiters=5000)
+        return float((r["u_end"].astype(np.float64) * wv).sum()) + w_reg * float(r["reg_val"])
+
+    fld = O.ConvField(W, H, C, Hc, p, nthreads=2)
+    b = O.node_backward(fld, u, 0.0, 1.0, tol, tol, wv, mode="unbiased", t1_or_rand=t1, w_reg=w_reg, maxiters=5000)
+    assert b["retcode"] == 0
+    eps = 2e-3
+    fd = (loss(p + eps * d) - loss(p - eps * d)) / (2 * eps)
+    an = float((b["dp"].astype(np.float64) * d).sum())
+    assert abs(fd - an) <= 2e-2 * max(abs(fd), abs(an)) + 1e-4
