@@ -227,6 +227,12 @@ int lrnde_conv_node_forward(lrnde_conv* c, const float* x, int32_t B, float t0, 
  * gp (device, flat parameter layout, may be NULL) = (df/dp)^T lam; train-mode BatchNorm is differentiated through its
  * batch statistics.  fp32 compute only. */
 int lrnde_conv_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int32_t B, float* dy, float* gp);
+/* the conv-field instances of lrnde_step_reg_grad / lrnde_node_backward (same meaning, same reference lines) */
+int lrnde_conv_step_reg_grad(lrnde_conv* c, const float* uprev, const float* k1, int32_t B, float t, float dt, float abstol,
+                             float reltol, int32_t reg_type, float* gp, float* reg_val_host);
+int lrnde_conv_node_backward(lrnde_conv* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
+                             int32_t mode, int32_t reg_type, float t1_or_rand, const float* du_end, float w_reg,
+                             float* dx, float* dp, lrnde_stats* st_fwd, lrnde_stats* st_bwd);
 /* average microseconds of one f-eval (3 conv + 2 batch-norm statistics launches), HIP events */
 int lrnde_conv_bench_rhs(lrnde_conv* c, const float* u, float t, int32_t B, int32_t reps, float* us_host);
 

@@ -89,6 +89,9 @@ SYMBOLS = [
     ("lrnde_conv_node_forward", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _i32, _i32, _f, _vp,
                                           _fp, C.POINTER(_i32), C.POINTER(Stats), _fp]),
     ("lrnde_conv_vjp", C.c_int, [_vp, _vp, _f, _vp, _i32, _vp, _vp]),
+    ("lrnde_conv_step_reg_grad", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _vp, _fp]),
+    ("lrnde_conv_node_backward", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _i32, _i32, _f, _vp, _f, _vp, _vp,
+                                           C.POINTER(Stats), C.POINTER(Stats)]),
     ("lrnde_conv_bench_rhs", C.c_int, [_vp, _vp, _f, _i32, _i32, _fp]),
     ("lrnde_bench_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _fp]),
     ("lrnde_last_solve_kernel_ms", C.c_int, [_vp, _fp, C.POINTER(_i32)]),

@@ -189,6 +189,28 @@ class ConvHandle:
                                        C.c_void_p(gp.data_ptr()) if want_gp else None))
         return dy, gp
 
+    def step_reg_grad(self, uprev, k1, t, dt, abstol, reltol, reg_type="error_estimate"):
+        """d reg_val / d ps of one local Tsit5 step (k1, dt, uprev constant)."""
+        gp = torch.empty(self.param_count(), dtype=torch.float32, device=uprev.device)
+        rv = C.c_float()
+        self._chk(L.lib.lrnde_conv_step_reg_grad(self._ctx, _ptr(uprev, "uprev"), _ptr(k1, "k1"), self._B(uprev), float(t),
+                                                 float(dt), float(abstol), float(reltol), L.REG_TYPE[reg_type],
+                                                 C.c_void_p(gp.data_ptr()), C.byref(rv)))
+        return gp, np.float32(rv.value)
+
+    def node_backward(self, x, t0, t2, abstol, reltol, du_end, mode="unbiased", reg_type="error_estimate", t1_or_rand=0.5,
+                      w_reg=0.0, maxiters=1000, save_start=False, exact_pow=False):
+        """Pullback of the layer for loss = <du_end, sol.u[end]> + w_reg*reg_val -> (dx, dp)."""
+        o = L.SolveOpts(float(abstol), float(reltol), int(maxiters), int(save_start), 0, int(exact_pow))
+        dx = torch.empty_like(x)
+        dp = torch.empty(self.param_count(), dtype=torch.float32, device=x.device)
+        sf, sb = L.Stats(), L.Stats()
+        self._chk(L.lib.lrnde_conv_node_backward(self._ctx, _ptr(x, "x"), self._B(x), float(t0), float(t2), C.byref(o),
+                                                 L.MODE[mode], L.REG_TYPE[reg_type], float(t1_or_rand), _ptr(du_end, "du_end"),
+                                                 float(w_reg), _ptr(dx, "dx"), C.c_void_p(dp.data_ptr()), C.byref(sf),
+                                                 C.byref(sb)))
+        return dict(dx=dx, dp=dp, stats_fwd=sf.asdict(), stats_bwd=sb.asdict())
+
     def bench_rhs(self, u, t, reps=20):
         """average microseconds of one f-eval (HIP events on the handle's stream)."""
         us = C.c_float()

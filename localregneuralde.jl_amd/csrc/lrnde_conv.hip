@@ -891,6 +891,8 @@ __global__ void k_wgrad_reduce(const float* pw, const float* pt, int nwg, int GC
   }
 }
 
+#include "lrnde_regseed.hpp"
+
 // ---- elementwise pieces of the Tsit5 step (src/perform_step.jl:11-27, same operation order) -----
 struct LinArgs {
   float* out; const float* base; float dt; int nk; size_t n;
@@ -994,6 +996,11 @@ struct lrnde_conv {
   float *bwm = nullptr;                                    // m1_2 m2_2 m1_1 m2_1 (4*Hc)
   float *g1 = nullptr, *g2 = nullptr;                      // NHWC cotangents of the hidden layers
   double* part_bw = nullptr; float *pw = nullptr, *pt = nullptr; int bwB = 0;
+  // dense record of the accepted forward steps ([uprev, k1..k7] each) and what else the backward pass needs
+  bool dense_on = false; size_t dense_n = 0;
+  std::vector<float*> dense; std::vector<float> dense_t, dense_dt;
+  float* rec_u1 = nullptr; size_t rec_n = 0;
+  float* adj = nullptr; size_t adj_elems = 0;
 };
 
 namespace {
@@ -1242,13 +1249,13 @@ int fetch_sums(lrnde_conv* c, double* s3) {
 }
 
 // ode_determine_initdt (OrdinaryDiffEq, un-vendored): f0 -> k1 (= fsalfirst)
-int init_dt(lrnde_conv* c, const float* u0, int B, float t0, float tend, float abstol, float reltol, float* f0,
-            float* tmp, float* f1, float* dt_out) {
-  const size_t n = state_n(c, B);
+template <class RHS>
+int init_dt_g(lrnde_conv* c, size_t n, RHS&& rhs, const float* u0, float t0, float tend, float abstol, float reltol, float* f0,
+              float* tmp, float* f1, float* dt_out) {
   const float dtmax = tend - t0;
   int rc;
   double s[3];
-  if ((rc = launch_rhs(c, u0, t0, B, f0))) return rc;
+  if ((rc = rhs(u0, t0, f0))) return rc;
   hipLaunchKernelGGL(k_sums_init, dim3(NSUMB), dim3(256), 0, c->stream, u0, f0, (const float*)nullptr, abstol, reltol, n, c->sums);
   if ((rc = fetch_sums(c, s))) return rc;
   const float d0 = (float)sqrt(s[0] / (double)n), d1 = (float)sqrt(s[1] / (double)n);
@@ -1256,7 +1263,7 @@ int init_dt(lrnde_conv* c, const float* u0, int B, float t0, float tend, float a
   dt0 = fminf(dt0, dtmax);
   const float* kk[1] = {f0};
   if ((rc = lincomb(c, tmp, u0, 0.f, 1, kk, &dt0, n))) return rc;
-  if ((rc = launch_rhs(c, tmp, t0 + dt0, B, f1))) return rc;
+  if ((rc = rhs(tmp, t0 + dt0, f1))) return rc;
   hipLaunchKernelGGL(k_sums_init, dim3(NSUMB), dim3(256), 0, c->stream, u0, f0, (const float*)f1, abstol, reltol, n, c->sums);
   if ((rc = fetch_sums(c, s))) return rc;
   const float d2 = (float)sqrt(s[2] / (double)n) / dt0;
@@ -1268,10 +1275,16 @@ int init_dt(lrnde_conv* c, const float* u0, int B, float t0, float tend, float a
   return LRNDE_OK;
 }
 
-// one Tsit5 step (src/perform_step.jl:3-32): ks = k2..k6 (5 vectors), g6, tmp work vectors
-int tsit5_step(lrnde_conv* c, const float* uprev, const float* k1, int B, float t, float dt, float abstol, float reltol,
-               float* u, float* k7, float* ks, float* g6, float* tmp, double* sums3) {
-  const size_t n = state_n(c, B);
+int init_dt(lrnde_conv* c, const float* u0, int B, float t0, float tend, float abstol, float reltol, float* f0,
+            float* tmp, float* f1, float* dt_out) {
+  auto rhs = [&](const float* x, float tt, float* k) { return launch_rhs(c, x, tt, B, k); };
+  return init_dt_g(c, state_n(c, B), rhs, u0, t0, tend, abstol, reltol, f0, tmp, f1, dt_out);
+}
+
+// one Tsit5 step (src/perform_step.jl:3-32) on vectors of length n: ks = k2..k6 (5 vectors), g6, tmp work vectors
+template <class RHS>
+int tsit5_step_g(lrnde_conv* c, size_t n, RHS&& rhs, const float* uprev, const float* k1, float t, float dt, float abstol,
+                 float reltol, float* u, float* k7, float* ks, float* g6, float* tmp, double* sums3) {
   float A[21];
   for (int i = 0; i < 21; ++i) A[i] = (float)Tsit5::A[i];
   const float cs[6] = {(float)Tsit5::C[0], (float)Tsit5::C[1], (float)Tsit5::C[2], (float)Tsit5::C[3], 1.0f, 1.0f};
@@ -1283,7 +1296,7 @@ int tsit5_step(lrnde_conv* c, const float* uprev, const float* k1, int B, float 
     float* x = (s == 6) ? g6 : (s == 7) ? u : tmp;
     if (s == 2) { const float a21 = dt * A[0]; if ((rc = lincomb(c, x, uprev, 0.f, 1, K, &a21, n))) return rc; }
     else if ((rc = lincomb(c, x, uprev, dt, s - 1, K, A + off, n))) return rc;
-    if ((rc = launch_rhs(c, x, t + cs[s - 2] * dt, B, Kw[s - 1]))) return rc;
+    if ((rc = rhs(x, t + cs[s - 2] * dt, Kw[s - 1]))) return rc;
   }
   ErrArgs e;
   e.uprev = uprev; e.u = u; for (int j = 0; j < 7; ++j) e.k[j] = K[j];
@@ -1291,6 +1304,11 @@ int tsit5_step(lrnde_conv* c, const float* uprev, const float* k1, int B, float 
   hipLaunchKernelGGL(k_sums_err, dim3(NSUMB), dim3(256), 0, c->stream, e);
   CHK(c, hipGetLastError());
   return fetch_sums(c, sums3);
+}
+int tsit5_step(lrnde_conv* c, const float* uprev, const float* k1, int B, float t, float dt, float abstol, float reltol,
+               float* u, float* k7, float* ks, float* g6, float* tmp, double* sums3) {
+  auto rhs = [&](const float* x, float tt, float* k) { return launch_rhs(c, x, tt, B, k); };
+  return tsit5_step_g(c, state_n(c, B), rhs, uprev, k1, t, dt, abstol, reltol, u, k7, ks, g6, tmp, sums3);
 }
 
 void reg_values(const double* s, size_t n, float dt, float* eest, float* re, float* rs) {
@@ -1351,6 +1369,9 @@ int lrnde_conv_destroy(lrnde_conv* c) {
   if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
   void* ptrs[] = {c->params, c->w1t, c->w2t, c->w3t, c->zeros, c->bwm, c->g1, c->g2, c->part_bw, c->pw, c->pt, c->w1, c->w2, c->w3, c->ts1, c->ts2, c->ts3, c->bn, c->stat, c->bn_state, c->y1, c->y2, c->part, c->vec, c->sums};
   for (void* p : ptrs) if (p) hipFree(p);
+  for (float* d : c->dense) if (d) hipFree(d);
+  if (c->rec_u1) hipFree(c->rec_u1);
+  if (c->adj) hipFree(c->adj);
   if (c->sums_host) hipHostFree(c->sums_host);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
@@ -1463,6 +1484,7 @@ int lrnde_conv_solve(lrnde_conv* c, const float* u0, int32_t B, float t0, float 
   float *uprev = V, *u = V + n, *k1 = V + 2 * n, *ks = V + 3 * n, *k7 = V + 8 * n, *g6 = V + 9 * n, *tmp = V + 10 * n;
   int nsaved = 0, isave = 0, ntrace = 0;
   c->last_ts.clear();
+  if (c->dense_on) { c->dense_t.clear(); c->dense_dt.clear(); }
   auto push = [&](float tt, const float* uu) -> int {
     if (nsaved >= cap_saved || !u_saved) return cfail(c, LRNDE_CAPACITY, "u_saved capacity %d exhausted", cap_saved);
     CHK(c, hipMemcpyAsync(u_saved + (size_t)nsaved * n, uu, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
@@ -1517,6 +1539,17 @@ int lrnde_conv_solve(lrnde_conv* c, const float* u0, int32_t B, float t0, float 
       const float tprev = t;
       t = (fabsf(ttmp - t1) < 100.0f * eps_f(fmaxf(t, t1))) ? t1 : ttmp;
       dtpropose = fmaxf(fminf(dtmax, dtnew), fmaxf(eps_f(t), dtmin));
+      if (c->dense_on) {  // [uprev, k1, k2..k6, k7] of this step, for the adjoint's interpolant
+        const size_t idx = c->dense_t.size();
+        if (c->dense_n != n) { for (float* d : c->dense) if (d) hipFree(d); c->dense.clear(); c->dense_n = n; }
+        if (idx >= c->dense.size()) { float* d = nullptr; CHK(c, hipMalloc(&d, sizeof(float) * 8 * n)); c->dense.push_back(d); }
+        float* d = c->dense[idx];
+        CHK(c, hipMemcpyAsync(d, uprev, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+        CHK(c, hipMemcpyAsync(d + n, k1, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+        CHK(c, hipMemcpyAsync(d + 2 * n, ks, sizeof(float) * 5 * n, hipMemcpyDeviceToDevice, c->stream));
+        CHK(c, hipMemcpyAsync(d + 7 * n, k7, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+        c->dense_t.push_back(tprev); c->dense_dt.push_back(dt);
+      }
       while (isave < nsave && saveat[isave] <= t) {  // savevalues!
         const float tsv = saveat[isave++];
         if (tsv != t) {
@@ -1589,6 +1622,10 @@ int lrnde_conv_node_forward(lrnde_conv* c, const float* x, int32_t B, float t0, 
     hipMemcpy(u_end, us + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice);
   }
   if (t1_used) *t1_used = t1;
+  if (c->dense_on) {
+    if (c->rec_n != n) { if (c->rec_u1) hipFree(c->rec_u1); c->rec_u1 = nullptr; if (hipMalloc(&c->rec_u1, sizeof(float) * n) != hipSuccess) return done2(cfail(c, LRNDE_HIP_ERROR, "allocation failed")); c->rec_n = n; }
+    hipMemcpy(c->rec_u1, u1, sizeof(float) * n, hipMemcpyDeviceToDevice);
+  }
   // _get_ode_integrator :33-38 => init on (t1,t2); _perform_step :77
   float* V = c->vec;
   float dtl, ee, re, rs;
@@ -1614,6 +1651,216 @@ int lrnde_conv_bench_rhs(lrnde_conv* c, const float* u, float t, int32_t B, int3
   float ms = 0.f;
   CHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   *us_host = ms * 1000.0f / (float)reps;
+  return LRNDE_OK;
+}
+
+}  // extern "C"
+
+// ---- backward drivers (same structure as the MLP ones in lrnde_kernels.hip) ----------------------
+namespace {
+
+int ensure_adj(lrnde_conv* c, size_t elems) {
+  if (c->adj_elems >= elems) return LRNDE_OK;
+  if (c->adj) CHK(c, hipFree(c->adj));
+  c->adj = nullptr; c->adj_elems = 0;
+  CHK(c, hipMalloc(&c->adj, sizeof(float) * elems));
+  c->adj_elems = elems;
+  return LRNDE_OK;
+}
+
+// gradient of the local regularisation value w.r.t. p: reverse sweep through one Tsit5 step with k1, dt, uprev constant
+int step_reg_grad(lrnde_conv* c, const float* uprev, const float* k1, int B, float t, float dt, float abstol, float reltol,
+                  int reg_type, float* gp, float* reg_val_host) {
+  const size_t n = state_n(c, B), P = lrnde_conv_param_count(&c->d);
+  int rc;
+  if ((rc = ensure_adj(c, 11 * n + P))) return rc;
+  float* V = c->vec;  // forward step: u = V+n, k7 = V+8n, ks = V+3n.., g6 = V+9n, tmp = V+10n
+  float *u = V + n, *k7 = V + 8 * n, *ks = V + 3 * n, *g6 = V + 9 * n, *tmp = V + 10 * n;
+  double sm[3];
+  if ((rc = tsit5_step(c, uprev, k1, B, t, dt, abstol, reltol, u, k7, ks, g6, tmp, sm))) return rc;
+  float ee, re, rs;
+  reg_values(sm, n, dt, &ee, &re, &rs);
+  if (reg_val_host) *reg_val_host = (reg_type == LRNDE_REG_STIFFNESS_ESTIMATE) ? rs : re;
+  const float* kk[7] = {k1, ks, ks + n, ks + 2 * n, ks + 3 * n, ks + 4 * n, k7};
+  float* A0 = c->adj;
+  float* kb[7] = {nullptr, A0, A0 + n, A0 + 2 * n, A0 + 3 * n, A0 + 4 * n, A0 + 5 * n};
+  float *ub = A0 + 6 * n, *g6b = A0 + 7 * n, *xs = A0 + 8 * n, *xb = A0 + 9 * n, *gtmp = A0 + 11 * n;
+  CHK(c, hipMemsetAsync(A0, 0, sizeof(float) * 8 * n, c->stream));
+  CHK(c, hipMemsetAsync(gp, 0, sizeof(float) * P, c->stream));
+  RegSeedArgs sa;
+  sa.n = n; sa.uprev = uprev; sa.u = u; sa.g6 = g6;
+  for (int j = 0; j < 7; ++j) sa.k[j] = kk[j];
+  sa.kb[0] = nullptr;
+  for (int j = 1; j < 7; ++j) sa.kb[j] = kb[j];
+  sa.ub = ub; sa.g6b = g6b; sa.dt = dt; sa.abstol = abstol; sa.reltol = reltol; sa.reg_type = reg_type;
+  sa.eest = ee; sa.num = (float)sqrt(sm[1] / (double)n); sa.den = (float)sqrt(sm[2] / (double)n);
+  { int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_reg_seed, dim3(nb), dim3(256), 0, c->stream, sa); CHK(c, hipGetLastError()); }
+  float A[21];
+  for (int i = 0; i < 21; ++i) A[i] = (float)Tsit5::A[i];
+  const float cs[6] = {(float)Tsit5::C[0], (float)Tsit5::C[1], (float)Tsit5::C[2], (float)Tsit5::C[3], 1.0f, 1.0f};
+  const float one = 1.0f;
+  for (int sidx = 7; sidx >= 2; --sidx) {
+    const int off = (sidx - 2) * (sidx - 1) / 2;
+    const float* x;
+    if (sidx == 7) x = u;
+    else if (sidx == 6) x = g6;
+    else {
+      if (sidx == 2) { const float a21 = dt * A[0]; if ((rc = lincomb(c, xs, uprev, 0.f, 1, kk, &a21, n))) return rc; }
+      else if ((rc = lincomb(c, xs, uprev, dt, sidx - 1, kk, A + off, n))) return rc;
+      x = xs;
+    }
+    if ((rc = launch_vjp(c, x, t + cs[sidx - 2] * dt, kb[sidx - 1], B, xb, gtmp))) return rc;
+    { const float* g1[1] = {gtmp}; if ((rc = lincomb(c, gp, gp, 0.f, 1, g1, &one, P))) return rc; }
+    if (sidx == 7) { const float* g1[1] = {ub}; if ((rc = lincomb(c, xb, xb, 0.f, 1, g1, &one, n))) return rc; }
+    if (sidx == 6) { const float* g1[1] = {g6b}; if ((rc = lincomb(c, xb, xb, 0.f, 1, g1, &one, n))) return rc; }
+    for (int j = 1; j < sidx - 1; ++j) {  // kbar_{j+1} += dt * a_{s,j+1} * xbar
+      const float cf = dt * A[off + j];
+      const float* g1[1] = {xb};
+      if ((rc = lincomb(c, kb[j], kb[j], 0.f, 1, g1, &cf, n))) return rc;
+    }
+  }
+  CHK(c, hipStreamSynchronize(c->stream));
+  return LRNDE_OK;
+}
+
+// adaptive Tsit5 on z = [lambda; mu] in reversed time (InterpolatingAdjoint restatement): s from s0 to s1 with tstops
+template <class RHS>
+int adjoint_solve(lrnde_conv* c, size_t N, RHS&& rhs, float* Z, float s0, float s1, const lrnde_solve_opts* o,
+                  const std::vector<float>& tstops, lrnde_stats* st) {
+  const float abstol = o->abstol, reltol = o->reltol;
+  const float gamma = 0.9f, qmin = 0.2f, qmax = 10.0f, qoldinit = 1e-4f;
+  const float beta1 = (float)(7.0 / 50.0), beta2 = (float)(2.0 / 25.0);
+  memset(st, 0, sizeof(*st));
+  float *z = Z, *zn = Z + N, *k1 = Z + 2 * N, *ks = Z + 3 * N, *k7 = Z + 8 * N, *g6 = Z + 9 * N, *tmp = Z + 10 * N;
+  int rc;
+  float t = s0;
+  const float dtmax = s1 - s0;
+  const float dtmin = fmaxf(eps_f(s1), eps_f(s0));
+  float dt;
+  if ((rc = init_dt_g(c, N, rhs, z, s0, s1, abstol, reltol, k1, tmp, g6, &dt))) return rc;
+  st->nf = 3; st->dt_init = dt;
+  float qold = qoldinit, q11 = 1.0f, dtpropose = dt;
+  int accept = 0, iter = 0;
+  size_t istop = 0;
+  while (istop < tstops.size() && tstops[istop] <= s0) ++istop;
+  rc = LRNDE_OK;
+  while (t < s1) {
+    while (istop < tstops.size() && tstops[istop] <= t) ++istop;
+    const float tstop = (istop < tstops.size() && tstops[istop] < s1) ? tstops[istop] : s1;
+    if (iter > 0) {
+      if (accept) { std::swap(z, zn); std::swap(k1, k7); dt = dtpropose; }
+      else dt = dt / fminf(1.0f / qmin, q11 / gamma);
+    }
+    ++iter;
+    dt = fminf(dtmax, dt); dt = fmaxf(dt, dtmin); dt = fminf(fabsf(dt), fabsf(tstop - t));
+    if (iter > o->maxiters) { rc = LRNDE_MAXITERS; break; }
+    if (dt != dt) { rc = LRNDE_DT_NAN; break; }
+    if (fabsf(dt) <= fabsf(dtmin)) { rc = LRNDE_DT_LESS_THAN_MIN; break; }
+    double sm[3];
+    int r2;
+    // g6 doubles as the stage-6 state; its stiffness sums are not used here
+    if ((r2 = tsit5_step_g(c, N, rhs, z, k1, t, dt, abstol, reltol, zn, k7, ks, g6, tmp, sm))) return r2;
+    st->nf += 6;
+    const float eest = (float)sqrt(sm[0] / (double)N);
+    st->eest_last = eest;
+    if (eest != eest) { rc = LRNDE_DT_NAN; break; }
+    const float ttmp = t + dt;
+    float q;
+    if (eest == 0.0f) q = 1.0f / qmax;
+    else {
+      if (o->exact_pow) { q11 = (float)pow((double)eest, (double)beta1); q = q11 / (float)pow((double)qold, (double)beta2); }
+      else { q11 = fastpow(eest, beta1); q = q11 / fastpow(qold, beta2); }
+      q = fmaxf(1.0f / qmax, fminf(1.0f / qmin, q / gamma));
+    }
+    accept = (eest <= 1.0f);
+    if (accept) {
+      st->naccept++;
+      const float dtnew = dt / q;
+      qold = fmaxf(eest, qoldinit);
+      t = (fabsf(ttmp - tstop) < 100.0f * eps_f(fmaxf(t, tstop))) ? tstop : ttmp;
+      dtpropose = fmaxf(fminf(dtmax, dtnew), fmaxf(eps_f(t), dtmin));
+    } else st->nreject++;
+  }
+  if (accept && rc == LRNDE_OK) std::swap(z, zn);
+  if (z != Z) CHK(c, hipMemcpyAsync(Z, z, sizeof(float) * N, hipMemcpyDeviceToDevice, c->stream));
+  st->retcode = rc; st->iters = iter; st->t_final = t; st->dt_final = dt;
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lrnde_conv_step_reg_grad(lrnde_conv* c, const float* uprev, const float* k1, int32_t B, float t, float dt, float abstol,
+                             float reltol, int32_t reg_type, float* gp, float* reg_val_host) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!uprev || !k1 || !gp) return cfail(c, LRNDE_BADARG, "null pointer");
+  return step_reg_grad(c, uprev, k1, B, t, dt, abstol, reltol, reg_type, gp, reg_val_host);
+}
+
+// backward of  loss = <du_end, sol.u[end]> + w_reg * reg_val  through the NeuralODE layer over the conv field
+int lrnde_conv_node_backward(lrnde_conv* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
+                             int32_t mode, int32_t reg_type, float t1_or_rand, const float* du_end, float w_reg,
+                             float* dx, float* dp, lrnde_stats* st_fwd, lrnde_stats* st_bwd) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!x || !o || !du_end || !dx || !dp || !st_fwd || !st_bwd) return cfail(c, LRNDE_BADARG, "null pointer");
+  if (c->d.compute_dtype != LRNDE_F32) return cfail(c, LRNDE_UNSUPPORTED, "the conv backward pass is fp32 only");
+  const size_t n = state_n(c, B), P = lrnde_conv_param_count(&c->d), N = n + P;
+  // 1. forward with the dense record
+  float* u_end = nullptr;
+  CHK(c, hipMalloc(&u_end, sizeof(float) * n));
+  float regv = 0.f, t1 = t2; int nfe = 0;
+  c->dense_on = true;
+  rc = lrnde_conv_node_forward(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, u_end, &regv, &nfe, st_fwd, &t1);
+  c->dense_on = false;
+  hipFree(u_end);
+  if (rc) return rc;
+  // the local step of node_forward re-solved nothing: last_ts / dense_t describe the main solve (dense record is
+  // only appended inside lrnde_conv_solve)
+  const std::vector<float> dts = c->dense_t, dds = c->dense_dt;
+  std::vector<float> stops;
+  if (mode != LRNDE_MODE_NONE)
+    for (int i = (int)c->last_ts.size() - 1; i >= 0; --i) { const float tv = c->last_ts[i]; if (tv > t0 && tv < t2) stops.push_back(-tv); }
+  // 2. adjoint solve
+  if ((rc = ensure_adj(c, 11 * N + n))) return rc;
+  float* Z = c->adj; float* ybuf = c->adj + 11 * N;
+  CHK(c, hipMemsetAsync(Z, 0, sizeof(float) * N, c->stream));
+  CHK(c, hipMemcpyAsync(Z, du_end, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  auto rhs = [&](const float* zs, float sg, float* K) -> int {
+    const float t = -sg;
+    int lo = 0, hi = (int)dts.size() - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (dts[mid] <= t) lo = mid; else hi = mid - 1; }
+    const float theta = (t - dts[lo]) / dds[lo];
+    float bw[7];
+    tsit5_bweights(theta, bw);
+    const float* d = c->dense[lo];
+    const float* K7[7] = {d + n, d + 2 * n, d + 3 * n, d + 4 * n, d + 5 * n, d + 6 * n, d + 7 * n};
+    int r;
+    if ((r = lincomb(c, ybuf, d, dds[lo], 7, K7, bw, n))) return r;
+    return launch_vjp(c, ybuf, t, zs, B, K, K + n);
+  };
+  rc = adjoint_solve(c, N, rhs, Z, -t2, -t0, o, stops, st_bwd);
+  if (rc) return cfail(c, rc, "adjoint solve stopped with retcode %d", rc);
+  CHK(c, hipMemcpyAsync(dx, Z, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  CHK(c, hipMemcpyAsync(dp, Z + n, sizeof(float) * P, hipMemcpyDeviceToDevice, c->stream));
+  CHK(c, hipStreamSynchronize(c->stream));
+  // 3. regulariser: dp += w_reg * d reg_val / d p
+  if (mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
+    float *k1 = nullptr, *gr = nullptr;
+    CHK(c, hipMalloc(&k1, sizeof(float) * n));
+    CHK(c, hipMalloc(&gr, sizeof(float) * P));
+    float dtl = 0.f, rv = 0.f;
+    float* V = c->vec;
+    rc = init_dt(c, c->rec_u1, B, t1, t2, o->abstol, o->reltol, k1, V + 10 * n, V + 9 * n, &dtl);
+    if (!rc) rc = step_reg_grad(c, c->rec_u1, k1, B, t1, dtl, o->abstol, o->reltol, reg_type, gr, &rv);
+    if (!rc) { const float* g1[1] = {gr}; rc = lincomb(c, dp, dp, 0.f, 1, g1, &w_reg, P); }
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = LRNDE_HIP_ERROR;
+    hipFree(k1); hipFree(gr);
+    if (rc) return rc;
+  }
   return LRNDE_OK;
 }
 

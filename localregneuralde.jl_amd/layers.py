@@ -411,9 +411,7 @@ class NeuralODE:
         """What `Zygote.pullback` returns for this layer in the reference's training step
         (experiments/src/utils.jl:104-115) for  loss = <du_end, sol.u[end]> + w_reg * reg_val:
         (dx, dps).  The forward is re-run with the same rng draw as `__call__` would make."""
-        if self._conv:
-            raise NotImplementedError("the conv field's backward pass is not built")
-        h = self._bind(ps)
+        h = self._bind(ps, x)
         t0, t2 = self.tspan
         kw = self.kwargs
         if kw.get("saveat", None) is not None:

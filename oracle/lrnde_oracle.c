@@ -1053,7 +1053,7 @@ void lro_conv_vjp(const lro_conv* m, const float* y, float t, const float* lam, 
   batchnorm_act_bwd(a1, d1, B, Hc, plane, p + o_g1, p + o_b1, m->bn_train, st ? st : NULL, st ? st + Hc : NULL, m->eps,
                     m->act, g ? g + o_g1 : NULL, g ? g + o_b1 : NULL, nth);
   conv3x3_t_bwd(y, d1, B, C, Hc, H, W, p + o_w1, t, dy, g ? g + o_w1 : NULL, nth);
-  if (gp) { for (int i = 0; i < P; ++i) gp[i] = (float)g[i]; free(g); }
+  if (gp) { for (int i = 0; i < P; ++i) gp[i] += (float)g[i]; free(g); } /* accumulates, like lro_mlp_vjp */
   free(a1); free(h1); free(a2); free(h2); free(d2); free(d1);
 }
 

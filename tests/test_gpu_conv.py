@@ -217,3 +217,43 @@ def test_conv_vjp_matches_oracle(W, H, B, train, act):
         sc = np.abs(gp_ref[sl]).max()
         err = np.abs(gp[sl] - gp_ref[sl]).max()
         assert err <= 5e-5 * sc, f"{name}: {err:.3e} vs scale {sc:.3e}"
+
+
+@pytest.mark.parametrize("reg_type", ["error_estimate", "stiffness_estimate"])
+def test_conv_step_reg_grad_matches_oracle(reg_type):
+    """d reg_val / d p through one Tsit5 step of the conv field; 2e-3 of the gradient's scale (the seed is a
+    cancellation-prone fp32 quantity, see test_conv_node_forward_matches_oracle)"""
+    P, O = _mods()
+    W = H = 8; B = 3
+    fld, h, p, u = _case(W, H, B, seed=31, scale=2.0)
+    ud = torch.from_numpy(u).cuda()
+    k1 = fld.rhs(u.reshape(B, -1), 0.2)
+    dt = 0.25
+    g_ref, rv_ref = O.step_reg_grad(fld, u.reshape(B, -1), k1, 0.2, dt, 1e-4, 1e-4, reg_type=reg_type)
+    g, rv = h.step_reg_grad(ud, torch.from_numpy(k1.reshape(u.shape)).cuda(), 0.2, dt, 1e-4, 1e-4, reg_type=reg_type)
+    assert abs(float(rv) - float(rv_ref)) <= 5e-3 * abs(float(rv_ref))
+    g = g.cpu().numpy()
+    assert np.abs(g - g_ref).max() <= 1e-2 * np.abs(g_ref).max()
+    assert _rel(g, g_ref) <= 1e-2
+
+
+def _rel(a, b):
+    return np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-30)
+
+
+@pytest.mark.parametrize("mode,w_reg", [("unbiased", 2.5), ("none", 0.0)])
+def test_conv_node_backward_matches_oracle(mode, w_reg):
+    P, O = _mods()
+    W = H = 8; B = 3
+    fld, h, p, u = _case(W, H, B, seed=41, scale=1.5)
+    wv = np.random.default_rng(3).standard_normal(u.shape).astype(np.float32)
+    tol = 1e-4
+    bo = O.node_backward(fld, u.reshape(B, -1), 0.0, 1.0, tol, tol, wv.reshape(B, -1), mode=mode, t1_or_rand=0.41, w_reg=w_reg,
+                         maxiters=5000)
+    bg = h.node_backward(torch.from_numpy(u).cuda(), 0.0, 1.0, tol, tol, torch.from_numpy(wv).cuda(), mode=mode, t1_or_rand=0.41,
+                         w_reg=w_reg, maxiters=5000)
+    assert bo["retcode"] == 0
+    assert bg["stats_fwd"]["naccept"] == bo["stats_fwd"]["naccept"]
+    assert abs(bg["stats_bwd"]["naccept"] - bo["stats_bwd"]["naccept"]) <= 1
+    assert _rel(bg["dx"].cpu().numpy().reshape(B, -1), bo["dx"]) <= 2e-3
+    assert _rel(bg["dp"].cpu().numpy(), bo["dp"]) <= 5e-3
