@@ -234,6 +234,20 @@ def conv_main(args):
         steps_total += r["stats"]["naccept"] + r["stats"]["nreject"] + 1
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    fwd_adj_ms, bwd = None, None
+    if dt == "f32" and args.adjoint_steps > 0:  # pullback of <g, sol.u[end]> + 2.5*reg_val, g ~ 1e-3*N(0,1) (a mean-loss cotangent's size)
+        g = torch.from_numpy((np.random.default_rng(2).standard_normal(xh.shape) * 1e-3).astype(np.float32)).cuda()
+        nb = min(args.adjoint_steps, 3)
+        h.node_backward(x, 0.0, 1.0, tol, tol, g, mode="unbiased", t1_or_rand=float(t1s[0]), w_reg=2.5, maxiters=10000)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for i in range(nb):
+            rb = h.node_backward(x, 0.0, 1.0, tol, tol, g, mode="unbiased", t1_or_rand=float(t1s[i % len(t1s)]), w_reg=2.5,
+                                 maxiters=10000)
+        torch.cuda.synchronize()
+        fwd_adj_ms = (time.perf_counter() - tb) / nb * 1e3
+        bwd = {"adjoint_naccept": rb["stats_bwd"]["naccept"], "adjoint_nreject": rb["stats_bwd"]["nreject"],
+               "adjoint_nf": rb["stats_bwd"]["nf"]}
     us = h.bench_rhs(x, 0.3, reps=20)  # HIP events on the handle's stream around 20 f-evals
     flop = CONV_FLOP_PER_PIXEL * W * H * B
     peak = PEAK_BF16_MFMA_TFLOPS if dt == "bf16" else PEAK_F32_MFMA_TFLOPS
@@ -247,7 +261,8 @@ def conv_main(args):
                                f"{W}x{H}x8xB={B}, BatchNorm {'batch' if train else 'running'} statistics, Tsit5 adaptive "
                                f"abstol=reltol={tol:g}, tspan=(0,1), regularize=unbiased/error_estimate, forward pass",
                    "global_batch": B, "parallelism": "single GPU", "nfe_per_pass": nfe_total / steps,
-                   "rk_steps_per_sec": steps_total / el, "fwd_ms_per_batch": el / steps * 1e3},
+                   "rk_steps_per_sec": steps_total / el, "fwd_ms_per_batch": el / steps * 1e3,
+                   "fwd_plus_adjoint_ms_per_batch": fwd_adj_ms, "adjoint": bwd},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": None, "kernel": "one f-eval = k_conv_wide(conv1) + k_bn_finalize + k_conv_wide(conv2) + "
                                                 "k_bn_finalize + k_conv_out(conv3)",

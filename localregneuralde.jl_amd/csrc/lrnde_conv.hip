@@ -868,26 +868,49 @@ __global__ __launch_bounds__(CNT) void k_conv_wgrad(WgradArgs a) {
     a.pt[((size_t)blockIdx.x * 9 + c) * GC + co] = t;
   }
 }
-// gp[kx + 3(ky + 3(ci + (CIN+1) co))] = sum over workgroups (fixed order); the t plane's weights from the class sums
-__global__ void k_wgrad_reduce(const float* pw, const float* pt, int nwg, int GC, int IC, int CIN, int COUT, float t, float* gw) {
-  const int total = 9 * (CIN + 1) * COUT;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int kx = i % 3, ky = (i / 3) % 3, ci = (i / 9) % (CIN + 1), co = i / (9 * (CIN + 1));
-    const int tp = ky * 3 + kx;
+// gp[kx + 3(ky + 3(ci + (CIN+1) co))] = sum over workgroups (fixed order).  Thread (e, pg): element e of the
+// [tap][co][ci] partial image (coalesced over ci), quarter pg of the workgroups; the quarters are added in order.
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* pw, int nwg, int GC, int IC, int CIN, int COUT, float* gw) {
+  __shared__ double red[4][64];
+  const int el = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int E = 9 * GC * IC;
+  const int e = blockIdx.x * 64 + el;
+  double s = 0.0;
+  if (e < E) {
+    const int w0 = (nwg * pg) / 4, w1 = (nwg * (pg + 1)) / 4;
+    for (int w = w0; w < w1; ++w) s += (double)pw[(size_t)w * E + e];
+  }
+  red[pg][el] = s;
+  __syncthreads();
+  if (pg == 0 && e < E) {
+    const double tot = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+    const int ci = e % IC, co = (e / IC) % GC, tp = e / (IC * GC);
+    if (ci < CIN && co < COUT) { const int ky = tp / 3, kx = tp % 3; gw[kx + 3 * (ky + 3 * (ci + (size_t)(CIN + 1) * co))] = (float)tot; }
+  }
+}
+// the t plane's weights: t * (sum over the border classes in which the tap is inside the image) of sum_p G[p][co]
+__global__ __launch_bounds__(256) void k_wgrad_reduce_t(const float* pt, int nwg, int GC, int CIN, int COUT, float t, float* gw) {
+  __shared__ double red[9][256];
+  const int co = blockIdx.x, tid = threadIdx.x;
+  for (int cls = 0; cls < 9; ++cls) {
     double s = 0.0;
-    if (ci < CIN) {
-      for (int w = 0; w < nwg; ++w) s += (double)pw[(((size_t)w * 9 + tp) * GC + co) * IC + ci];
-    } else {
-      for (int cls = 0; cls < 9; ++cls) {
-        const int rc = cls / 3, cc = cls % 3;
-        if ((rc == 0 && ky == 2) || (rc == 2 && ky == 0) || (cc == 0 && kx == 2) || (cc == 2 && kx == 0)) continue;
-        double d = 0.0;
-        for (int w = 0; w < nwg; ++w) d += (double)pt[((size_t)w * 9 + cls) * GC + co];
-        s += d;
-      }
-      s *= (double)t;
+    for (int w = tid; w < nwg; w += 256) s += (double)pt[((size_t)w * 9 + cls) * GC + co];
+    red[cls][tid] = s;
+  }
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (tid < o) for (int cls = 0; cls < 9; ++cls) red[cls][tid] += red[cls][tid + o];
+    __syncthreads();
+  }
+  if (tid < 9 && co < COUT) {
+    const int ky = tid / 3, kx = tid % 3;
+    double s = 0.0;
+    for (int cls = 0; cls < 9; ++cls) {
+      const int rc = cls / 3, cc = cls % 3;
+      if ((rc == 0 && ky == 2) || (rc == 2 && ky == 0) || (cc == 0 && kx == 2) || (cc == 2 && kx == 0)) continue;
+      s += red[cls][0];
     }
-    gw[i] = (float)s;
+    gw[kx + 3 * (ky + 3 * (CIN + (size_t)(CIN + 1) * co))] = (float)(s * (double)t);
   }
 }
 
@@ -1205,7 +1228,8 @@ int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, 
     if (GM && IM) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
     else if (GM) hipLaunchKernelGGL((k_conv_wgrad<1, 0>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
     else hipLaunchKernelGGL((k_conv_wgrad<0, 1>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(64), dim3(256), 0, c->stream, (const float*)c->pw, (const float*)c->pt, nwgw, GC, IC, CINr, COUTr, t, gw);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((9 * GC * IC + 63) / 64), dim3(256), 0, c->stream, (const float*)c->pw, nwgw, GC, IC, CINr, COUTr, gw);
+    hipLaunchKernelGGL(k_wgrad_reduce_t, dim3(GC), dim3(256), 0, c->stream, (const float*)c->pt, nwgw, GC, CINr, COUTr, t, gw);
     CHK(c, hipGetLastError());
     return LRNDE_OK;
   };
