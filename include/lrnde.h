@@ -236,6 +236,13 @@ int lrnde_conv_node_backward(lrnde_conv* c, const float* x, int32_t B, float t0,
 /* average microseconds of one f-eval (3 conv + 2 batch-norm statistics launches), HIP events */
 int lrnde_conv_bench_rhs(lrnde_conv* c, const float* u, float t, int32_t B, int32_t reps, float* us_host);
 
+/* `_perform_step(integrator, cache::RKMilCommuteConstantCache, p)`, src/perform_step.jl:108-170, diagonal noise,
+ * Ito interpretation: u = K + L*dW + Dgj*J with J = dW^2/2 - |dt|/2, EEst from the 4-argument
+ * _calculate_residuals (:218-220); returns u, EEst and EEst*dt.  The reference's du2/En are dead code there
+ * (their `tmp` is overwritten at :166) and are not evaluated: 1 drift + 2 diffusion evaluations. */
+int lrnde_sde_rkmil_step(lrnde_sde* sde, const float* uprev, const float* dW, int32_t B, float t, float dt,
+                         float abstol, float reltol, float* u, float* eest_host, float* reg_val_host);
+
 /* ---- backward pass ----
  * lrnde_vjp: the vector-Jacobian product Zygote.pullback(dudt, y, p, t) computes inside the adjoint
  * RHS (SciMLSensitivity ZygoteVJP): dy = (df/dy)^T lam, gp = (df/dp)^T lam (flat Lux layout, may be

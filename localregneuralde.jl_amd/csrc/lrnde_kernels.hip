@@ -1313,6 +1313,69 @@ template <int W> __global__ __launch_bounds__(NT) void k_sde_step(StepArgs a) {
   }
 }
 
+// Milstein step, diagonal noise, Ito (src/perform_step.jl:108-170): 1 drift + 2 diffusion evaluations.  The
+// reference's du2 = f(K, t+dt) and En only feed a `tmp` that is overwritten before EEst (:163-166), so they
+// are not evaluated.  EEst = rms((u - uprev) / (abstol + max(|uprev|,|u|) reltol)) (:166, :218-220).
+template <int W> __global__ __launch_bounds__(NT) void k_sde_rkmil(StepArgs a) {
+  const Smem s = carve(a.m);
+  const int b0 = blockIdx.x * NB, nvalid = min(NB, a.B - b0);
+  const size_t n = (size_t)a.n_local;
+  float *du1 = a.sde_scratch, *Kb = du1 + n, *L = du1 + 2 * n, *gt = du1 + 3 * n;
+  const float* up = a.sde_uprev;
+  const float t = a.t0, dt = a.bench_dt;
+  const float sqdt = __builtin_sqrtf(dt);
+  {
+    const int KG2a = ((a.m.KG2 + SEGK - 1) / SEGK) * SEGK, KG2b = ((a.m2.KG2 + SEGK - 1) / SEGK) * SEGK;
+    const int kmax = KG2a > KG2b ? KG2a : KG2b;
+    for (int i = threadIdx.x; i < kmax * 256; i += NT) s.hl[i] = 0.f;
+  }
+  auto fill = [&](auto&& fn) {
+    __syncthreads();
+    tile_foreach<W>(a.m, b0, nvalid, [&](int row, int nn, bool valid, size_t g) {
+      Vec<W> x = vzero<W>();
+      if (valid) x = fn(g);
+      lds_put<W>(s.xl, row, nn, x);
+    });
+    __syncthreads();
+  };
+  fill([&](size_t g) { return vload<W>(up + g); });
+  sde_feval<W>(a.m, t, du1, b0, nvalid);                      // :130 du1 = f(uprev, t)
+  sde_feval<W>(a.m2, t, L, b0, nvalid);                       // :131 L = g(uprev, t)
+  fill([&](size_t g) {                                        // :133, :136-137 tmp = K + sqdt*L (Ito)
+    const Vec<W> u = vload<W>(up + g), d = vload<W>(du1 + g), l = vload<W>(L + g);
+    Vec<W> k, x;
+#pragma unroll
+    for (int h = 0; h < W; ++h) { k.v[h] = u.v[h] + dt * d.v[h]; x.v[h] = k.v[h] + sqdt * l.v[h]; }
+    vstore<W>(Kb + g, k);
+    return x;
+  });
+  sde_feval<W>(a.m2, t, gt, b0, nvalid);                      // :138 gtmp = g(tmp, t)
+  __syncthreads();
+  const float hdt = 0.5f * __builtin_fabsf(dt);
+  double acc = 0.0, z1 = 0.0, z2 = 0.0;
+  tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
+    if (!valid) return;
+    const Vec<W> u = vload<W>(up + g), k = vload<W>(Kb + g), l = vload<W>(L + g), gg = vload<W>(gt + g), w = vload<W>(a.dW + g);
+    Vec<W> un;
+#pragma unroll
+    for (int h = 0; h < W; ++h) {
+      const float J = (0.5f * w.v[h]) * w.v[h] - hdt;                         // :117, :122
+      const float Dgj = (gg.v[h] - l.v[h]) / sqdt;                            // :139
+      un.v[h] = (k.v[h] + l.v[h] * w.v[h]) + Dgj * J;                         // :141
+      const float sc = a.abstol + fmaxf_(__builtin_fabsf(u.v[h]), __builtin_fabsf(un.v[h])) * a.reltol;
+      const float r = (un.v[h] - u.v[h]) / sc;                                // :166, :218-220
+      const float sq = r * r;
+      acc += (double)sq;
+    }
+    vstore<W>(a.sde_u + g, un);
+  });
+  block_sum3(s.red, acc, z1, z2);
+  if (threadIdx.x == 0) {
+    double* p = a.part_send + ((size_t)a.nwg_global + a.wg_offset + blockIdx.x) * PSTRIDE;
+    p[0] = acc; p[1] = 0.0; p[2] = 0.0;
+  }
+}
+
 #include "lrnde_qtile.hpp"
 #include "lrnde_backward.hpp"
 
@@ -1630,6 +1693,8 @@ int set_smem_attr() {
   hipFuncSetAttribute((const void*)k_vjp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_sde_step<4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_sde_step<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_sde_rkmil<4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_sde_rkmil<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   done = true;
   return 0;
 }
@@ -2153,9 +2218,19 @@ int lrnde_sde_set_params(lrnde_sde* s, const float* p_drift, size_t n_drift, con
   return lrnde_set_params(s->diff, s->p2, lrnde_param_count(&s->diff->desc));
 }
 
+static int sde_step_impl(lrnde_sde* s, int which, const float* uprev, const float* dW, int32_t B, float t, float dt,
+                         float abstol, float reltol, float delta, float* u, float* eest_host, float* reg_val_host);
 int lrnde_sde_euler_heun_step(lrnde_sde* s, const float* uprev, const float* dW, int32_t B, float t, float dt,
                               float abstol, float reltol, float delta, float* u, float* eest_host,
                               float* reg_val_host) {
+  return sde_step_impl(s, 0, uprev, dW, B, t, dt, abstol, reltol, delta, u, eest_host, reg_val_host);
+}
+int lrnde_sde_rkmil_step(lrnde_sde* s, const float* uprev, const float* dW, int32_t B, float t, float dt,
+                         float abstol, float reltol, float* u, float* eest_host, float* reg_val_host) {
+  return sde_step_impl(s, 1, uprev, dW, B, t, dt, abstol, reltol, 0.f, u, eest_host, reg_val_host);
+}
+static int sde_step_impl(lrnde_sde* s, int which, const float* uprev, const float* dW, int32_t B, float t, float dt,
+                         float abstol, float reltol, float delta, float* u, float* eest_host, float* reg_val_host) {
   if (!s) return LRNDE_BADARG;
   lrnde_ctx* c = s->drift;
   int rc = check_ready(c, B);
@@ -2174,7 +2249,10 @@ int lrnde_sde_euler_heun_step(lrnde_sde* s, const float* uprev, const float* dW,
   const size_t sm2 = smem_bytes(s->diff->m.Dp, s->diff->m.Hp);
   if (sm2 > sm) sm = sm2;
   hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t, dt, 0, 0);
-  if (vecw(c) == 4) hipLaunchKernelGGL(k_sde_step<4>, dim3(nwg), dim3(NT), sm, c->stream, a);
+  if (which == 1) {
+    if (vecw(c) == 4) hipLaunchKernelGGL(k_sde_rkmil<4>, dim3(nwg), dim3(NT), sm, c->stream, a);
+    else hipLaunchKernelGGL(k_sde_rkmil<1>, dim3(nwg), dim3(NT), sm, c->stream, a);
+  } else if (vecw(c) == 4) hipLaunchKernelGGL(k_sde_step<4>, dim3(nwg), dim3(NT), sm, c->stream, a);
   else hipLaunchKernelGGL(k_sde_step<1>, dim3(nwg), dim3(NT), sm, c->stream, a);
   HIPCHK(c, hipGetLastError());
   const size_t cnt = (size_t)a.nwg_global * PSTRIDE;

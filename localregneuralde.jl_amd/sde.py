@@ -63,6 +63,16 @@ class SdeHandle:
                                                   _dev_ptr(u, "u"), C.byref(ee), C.byref(rv)))
         return dict(u=u, eest=np.float32(ee.value), reg_val=np.float32(rv.value))
 
+    def rkmil_step(self, uprev, dW, t, dt, abstol, reltol):
+        """`_perform_step(integrator, ::RKMilCommuteConstantCache, p)` (src/perform_step.jl:108-170), diagonal noise, Ito."""
+        B = uprev.numel() // self.D
+        u = torch.empty_like(uprev)
+        ee, rv = C.c_float(), C.c_float()
+        self._chk(L.lib.lrnde_sde_rkmil_step(self._h, _dev_ptr(uprev, "uprev", self.D), _dev_ptr(dW, "dW", self.D), B,
+                                             float(t), float(dt), float(abstol), float(reltol), _dev_ptr(u, "u"),
+                                             C.byref(ee), C.byref(rv)))
+        return dict(u=u, eest=np.float32(ee.value), reg_val=np.float32(rv.value))
+
 
 class NeuralDSDE:
     """`(sol, st) = nsde(x, ps, st)`; ps = dict(drift=flat, diffusion=[vec(Wg); bg]).

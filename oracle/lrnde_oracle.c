@@ -899,6 +899,41 @@ int lro_euler_heun_step(const lro_field* fd, const lro_field* gd, const float* u
   return LRO_OK;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Milstein step, diagonal noise, Ito (src/perform_step.jl:108-170)            */
+/* J = get_iterated_I (diagonal noise: dW.^2 ./ 2, UPSTREAM-RECALL) - |dt|/2.   */
+/* du2 = f(K, t+dt) and En of the reference only feed a `tmp` that the next     */
+/* line overwrites (:163-166): they do not reach u or EEst and are not          */
+/* evaluated here.  EEst = rms((u - uprev) / (abstol + max(|uprev|,|u|) reltol)).*/
+/* ------------------------------------------------------------------------- */
+int lro_rkmil_step(const lro_field* fd, const lro_field* gd, const float* uprev, const float* dW, float t, float dt,
+                   float abstol, float reltol, int B, float* u, float* eest, float* reg_val) {
+  const long n = (long)fd->D * B;
+  float* w = (float*)malloc(sizeof(float) * (size_t)n * 5);
+  float *du1 = w, *L = w + n, *K = w + 2 * n, *tmp = w + 3 * n, *gt = w + 4 * n;
+  const float sqdt = sqrtf(dt);
+  fd->fn(fd->ctx, uprev, t, B, du1);                               /* :130 */
+  gd->fn(gd->ctx, uprev, t, B, L);                                 /* :131 */
+  for (long i = 0; i < n; ++i) { K[i] = uprev[i] + dt * du1[i]; tmp[i] = K[i] + sqdt * L[i]; } /* :133, :136-137 (Ito) */
+  gd->fn(gd->ctx, tmp, t, B, gt);                                  /* :138 */
+  const float hdt = 0.5f * fabsf(dt);
+  double acc = 0.0;
+  for (long i = 0; i < n; ++i) {
+    float J = (0.5f * dW[i]) * dW[i] - hdt;                        /* :117, :122 */
+    float Dgj = (gt[i] - L[i]) / sqdt;                             /* :139 */
+    u[i] = (K[i] + L[i] * dW[i]) + Dgj * J;                        /* :141 */
+    float sc = abstol + fmaxf(fabsf(uprev[i]), fabsf(u[i])) * reltol;
+    float r = (u[i] - uprev[i]) / sc;                              /* :166, :218-220 */
+    float sq = r * r;
+    acc += (double)sq;
+  }
+  float ee = rms_from_sumsq(acc, n);
+  if (eest) *eest = ee;
+  if (reg_val) *reg_val = ee * dt;                                 /* :169 */
+  free(w);
+  return LRO_OK;
+}
+
 /* ========================================================================= */
 /* Backward pass: continuous adjoint of the solve            */
 /* (SciMLSensitivity InterpolatingAdjoint(autojacvec=ZygoteVJP()), un-vendored) */

@@ -29,6 +29,7 @@
  *                         as called from src/layers/neural_ode.jl:42-54
  *   lro_node_forward      src/layers/neural_ode.jl:56-116 (none / unbiased / biased)
  *   lro_euler_heun_step   src/perform_step.jl:172-206, 214-216
+ *   lro_rkmil_step        src/perform_step.jl:108-170 (diagonal noise, Ito), 218-220
  *   lro_conv_rhs          experiments/src/construct.jl:213-218 (the CIFAR10 node_core:
  *                         TDChain(Chain(Conv3x3 C+1=>Hc no-bias, BatchNorm(Hc, act)),
  *                         Chain(Conv Hc+1=>Hc, BatchNorm(Hc, act)), Conv Hc+1=>C)),
@@ -199,6 +200,8 @@ int lro_node_backward(const lro_mlp* m, const float* x, int B, float t0, float t
                       lro_stats* st_fwd, lro_stats* st_bwd);
 
 /* ---- SDE: adaptive Euler-Heun local step with supplied dW (src/perform_step.jl:172-206) ---- */
+int lro_rkmil_step(const lro_field* drift, const lro_field* diffusion, const float* uprev, const float* dW, float t,
+                   float dt, float abstol, float reltol, int B, float* u, float* eest, float* reg_val);
 /* classifier head + logitcrossentropy (experiments/src/construct.jl:199, experiments/src/utils.jl:88):
  * pc = [vec(W) (K x D column-major); b]; returns mean CE; optional logits (B,K), du (B,D), dpc (K*(D+1)) */
 float lro_classifier_ce(const float* u, int B, int D, const float* pc, int K, const int* labels, float* logits,

@@ -111,6 +111,8 @@ def lib():
         L.lro_euler_heun_step.argtypes = [C.POINTER(Field), C.POINTER(Field), fp, fp, C.c_float,
                                           C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, fp, fp,
                                           fp]
+        L.lro_rkmil_step.argtypes = [C.POINTER(Field), C.POINTER(Field), fp, fp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_int, fp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.lro_tsit5_tableau.argtypes = [C.POINTER(C.c_double)] * 4
         L.lro_mlp_vjp.restype = None
         L.lro_mlp_vjp.argtypes = [C.POINTER(Mlp), fp, C.c_float, fp, C.c_int, fp, fp]
@@ -382,3 +384,14 @@ def classifier_ce(u, pc, K, labels):
     loss = lib().lro_classifier_ce(_fp(u), B, D, _fp(pc), K, lab.ctypes.data_as(C.POINTER(C.c_int)), _fp(logits),
                                    _fp(du), _fp(dpc))
     return np.float32(loss), logits, du, dpc
+
+
+def rkmil_step(drift, diffusion, uprev, dW, t, dt, abstol, reltol):
+    uprev = _f32(uprev); dW = _f32(dW)
+    B = uprev.size // drift.D
+    u = np.empty_like(uprev)
+    ee, rv = C.c_float(), C.c_float()
+    rc = lib().lro_rkmil_step(C.byref(drift.field), C.byref(diffusion.field), _fp(uprev), _fp(dW), float(t), float(dt),
+                              float(abstol), float(reltol), B, _fp(u), C.byref(ee), C.byref(rv))
+    assert rc == 0
+    return dict(u=u, eest=np.float32(ee.value), reg_val=np.float32(rv.value))

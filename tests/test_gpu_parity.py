@@ -162,6 +162,24 @@ def test_sde_euler_heun_step_bit_exact(oracle, gpu_pkg, D, H, B):
     assert got["eest"] == ref["eest"] and got["reg_val"] == ref["reg_val"], (got, ref["eest"], ref["reg_val"])
 
 
+@pytest.mark.parametrize("D,H,B", [(32, 64, 512), (32, 64, 37), (20, 48, 16)])
+def test_sde_rkmil_step_bit_exact(oracle, gpu_pkg, D, H, B):
+    """src/perform_step.jl:108-170 (diagonal noise, Ito) and the 4-argument _calculate_residuals (:218-220)."""
+    import torch
+    from localregneuralde_jl_amd.layers import _mlp_desc
+    pd, pg, drift, diff = _sde_fields(oracle, D, H)
+    rng = np.random.default_rng(11)
+    u = rng.standard_normal((B, D)).astype(np.float32)
+    dt = np.float32(0.04)
+    dW = (rng.standard_normal((B, D)) * np.sqrt(dt)).astype(np.float32)
+    ref = oracle.rkmil_step(drift, diff, u, dW, 0.3, dt, 0.14, 0.14)
+    h = gpu_pkg.SdeHandle(_mlp_desc(gpu_pkg.Chain(gpu_pkg.Dense(D, H, "tanh"), gpu_pkg.Dense(H, D))))
+    h.set_params(pd, pg)
+    got = h.rkmil_step(torch.from_numpy(u).cuda(), torch.from_numpy(dW).cuda(), 0.3, dt, 0.14, 0.14)
+    _eq(got["u"].cpu().numpy(), ref["u"], "u")
+    assert got["eest"] == ref["eest"] and got["reg_val"] == ref["reg_val"], (got, ref["eest"], ref["reg_val"])
+
+
 def test_neural_dsde_forward_behaviour(oracle, gpu_pkg):
     """NeuralDSDE mirror: reg_val is zero iff regularize == :none / test mode (test/runtests.jl:340-433
     assert exactly this plus finiteness); the fixed-grid solve equals the same loop over the oracle step."""

@@ -193,3 +193,27 @@ def test_golden_fixtures(oracle):
     n = oracle.node_forward(f, g["x"], 0.0, 1.0, float(g["tol"]), float(g["tol"]), mode="unbiased", t1_or_rand=0.37,
                             maxiters=10000)
     assert n["reg_val"] == g["node_reg_val"] and n["nfe"] == int(g["node_nfe"])
+
+
+def test_rkmil_step_is_milstein_for_linear_noise(oracle):
+    """dX = a X dt + b X dW (diagonal, Ito).  With K = X(1 + a dt), the derivative-free quotient of
+    src/perform_step.jl:136-139 is Dg = (g(K + sqrt(dt) g(X)) - g(X))/sqrt(dt) = b^2 X + a b X sqrt(dt), so the step is
+    K + b X dW + Dg (dW^2 - dt)/2 — Milstein's X(1 + a dt + b dW + b^2/2 (dW^2 - dt)) up to the O(dt^1.5) quotient
+    term; EEst is the 4-argument residual norm (:218-220)."""
+    O = oracle
+    a, b = -0.7, 0.4
+    drift = O.PyField(3, lambda u, t: np.float32(a) * u)
+    diff = O.PyField(3, lambda u, t: np.float32(b) * u)
+    rng = np.random.default_rng(0)
+    u = rng.uniform(0.5, 2.0, (5, 3)).astype(np.float32)
+    dt = np.float32(0.01)
+    dW = (rng.standard_normal((5, 3)) * np.sqrt(dt)).astype(np.float32)
+    r = O.rkmil_step(drift, diff, u, dW, 0.0, dt, 1e-2, 1e-2)
+    u64, w64, h = u.astype(np.float64), dW.astype(np.float64), float(dt)
+    expect = u64 * (1 + a * h) + b * u64 * w64 + (b * b * u64 + a * b * u64 * np.sqrt(h)) * (w64 ** 2 - h) / 2
+    np.testing.assert_allclose(r["u"], expect, rtol=5e-6)
+    milstein = u64 * (1 + a * h + b * w64 + 0.5 * b * b * (w64 ** 2 - h))
+    assert np.abs(r["u"] - milstein).max() < 5 * abs(a * b) * h ** 1.5 * np.abs(u64).max()
+    res = (r["u"].astype(np.float64) - u) / (1e-2 + np.maximum(np.abs(u), np.abs(r["u"])) * 1e-2)
+    assert abs(float(r["eest"]) - np.sqrt(np.mean(res ** 2))) <= 1e-5 * float(r["eest"])
+    assert r["reg_val"] == np.float32(r["eest"] * dt)
