@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -260,24 +261,42 @@ __device__ __forceinline__ int tap_pos(const ConvArgs& a, int tap) {  // tap = k
   return (2 - ky) * (a.W + 2) + (2 - kx);
 }
 
-// raw NHWC store (+ t * tsum[class]) of a wide kernel's accumulators, and the lane's share of the
-// batch statistics (from the fp32 values, before any bf16 rounding of the stored copy)
+// Epilogue of a wide kernel: + t * tsum[class], the lane's share of the batch statistics (from the fp32 values,
+// before any bf16 rounding of the stored copy), and the raw NHWC store.  The accumulators (lane = 4 pixels x 1
+// channel) are transposed through LDS (row stride 68 floats: conflict-free) so that the strip — contiguous in
+// NHWC — leaves as full 256-byte pixel rows with 16-byte stores.  `stg` aliases the halo tile (all waves are done
+// with it at the first barrier).
+constexpr int STG = 68;
 template <int MT, bool OBF>
 __device__ __forceinline__ void wide_epilogue(const ConvArgs& a, const f32x4 (&acc)[MT], const float (&ts)[9], int n, int y0,
-                                              int co, int kg, double& s1, double& s2) {
+                                              int co, int kg, double& s1, double& s2, float* stg) {
+  __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = mt * 16 + kg * 4;  // 4 consecutive pixels of one row (W % 4 == 0)
     if (p < a.TP) {
       const int y = y0 + p / a.W, x = p % a.W;
-      const size_t o = (((size_t)n * a.H + y) * a.W + x) * a.COUT + co;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = fma_(ts[border_class(y, x + r, a.H, a.W)], a.t, acc[mt][r]);
-        if constexpr (OBF) reinterpret_cast<__bf16*>(a.out)[o + (size_t)r * a.COUT] = (__bf16)v;
-        else a.out[o + (size_t)r * a.COUT] = v;
+        stg[(p + r) * STG + co] = v;
         s1 += (double)v; s2 += (double)v * (double)v;
       }
+    }
+  }
+  __syncthreads();
+  const int q = threadIdx.x & 15;
+  const size_t base = ((size_t)n * a.H * a.W + (size_t)y0 * a.W) * 64 + q * 4;
+  for (int p = threadIdx.x >> 4; p < a.TP; p += CNT / 16) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stg + p * STG + q * 4);
+    if constexpr (OBF) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 b;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) b[h] = (__bf16)v[h];
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.out) + base + (size_t)p * 64) = b;
+    } else {
+      *reinterpret_cast<f32x4*>(a.out + base + (size_t)p * 64) = v;
     }
   }
 }
@@ -376,7 +395,7 @@ __global__ __launch_bounds__(CNT) void k_conv_wide_f32(ConvArgs a) {
 #pragma unroll
   for (int c = 0; c < 9; ++c) ts[c] = a.tsum[c * NT * 16 + co];
   double s1 = 0.0, s2 = 0.0;
-  wide_epilogue<MT, OBF>(a, acc, ts, n, y0, co, kg, s1, s2);
+  wide_epilogue<MT, OBF>(a, acc, ts, n, y0, co, kg, s1, s2, tile);
   if (a.part) {
     // lanes li share a channel across the 4 lane groups
     s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
@@ -562,7 +581,7 @@ __global__ __launch_bounds__(CNT) void k_conv_wide_bf16(ConvArgs a) {
 #pragma unroll
   for (int c = 0; c < 9; ++c) ts[c] = a.tsum[c * NT * 16 + co];
   double s1 = 0.0, s2 = 0.0;
-  wide_epilogue<MT, true>(a, acc, ts, n, y0, co, kg, s1, s2);
+  wide_epilogue<MT, true>(a, acc, ts, n, y0, co, kg, s1, s2, reinterpret_cast<float*>(tile));
   if (a.part) {
     s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
     s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
@@ -1124,14 +1143,15 @@ int launch_rhs_ex(lrnde_conv* c, const float* u, float t, int B, float* du, bool
   // conv1: state -> y1
   a.CIN = C; a.CINP = cinp_of(C); a.COUT = Hc; a.in = u; a.out = c->y1; a.wpk = c->w1; a.tsum = c->ts1; a.t = t;
   a.part = train ? c->part : nullptr;
-  launch_mt(c, 0, a, sizeof(float) * rows * WP * a.CINP);
+  const size_t stg_bytes = sizeof(float) * (size_t)a.TP * 68;  // epilogue transpose buffer (aliases the tile)
+  launch_mt(c, 0, a, std::max(sizeof(float) * rows * WP * a.CINP, stg_bytes));
   CHK(c, hipGetLastError());
   if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(256), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat, c->stat + Hc);
   // conv2: BN1+act(y1) -> y2
   a.CIN = Hc; a.CINP = cinp_of(Hc); a.in = c->y1; a.out = c->y2; a.wpk = c->w2; a.tsum = c->ts2;
   a.mean = c->stat; a.inv = c->stat + Hc; a.scale = c->bn; a.bias = c->bn + Hc;
   const size_t esz = c->d.compute_dtype == LRNDE_BF16 ? 2 : 4;
-  launch_mt(c, 1, a, esz * rows * WP * a.CINP);
+  launch_mt(c, 1, a, std::max(esz * rows * WP * a.CINP, stg_bytes));
   CHK(c, hipGetLastError());
   if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(256), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat + 2 * Hc, c->stat + 3 * Hc);
   if (!last) return LRNDE_OK;
@@ -1235,14 +1255,15 @@ int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, 
   };
   // conv3^T: lam (planar) -> g2 = d h2
   a.CIN = C; a.CINP = cinp_of(C); a.COUT = Hc; a.in = lam; a.out = c->g2; a.wpk = c->w3t; a.tsum = c->zeros; a.t = 0.f; a.part = nullptr;
-  launch_mt(c, 0, a, sizeof(float) * rows * WP * a.CINP);
+  const size_t stg_bytes = sizeof(float) * (size_t)a.TP * 68;
+  launch_mt(c, 0, a, std::max(sizeof(float) * rows * WP * a.CINP, stg_bytes));
   if ((rc = bn_bwd(c->g2, c->y2, 1))) return rc;                        // g2 = dz2 ; m(2) ; d scale2, d bias2
   if (gp && (rc = wgrad(0, 1, lam, nullptr, 0, c->y2, 1, Hc, C, gp + o_w3))) return rc;
   // conv2^T: d a2 (from dz2, y2) -> g1 = d h1
   a.CIN = Hc; a.CINP = cinp_of(Hc); a.COUT = Hc; a.in = c->g2; a.in2 = c->y2; a.smode = 1; a.out = c->g1; a.wpk = c->w2t;
   a.mean = c->stat + 2 * Hc; a.inv = c->stat + 3 * Hc; a.scale = c->bn + 2 * Hc; a.bias = c->bn + 3 * Hc;
   a.m1 = c->bwm + 2 * Hc; a.m2 = c->bwm + 3 * Hc;
-  launch_mt(c, 1, a, sizeof(float) * rows * WP * a.CINP);
+  launch_mt(c, 1, a, std::max(sizeof(float) * rows * WP * a.CINP, stg_bytes));
   if ((rc = bn_bwd(c->g1, c->y1, 0))) return rc;                        // g1 = dz1 ; m(1) ; d scale1, d bias1
   if (gp && (rc = wgrad(1, 1, c->g2, c->y2, 1, c->y1, 0, Hc, Hc, gp + o_w2))) return rc;
   // conv1^T: d a1 (from dz1, y1) -> dy (planar)
