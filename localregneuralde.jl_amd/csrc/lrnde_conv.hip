@@ -134,6 +134,22 @@ __device__ __forceinline__ int border_class(int y, int x, int H, int W) {
   return rc * 3 + cc;
 }
 
+// Activations of the conv path: hardware exp2 / rcp (v_exp_f32, v_rcp_f32; ~1 ulp each).  Parity of this path is
+// by tolerance (1e-5 of the output scale, tests/test_gpu_conv.py), so the ~60-instruction canonical forms of
+// lrnde_math.hpp (needed by the bit-exact MLP path) are not used here: with them the halo staging was VALU bound.
+__device__ __forceinline__ float sigmoid_fast(float a) {  // 1 / (1 + exp(-a)); exp2 overflow -> inf -> 0
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a * -1.4426950408889634f));
+}
+__device__ __forceinline__ float gelu_fast(float x) {     // x * sigmoid(2 sqrt(2/pi) (x + 0.044715 x^3)) = NNlib's tanh form
+  const float a = (1.5957691216057308f * x) * fma_(x * x, 0.044715f, 1.0f);
+  return x * sigmoid_fast(a);
+}
+__device__ __forceinline__ float tanh_fast(float x) { return fma_(2.0f, sigmoid_fast(2.0f * x), -1.0f); }
+template <int ACT> __device__ __forceinline__ float act_fast(float z) {
+  return ACT == 2 ? gelu_fast(z) : (ACT == 1 ? tanh_fast(z) : z);
+}
+__device__ __forceinline__ float act_fast_rt(int act, float z) { return act == 2 ? gelu_fast(z) : (act == 1 ? tanh_fast(z) : z); }
+
 // ---- halo tile staging ---------------------------------------------------------------------
 // LDS tile [(TR+2)][(W+2)][CINP], zero outside the image.  T = float or __hip_bfloat16.
 template <class T> __device__ __forceinline__ T cvt_to(float v);
@@ -231,7 +247,7 @@ __device__ __forceinline__ void stage_nhwc_bn_f32(const ConvArgs& a, int n, int 
         for (int h = 0; h < 4; ++h) {
           const float xn = (raw[u][h] - mu[h]) * iv[h];
           const float z = xn * sc[h] + bi[h];
-          v[h] = ACT == 2 ? geluf_c(z) : (ACT == 1 ? tanhf_c(z) : z);
+          v[h] = act_fast<ACT>(z);
         }
       }
       *reinterpret_cast<f32x4*>(tile + swz_f32(pos, q)) = v;
@@ -417,7 +433,7 @@ __global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
   constexpr int NG = 36;
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * 1024, 0x00020000);
   const int wv = lane * 16;
-  stage_nhwc_bn_f32(a, n, y0, tile);
+  if (!(a.dbg & 32)) stage_nhwc_bn_f32(a, n, y0, tile);
   int ab[MAXMT];
   pixel_bases(a, ab, 1);
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -428,8 +444,9 @@ __global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
   f32x4 wc[4], wn[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) wc[q] = wload4(rsW, wv, q * 1024);
+  const int ntap = (a.dbg & 8) ? 0 : 9;
 #pragma unroll 1
-  for (int tap = 0; tap < 9; ++tap) {
+  for (int tap = 0; tap < ntap; ++tap) {
     const int tn = tap < 8 ? tap + 1 : 8;
 #pragma unroll
     for (int q = 0; q < 4; ++q) wn[q] = wload4(rsW, wv, (tn * 4 + q) * 1024);
@@ -513,7 +530,7 @@ __device__ __forceinline__ void stage_nhwc_bn_bf16(const ConvArgs& a, int n, int
         if (ok[u]) {
           const float xn = ((float)raw[u][h] - mu[h]) * iv[h];
           const float z = xn * sc[h] + bi[h];
-          o = ACT == 2 ? geluf_c(z) : (ACT == 1 ? tanhf_c(z) : z);
+          o = act_fast<ACT>(z);
         }
         v[h] = (__bf16)o;
       }
@@ -681,13 +698,13 @@ struct BnBwdArgs {
   const float* mean; const float* inv; const float* scale; const float* bias; int act;
   double* part;  // [gridDim.x][64][2]
 };
-__device__ __forceinline__ float act_deriv_c(int act, float pre, float h) {
-  if (act == 1) return 1.0f - h * h;
+__device__ __forceinline__ float act_deriv_fast(int act, float pre) {
+  if (act == 1) { const float h = tanh_fast(pre); return 1.0f - h * h; }
   if (act == 2) {
     const float two_lambda = 1.5957691216057308f;
     const float x2 = pre * pre;
     const float aa = (two_lambda * pre) * fma_(x2, 0.044715f, 1.0f);
-    const float sg = 1.0f / (1.0f + expf_c(-aa));
+    const float sg = sigmoid_fast(aa);
     const float da = two_lambda * fma_(x2, 3.0f * 0.044715f, 1.0f);
     return sg + pre * sg * (1.0f - sg) * da;
   }
@@ -707,8 +724,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd1(BnBwdArgs a) {
     for (int h = 0; h < 4; ++h) {
       const float xn = (ar[h] - mu[h]) * iv[h];
       const float z = xn * sc[h] + bi[h];
-      const float hh = act_apply(a.act, z);
-      dz[h] = dh[h] * act_deriv_c(a.act, z, hh);
+      dz[h] = dh[h] * act_deriv_fast(a.act, z);
       s1[h] += (double)dz[h]; s2[h] += (double)dz[h] * (double)xn;
     }
     *reinterpret_cast<f32x4*>(a.g + o) = dz;
@@ -834,7 +850,7 @@ __global__ __launch_bounds__(CNT) void k_conv_wgrad(WgradArgs a) {
         if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
           const f32x4 raw = *reinterpret_cast<const f32x4*>(a.in + ((size_t)n * a.H * a.W + (size_t)y * a.W + x) * 64 + q * 4);
 #pragma unroll
-          for (int h = 0; h < 4; ++h) { const float xn = (raw[h] - mu[h]) * iv[h]; v[h] = act_apply(a.act, xn * sc[h] + bi[h]); }
+          for (int h = 0; h < 4; ++h) { const float xn = (raw[h] - mu[h]) * iv[h]; v[h] = act_fast_rt(a.act, xn * sc[h] + bi[h]); }
         }
         *reinterpret_cast<f32x4*>(it + pos * IS + q * 4) = v;
       }
