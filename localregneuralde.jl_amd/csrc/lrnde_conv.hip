@@ -1082,10 +1082,11 @@ int cfail(lrnde_conv* c, int code, const char* fmt, ...) {
 inline size_t state_n(const lrnde_conv* c, int B) { return (size_t)B * c->d.width * c->d.height * c->d.channels; }
 inline int strip_rows(const lrnde_conv* c) {
   // largest TR dividing H with TR*W <= 128 pixels (8 M tiles)
+  static const int maxpx = getenv("LRNDE_CONV_STRIP_PX") ? atoi(getenv("LRNDE_CONV_STRIP_PX")) : 16 * MAXMT;
   int best = 0;
   for (int tr = 1; tr <= c->d.height; ++tr)
-    if (c->d.height % tr == 0 && tr * c->d.width <= 16 * MAXMT) best = tr;
-  return best;
+    if (c->d.height % tr == 0 && tr * c->d.width <= maxpx) best = tr;
+  return best ? best : 1;
 }
 inline int cinp_of(int cin) { return cin == 8 ? 12 : cin; }  // 64-channel tiles are swizzled, not padded
 
@@ -1133,6 +1134,8 @@ template <int MT> void launch_one(lrnde_conv* c, int which, const ConvArgs& a, s
   else hipLaunchKernelGGL(k_conv_out_f32<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
 }
 void launch_mt(lrnde_conv* c, int which, const ConvArgs& a, size_t sm) {
+  static const size_t lds_min = getenv("LRNDE_CONV_LDS_MIN") ? (size_t)atoi(getenv("LRNDE_CONV_LDS_MIN")) : 0;  // occupancy experiments
+  if (sm < lds_min) sm = lds_min;
   switch (a.MT) {
     case 1: launch_one<1>(c, which, a, sm); break;
     case 2: launch_one<2>(c, which, a, sm); break;

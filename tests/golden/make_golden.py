@@ -23,3 +23,20 @@ np.savez_compressed(os.path.join(HERE, "mnist_mlp_b16.npz"), params=p.astype(np.
                     step_reg_stiff=st["reg_stiff"], solve_dt_trace=sv["trace"]["dt"], solve_u=sv["u"],
                     solve_nf=sv["stats"]["nf"], node_reg_val=nd["reg_val"], node_nfe=nd["nfe"])
 print("wrote", os.path.getsize(os.path.join(HERE, "mnist_mlp_b16.npz")), "bytes")
+
+# ---- conv vector field (experiments/src/construct.jl:213-218): small image, the CIFAR block's channel counts ----
+Wc, Hh, Cc, Hc, Bc = 8, 8, 8, 64, 2
+pc = O.glorot_conv_params(Cc, Hc, seed=0)
+rngc = np.random.default_rng(0)
+n1 = 9 * (Cc + 1) * Hc
+pc[n1:n1 + Hc] = rngc.uniform(0.5, 1.5, Hc); pc[n1 + Hc:n1 + 2 * Hc] = rngc.uniform(-0.3, 0.3, Hc)
+xc = rngc.standard_normal((Bc, Wc * Hh * Cc)).astype(np.float32)
+lamc = rngc.standard_normal(xc.shape).astype(np.float32)
+fc = O.ConvField(Wc, Hh, Cc, Hc, pc, act="gelu", bn_train=True, nthreads=4)
+duc = fc.rhs(xc, 0.3)
+dyc, gpc = O.conv_vjp(fc, xc, 0.3, lamc)
+ndc = O.node_forward(fc, xc, 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.41)
+np.savez_compressed(os.path.join(HERE, "conv_block_8x8_b2.npz"), params=pc, x=xc, lam=lamc, t=np.float32(0.3), du=duc, vjp_dy=dyc,
+                    vjp_gp=gpc, node_u_end=ndc["u_end"], node_nfe=ndc["nfe"], node_naccept=ndc["stats"]["naccept"],
+                    node_reg_val=ndc["reg_val"])
+print("wrote", os.path.getsize(os.path.join(HERE, "conv_block_8x8_b2.npz")), "bytes")

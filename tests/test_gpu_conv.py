@@ -259,3 +259,19 @@ def test_conv_node_backward_matches_oracle(mode, w_reg):
     assert abs(bg["stats_bwd"]["naccept"] - bo["stats_bwd"]["naccept"]) <= 1
     assert _rel(bg["dx"].cpu().numpy().reshape(B, -1), bo["dx"]) <= 2e-3
     assert _rel(bg["dp"].cpu().numpy(), bo["dp"]) <= 5e-3
+
+
+def test_conv_golden_fixture_on_gpu():
+    """the committed fixture tests/golden/conv_block_8x8_b2.npz (generated from the oracle) through the C ABI"""
+    P, O = _mods()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "conv_block_8x8_b2.npz"))
+    h = P.ConvHandle(8, 8, 8, 64, act="gelu", bn_train=True)
+    h.set_params(g["params"])
+    x = torch.from_numpy(g["x"].reshape(2, 8, 8, 8)).cuda()
+    _close(h.rhs(x, float(g["t"])), g["du"])
+    dy, gp = h.vjp(x, float(g["t"]), torch.from_numpy(g["lam"].reshape(2, 8, 8, 8)).cuda())
+    _close(dy, g["vjp_dy"], rtol=5e-5)
+    assert _rel(gp.cpu().numpy(), g["vjp_gp"]) <= 5e-5
+    nd = h.node_forward(x, 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.41)
+    assert nd["nfe"] == int(g["node_nfe"]) and nd["stats"]["naccept"] == int(g["node_naccept"])
+    _close(nd["u_end"], g["node_u_end"], rtol=2e-5)

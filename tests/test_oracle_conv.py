@@ -207,3 +207,15 @@ def test_conv_node_backward_matches_finite_differences():
     fd = (loss(p + eps * d) - loss(p - eps * d)) / (2 * eps)
     an = float((b["dp"].astype(np.float64) * d).sum())
     assert abs(fd - an) <= 2e-2 * max(abs(fd), abs(an)) + 1e-4
+
+
+def test_conv_golden_fixture():
+    """regression pin generated by tests/golden/make_golden.py from this oracle (conv_block_8x8_b2.npz)"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "conv_block_8x8_b2.npz"))
+    fld = O.ConvField(8, 8, 8, 64, g["params"], act="gelu", bn_train=True, nthreads=3)  # thread count must not matter
+    assert np.array_equal(fld.rhs(g["x"], float(g["t"])), g["du"])
+    dy, gp = O.conv_vjp(fld, g["x"], float(g["t"]), g["lam"])
+    assert np.array_equal(dy, g["vjp_dy"]) and np.array_equal(gp, g["vjp_gp"])
+    nd = O.node_forward(fld, g["x"], 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.41)
+    assert nd["nfe"] == int(g["node_nfe"]) and nd["stats"]["naccept"] == int(g["node_naccept"])
+    assert np.array_equal(nd["u_end"], g["node_u_end"]) and nd["reg_val"] == g["node_reg_val"]
