@@ -50,3 +50,16 @@ def test_neural_ode_recognises_the_conv_field_without_a_gpu():
     assert node._conv == (8, 64, "gelu", 1e-5) and node.desc is None
     with pytest.raises(ValueError):
         node.handle()  # needs the input to size the handle
+
+
+def test_conv_create_rejects_unsupported_shapes_before_touching_a_device():
+    """shape checks come first in lrnde_conv_create, so the status is visible without a GPU"""
+    import ctypes as C
+    from localregneuralde_jl_amd import _lib as L
+    for (w, h, c, hc, dt) in [(32, 32, 3, 64, 0), (32, 32, 8, 32, 0), (30, 32, 8, 64, 0), (32, 32, 8, 64, 7), (256, 4, 8, 64, 0)]:
+        d = L.ConvDesc(w, h, c, hc, L.ACT["gelu"], 1, dt, 1e-5)
+        ctx = C.c_void_p()
+        assert L.lib.lrnde_conv_create(C.byref(ctx), C.byref(d), 0, None) == 8  # LRNDE_UNSUPPORTED
+        assert not ctx.value
+    assert L.lib.lrnde_conv_create(None, None, 0, None) == 4  # LRNDE_BADARG
+    assert L.lib.lrnde_conv_last_error(None) == b"null handle"
