@@ -1578,7 +1578,7 @@ int ensure_workspace(lrnde_ctx* c, int B) {
     HIPCHK(c, hipMalloc(&c->pinit, pb));
     HIPCHK(c, hipMemsetAsync(c->part, 0, pb, c->stream));
     HIPCHK(c, hipMemsetAsync(c->pinit, 0, pb, c->stream));
-    if (c->nranks > 1) {
+    if (c->comm) {  // nranks > 1 (or LRNDE_FORCE_COMM: the same path on one rank)
       HIPCHK(c, hipMalloc(&c->part_rx, pb));
       HIPCHK(c, hipMalloc(&c->pinit_rx, pb));
       HIPCHK(c, hipMemsetAsync(c->part_rx, 0, pb, c->stream));
@@ -1609,9 +1609,9 @@ void fill_args(lrnde_ctx* c, StepArgs& a, int B, int force_nb = 0) {
   a.n_global = (double)c->desc.state_dim * (double)B * (double)c->nranks;
   a.ctrl = c->ctrl;
   a.part_send = c->part;
-  a.part_recv = c->nranks > 1 ? c->part_rx : c->part;
+  a.part_recv = c->comm ? c->part_rx : c->part;
   a.pinit_send = c->pinit;
-  a.pinit_recv = c->nranks > 1 ? c->pinit_rx : c->pinit;
+  a.pinit_recv = c->comm ? c->pinit_rx : c->pinit;
 }
 
 size_t smem_q(const lrnde_ctx* c) { return smem_bytes_q(c->m.KQ1p, c->m.KQ2p, c->m.RG1, c->m.RG2); }
@@ -1648,7 +1648,7 @@ int launch_step(lrnde_ctx* c, int B, const StepArgs& a, int j, bool spec = false
 // exchange of the per-tile fp64 partial sums between ranks: ONE all-reduce (sum) of a vector
 // in which every rank has zeros outside its own segment, so the result is the exact gather.
 int exchange(lrnde_ctx* c, double* send, double* recv, size_t count) {
-  if (c->nranks <= 1) return LRNDE_OK;
+  if (!c->comm) return LRNDE_OK;
   NCCLCHK(c, ncclAllReduce(send, recv, count, ncclDouble, ncclSum, c->comm, c->stream));
   return LRNDE_OK;
 }

@@ -208,3 +208,24 @@ def test_neural_dsde_forward_behaviour(oracle, gpu_pkg):
     _eq(outs["none"][0], u, "NeuralDSDE end state")
     with pytest.raises(NotImplementedError):
         gpu_pkg.NeuralDSDE(gpu_pkg.Chain(gpu_pkg.Dense(D, H), gpu_pkg.Dense(H, D)), gpu_pkg.Dense(D, D), solver="SOSRI")
+
+
+def test_rccl_exchange_path_on_one_rank(oracle, gpu_pkg, monkeypatch):
+    """LRNDE_FORCE_COMM: a one-rank RCCL communicator, so that every per-step exchange really goes through
+    ncclAllReduce on the handle's stream into the separate receive buffers — the code path of the sharded run
+    (tests/test_sharded_gloo.py covers the multi-rank arithmetic on CPU).  Results stay bit-equal to the oracle."""
+    import torch
+    from localregneuralde_jl_amd.layers import Handle, _mlp_desc
+    monkeypatch.setenv("LRNDE_FORCE_COMM", "1")
+    D, H, B = 784, 100, 40
+    model = gpu_pkg.TDChain(gpu_pkg.Chain(gpu_pkg.Dense(D + 1, H, "tanh"), gpu_pkg.Dense(H + 1, D)))
+    p = gpu_pkg.glorot_params(model, seed=0)
+    x = np.random.default_rng(0).random((B, D), dtype=np.float32)
+    h = Handle(_mlp_desc(model))
+    h.set_params(torch.from_numpy(p))
+    gpu_pkg.init_comm(h, 0, 1)
+    got = h.node_forward(torch.from_numpy(x).cuda(), 0.0, 1.0, 1e-5, 1e-5, mode="unbiased", t1_or_rand=0.37, maxiters=2000)
+    fld = oracle.MlpField(D, H, p, nthreads=8)
+    ref = oracle.node_forward(fld, x, 0.0, 1.0, 1e-5, 1e-5, mode="unbiased", t1_or_rand=0.37, maxiters=2000)
+    assert got["nfe"] == ref["nfe"] and got["reg_val"] == ref["reg_val"]
+    _eq(got["u_end"].cpu().numpy(), ref["u_end"], "u_end")
