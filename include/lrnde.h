@@ -138,6 +138,10 @@ int lrnde_node_forward(lrnde_ctx* ctx, const float* x, int32_t B, float t0, floa
  * (SURVEY.md §2 rows 16-17): each rank owns B columns of a global batch of
  * nranks*B; the only exchange is one RCCL all-reduce of the per-tile fp64
  * partial sums of the error norm per attempted step (plus two at init).
+ * Backward pass on a sharded handle: the parameter cotangent (gp of lrnde_vjp,
+ * dp of lrnde_node_backward*) is all-reduced over the ranks — it is a sum over
+ * all samples — and comes out replicated; dx stays sharded; the adjoint's error
+ * norm runs over [lambda of all ranks; mu once].
  * unique_id: the 128 bytes of an ncclUniqueId made by lrnde_comm_unique_id on
  * rank 0 and broadcast by the host (torch.distributed). */
 int lrnde_comm_unique_id(void* unique_id_128_host);

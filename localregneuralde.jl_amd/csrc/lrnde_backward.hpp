@@ -342,6 +342,18 @@ __global__ __launch_bounds__(256) void k_norm(NormArgs a) {
   if (threadIdx.x == 0) a.part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// the rank's own fp64 sum (256 block partials, fixed order) into slot[rank] of a zeroed per-rank vector: the
+// all-reduce (sum) of that vector is the exact gather
+__global__ void k_rank_slot(const double* part, double* slots, int rank, int nranks) {
+  if (threadIdx.x < nranks) slots[threadIdx.x] = 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < 256; ++i) s += part[i];
+    slots[rank] = s;
+  }
+}
+
 #include "lrnde_regseed.hpp"
 
 // ===========================================================================================

@@ -1752,7 +1752,7 @@ int step_reg_grad(lrnde_conv* c, const float* uprev, const float* k1, int B, flo
   CHK(c, hipMemsetAsync(A0, 0, sizeof(float) * 8 * n, c->stream));
   CHK(c, hipMemsetAsync(gp, 0, sizeof(float) * P, c->stream));
   RegSeedArgs sa;
-  sa.n = n; sa.uprev = uprev; sa.u = u; sa.g6 = g6;
+  sa.n = n; sa.n_norm = n; sa.uprev = uprev; sa.u = u; sa.g6 = g6;
   for (int j = 0; j < 7; ++j) sa.k[j] = kk[j];
   sa.kb[0] = nullptr;
   for (int j = 1; j < 7; ++j) sa.kb[j] = kb[j];

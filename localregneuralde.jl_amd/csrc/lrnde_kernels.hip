@@ -2292,6 +2292,8 @@ static int launch_pgrad(lrnde_ctx* c, int B, float t, const float* lam, float* g
   g.ntile1 = th * g.nt1c; g.ntile2 = td16 * g.nt2c;
   hipLaunchKernelGGL(k_pgrad, dim3(g.ntile1 + g.ntile2), dim3(256), 0, c->stream, g);
   HIPCHK(c, hipGetLastError());
+  // batch-sharded run: the parameter cotangent is a sum over all samples (SURVEY.md §8e caveat 1)
+  if (c->comm) NCCLCHK(c, ncclAllReduce(gp, gp, lrnde_param_count(&c->desc), ncclFloat, ncclSum, c->comm, c->stream));
   return LRNDE_OK;
 }
 
@@ -2335,9 +2337,10 @@ int lrnde_vjp(lrnde_ctx* c, const float* y, float t, const float* lam, int32_t B
 }  // extern "C"
 namespace {
 
-struct AdjVec {  // device vectors of the augmented adjoint state
+struct AdjVec {  // device vectors of the augmented adjoint state [lambda (local columns); mu (replicated)]
   float *z, *zn, *zs, *ut, *K[7];
-  size_t N;
+  size_t N;         // local length n_lam + P
+  size_t n_lam, P;  // split of the vector; the norm runs over n_lam * nranks + P elements
 };
 
 int adj_alloc(lrnde_ctx* c, size_t N, AdjVec& v) {
@@ -2347,11 +2350,11 @@ int adj_alloc(lrnde_ctx* c, size_t N, AdjVec& v) {
     HIPCHK(c, hipMalloc(&c->adj, sizeof(float) * 11 * N));
     c->adj_elems = 11 * N;
   }
-  if (!c->adj_part) {
-    HIPCHK(c, hipMalloc(&c->adj_part, sizeof(double) * 256));
-    HIPCHK(c, hipHostMalloc(&c->adj_part_host, sizeof(double) * 256));
+  if (!c->adj_part) {  // [256 lambda partials][256 mu partials][64 per-rank lambda sums]
+    HIPCHK(c, hipMalloc(&c->adj_part, sizeof(double) * (512 + 64)));
+    HIPCHK(c, hipHostMalloc(&c->adj_part_host, sizeof(double) * (512 + 64)));
   }
-  v.N = N; v.z = c->adj; v.zn = c->adj + N; v.zs = c->adj + 2 * N; v.ut = c->adj + 3 * N;
+  v.N = N; v.n_lam = N; v.P = 0; v.z = c->adj; v.zn = c->adj + N; v.zs = c->adj + 2 * N; v.ut = c->adj + 3 * N;
   for (int j = 0; j < 7; ++j) v.K[j] = c->adj + (4 + j) * N;
   return LRNDE_OK;
 }
@@ -2366,18 +2369,34 @@ int vec_axpy(lrnde_ctx* c, float* out, const float* base, float dt, int nk, cons
   return LRNDE_OK;
 }
 
-// sqrt(sum(((num[-num2]) / (abstol + max(|sa|,|sb|)*reltol))^2) / n), fp64 accumulation
+// sqrt(sum(((num[-num2]) / (abstol + max(|sa|,|sb|)*reltol))^2) / n_total), fp64 accumulation, over the augmented
+// vector [lambda; mu]: the lambda part is summed over all ranks (exact gather of one fp64 sum per rank, added in
+// rank order), the replicated mu part is counted once; n_total = n_lam * nranks + P.
 int vec_norm(lrnde_ctx* c, const float* num, const float* num2, const float* sa, const float* sb, float abstol,
-             float reltol, size_t n, float* out) {
+             float reltol, size_t n_lam, size_t P, float* out) {
   NormArgs a;
-  a.num = num; a.num2 = num2; a.sa = sa; a.sb = sb; a.abstol = abstol; a.reltol = reltol; a.n = n; a.part = c->adj_part;
+  a.num = num; a.num2 = num2; a.sa = sa; a.sb = sb; a.abstol = abstol; a.reltol = reltol; a.n = n_lam; a.part = c->adj_part;
   hipLaunchKernelGGL(k_norm, dim3(256), dim3(256), 0, c->stream, a);
+  if (P) {
+    NormArgs b = a;
+    b.num = num + n_lam; b.num2 = num2 ? num2 + n_lam : nullptr; b.sa = sa + n_lam; b.sb = sb ? sb + n_lam : nullptr;
+    b.n = P; b.part = c->adj_part + 256;
+    hipLaunchKernelGGL(k_norm, dim3(256), dim3(256), 0, c->stream, b);
+  }
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->adj_part_host, c->adj_part, sizeof(double) * 256, hipMemcpyDeviceToHost, c->stream));
+  const int nr = c->comm ? c->nranks : 1;
+  if (c->comm) {
+    if (nr > 64) return fail(c, LRNDE_UNSUPPORTED, "more than 64 ranks");
+    hipLaunchKernelGGL(k_rank_slot, dim3(1), dim3(64), 0, c->stream, c->adj_part, c->adj_part + 512, c->rank, nr);
+    NCCLCHK(c, ncclAllReduce(c->adj_part + 512, c->adj_part + 512, nr, ncclDouble, ncclSum, c->comm, c->stream));
+  }
+  HIPCHK(c, hipMemcpyAsync(c->adj_part_host, c->adj_part, sizeof(double) * (512 + 64), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   double s = 0.0;
-  for (int i = 0; i < 256; ++i) s += c->adj_part_host[i];
-  *out = (float)sqrt(s / (double)n);
+  if (c->comm) { for (int r = 0; r < nr; ++r) s += c->adj_part_host[512 + r]; }
+  else { for (int i = 0; i < 256; ++i) s += c->adj_part_host[i]; }
+  if (P) for (int i = 0; i < 256; ++i) s += c->adj_part_host[256 + i];
+  *out = (float)sqrt(s / ((double)n_lam * (double)nr + (double)P));
   return LRNDE_OK;
 }
 
@@ -2415,14 +2434,14 @@ int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, float s0, float s1, float 
   {
     if ((rc = rhs(z, t, K[0]))) return rc;
     float d0, d1, d2;
-    if ((rc = vec_norm(c, z, nullptr, z, nullptr, abstol, reltol, N, &d0))) return rc;
-    if ((rc = vec_norm(c, K[0], nullptr, z, nullptr, abstol, reltol, N, &d1))) return rc;
+    if ((rc = vec_norm(c, z, nullptr, z, nullptr, abstol, reltol, v.n_lam, v.P, &d0))) return rc;
+    if ((rc = vec_norm(c, K[0], nullptr, z, nullptr, abstol, reltol, v.n_lam, v.P, &d1))) return rc;
     float dt0 = ((double)d0 < 1e-5 || (double)d1 < 1e-5) ? 1e-6f : (d0 / d1) / 100.0f;
     dt0 = fminf(dt0, dtmax);
     const float one = 1.0f; const float* kk[1] = {K[0]};
     if ((rc = vec_axpy(c, v.zs, z, dt0, 1, kk, &one, N))) return rc;
     if ((rc = rhs(v.zs, t + dt0, K[1]))) return rc;
-    if ((rc = vec_norm(c, K[1], K[0], z, nullptr, abstol, reltol, N, &d2))) return rc;
+    if ((rc = vec_norm(c, K[1], K[0], z, nullptr, abstol, reltol, v.n_lam, v.P, &d2))) return rc;
     d2 = d2 / dt0;
     const float maxd = fmaxf(d1, d2);
     float dt1;
@@ -2458,7 +2477,7 @@ int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, float s0, float s1, float 
     st->nf += 6;
     if ((rc = vec_axpy(c, v.ut, nullptr, dt, 7, K, BT, N))) return rc;
     float eest;
-    if ((rc = vec_norm(c, v.ut, nullptr, z, zn, abstol, reltol, N, &eest))) return rc;
+    if ((rc = vec_norm(c, v.ut, nullptr, z, zn, abstol, reltol, v.n_lam, v.P, &eest))) return rc;
     st->eest_last = eest;
     if (eest != eest) { rc = LRNDE_DT_NAN; break; }
     const float ttmp = t + dt;
@@ -2516,7 +2535,7 @@ int lrnde_step_reg_grad(lrnde_ctx* c, const float* uprev, const float* k1, int32
   HIPCHK(c, hipMemsetAsync(c->adj, 0, sizeof(float) * 8 * N, c->stream));
   HIPCHK(c, hipMemsetAsync(gp, 0, sizeof(float) * P, c->stream));
   RegSeedArgs sa;
-  sa.n = n; sa.uprev = uprev; sa.u = u; sa.g6 = g6;
+  sa.n = n; sa.n_norm = n * (size_t)(c->comm ? c->nranks : 1); sa.uprev = uprev; sa.u = u; sa.g6 = g6;
   for (int j = 0; j < 7; ++j) sa.k[j] = kk[j];
   for (int j = 1; j < 7; ++j) sa.kb[j] = kb[j];
   sa.ub = ub; sa.g6b = g6b; sa.dt = dt; sa.abstol = abstol; sa.reltol = reltol; sa.reg_type = reg_type;
@@ -2554,7 +2573,6 @@ int lrnde_node_forward_record(lrnde_ctx* c, const float* x, int32_t B, float t0,
   int rc = check_ready(c, B);
   if (rc) return rc;
   if (!x || !o || !u_end || !reg_val_host || !nfe_host || !st) return fail(c, LRNDE_BADARG, "null pointer");
-  if (c->nranks > 1) return fail(c, LRNDE_UNSUPPORTED, "the adjoint is single-GPU in this build");
   const size_t n = (size_t)B * c->desc.state_dim;
   c->rec_valid = false;
   float t1 = t2;
@@ -2603,6 +2621,7 @@ int lrnde_node_backward_recorded(lrnde_ctx* c, int32_t B, const float* du_end, f
   const size_t N = n + P;
   AdjVec v;
   if ((rc = adj_alloc(c, N, v))) return rc;
+  v.n_lam = n; v.P = P;
   HIPCHK(c, hipMemsetAsync(v.z, 0, sizeof(float) * N, c->stream));
   HIPCHK(c, hipMemcpyAsync(v.z, du_end, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   std::vector<float> stops;

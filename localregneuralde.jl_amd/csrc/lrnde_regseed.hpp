@@ -1,7 +1,8 @@
 // lrnde_regseed.hpp — included inside the anonymous namespace of both translation units.
 // cotangent seeds of the regulariser's reverse sweep (src/perform_step.jl:34-47): kbar_2..7, ubar, g6bar
 struct RegSeedArgs {
-  size_t n;
+  size_t n;       // local elements
+  size_t n_norm;  // elements of the (global) norm the regularisation value was taken over
   const float *uprev, *u, *g6;
   const float* k[7];
   float* kb[7];  // kb[1..6] <-> k2..k7
@@ -10,7 +11,7 @@ struct RegSeedArgs {
   int reg_type;
 };
 __global__ void k_reg_seed(RegSeedArgs a) {
-  const float nf = (float)a.n;
+  const float nf = (float)a.n_norm;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
     if (a.reg_type == 0) {  // reg = EEst*dt, EEst = sqrt(mean(r^2)), r = utilde / sc
       float sum = (float)Tsit5::BT[0] * a.k[0][i] + (float)Tsit5::BT[1] * a.k[1][i];

@@ -128,3 +128,21 @@ def test_training_step_matches_oracle_and_one_call_backward(oracle, gpu_pkg):
     one = h.node_backward(torch.from_numpy(x).cuda(), 0.0, 1.0, 1e-5, 1e-5, torch.from_numpy(du).cuda(), mode="unbiased",
                           t1_or_rand=float(t1), w_reg=w_reg, maxiters=2000)
     assert np.abs(one["dp"].cpu().numpy() - gp).max() <= 1e-4 * np.abs(gp).max()
+
+
+def test_sharded_adjoint_path_on_one_rank(oracle, gpu_pkg, monkeypatch):
+    """LRNDE_FORCE_COMM: the sharded adjoint's collectives (parameter-cotangent all-reduce per adjoint RHS, per-rank
+    lambda sums gathered for the error norm, the forward's per-step exchange) run through RCCL on one rank; the
+    result must agree with the oracle exactly as the unsharded path does (SURVEY.md §8e caveat 1: mu all-reduced)."""
+    import torch
+    monkeypatch.setenv("LRNDE_FORCE_COMM", "1")
+    fld, h, p, x = _mk(oracle, gpu_pkg, 32, 64, 24, "tanh", True, seed=5)
+    gpu_pkg.init_comm(h, 0, 1)
+    g = np.random.default_rng(4).standard_normal(x.shape).astype(np.float32)
+    bo = oracle.node_backward(fld, x, 0.0, 1.0, 1e-5, 1e-5, g, mode="unbiased", t1_or_rand=0.37, w_reg=2.5, maxiters=5000)
+    bg = h.node_backward(torch.from_numpy(x).cuda(), 0.0, 1.0, 1e-5, 1e-5, torch.from_numpy(g).cuda(), mode="unbiased",
+                         t1_or_rand=0.37, w_reg=2.5, maxiters=5000)
+    assert bg["stats_fwd"]["naccept"] == bo["stats_fwd"]["naccept"]
+    assert abs(bg["stats_bwd"]["naccept"] - bo["stats_bwd"]["naccept"]) <= 1
+    assert _rel(bg["dx"].cpu().numpy(), bo["dx"]) < 2e-4
+    assert _rel(bg["dp"].cpu().numpy(), bo["dp"]) < 2e-4
