@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--tol", type=float, default=1.4e-8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=512)
+    ap.add_argument("--no-conv", action="store_true", help="skip the 28x28 conv-field side measurement of the default run")
     ap.add_argument("--adjoint-steps", type=int, default=5, help="timed forward+adjoint passes (single GPU)")
     ap.add_argument("--workload", default="mlp", choices=["mlp", "cifar_conv_bf16", "cifar_conv_f32", "mnist_conv_f32"],
                     help="mlp: the headline MNIST-ODE MLP field (default).  The conv workloads time the CIFAR10 node_core "
@@ -178,6 +179,11 @@ def main():
                                if args.batch <= 1024 else "k_step<4,false>",
                      "us_per_launch": us, "flop_per_launch": flop_per_launch},
     }
+    if rank == 0 and world == 1 and not args.no_conv:
+        # BASELINE.json configs[1] read literally ("28x28 conv vector field, batch=512 fp32"): the CIFAR block topology on a
+        # 28x28x8 state (not a model of the reference) — measured alongside, `--workload
+        # mnist_conv_f32` gives its full line
+        out["config"]["conv_field_28x28_b512"] = conv_measure(args, "mnist_conv_f32", brief=True)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the GPU box gives one GPU's share of the host: 16 cores (os.cpu_count() reports the whole host)
         cores = int(os.environ.get("LRNDE_CPU_CORES", min(len(os.sched_getaffinity(0)), 16)))
@@ -205,13 +211,17 @@ def conv_main(args):
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         raise SystemExit("the conv workloads are single-GPU (train-mode BatchNorm couples the batch: replicas only)")
     torch.cuda.set_device(0)
+    print(json.dumps(conv_measure(args, args.workload)))
+
+
+def conv_measure(args, workload, brief=False):
     import lrnde_amd as P
     W, H, B, dt, tol, train = {"cifar_conv_bf16": (32, 32, 256, "bf16", 1e-4, True),
                                "cifar_conv_f32": (32, 32, 256, "f32", 1e-4, True),
-                               "mnist_conv_f32": (28, 28, 512, "f32", 1e-4, False)}[args.workload]
-    if args.batch != 512:
+                               "mnist_conv_f32": (28, 28, 512, "f32", 1e-4, False)}[workload]
+    if args.batch != 512 and not brief:
         B = args.batch
-    steps, warmup = min(args.steps, 10), min(args.warmup, 2)
+    steps, warmup = (3, 1) if brief else (min(args.steps, 10), min(args.warmup, 2))
     params = P.glorot_conv_params(8, 64, seed=0)
     xh = np.random.default_rng(0).standard_normal((B, 8, H, W)).astype(np.float32)  # u0 ~ N(0,1)
     x = torch.from_numpy(xh).cuda()
@@ -235,7 +245,7 @@ def conv_main(args):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     fwd_adj_ms, bwd = None, None
-    if dt == "f32" and args.adjoint_steps > 0:  # pullback of <g, sol.u[end]> + 2.5*reg_val, g ~ 1e-3*N(0,1) (a mean-loss cotangent's size)
+    if dt == "f32" and args.adjoint_steps > 0 and not brief:  # pullback of <g, sol.u[end]> + 2.5*reg_val, g ~ 1e-3*N(0,1) (a mean-loss cotangent's size)
         g = torch.from_numpy((np.random.default_rng(2).standard_normal(xh.shape) * 1e-3).astype(np.float32)).cuda()
         nb = min(args.adjoint_steps, 3)
         h.node_backward(x, 0.0, 1.0, tol, tol, g, mode="unbiased", t1_or_rand=float(t1s[0]), w_reg=2.5, maxiters=10000)
@@ -257,7 +267,7 @@ def conv_main(args):
         "value": nfe_total / el, "unit": "NFE/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
         "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": dt, "data": "synthetic",
-        "config": {"workload": f"{args.workload}: TDChain(Conv3x3(9=>64)+BN+gelu, Conv3x3(65=>64)+BN+gelu, Conv3x3(65=>8)) on "
+        "config": {"workload": f"{workload}: TDChain(Conv3x3(9=>64)+BN+gelu, Conv3x3(65=>64)+BN+gelu, Conv3x3(65=>8)) on "
                                f"{W}x{H}x8xB={B}, BatchNorm {'batch' if train else 'running'} statistics, Tsit5 adaptive "
                                f"abstol=reltol={tol:g}, tspan=(0,1), regularize=unbiased/error_estimate, forward pass",
                    "global_batch": B, "parallelism": "single GPU", "nfe_per_pass": nfe_total / steps,
@@ -268,6 +278,10 @@ def conv_main(args):
                                                 "k_bn_finalize + k_conv_out(conv3)",
                      "us_per_launch": us, "flop_per_launch": flop},
     }
+    if brief:
+        return {"workload": out["config"]["workload"], "value": out["value"], "unit": "NFE/s", "nfe_per_pass": nfe_total / steps,
+                "fwd_ms_per_batch": el / steps * 1e3, "us_per_feval": us, "achieved_tflops": achieved, "roofline_frac": achieved / peak,
+                "dtype": dt}
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as O
@@ -283,7 +297,7 @@ def conv_main(args):
         out["cpu_baseline"] = {"value": n / cel * (cb / B), "unit": "NFE/s", "cores": cores, "kind": "port",
                                "sample": f"{n} f-evals of the C oracle (OpenMP, {cores} threads) on a {cb}-sample slice in "
                                          f"{cel:.1f} s, scaled by {cb}/{B} to whole-batch f-evals per second"}
-    print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":
