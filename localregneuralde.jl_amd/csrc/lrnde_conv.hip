@@ -53,6 +53,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int CNT = 256;        // threads per conv workgroup (4 waves)
 constexpr int MAXMT = 8;        // M tiles (16 pixels) per strip
 constexpr int NSUMB = 256;      // blocks of the elementwise reduction kernels
+#ifndef STAGE_UN
+#define STAGE_UN 4      // halo positions per thread whose loads are issued before any is used (fp32 tile: 16 threads per position)
+#endif
+#ifndef STAGE_UN_BF
+#define STAGE_UN_BF 4   // bf16 tile: 8 threads per position
+#endif
 
 struct ConvArgs {
   int W, H, B, TR, MT, TP;      // strip: TR rows, TP = TR*W pixels, MT = ceil(TP/16)
@@ -178,7 +184,7 @@ __device__ __forceinline__ int swz_f32(int pos, int cq) { return pos * 64 + ((cq
 
 // backward staging: the cotangent of the raw activation from dz (a.in) and the raw activation itself (a.in2)
 __device__ __forceinline__ void stage_nhwc_bnbwd_f32(const ConvArgs& a, int n, int y0, float* tile) {
-  constexpr int CQ = 16, PSTEP = CNT / CQ, UN = 4;
+  constexpr int CQ = 16, PSTEP = CNT / CQ, UN = STAGE_UN;
   const int WP = a.W + 2, npos = (a.TR + 2) * WP;
   const int q = threadIdx.x % CQ;
   const size_t base = (size_t)n * a.H * a.W * 64 + q * 4;
@@ -219,7 +225,7 @@ __device__ __forceinline__ void stage_nhwc_bnbwd_f32(const ConvArgs& a, int n, i
 }
 template <int ACT>
 __device__ __forceinline__ void stage_nhwc_bn_f32(const ConvArgs& a, int n, int y0, float* tile) {
-  constexpr int CQ = 16, PSTEP = CNT / CQ, UN = 4;
+  constexpr int CQ = 16, PSTEP = CNT / CQ, UN = STAGE_UN;
   const int WP = a.W + 2, npos = (a.TR + 2) * WP;
   const int q = threadIdx.x % CQ;
   const float* src = a.in + (size_t)n * a.H * a.W * 64 + q * 4;
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
 // so one tap of 64 channels is two k-groups.  Accumulation, the t-plane term, batch statistics: fp32/fp64.
 template <int ACT>
 __device__ __forceinline__ void stage_nhwc_bn_bf16(const ConvArgs& a, int n, int y0, __bf16* tile) {
-  constexpr int CQ = 8, PSTEP = CNT / CQ, UN = 4;
+  constexpr int CQ = 8, PSTEP = CNT / CQ, UN = STAGE_UN_BF;
   const int WP = a.W + 2, npos = (a.TR + 2) * WP;
   const int q = threadIdx.x % CQ;
   const __bf16* src = reinterpret_cast<const __bf16*>(a.in) + (size_t)n * a.H * a.W * 64 + q * 8;
