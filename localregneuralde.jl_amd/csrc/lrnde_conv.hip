@@ -431,153 +431,6 @@ __global__ __launch_bounds__(CNT) void k_conv_wide_f32(ConvArgs a) {
   }
 }
 
-// ---- producer/consumer form of the 64 -> 64 fp32 convolution -----------------------------------------------
-// One persistent 512-thread workgroup per CU walks strips blockIdx.x, +gridDim.x, ...  Waves 0-3 run the MFMA
-// loop of strip i on tile[i&1]; meanwhile waves 4-7 write strip i-1's output rows (from the transpose buffer)
-// with its batch statistics and stage strip i+1 into tile[(i+1)&1] (all of a thread's halo loads in flight at
-// once: there are only 256 staging threads per CU).  With one-strip workgroups all strips of a launch run their
-// staging / MFMA / epilogue phases in lockstep and the phases add up; here the MFMA pipe only idles while the
-// accumulators are written to the transpose buffer.  LDS: 2 tiles + transpose buffer + 4 KB.
-#ifndef STAGE_UN_PC
-#define STAGE_UN_PC 13
-#endif
-template <int MT, bool OBF>
-__global__ __launch_bounds__(512) void k_conv_wide_pc(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tsz = (a.TR + 2) * (a.W + 2) * 64;
-  float* tile0 = reinterpret_cast<float*>(smem);
-  float* tile1 = tile0 + tsz;
-  float* stg = tile1 + tsz;
-  double* red = reinterpret_cast<double*>(stg + (size_t)a.TP * STG);  // [4 waves][64][2]
-  const bool consumer = threadIdx.x < CNT;
-  const int ltid = threadIdx.x & (CNT - 1);
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(ltid >> 6);
-  const int li = lane & 15, kg = lane >> 4;
-  const int strips = a.H / a.TR, nstrips = a.B * strips;
-  constexpr int NT = 4, NG = 36;
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * NT * 1024, 0x00020000);
-  const int wv = lane * 16;
-  int ab[MAXMT];
-  pixel_bases(a, ab, 1);
-  const int co = wave * 16 + li;
-  float ts[9];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) ts[c] = a.tsum[c * NT * 16 + co];
-
-  // producer: rows of the finished strip `sp` from the transpose buffer to global memory + its statistics partials
-  auto flush = [&](int sp) {
-    const int n = sp / strips, y0 = (sp % strips) * a.TR;
-    const int q = ltid & 15;
-    const size_t base = ((size_t)n * a.H * a.W + (size_t)y0 * a.W) * 64 + q * 4;
-    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    for (int p = ltid >> 4; p < a.TP; p += CNT / 16) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + p * STG + q * 4);
-      if constexpr (OBF) {
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        bf16x4 b;
-#pragma unroll
-        for (int h = 0; h < 4; ++h) b[h] = (__bf16)v[h];
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.out) + base + (size_t)p * 64) = b;
-      } else {
-        *reinterpret_cast<f32x4*>(a.out + base + (size_t)p * 64) = v;
-      }
-#pragma unroll
-      for (int h = 0; h < 4; ++h) { s1[h] += (double)v[h]; s2[h] += (double)v[h] * (double)v[h]; }
-    }
-    if (a.part) {  // lanes q, q+16, q+32, q+48 of a wave hold the same channel quad: fold them; waves via LDS
-#pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        s1[h] += __shfl_xor(s1[h], 16); s2[h] += __shfl_xor(s2[h], 16);
-        s1[h] += __shfl_xor(s1[h], 32); s2[h] += __shfl_xor(s2[h], 32);
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int h = 0; h < 4; ++h) { red[((size_t)wave * 64 + q * 4 + h) * 2] = s1[h]; red[((size_t)wave * 64 + q * 4 + h) * 2 + 1] = s2[h]; }
-      }
-    }
-  };
-  auto flush_stats = [&](int sp) {  // after a workgroup barrier: producer wave 0 adds the four waves' partials in order
-    if (!a.part || wave != 0) return;
-    const int c = lane;
-    const double t1 = ((red[(0 * 64 + c) * 2] + red[(1 * 64 + c) * 2]) + red[(2 * 64 + c) * 2]) + red[(3 * 64 + c) * 2];
-    const double t2 = ((red[(0 * 64 + c) * 2 + 1] + red[(1 * 64 + c) * 2 + 1]) + red[(2 * 64 + c) * 2 + 1]) + red[(3 * 64 + c) * 2 + 1];
-    double* pp = a.part + ((size_t)sp * a.COUT + c) * 2;
-    pp[0] = t1; pp[1] = t2;
-  };
-
-  int s = blockIdx.x;
-  if (!consumer && s < nstrips) stage_nhwc_bn_f32<STAGE_UN_PC>(a, s / strips, (s % strips) * a.TR, tile0, ltid);
-  __syncthreads();
-  int sprev = -1;
-  for (int it = 0; s < nstrips; s += gridDim.x, ++it) {
-    float* cur = (it & 1) ? tile1 : tile0;
-    float* nxt = (it & 1) ? tile0 : tile1;
-    const int y0 = (s % strips) * a.TR;
-    f32x4 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (consumer) {
-      f32x4 wc[4], wn[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) wc[q] = wload4(rsW, wv, ((0 * 4 + q) * NT + wave) * 1024);
-#pragma unroll 1
-      for (int tap = 0; tap < 9; ++tap) {
-        const int tn = tap < 8 ? tap + 1 : 8;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) wn[q] = wload4(rsW, wv, ((tn * 4 + q) * NT + wave) * 1024);
-        const int tp = tap_pos(a, tap);
-        int pb[MT], hi[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int pos = ab[mt] + tp;
-          pb[mt] = pos * 64 + ((kg ^ (pos & 3)) << 2);
-          hi[mt] = (pos & 12) << 2;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 av[MT];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(cur + pb[mt] + ((16 * q) ^ hi[mt]));
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, wc[q].x, acc[mt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, wc[q].y, acc[mt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, wc[q].z, acc[mt], 0, 0, 0);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, wc[q].w, acc[mt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) wc[q] = wn[q];
-      }
-    } else {
-      if (sprev >= 0) flush(sprev);
-      const int sn = s + gridDim.x;
-      if (sn < nstrips) stage_nhwc_bn_f32<STAGE_UN_PC>(a, sn / strips, (sn % strips) * a.TR, nxt, ltid);
-    }
-    __syncthreads();  // stg(i-1) has been read, tile(i+1) is staged, the statistics partials of strip i-1 are in LDS
-    if (consumer) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int p = mt * 16 + kg * 4;
-        if (p < a.TP) {
-          const int y = y0 + p / a.W, x = p % a.W;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) stg[(p + r) * STG + co] = fma_(ts[border_class(y, x + r, a.H, a.W)], a.t, acc[mt][r]);
-        }
-      }
-    } else if (sprev >= 0) {
-      flush_stats(sprev);
-    }
-    __syncthreads();
-    sprev = s;
-  }
-  if (!consumer && sprev >= 0) flush(sprev);
-  __syncthreads();
-  if (!consumer && sprev >= 0) flush_stats(sprev);
-}
-
 // out: CIN = Hc (64) NHWC + BatchNorm input -> COUT <= 16 planar output; waves split the M tiles
 template <int MT>
 __global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
@@ -1289,16 +1142,7 @@ template <int MT> void launch_one(lrnde_conv* c, int which, const ConvArgs& a, s
     return;
   }
   if (which == 0) hipLaunchKernelGGL((k_conv_wide_f32<8, MT, false>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
-  else if (which == 1) {
-    static const bool use_pc = getenv("LRNDE_CONV_PC") != nullptr;
-    const size_t tsz = sizeof(float) * (size_t)(a.TR + 2) * (a.W + 2) * 64;
-    const size_t smpc = 2 * tsz + sizeof(float) * (size_t)a.TP * 68 + 4 * 64 * 2 * sizeof(double);
-    if (use_pc && smpc <= 160 * 1024) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wide_pc<MT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      const int grid = c->nwg < c->num_cu ? c->nwg : c->num_cu;
-      hipLaunchKernelGGL((k_conv_wide_pc<MT, false>), dim3(grid), dim3(512), smpc, c->stream, a);
-    } else hipLaunchKernelGGL((k_conv_wide_f32<64, MT, false>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
-  }
+  else if (which == 1) hipLaunchKernelGGL((k_conv_wide_f32<64, MT, false>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
   else hipLaunchKernelGGL(k_conv_out_f32<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
 }
 void launch_mt(lrnde_conv* c, int which, const ConvArgs& a, size_t sm) {
