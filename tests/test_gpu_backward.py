@@ -146,3 +146,14 @@ def test_sharded_adjoint_path_on_one_rank(oracle, gpu_pkg, monkeypatch):
     assert abs(bg["stats_bwd"]["naccept"] - bo["stats_bwd"]["naccept"]) <= 1
     assert _rel(bg["dx"].cpu().numpy(), bo["dx"]) < 2e-4
     assert _rel(bg["dp"].cpu().numpy(), bo["dp"]) < 2e-4
+
+
+def test_vjp_sixteen_column_family_at_mnist_shape(oracle, gpu_pkg):
+    """B > 1024: k_vjp<4> (16 columns per workgroup) instead of k_vjp_q; same tolerance as test_vjp_matches_oracle"""
+    import torch
+    fld, h, p, x = _mk(oracle, gpu_pkg, 784, 100, 1040, "tanh", True)
+    lam = np.random.default_rng(9).standard_normal(x.shape).astype(np.float32)
+    dy_ref, gp_ref = oracle.mlp_vjp(fld, x, 0.3, lam)
+    dy, gp = h.vjp(torch.from_numpy(x).cuda(), 0.3, torch.from_numpy(lam).cuda())
+    assert _rel(dy.cpu().numpy(), dy_ref) < 2e-5
+    assert _rel(gp.cpu().numpy(), gp_ref) < 2e-5

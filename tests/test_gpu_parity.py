@@ -229,3 +229,25 @@ def test_rccl_exchange_path_on_one_rank(oracle, gpu_pkg, monkeypatch):
     ref = oracle.node_forward(fld, x, 0.0, 1.0, 1e-5, 1e-5, mode="unbiased", t1_or_rand=0.37, maxiters=2000)
     assert got["nfe"] == ref["nfe"] and got["reg_val"] == ref["reg_val"]
     _eq(got["u_end"].cpu().numpy(), ref["u_end"], "u_end")
+
+
+def test_sixteen_column_family_at_mnist_shape(oracle, gpu_pkg):
+    """B > 1024 runs the 16-column kernels (k_rhs/k_init*/k_step<4,..>) instead of the 4-column streaming family:
+    same canonical arithmetic, so the same bits as the oracle (and as the 4-column kernels)."""
+    import torch
+    D, H, B = 784, 100, 1040
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, D, H, B, "tanh", True)
+    xd = torch.from_numpy(x).cuda()
+    k1 = fld.rhs(x, 0.1)
+    _eq(h.rhs(xd, 0.1).cpu().numpy(), k1, "rhs")
+    ref = oracle.tsit5_step(fld, x, k1, 0.1, 0.05, 1e-4, 1e-4)
+    got = h.perform_step(xd, torch.from_numpy(k1).cuda(), 0.1, 0.05, 1e-4, 1e-4)
+    _eq(got["u"].cpu().numpy(), ref["u"], "u")
+    for k in ("eest", "reg_error", "reg_stiff"):
+        assert got[k] == ref[k], (k, got[k], ref[k])
+    ro = oracle.node_forward(fld, x, 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.37)
+    rg = h.node_forward(xd, 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.37)
+    assert rg["nfe"] == ro["nfe"] and rg["reg_val"] == ro["reg_val"]
+    _eq(rg["u_end"].cpu().numpy(), ro["u_end"], "u_end")
+    # and the 4-column family on a slice of the same batch gives the same columns
+    _eq(h.rhs(xd[:64].contiguous(), 0.1).cpu().numpy(), k1[:64], "rhs (4-column family)")
