@@ -214,6 +214,11 @@ int lrnde_conv_destroy(lrnde_conv* c);
 const char* lrnde_conv_last_error(const lrnde_conv* c);
 int lrnde_conv_set_params(lrnde_conv* c, const float* p, size_t n);               /* device pointer */
 int lrnde_conv_set_bn_state(lrnde_conv* c, const float* mean_var, size_t n);      /* device, [mean1 var1 mean2 var2] */
+/* The running statistics (st.model of the layer).  With bn_train = 1 every f-eval of rhs / solve / node_forward
+ * advances them as Lux's training-mode BatchNorm does on each call (momentum 0.1, unbiased variance), which is
+ * what the reference's dudt closure does to its captured st_ (src/layers/neural_ode.jl:44-48); the backward
+ * pass's recomputations do not.  Initial value: mean 0, var 1 (Lux initialstates). */
+int lrnde_conv_get_bn_state(lrnde_conv* c, float* mean_var, size_t n);            /* device */
 int lrnde_conv_rhs(lrnde_conv* c, const float* u, float t, int32_t B, float* du);
 int lrnde_conv_init_dt(lrnde_conv* c, const float* u0, int32_t B, float t0, float t1, float abstol,
                        float reltol, float* k1, float* dt_host);

@@ -122,6 +122,12 @@ class ConvHandle:
         self._keep.append(mv)
         self._chk(L.lib.lrnde_conv_set_bn_state(self._ctx, C.c_void_p(mv.data_ptr()), mv.numel()))
 
+    def get_bn_state(self):
+        """running [mean1 var1 mean2 var2] (st.model of the layer), advanced by every training-mode f-eval"""
+        out = torch.empty(4 * self.desc.hidden, dtype=torch.float32, device=f"cuda:{self.device}")
+        self._chk(L.lib.lrnde_conv_get_bn_state(self._ctx, C.c_void_p(out.data_ptr()), out.numel()))
+        return out
+
     def rhs(self, u, t):
         du = torch.empty_like(u)
         self._chk(L.lib.lrnde_conv_rhs(self._ctx, _ptr(u, "u"), float(t), self._B(u), _ptr(du, "du")))

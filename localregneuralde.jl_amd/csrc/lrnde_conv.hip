@@ -674,8 +674,10 @@ __global__ __launch_bounds__(CNT) void k_conv_out_bf16(ConvArgs a) {
 }
 
 // ---- batch statistics: fixed-order reduction of the per-workgroup partials --------------------
+// run_mean / run_var (may be null): Lux's running statistics, updated as its training-mode BatchNorm does on every
+// call (momentum m: mean <- (1-m) mean + m batch_mean; var <- (1-m) var + m n/(n-1) batch_var; UPSTREAM-RECALL)
 __global__ __launch_bounds__(256) void k_bn_finalize(const double* part, int nwg, int ch, double count, float eps,
-                                                     float* mean, float* inv) {
+                                                     float* mean, float* inv, float* run_mean, float* run_var, float momentum) {
   // one block per channel; thread i sums partials i, i+256, ... (independent loads), then a fixed tree
   __shared__ double r1[256], r2[256];
   const int c = blockIdx.x, tid = threadIdx.x;
@@ -693,7 +695,17 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const double* part, int nwg
     if (var < 0.0) var = 0.0;
     mean[c] = (float)mu;
     inv[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+      const float bm = (float)mu, bv = (float)var;
+      const float mcorr = momentum * (float)count / ((float)count - 1.0f);
+      run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * bm;
+      run_var[c] = (1.0f - momentum) * run_var[c] + mcorr * bv;
+    }
   }
+}
+__global__ void k_bn_state_default(float* st, int ch) {  // running mean 0 / var 1 for both layers
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 4 * ch) st[i] = ((i / ch) & 1) ? 1.0f : 0.0f;
 }
 __global__ void k_bn_from_state(const float* mean_var, int ch, float eps, float* mean, float* inv) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1177,14 +1189,17 @@ int launch_rhs_ex(lrnde_conv* c, const float* u, float t, int B, float* du, bool
   const size_t stg_bytes = sizeof(float) * (size_t)a.TP * 68;  // epilogue transpose buffer (aliases the tile)
   launch_mt(c, 0, a, std::max(sizeof(float) * rows * WP * a.CINP, stg_bytes));
   CHK(c, hipGetLastError());
-  if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(256), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat, c->stat + Hc);
+  float* rs = (train && last) ? c->bn_state : nullptr;  // the VJP's recompute does not advance the running statistics
+  if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(256), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat, c->stat + Hc,
+                                rs, rs ? rs + Hc : nullptr, 0.1f);
   // conv2: BN1+act(y1) -> y2
   a.CIN = Hc; a.CINP = cinp_of(Hc); a.in = c->y1; a.out = c->y2; a.wpk = c->w2; a.tsum = c->ts2;
   a.mean = c->stat; a.inv = c->stat + Hc; a.scale = c->bn; a.bias = c->bn + Hc;
   const size_t esz = c->d.compute_dtype == LRNDE_BF16 ? 2 : 4;
   launch_mt(c, 1, a, std::max(esz * rows * WP * a.CINP, stg_bytes));
   CHK(c, hipGetLastError());
-  if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(256), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat + 2 * Hc, c->stat + 3 * Hc);
+  if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(256), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat + 2 * Hc, c->stat + 3 * Hc,
+                                rs ? rs + 2 * Hc : nullptr, rs ? rs + 3 * Hc : nullptr, 0.1f);
   if (!last) return LRNDE_OK;
   // conv3: BN2+act(y2) -> du (planar)
   a.COUT = C; a.in = c->y2; a.out = du; a.wpk = c->w3; a.tsum = c->ts3; a.part = nullptr;
@@ -1432,10 +1447,12 @@ int lrnde_conv_create(lrnde_conv** out, const lrnde_conv_desc* d, int device, vo
             hipMalloc(&c->ts1, sizeof(float) * 9 * 64) == hipSuccess && hipMalloc(&c->ts2, sizeof(float) * 9 * 64) == hipSuccess &&
             hipMalloc(&c->ts3, sizeof(float) * 9 * 16) == hipSuccess &&
             hipMalloc(&c->bn, sizeof(float) * 4 * Hc) == hipSuccess && hipMalloc(&c->stat, sizeof(float) * 4 * Hc) == hipSuccess &&
+            hipMalloc(&c->bn_state, sizeof(float) * 4 * Hc) == hipSuccess &&
             hipMalloc(&c->sums, sizeof(double) * NSUMB * 3) == hipSuccess &&
             hipHostMalloc(&c->sums_host, sizeof(double) * NSUMB * 3) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
   if (!ok) { lrnde_conv_destroy(c); return LRNDE_HIP_ERROR; }
+  hipLaunchKernelGGL(k_bn_state_default, dim3(1), dim3(256), 0, c->stream, c->bn_state, Hc);
   *out = c;
   return LRNDE_OK;
 }
@@ -1491,13 +1508,22 @@ int lrnde_conv_set_bn_state(lrnde_conv* c, const float* mean_var, size_t n) {
   const int Hc = c->d.hidden;
   if (n != (size_t)4 * Hc) return cfail(c, LRNDE_BADARG, "bn state has %zu entries, expected %d", n, 4 * Hc);
   CHK(c, hipSetDevice(c->device));
-  if (!c->bn_state) CHK(c, hipMalloc(&c->bn_state, sizeof(float) * 4 * Hc));
   CHK(c, hipMemcpyAsync(c->bn_state, mean_var, sizeof(float) * 4 * Hc, hipMemcpyDeviceToDevice, c->stream));
   if (!c->d.bn_train) {
     hipLaunchKernelGGL(k_bn_from_state, dim3(1), dim3(64), 0, c->stream, (const float*)c->bn_state, Hc, c->d.bn_eps, c->stat, c->stat + Hc);
     hipLaunchKernelGGL(k_bn_from_state, dim3(1), dim3(64), 0, c->stream, (const float*)(c->bn_state + 2 * Hc), Hc, c->d.bn_eps, c->stat + 2 * Hc, c->stat + 3 * Hc);
     CHK(c, hipGetLastError());
   }
+  return LRNDE_OK;
+}
+
+int lrnde_conv_get_bn_state(lrnde_conv* c, float* mean_var, size_t n) {
+  if (!c || !mean_var) return LRNDE_BADARG;
+  const int Hc = c->d.hidden;
+  if (n != (size_t)4 * Hc) return cfail(c, LRNDE_BADARG, "bn state has %zu entries, expected %d", n, 4 * Hc);
+  CHK(c, hipSetDevice(c->device));
+  CHK(c, hipMemcpyAsync(mean_var, c->bn_state, sizeof(float) * 4 * Hc, hipMemcpyDeviceToDevice, c->stream));
+  CHK(c, hipStreamSynchronize(c->stream));
   return LRNDE_OK;
 }
 
@@ -1703,13 +1729,18 @@ int lrnde_conv_node_forward(lrnde_conv* c, const float* x, int32_t B, float t0, 
     if (c->rec_n != n) { if (c->rec_u1) hipFree(c->rec_u1); c->rec_u1 = nullptr; if (hipMalloc(&c->rec_u1, sizeof(float) * n) != hipSuccess) return done2(cfail(c, LRNDE_HIP_ERROR, "allocation failed")); c->rec_n = n; }
     hipMemcpy(c->rec_u1, u1, sizeof(float) * n, hipMemcpyDeviceToDevice);
   }
-  // _get_ode_integrator :33-38 => init on (t1,t2); _perform_step :77
+  // _get_ode_integrator :33-38 => init on (t1,t2); _perform_step :77.  The layer returns the model state as it was
+  // when the solve returned (src/layers/neural_ode.jl:52): the local step's f-evals leave no trace in it.
   float* V = c->vec;
   float dtl, ee, re, rs;
+  const int Hc4 = 4 * c->d.hidden;
+  hipMemcpyAsync(V, c->bn_state, sizeof(float) * Hc4, hipMemcpyDeviceToDevice, c->stream);  // V[0..n) is free here
   if ((rc = init_dt(c, u1, B, t1, t2, oo.abstol, oo.reltol, V + 2 * n, V + 10 * n, V + 9 * n, &dtl))) return done2(rc);
   double s[3];
   if ((rc = tsit5_step(c, u1, V + 2 * n, B, t1, dtl, oo.abstol, oo.reltol, V + n, V + 8 * n, V + 3 * n, V + 9 * n, V + 10 * n, s))) return done2(rc);
   reg_values(s, n, dtl, &ee, &re, &rs);
+  hipMemcpyAsync(c->bn_state, V, sizeof(float) * Hc4, hipMemcpyDeviceToDevice, c->stream);
+  hipStreamSynchronize(c->stream);
   *reg_val = (reg_type == LRNDE_REG_STIFFNESS_ESTIMATE) ? rs : re;
   *nfe = st->nf + (6 + 3);
   return done2(LRNDE_OK);

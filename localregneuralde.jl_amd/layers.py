@@ -364,8 +364,19 @@ class NeuralODE:
             self._ps_key = key
         return h
 
+    def _model_state_in(self, h, st):
+        """conv field: the BatchNorm running statistics are the layer's model state (src/layers/neural_ode.jl:44-48)"""
+        if self._conv and isinstance(st.get("model"), dict) and st["model"].get("bn_state") is not None:
+            h.set_bn_state(st["model"]["bn_state"])
+
+    def _model_state_out(self, h, st):
+        if self._conv:
+            return dict(st["model"] if isinstance(st.get("model"), dict) else {}, bn_state=h.get_bn_state())
+        return st["model"]
+
     def __call__(self, x, ps, st):
         h = self._bind(ps, x)
+        self._model_state_in(h, st)
         t0, t2 = self.tspan
         kw = self.kwargs
         abstol, reltol = kw.get("abstol", 1e-6), kw.get("reltol", 1e-3)  # OrdinaryDiffEq defaults
@@ -377,7 +388,7 @@ class NeuralODE:
             sv = [t2] if saveat is None else list(saveat)
             r = h.solve(x, t0, t2, abstol, reltol, saveat=sv, save_everystep=False, **common)
             sol = ODESolution(r["u"], r["t"], r["stats"]["nf"], r["stats"]["naccept"], r["stats"]["nreject"])
-            return sol, dict(model=st["model"], nfe=r["stats"]["nf"], reg_val=np.float32(0.0), rng=st["rng"],
+            return sol, dict(model=self._model_state_out(h, st), nfe=r["stats"]["nf"], reg_val=np.float32(0.0), rng=st["rng"],
                              training=st["training"])
         rng = copy.deepcopy(st["rng"])  # Lux.replicate(st.rng)
         if mode == "unbiased":  # :68-84
@@ -395,6 +406,7 @@ class NeuralODE:
             needs_correction = False
             i1 = int(rng.integers(0, len(ts) - 1))  # rand(rng, sol.t[1:end-1])
             t1, u1 = ts[i1], r["u"][i1]
+        model_state = self._model_state_out(h, st)  # as it is when the solve returns (:52); the local step leaves no trace
         # _get_ode_integrator :33-38 + _perform_step :77
         dt, k1 = h.init_dt(u1.contiguous(), t1, t2, abstol, reltol)
         ps_out = h.perform_step(u1.contiguous(), k1, t1, dt, abstol, reltol)
@@ -405,7 +417,9 @@ class NeuralODE:
             keep = [i for i, tv in enumerate(tt) if tv != t1]
             us, tt = [us[i] for i in keep], [tt[i] for i in keep]
         sol = ODESolution(us, tt, r["stats"]["nf"], r["stats"]["naccept"], r["stats"]["nreject"])
-        return sol, dict(model=st["model"], nfe=nfe, reg_val=reg_val, rng=rng, training=st["training"])
+        if self._conv:
+            h.set_bn_state(model_state["bn_state"])
+        return sol, dict(model=model_state, nfe=nfe, reg_val=reg_val, rng=rng, training=st["training"])
 
     def pullback(self, x, ps, st, du_end, w_reg=0.0):
         """What `Zygote.pullback` returns for this layer in the reference's training step

@@ -300,7 +300,8 @@ static void conv3x3_t(const float* in, int B, int cin, int cout, int H, int W, c
 
 /* Lux BatchNorm(ch, act) over (W,H,N) per channel, in place on (B, ch, H, W) */
 static void batchnorm_act_ex(float* x, int B, int ch, long plane, const float* scale, const float* bias,
-                             int train, const float* rmean, const float* rvar, float eps, int act, int nth, int round_raw) {
+                             int train, const float* rmean, const float* rvar, float eps, int act, int nth, int round_raw,
+                             float* run_mean, float* run_var) {
 #pragma omp parallel for schedule(static) num_threads(nth)
   for (int c = 0; c < ch; ++c) {
     float mean, inv;
@@ -313,6 +314,12 @@ static void batchnorm_act_ex(float* x, int B, int ch, long plane, const float* s
       v /= ((double)B * (double)plane);
       mean = (float)mu;
       inv = (float)(1.0 / sqrt(v + (double)eps));
+      if (run_mean) { /* Lux training-mode BatchNorm: running statistics advance on every call (UPSTREAM-RECALL) */
+        const float momentum = 0.1f, cnt = (float)((double)B * (double)plane);
+        const float mcorr = momentum * cnt / (cnt - 1.0f);
+        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mu;
+        run_var[c] = (1.0f - momentum) * run_var[c] + mcorr * (float)v;
+      }
     } else {
       mean = rmean ? rmean[c] : 0.0f;
       inv = (float)(1.0 / sqrt((double)(rvar ? rvar[c] : 1.0f) + (double)eps));
@@ -330,7 +337,7 @@ static void batchnorm_act_ex(float* x, int B, int ch, long plane, const float* s
 }
 static void batchnorm_act(float* x, int B, int ch, long plane, const float* scale, const float* bias,
                           int train, const float* rmean, const float* rvar, float eps, int act, int nth) {
-  batchnorm_act_ex(x, B, ch, plane, scale, bias, train, rmean, rvar, eps, act, nth, 0);
+  batchnorm_act_ex(x, B, ch, plane, scale, bias, train, rmean, rvar, eps, act, nth, 0, NULL, NULL);
 }
 
 static float bf16_round(float x) { /* round to nearest even on the top 16 bits */
@@ -361,23 +368,24 @@ void lro_conv_rhs(const lro_conv* m, const float* u, float t, int B, float* du) 
   float* y2 = (float*)malloc(sizeof(float) * (size_t)B * Hc * plane);
   const float* st = m->bn_state;
   const long ny = (long)B * Hc * plane;
+  float* run = m->bn_train ? m->bn_run : NULL; /* running statistics advance on every training-mode call */
   if (m->bf16) {
     /* statistics come from the fp32 conv output, the normalised copy is the bf16-rounded one */
     float* w2r = bf16_weights(w2, Hc, Hc);
     float* w3r = bf16_weights(w3, Hc, C);
     conv3x3_t(u, B, C, Hc, H, W, w1, t, y1, nth);
-    batchnorm_act_ex(y1, B, Hc, plane, g1, b1, m->bn_train, st ? st : NULL, st ? st + Hc : NULL, m->eps, m->act, nth, 1);
+    batchnorm_act_ex(y1, B, Hc, plane, g1, b1, m->bn_train, st ? st : NULL, st ? st + Hc : NULL, m->eps, m->act, nth, 1, run, run ? run + Hc : NULL);
     bf16_round_array(y1, ny);
     conv3x3_t(y1, B, Hc, Hc, H, W, w2r, t, y2, nth);
-    batchnorm_act_ex(y2, B, Hc, plane, g2, b2, m->bn_train, st ? st + 2 * Hc : NULL, st ? st + 3 * Hc : NULL, m->eps, m->act, nth, 1);
+    batchnorm_act_ex(y2, B, Hc, plane, g2, b2, m->bn_train, st ? st + 2 * Hc : NULL, st ? st + 3 * Hc : NULL, m->eps, m->act, nth, 1, run ? run + 2 * Hc : NULL, run ? run + 3 * Hc : NULL);
     bf16_round_array(y2, ny);
     conv3x3_t(y2, B, Hc, C, H, W, w3r, t, du, nth);
     free(w2r); free(w3r);
   } else {
     conv3x3_t(u, B, C, Hc, H, W, w1, t, y1, nth);
-    batchnorm_act(y1, B, Hc, plane, g1, b1, m->bn_train, st ? st : NULL, st ? st + Hc : NULL, m->eps, m->act, nth);
+    batchnorm_act_ex(y1, B, Hc, plane, g1, b1, m->bn_train, st ? st : NULL, st ? st + Hc : NULL, m->eps, m->act, nth, 0, run, run ? run + Hc : NULL);
     conv3x3_t(y1, B, Hc, Hc, H, W, w2, t, y2, nth);
-    batchnorm_act(y2, B, Hc, plane, g2, b2, m->bn_train, st ? st + 2 * Hc : NULL, st ? st + 3 * Hc : NULL, m->eps, m->act, nth);
+    batchnorm_act_ex(y2, B, Hc, plane, g2, b2, m->bn_train, st ? st + 2 * Hc : NULL, st ? st + 3 * Hc : NULL, m->eps, m->act, nth, 0, run ? run + 2 * Hc : NULL, run ? run + 3 * Hc : NULL);
     conv3x3_t(y2, B, Hc, C, H, W, w3, t, du, nth);
   }
   free(y1); free(y2);

@@ -101,6 +101,10 @@ typedef struct {
   const float* p;
   const float* bn_state; /* may be NULL in test mode: mean 0, var 1 */
   int nthreads;
+  float* bn_run;         /* optional (4*Hc): running [mean1 var1 mean2 var2], advanced by every training-mode
+                            lro_conv_rhs call as Lux's BatchNorm does (momentum 0.1, n/(n-1) variance correction) —
+                            what the reference's dudt closure does to its captured st_ (src/layers/neural_ode.jl:44-48);
+                            lro_conv_vjp's recomputation leaves it alone */
   int bf16;              /* 1: emulate the bf16 compute mode of the HIP path: y1, y2 and the activated
                             conv2/conv3 inputs rounded to bf16 (RNE), conv2/conv3 weights (not the t
                             plane's) rounded to bf16, fp32 accumulation; conv1 stays fp32 */

@@ -34,7 +34,8 @@ class Mlp(C.Structure):
 class Conv(C.Structure):
     _fields_ = [("W", C.c_int), ("H", C.c_int), ("C", C.c_int), ("Hc", C.c_int), ("act", C.c_int),
                 ("bn_train", C.c_int), ("eps", C.c_float), ("p", C.POINTER(C.c_float)),
-                ("bn_state", C.POINTER(C.c_float)), ("nthreads", C.c_int), ("bf16", C.c_int)]
+                ("bn_state", C.POINTER(C.c_float)), ("nthreads", C.c_int), ("bn_run", C.POINTER(C.c_float)),
+                ("bf16", C.c_int)]
 
 
 class Opts(C.Structure):
@@ -174,8 +175,10 @@ class ConvField:
         self.params = _f32(params)
         assert self.params.size == lib().lro_conv_param_count(self.C, self.Hc), "param count"
         self.bn_state = None if bn_state is None else _f32(bn_state)
+        self.bn_run = np.concatenate([np.zeros(Hc), np.ones(Hc), np.zeros(Hc), np.ones(Hc)]).astype(np.float32)
         self.m = Conv(self.W, self.H, self.C, self.Hc, ACT[act], int(bool(bn_train)), float(eps), _fp(self.params),
-                      _fp(self.bn_state) if self.bn_state is not None else None, int(nthreads), int(bool(bf16)))
+                      _fp(self.bn_state) if self.bn_state is not None else None, int(nthreads), _fp(self.bn_run),
+                      int(bool(bf16)))
         self.field = Field()
         lib().lro_conv_as_field(C.byref(self.m), C.byref(self.field))
 

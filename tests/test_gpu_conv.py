@@ -160,6 +160,10 @@ def test_conv_layer_surface_runs_the_cifar_block():
     sol, st2 = node(x, ps, st)
     assert st2["nfe"] == sol.destats.nf + 9 and st2["reg_val"] > 0 and len(sol.u) == 2
     assert torch.isfinite(sol.u[-1]).all() and tuple(sol.u[-1].shape) == tuple(x.shape)
+    bn = st2["model"]["bn_state"]  # running statistics moved away from (0, 1) and are threaded through st.model
+    assert bn.shape == (256,) and not torch.allclose(bn[64:128], torch.ones(64, device=bn.device))
+    sol_b, st2b = node(x, ps, st2)
+    assert not torch.equal(st2b["model"]["bn_state"], bn)
     st_test = dict(st, training=False)
     sol_t, st3 = node(x, ps, st_test)
     assert st3["reg_val"] == 0.0 and st3["nfe"] == sol_t.destats.nf
@@ -275,3 +279,29 @@ def test_conv_golden_fixture_on_gpu():
     nd = h.node_forward(x, 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.41)
     assert nd["nfe"] == int(g["node_nfe"]) and nd["stats"]["naccept"] == int(g["node_naccept"])
     _close(nd["u_end"], g["node_u_end"], rtol=2e-5)
+
+
+def test_conv_running_statistics_match_oracle():
+    """st.model of the layer: every training-mode f-eval advances BatchNorm's running statistics
+    (lrnde_conv_get_bn_state); node_forward returns them as they were when the solve returned."""
+    P, O = _mods()
+    W = H = 8; B = 3
+    fld, h, p, u = _case(W, H, B, seed=51, scale=1.5)
+    ud = torch.from_numpy(u).cuda()
+    st0 = h.get_bn_state().cpu().numpy()
+    assert np.array_equal(st0, np.concatenate([np.zeros(64), np.ones(64), np.zeros(64), np.ones(64)]).astype(np.float32))
+    h.rhs(ud, 0.2); fld.rhs(u.reshape(B, -1), 0.2)
+    np.testing.assert_allclose(h.get_bn_state().cpu().numpy(), fld.bn_run, rtol=2e-5, atol=1e-6)
+    rg = h.solve(ud, 0.0, 1.0, 1e-3, 1e-3, saveat=[1.0]); ro = O.solve(fld, u.reshape(B, -1), 0.0, 1.0, 1e-3, 1e-3, saveat=[1.0])
+    assert rg["stats"]["nf"] == ro["stats"]["nf"]
+    after_solve = h.get_bn_state().cpu().numpy()
+    # the stage states of the two solves differ by their dt sequences (1e-3 relative, see above)
+    np.testing.assert_allclose(after_solve, fld.bn_run, rtol=5e-3, atol=5e-4)
+    # VJP: no update; node_forward: only its solve's f-evals count
+    h.vjp(ud, 0.3, ud)
+    assert np.array_equal(h.get_bn_state().cpu().numpy(), after_solve)
+    h2 = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=True); h2.set_params(p)
+    h3 = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=True); h3.set_params(p)
+    h2.node_forward(ud, 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.41)
+    h3.solve(ud, 0.0, 1.0, 1e-3, 1e-3, saveat=[0.41, 1.0])
+    assert np.array_equal(h2.get_bn_state().cpu().numpy(), h3.get_bn_state().cpu().numpy())

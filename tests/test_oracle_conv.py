@@ -219,3 +219,42 @@ def test_conv_golden_fixture():
     nd = O.node_forward(fld, g["x"], 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.41)
     assert nd["nfe"] == int(g["node_nfe"]) and nd["stats"]["naccept"] == int(g["node_naccept"])
     assert np.array_equal(nd["u_end"], g["node_u_end"]) and nd["reg_val"] == g["node_reg_val"]
+
+
+def test_running_statistics_follow_torch_batchnorm():
+    """training-mode BatchNorm advances its running statistics on every f-eval (what the reference's dudt closure does
+    to its captured st_): momentum 0.1, unbiased variance — torch.nn.functional.batch_norm has the same rule"""
+    W = H = 6; C = 8; Hc = 16; B = 3
+    p, u = _case(W, H, C, Hc, B, seed=6)
+    fld = O.ConvField(W, H, C, Hc, p, act="gelu", bn_train=True, nthreads=2)
+    fld.rhs(u, 0.2); fld.rhs(u * np.float32(0.5), 0.7)
+    # float64 restatement with torch's batch_norm keeping the running statistics
+    rm = [torch.zeros(Hc, dtype=torch.float64) for _ in range(2)]
+    rv = [torch.ones(Hc, dtype=torch.float64) for _ in range(2)]
+    pt = torch.from_numpy(p.astype(np.float64))
+
+    def run(uu, t):
+        off = [0]
+
+        def take(n):
+            v = pt[off[0]:off[0] + n]; off[0] += n
+            return v
+
+        x = torch.from_numpy(uu.astype(np.float64)).reshape(B, C, H, W)
+        tc = lambda z: torch.cat([z, torch.full((B, 1, H, W), t, dtype=torch.float64)], dim=1)
+        wgt = lambda ci, co: torch.flip(take(9 * ci * co).reshape(co, ci, 3, 3), dims=(2, 3))
+        gelu = lambda z: 0.5 * z * (1.0 + torch.tanh(np.sqrt(2.0 / np.pi) * (z + 0.044715 * z ** 3)))
+        z = torch.nn.functional.conv2d(tc(x), wgt(C + 1, Hc), padding=1)
+        g, b = take(Hc), take(Hc)
+        z = gelu(torch.nn.functional.batch_norm(z, rm[0], rv[0], g, b, training=True, momentum=0.1, eps=1e-5))
+        z = torch.nn.functional.conv2d(tc(z), wgt(Hc + 1, Hc), padding=1)
+        g, b = take(Hc), take(Hc)
+        torch.nn.functional.batch_norm(z, rm[1], rv[1], g, b, training=True, momentum=0.1, eps=1e-5)
+
+    run(u, 0.2); run(u * np.float32(0.5), 0.7)
+    ref = np.concatenate([rm[0].numpy(), rv[0].numpy(), rm[1].numpy(), rv[1].numpy()])
+    np.testing.assert_allclose(fld.bn_run, ref, rtol=2e-5, atol=1e-6)
+    # the VJP's recomputation leaves them alone
+    before = fld.bn_run.copy()
+    O.conv_vjp(fld, u, 0.3, u)
+    assert np.array_equal(fld.bn_run, before)
