@@ -118,7 +118,8 @@ class ConvHandle:
         self._chk(L.lib.lrnde_conv_set_params(self._ctx, C.c_void_p(ps.data_ptr()), ps.numel()))
 
     def set_bn_state(self, mean_var):
-        mv = torch.as_tensor(np.asarray(mean_var, dtype=np.float32)).to(f"cuda:{self.device}").contiguous().reshape(-1)
+        mv = mean_var if isinstance(mean_var, torch.Tensor) else torch.as_tensor(np.asarray(mean_var, dtype=np.float32))
+        mv = mv.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous().reshape(-1)
         self._keep.append(mv)
         self._chk(L.lib.lrnde_conv_set_bn_state(self._ctx, C.c_void_p(mv.data_ptr()), mv.numel()))
 
