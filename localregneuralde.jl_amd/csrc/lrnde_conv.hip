@@ -1222,8 +1222,8 @@ int ensure_bw(lrnde_conv* c, int B) {
     CHK(c, hipMemsetAsync(c->zeros, 0, sizeof(float) * 9 * 64, c->stream));
     CHK(c, hipMalloc(&c->bwm, sizeof(float) * 4 * Hc));
     CHK(c, hipMalloc(&c->part_bw, sizeof(double) * NBW1 * 64 * 2));
-    CHK(c, hipMalloc(&c->pw, sizeof(float) * (size_t)NWGW * 9 * 64 * 64));
-    CHK(c, hipMalloc(&c->pt, sizeof(float) * (size_t)NWGW * 9 * 64));
+    CHK(c, hipMalloc(&c->pw, sizeof(float) * (size_t)2 * NWGW * 9 * 64 * 64));
+    CHK(c, hipMalloc(&c->pt, sizeof(float) * (size_t)2 * NWGW * 9 * 64));
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1264,7 +1264,6 @@ int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, 
   const size_t o_g1 = (size_t)9 * (C + 1) * Hc, o_w2 = o_g1 + 2 * Hc, o_g2 = o_w2 + (size_t)9 * (Hc + 1) * Hc, o_w3 = o_g2 + 2 * Hc;
   ConvArgs a = base_args(c, B);
   const int rows = a.TR + 2, WP = a.W + 2;
-  const int nstrips = c->nwg, nwgw = nstrips < NWGW ? nstrips : NWGW;
   auto bn_bwd = [&](float* g, const float* araw, int layer) -> int {
     BnBwdArgs b;
     b.g = g; b.a = araw; b.npix = npix; b.mean = c->stat + 2 * layer * Hc; b.inv = c->stat + (2 * layer + 1) * Hc;
@@ -1280,7 +1279,14 @@ int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, 
                    float* gw) -> int {
     WgradArgs w;
     memset(&w, 0, sizeof(w));
-    w.W = W; w.H = H; w.B = B; w.TR = a.TR; w.TP = a.TP; w.nstrips = nstrips;
+    // strips of <= LRNDE_WGRAD_PX pixels (128; 64 gives two workgroups per CU and measured the same)
+    static const int wpx = getenv("LRNDE_WGRAD_PX") ? atoi(getenv("LRNDE_WGRAD_PX")) : 128;
+    int trw = 1;
+    for (int tr = 1; tr <= H; ++tr) if (H % tr == 0 && tr * W <= wpx) trw = tr;
+    const int nstrips_w = B * (H / trw);
+    const int maxwg = (trw * W <= 64) ? 2 * NWGW : NWGW;
+    const int nwgw = nstrips_w < maxwg ? nstrips_w : maxwg;
+    w.W = W; w.H = H; w.B = B; w.TR = trw; w.TP = trw * W; w.nstrips = nstrips_w;
     w.g = g; w.g2 = graw;
     if (GM) { w.gmean = c->stat + 2 * glayer * Hc; w.ginv = c->stat + (2 * glayer + 1) * Hc; w.gscale = c->bn + 2 * glayer * Hc;
               w.gm1 = c->bwm + 2 * glayer * Hc; w.gm2 = c->bwm + (2 * glayer + 1) * Hc; }
@@ -1289,7 +1295,7 @@ int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, 
               w.bias = c->bn + (2 * ilayer + 1) * Hc; }
     w.act = c->d.act; w.pw = c->pw; w.pt = c->pt;
     const int GS = GM ? 80 : 16, IS = IM ? 80 : 16, GC = GM ? 64 : 16, IC = IM ? 64 : 16;
-    size_t sm = sizeof(float) * ((size_t)a.TP * GS + (size_t)rows * WP * IS);
+    size_t sm = sizeof(float) * ((size_t)w.TP * GS + (size_t)(trw + 2) * WP * IS);
     if (sm < sizeof(float) * CNT * 9) sm = sizeof(float) * CNT * 9;
     if (GM && IM) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
     else if (GM) hipLaunchKernelGGL((k_conv_wgrad<1, 0>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
