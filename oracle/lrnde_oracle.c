@@ -1439,3 +1439,172 @@ int lro_conv_node_backward(const lro_conv* m, const float* x, int B, float t0, f
   lro_diff_field d; diff_from_conv(m, &d);
   return node_backward_generic(&d, x, B, t0, t2, o, mode, reg_type, t1_or_rand, du_end, w_reg, dx, dp, st_fwd, st_bwd);
 }
+
+/* ------------------------------------------------------------------------- */
+/* CIFAR10 stem and head (experiments/src/construct.jl:224-227)                */
+/* ------------------------------------------------------------------------- */
+int lro_cifar_stem_param_count(void) { return 135 + 5 + 8 + 8; }
+int lro_cifar_head_param_count(int H, int W, int K) { return 72 + 1 + K * H * W + K; }
+
+/* raw stem activation a0 = cat(x, conv(x) + bias) (B,8,H,W); conv is NNlib.conv (flipped kernel), pad 1 */
+static void stem_raw(const float* x, int B, int H, int W, const float* ps, float* a0) {
+  const long plane = (long)H * W;
+  const float* w = ps; const float* b = ps + 135;
+  for (int n = 0; n < B; ++n) {
+    for (int c = 0; c < 3; ++c) memcpy(a0 + ((long)n * 8 + c) * plane, x + ((long)n * 3 + c) * plane, sizeof(float) * plane);
+    for (int co = 0; co < 5; ++co)
+      for (int y = 0; y < H; ++y)
+        for (int xx = 0; xx < W; ++xx) {
+          double acc = (double)b[co];
+          for (int ci = 0; ci < 3; ++ci)
+            for (int ky = 0; ky < 3; ++ky)
+              for (int kx = 0; kx < 3; ++kx) {
+                const int yy = y + 1 - ky, xi = xx + 1 - kx;
+                if (yy < 0 || yy >= H || xi < 0 || xi >= W) continue;
+                acc += (double)w[kx + 3 * (ky + 3 * (ci + 3 * co))] * (double)x[((long)n * 3 + ci) * plane + (long)yy * W + xi];
+              }
+          a0[((long)n * 8 + 3 + co) * plane + (long)y * W + xx] = (float)acc;
+        }
+  }
+}
+static void stem_stats(const float* a0, int B, long plane, int c, int train, const float* st, float eps, float* mean, float* inv) {
+  if (train) {
+    const double N = (double)B * (double)plane;
+    double s = 0.0;
+    for (int n = 0; n < B; ++n) { const float* p = a0 + ((long)n * 8 + c) * plane; for (long i = 0; i < plane; ++i) s += (double)p[i]; }
+    const double mu = s / N;
+    double v = 0.0;
+    for (int n = 0; n < B; ++n) { const float* p = a0 + ((long)n * 8 + c) * plane; for (long i = 0; i < plane; ++i) { const double d = (double)p[i] - mu; v += d * d; } }
+    *mean = (float)mu; *inv = (float)(1.0 / sqrt(v / N + (double)eps));
+  } else {
+    *mean = st ? st[c] : 0.0f; *inv = (float)(1.0 / sqrt((double)(st ? st[8 + c] : 1.0f) + (double)eps));
+  }
+}
+void lro_cifar_stem_forward(const float* x, int B, int H, int W, const float* ps, int bn_train, const float* bn_state, float eps,
+                            float* u0) {
+  const long plane = (long)H * W;
+  float* a0 = (float*)malloc(sizeof(float) * (size_t)B * 8 * plane);
+  stem_raw(x, B, H, W, ps, a0);
+  const float* g = ps + 140; const float* be = ps + 148;
+  for (int c = 0; c < 8; ++c) {
+    float mean, inv;
+    stem_stats(a0, B, plane, c, bn_train, bn_state, eps, &mean, &inv);
+    for (int n = 0; n < B; ++n)
+      for (long i = 0; i < plane; ++i) {
+        const long o = ((long)n * 8 + c) * plane + i;
+        const float xn = (a0[o] - mean) * inv;
+        u0[o] = xn * g[c] + be[c];
+      }
+  }
+  free(a0);
+}
+void lro_cifar_stem_backward(const float* x, int B, int H, int W, const float* ps, int bn_train, const float* bn_state, float eps,
+                             const float* du0, float* dps) {
+  const long plane = (long)H * W;
+  const double N = (double)B * (double)plane;
+  float* a0 = (float*)malloc(sizeof(float) * (size_t)B * 8 * plane);
+  float* da = (float*)malloc(sizeof(float) * (size_t)B * 8 * plane);
+  stem_raw(x, B, H, W, ps, a0);
+  const float* g = ps + 140;
+  for (int c = 0; c < 8; ++c) {
+    float mean, inv;
+    stem_stats(a0, B, plane, c, bn_train, bn_state, eps, &mean, &inv);
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < B; ++n)
+      for (long i = 0; i < plane; ++i) {
+        const long o = ((long)n * 8 + c) * plane + i;
+        const float xn = (a0[o] - mean) * inv;
+        s1 += (double)du0[o]; s2 += (double)du0[o] * (double)xn;
+      }
+    dps[140 + c] = (float)s2; dps[148 + c] = (float)s1;
+    const float m1 = bn_train ? (float)(s1 / N) : 0.0f, m2 = bn_train ? (float)(s2 / N) : 0.0f;
+    for (int n = 0; n < B; ++n)
+      for (long i = 0; i < plane; ++i) {
+        const long o = ((long)n * 8 + c) * plane + i;
+        const float xn = (a0[o] - mean) * inv;
+        da[o] = (inv * g[c]) * ((du0[o] - m1) - xn * m2);
+      }
+  }
+  for (int co = 0; co < 5; ++co) {
+    double sb = 0.0;
+    for (int n = 0; n < B; ++n) for (long i = 0; i < plane; ++i) sb += (double)da[((long)n * 8 + 3 + co) * plane + i];
+    dps[135 + co] = (float)sb;
+    for (int ci = 0; ci < 3; ++ci)
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+          double acc = 0.0;
+          for (int n = 0; n < B; ++n)
+            for (int y = 0; y < H; ++y)
+              for (int xx = 0; xx < W; ++xx) {
+                const int yy = y + 1 - ky, xi = xx + 1 - kx;
+                if (yy < 0 || yy >= H || xi < 0 || xi >= W) continue;
+                acc += (double)da[((long)n * 8 + 3 + co) * plane + (long)y * W + xx] * (double)x[((long)n * 3 + ci) * plane + (long)yy * W + xi];
+              }
+          dps[kx + 3 * (ky + 3 * (ci + 3 * co))] = (float)acc;
+        }
+  }
+  free(a0); free(da);
+}
+float lro_cifar_head_ce(const float* u, int B, int H, int W, const float* ph, int K, const int* labels, float* logits, float* du,
+                        float* dph) {
+  const long plane = (long)H * W;
+  const int D = (int)plane;
+  const float* wc = ph; const float bc = ph[72]; const float* pd = ph + 73; /* [vec(Wd) K x D; bd] */
+  float* z = (float*)malloc(sizeof(float) * (size_t)B * plane);
+  float* v = (float*)malloc(sizeof(float) * (size_t)B * plane);
+  for (int n = 0; n < B; ++n)
+    for (int y = 0; y < H; ++y)
+      for (int xx = 0; xx < W; ++xx) {
+        double acc = (double)bc;
+        for (int ci = 0; ci < 8; ++ci)
+          for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+              const int yy = y + 1 - ky, xi = xx + 1 - kx;
+              if (yy < 0 || yy >= H || xi < 0 || xi >= W) continue;
+              acc += (double)wc[kx + 3 * (ky + 3 * ci)] * (double)u[((long)n * 8 + ci) * plane + (long)yy * W + xi];
+            }
+        z[(long)n * plane + (long)y * W + xx] = (float)acc;
+        v[(long)n * plane + (long)y * W + xx] = act_apply(LRO_ACT_GELU, (float)acc);
+      }
+  float* dv = (du || dph) ? (float*)malloc(sizeof(float) * (size_t)B * plane) : NULL;
+  float* dpd = dph ? dph + 73 : NULL;
+  const float loss = lro_classifier_ce(v, B, D, pd, K, labels, logits, dv, dpd);
+  if (du || dph) {
+    for (long i = 0; i < (long)B * plane; ++i) { const float hh = act_apply(LRO_ACT_GELU, z[i]); dv[i] = dv[i] * act_deriv(LRO_ACT_GELU, z[i], hh); }
+    if (dph) {
+      double sb = 0.0;
+      for (long i = 0; i < (long)B * plane; ++i) sb += (double)dv[i];
+      dph[72] = (float)sb;
+      for (int ci = 0; ci < 8; ++ci)
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx) {
+            double acc = 0.0;
+            for (int n = 0; n < B; ++n)
+              for (int y = 0; y < H; ++y)
+                for (int xx = 0; xx < W; ++xx) {
+                  const int yy = y + 1 - ky, xi = xx + 1 - kx;
+                  if (yy < 0 || yy >= H || xi < 0 || xi >= W) continue;
+                  acc += (double)dv[(long)n * plane + (long)y * W + xx] * (double)u[((long)n * 8 + ci) * plane + (long)yy * W + xi];
+                }
+            dph[kx + 3 * (ky + 3 * ci)] = (float)acc;
+          }
+    }
+    if (du)
+      for (int n = 0; n < B; ++n)
+        for (int ci = 0; ci < 8; ++ci)
+          for (int y = 0; y < H; ++y)
+            for (int xx = 0; xx < W; ++xx) {
+              double acc = 0.0;
+              for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                  const int yo = y - 1 + ky, xo = xx - 1 + kx;
+                  if (yo < 0 || yo >= H || xo < 0 || xo >= W) continue;
+                  acc += (double)wc[kx + 3 * (ky + 3 * ci)] * (double)dv[(long)n * plane + (long)yo * W + xo];
+                }
+              du[((long)n * 8 + ci) * plane + (long)y * W + xx] = (float)acc;
+            }
+    free(dv);
+  }
+  free(z); free(v);
+  return loss;
+}

@@ -204,6 +204,21 @@ int lro_node_backward(const lro_mlp* m, const float* x, int B, float t0, float t
                       lro_stats* st_fwd, lro_stats* st_bwd);
 
 /* ---- SDE: adaptive Euler-Heun local step with supplied dW (src/perform_step.jl:172-206) ---- */
+/* ---- layers around the CIFAR10 NeuralODE (experiments/src/construct.jl:224-227) ----
+ * stem: AugmenterLayer(Conv((3,3), 3=>5; pad=1), 3) (src/layers/common.jl:80-92: cat(x, conv(x); dims=3)) then
+ * BatchNorm(8) (no activation).  Flat parameters ps = [conv.weight (3x3x3x5 column-major kx,ky,ci,co); conv.bias (5);
+ * bn.scale (8); bn.bias (8)].  x: (B,3,H,W).  Forward writes u0 (B,8,H,W); backward takes du0 and returns dps (156).
+ * head: Chain(Conv((3,3), 8=>1, gelu; pad=1), FlattenLayer(), Dense(H*W => K)) + logitcrossentropy; ph = [conv.weight
+ * (3x3x8x1); conv.bias (1); dense.weight (K x H*W column-major); dense.bias (K)].  Returns the mean loss and, optionally,
+ * logits (B,K), du (B,8,H,W) and dph. */
+int lro_cifar_stem_param_count(void);
+int lro_cifar_head_param_count(int H, int W, int K);
+void lro_cifar_stem_forward(const float* x, int B, int H, int W, const float* ps, int bn_train, const float* bn_state, float eps,
+                            float* u0);
+void lro_cifar_stem_backward(const float* x, int B, int H, int W, const float* ps, int bn_train, const float* bn_state, float eps,
+                             const float* du0, float* dps);
+float lro_cifar_head_ce(const float* u, int B, int H, int W, const float* ph, int K, const int* labels, float* logits, float* du,
+                        float* dph);
 int lro_rkmil_step(const lro_field* drift, const lro_field* diffusion, const float* uprev, const float* dW, float t,
                    float dt, float abstol, float reltol, int B, float* u, float* eest, float* reg_val);
 /* classifier head + logitcrossentropy (experiments/src/construct.jl:199, experiments/src/utils.jl:88):

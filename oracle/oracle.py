@@ -82,6 +82,14 @@ def lib():
         L.lro_mlp_rhs.argtypes = [C.POINTER(Mlp), fp, C.c_float, C.c_int, fp]
         L.lro_classifier_ce.restype = C.c_float
         L.lro_classifier_ce.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_int), fp, fp, fp]
+        ip = C.POINTER(C.c_int)
+        L.lro_cifar_stem_forward.restype = None
+        L.lro_cifar_stem_forward.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_float, fp]
+        L.lro_cifar_stem_backward.restype = None
+        L.lro_cifar_stem_backward.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_float, fp, fp]
+        L.lro_cifar_head_ce.restype = C.c_float
+        L.lro_cifar_head_ce.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, ip, fp, fp, fp]
+        L.lro_cifar_head_param_count.argtypes = [C.c_int] * 3
         L.lro_conv_param_count.argtypes = [C.c_int] * 2
         L.lro_conv_rhs.restype = None
         L.lro_conv_rhs.argtypes = [C.POINTER(Conv), fp, C.c_float, C.c_int, fp]
@@ -398,3 +406,32 @@ def rkmil_step(drift, diffusion, uprev, dW, t, dt, abstol, reltol):
                               float(abstol), float(reltol), B, _fp(u), C.byref(ee), C.byref(rv))
     assert rc == 0
     return dict(u=u, eest=np.float32(ee.value), reg_val=np.float32(rv.value))
+
+
+def cifar_stem_forward(x, ps, bn_train=True, bn_state=None, eps=1e-5):
+    """AugmenterLayer(Conv 3=>5) + BatchNorm(8): x (B,3,H,W) -> u0 (B,8,H,W)"""
+    x = _f32(x); ps = _f32(ps)
+    B, _, H, W = x.shape
+    u0 = np.empty((B, 8, H, W), np.float32)
+    st = None if bn_state is None else _f32(bn_state)
+    lib().lro_cifar_stem_forward(_fp(x), B, H, W, _fp(ps), int(bn_train), _fp(st), float(eps), _fp(u0))
+    return u0
+
+
+def cifar_stem_backward(x, ps, du0, bn_train=True, bn_state=None, eps=1e-5):
+    x = _f32(x); ps = _f32(ps); du0 = _f32(du0)
+    B, _, H, W = x.shape
+    dps = np.zeros(156, np.float32)
+    st = None if bn_state is None else _f32(bn_state)
+    lib().lro_cifar_stem_backward(_fp(x), B, H, W, _fp(ps), int(bn_train), _fp(st), float(eps), _fp(du0), _fp(dps))
+    return dps
+
+
+def cifar_head_ce(u, ph, K, labels):
+    """Conv(8=>1, gelu) + flatten + Dense(H*W=>K) + logitcrossentropy: (loss, logits, du, dph)"""
+    u = _f32(u); ph = _f32(ph)
+    B, _, H, W = u.shape
+    lab = np.ascontiguousarray(labels, dtype=np.int32)
+    logits = np.empty((B, K), np.float32); du = np.empty_like(u); dph = np.zeros_like(ph)
+    loss = lib().lro_cifar_head_ce(_fp(u), B, H, W, _fp(ph), K, lab.ctypes.data_as(C.POINTER(C.c_int)), _fp(logits), _fp(du), _fp(dph))
+    return np.float32(loss), logits, du, dph
