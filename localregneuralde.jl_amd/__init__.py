@@ -11,5 +11,5 @@ from .layers import (Chain, Dense, Handle, NeuralODE, ODESolution, TDChain,  # n
                      glorot_params)
 from .sde import NeuralDSDE, SdeHandle  # noqa: F401
 from .conv import BatchNorm, Conv, ConvHandle, glorot_conv_params  # noqa: F401
-from .training import run_training_step  # noqa: F401
+from .training import run_cifar_training_step, run_training_step  # noqa: F401
 from .sharding import shard_columns, init_comm  # noqa: F401

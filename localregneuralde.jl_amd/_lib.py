@@ -94,6 +94,11 @@ SYMBOLS = [
     ("lrnde_conv_step_reg_grad", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _vp, _fp]),
     ("lrnde_conv_node_backward", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _i32, _i32, _f, _vp, _f, _vp, _vp,
                                            C.POINTER(Stats), C.POINTER(Stats)]),
+    ("lrnde_cifar_stem_param_count", C.c_size_t, []),
+    ("lrnde_cifar_head_param_count", C.c_size_t, [_i32, _i32, _i32]),
+    ("lrnde_cifar_stem_forward", C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    ("lrnde_cifar_stem_backward", C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    ("lrnde_cifar_head_ce", C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _fp, _vp, _vp, _vp]),
     ("lrnde_conv_bench_rhs", C.c_int, [_vp, _vp, _f, _i32, _i32, _fp]),
     ("lrnde_bench_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _fp]),
     ("lrnde_last_solve_kernel_ms", C.c_int, [_vp, _fp, C.POINTER(_i32)]),

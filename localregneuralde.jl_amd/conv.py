@@ -218,6 +218,37 @@ class ConvHandle:
                                                  C.byref(sb)))
         return dict(dx=dx, dp=dp, stats_fwd=sf.asdict(), stats_bwd=sb.asdict())
 
+    # ---- layers around the CIFAR10 NeuralODE (experiments/src/construct.jl:224-227) ----
+    def cifar_stem_forward(self, x, ps, bn_state=None):
+        """AugmenterLayer(Conv 3=>5) + BatchNorm(8): x (B,3,H,W) -> u0 (B,8,H,W)"""
+        B = x.shape[0]
+        u0 = torch.empty((B, 8, self.desc.height, self.desc.width), dtype=torch.float32, device=x.device)
+        self._chk(L.lib.lrnde_cifar_stem_forward(self._ctx, _ptr(x, "x"), B, _ptr(ps, "ps"),
+                                                 _ptr(bn_state, "bn_state") if bn_state is not None else None, _ptr(u0, "u0")))
+        return u0
+
+    def cifar_stem_backward(self, x, ps, du0, bn_state=None):
+        dps = torch.empty(156, dtype=torch.float32, device=x.device)
+        self._chk(L.lib.lrnde_cifar_stem_backward(self._ctx, _ptr(x, "x"), x.shape[0], _ptr(ps, "ps"),
+                                                  _ptr(bn_state, "bn_state") if bn_state is not None else None, _ptr(du0, "du0"),
+                                                  _ptr(dps, "dps")))
+        return dps
+
+    def cifar_head_ce(self, u, ph, K, labels, want_grads=True):
+        """Conv(8=>1, gelu) + flatten + Dense(H*W=>K) + logitcrossentropy: dict(loss, logits, du, dph)"""
+        B = u.shape[0]
+        if not (labels.is_cuda and labels.dtype == torch.int32 and labels.numel() == B):
+            raise ValueError("labels must be a CUDA int32 tensor of length B")
+        logits = torch.empty((B, K), dtype=torch.float32, device=u.device)
+        du = torch.empty_like(u) if want_grads else None
+        dph = torch.empty_like(ph) if want_grads else None
+        loss = C.c_float()
+        self._chk(L.lib.lrnde_cifar_head_ce(self._ctx, _ptr(u, "u"), B, _ptr(ph, "ph"), int(K), C.c_void_p(labels.data_ptr()),
+                                            C.byref(loss), C.c_void_p(logits.data_ptr()),
+                                            C.c_void_p(du.data_ptr()) if want_grads else None,
+                                            C.c_void_p(dph.data_ptr()) if want_grads else None))
+        return dict(loss=np.float32(loss.value), logits=logits, du=du, dph=dph)
+
     def bench_rhs(self, u, t, reps=20):
         """average microseconds of one f-eval (HIP events on the handle's stream)."""
         us = C.c_float()

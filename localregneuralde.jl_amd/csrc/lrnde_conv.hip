@@ -1979,3 +1979,302 @@ int lrnde_conv_node_backward(lrnde_conv* c, const float* x, int32_t B, float t0,
 }
 
 }  // extern "C"
+
+// =============================================================================================
+// Layers around the CIFAR10 NeuralODE (experiments/src/construct.jl:224-227): the stem
+// AugmenterLayer(Conv((3,3), 3=>5; pad=1), 3) + BatchNorm(8) (src/layers/common.jl:80-92) and the head
+// Chain(Conv((3,3), 8=>1, gelu; pad=1), FlattenLayer(), Dense(H*W=>K)) + logitcrossentropy.  They run once per
+// batch (<1 % of a training step): direct convolutions, one thread per pixel, fixed-order fp64 block partials.
+// =============================================================================================
+namespace {
+
+#include "lrnde_cls.hpp"
+
+constexpr int SH_T = 256;
+
+// sum of `nv` per-thread values over the block -> out[nv] (thread 0..nv-1 hold the totals); red: [4][nv] floats
+template <int NV>
+__device__ __forceinline__ void block_reduce_vals(float (&v)[NV], float* red, float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float s = v[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[wave * NV + i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) out[threadIdx.x] = ((red[threadIdx.x] + red[NV + threadIdx.x]) + red[2 * NV + threadIdx.x]) + red[3 * NV + threadIdx.x];
+}
+
+// a0 = cat(x, conv(x) + bias): (B,8,H,W); per-block per-channel (sum, sum of squares) for BatchNorm(8)
+__global__ __launch_bounds__(SH_T) void k_stem_raw(const float* x, const float* ps, int B, int H, int W, float* a0, double* part) {
+  __shared__ float red[4 * 16];
+  __shared__ float tot[16];
+  const long plane = (long)H * W, npx = (long)B * plane;
+  const long i = blockIdx.x * (long)SH_T + threadIdx.x;
+  float v[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) v[c] = 0.f;
+  if (i < npx) {
+    const int n = (int)(i / plane), p = (int)(i % plane), y = p / W, xx = p % W;
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = x[((long)n * 3 + c) * plane + p];
+#pragma unroll
+    for (int co = 0; co < 5; ++co) {
+      float acc = ps[135 + co];
+      for (int ci = 0; ci < 3; ++ci)
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + 1 - ky, xi = xx + 1 - kx;
+            if (yy < 0 || yy >= H || xi < 0 || xi >= W) continue;
+            acc = fma_(ps[kx + 3 * (ky + 3 * (ci + 3 * co))], x[((long)n * 3 + ci) * plane + (long)yy * W + xi], acc);
+          }
+      o[3 + co] = acc;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { a0[((long)n * 8 + c) * plane + p] = o[c]; v[c] = o[c]; v[8 + c] = o[c] * o[c]; }
+  }
+  block_reduce_vals<16>(v, red, tot);
+  __syncthreads();
+  if (threadIdx.x < 8) { part[((size_t)blockIdx.x * 8 + threadIdx.x) * 2] = (double)tot[threadIdx.x]; part[((size_t)blockIdx.x * 8 + threadIdx.x) * 2 + 1] = (double)tot[8 + threadIdx.x]; }
+}
+__global__ void k_stem_state(const float* st, float eps, float* mean, float* inv) {
+  const int c = threadIdx.x;
+  if (c < 8) { mean[c] = st ? st[c] : 0.f; inv[c] = (float)(1.0 / sqrt((double)(st ? st[8 + c] : 1.0f) + (double)eps)); }
+}
+__global__ void k_stem_norm(const float* a0, const float* mean, const float* inv, const float* ps, long plane, long total, float* u0) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / plane) % 8);
+    const float xn = (a0[i] - mean[c]) * inv[c];
+    u0[i] = xn * ps[140 + c] + ps[148 + c];
+  }
+}
+// per-block partials of sum(du0), sum(du0 * xhat) per channel
+__global__ __launch_bounds__(SH_T) void k_stem_bwd1(const float* a0, const float* du0, const float* mean, const float* inv, int B,
+                                                    long plane, double* part) {
+  __shared__ float red[4 * 16];
+  __shared__ float tot[16];
+  const long npx = (long)B * plane;
+  const long i = blockIdx.x * (long)SH_T + threadIdx.x;
+  float v[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) v[c] = 0.f;
+  if (i < npx) {
+    const int n = (int)(i / plane), p = (int)(i % plane);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const long o = ((long)n * 8 + c) * plane + p;
+      const float xn = (a0[o] - mean[c]) * inv[c];
+      v[c] = du0[o]; v[8 + c] = du0[o] * xn;
+    }
+  }
+  block_reduce_vals<16>(v, red, tot);
+  __syncthreads();
+  if (threadIdx.x < 8) { part[((size_t)blockIdx.x * 8 + threadIdx.x) * 2] = (double)tot[threadIdx.x]; part[((size_t)blockIdx.x * 8 + threadIdx.x) * 2 + 1] = (double)tot[8 + threadIdx.x]; }
+}
+__global__ void k_stem_bwd_finalize(const double* part, int nblk, double count, int train, float* m1, float* m2, float* dps) {
+  const int c = threadIdx.x;
+  if (c >= 8) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int w = 0; w < nblk; ++w) { s1 += part[((size_t)w * 8 + c) * 2]; s2 += part[((size_t)w * 8 + c) * 2 + 1]; }
+  m1[c] = train ? (float)(s1 / count) : 0.f; m2[c] = train ? (float)(s2 / count) : 0.f;
+  dps[140 + c] = (float)s2; dps[148 + c] = (float)s1;
+}
+// per-block partials of the conv weight (135) and bias (5) gradients from da = inv*gamma*((du0 - m1) - xhat*m2)
+__global__ __launch_bounds__(SH_T) void k_stem_bwd2(const float* x, const float* a0, const float* du0, const float* mean, const float* inv,
+                                                    const float* ps, const float* m1, const float* m2, int B, int H, int W, float* partw) {
+  __shared__ float red[4 * 28];
+  __shared__ float tot[28];
+  const long plane = (long)H * W, npx = (long)B * plane;
+  const long i = blockIdx.x * (long)SH_T + threadIdx.x;
+  const bool ok = i < npx;
+  const int n = ok ? (int)(i / plane) : 0, p = ok ? (int)(i % plane) : 0, y = p / W, xx = p % W;
+  for (int co = 0; co < 5; ++co) {  // one output channel at a time: 27 weights + 1 bias
+    float v[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) v[k] = 0.f;
+    if (ok) {
+      const int c = 3 + co;
+      const long o = ((long)n * 8 + c) * plane + p;
+      const float xn = (a0[o] - mean[c]) * inv[c];
+      const float da = (inv[c] * ps[140 + c]) * ((du0[o] - m1[c]) - xn * m2[c]);
+      v[27] = da;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + 1 - ky, xi = xx + 1 - kx;
+            if (yy >= 0 && yy < H && xi >= 0 && xi < W) v[kx + 3 * (ky + 3 * ci)] = da * x[((long)n * 3 + ci) * plane + (long)yy * W + xi];
+          }
+    }
+    __syncthreads();
+    block_reduce_vals<28>(v, red, tot);
+    __syncthreads();
+    if (threadIdx.x < 27) partw[(size_t)blockIdx.x * 140 + 27 * co + threadIdx.x] = tot[threadIdx.x];
+    if (threadIdx.x == 27) partw[(size_t)blockIdx.x * 140 + 135 + co] = tot[27];
+  }
+}
+// out[j] = sum over blocks of part[blk][j] (fixed order, fp64)
+__global__ void k_sum_partials(const float* part, int nblk, int nv, float* out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nv) return;
+  double s = 0.0;
+  for (int w = 0; w < nblk; ++w) s += (double)part[(size_t)w * nv + j];
+  out[j] = (float)s;
+}
+// head conv: z = conv(u; 8 => 1) + b, v = gelu(z)
+__global__ void k_head_conv(const float* u, const float* ph, int B, int H, int W, float* z, float* v) {
+  const long plane = (long)H * W, npx = (long)B * plane;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= npx) return;
+  const int n = (int)(i / plane), p = (int)(i % plane), y = p / W, xx = p % W;
+  float acc = ph[72];
+  for (int ci = 0; ci < 8; ++ci)
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + 1 - ky, xi = xx + 1 - kx;
+        if (yy < 0 || yy >= H || xi < 0 || xi >= W) continue;
+        acc = fma_(ph[kx + 3 * (ky + 3 * ci)], u[((long)n * 8 + ci) * plane + (long)yy * W + xi], acc);
+      }
+  z[i] = acc; v[i] = gelu_fast(acc);
+}
+__global__ void k_head_dz(const float* z, float* dv, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) dv[i] = dv[i] * act_deriv_fast(2, z[i]);
+}
+// du[n][ci][y][x] = sum_taps w[kx,ky,ci] dz[n][y-1+ky][x-1+kx]; per-block partials of dw (72) and db (1)
+__global__ __launch_bounds__(SH_T) void k_head_bwd(const float* u, const float* dz, const float* ph, int B, int H, int W, float* du, float* partw) {
+  __shared__ float red[4 * 10];
+  __shared__ float tot[10];
+  const long plane = (long)H * W, npx = (long)B * plane;
+  const long i = blockIdx.x * (long)SH_T + threadIdx.x;
+  const bool ok = i < npx;
+  const int n = ok ? (int)(i / plane) : 0, p = ok ? (int)(i % plane) : 0, y = p / W, xx = p % W;
+  const float d0 = ok ? dz[i] : 0.f;
+  if (ok && du) {
+    for (int ci = 0; ci < 8; ++ci) {
+      float acc = 0.f;
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yo = y - 1 + ky, xo = xx - 1 + kx;
+          if (yo < 0 || yo >= H || xo < 0 || xo >= W) continue;
+          acc = fma_(ph[kx + 3 * (ky + 3 * ci)], dz[(long)n * plane + (long)yo * W + xo], acc);
+        }
+      du[((long)n * 8 + ci) * plane + p] = acc;
+    }
+  }
+  if (!partw) return;
+  for (int ci = 0; ci < 8; ++ci) {  // 9 weights of input channel ci (+ the bias with ci == 0)
+    float v[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) v[k] = 0.f;
+    if (ok) {
+      if (ci == 0) v[9] = d0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = y + 1 - ky, xi = xx + 1 - kx;
+          if (yy >= 0 && yy < H && xi >= 0 && xi < W) v[kx + 3 * ky] = d0 * u[((long)n * 8 + ci) * plane + (long)yy * W + xi];
+        }
+    }
+    __syncthreads();
+    block_reduce_vals<10>(v, red, tot);
+    __syncthreads();
+    if (threadIdx.x < 9) partw[(size_t)blockIdx.x * 73 + 9 * ci + threadIdx.x] = tot[threadIdx.x];
+    if (ci == 0 && threadIdx.x == 9) partw[(size_t)blockIdx.x * 73 + 72] = tot[9];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t lrnde_cifar_stem_param_count(void) { return 135 + 5 + 8 + 8; }
+size_t lrnde_cifar_head_param_count(int32_t H, int32_t W, int32_t K) { return (size_t)72 + 1 + (size_t)K * H * W + K; }
+
+static int stem_common(lrnde_conv* c, const float* x, int B, const float* ps, const float* bn_state, float* a0, float* mi /* mean[8] inv[8] */,
+                       double* part, int nblk) {
+  const int H = c->d.height, W = c->d.width;
+  hipLaunchKernelGGL(k_stem_raw, dim3(nblk), dim3(SH_T), 0, c->stream, x, ps, B, H, W, a0, part);
+  if (c->d.bn_train) hipLaunchKernelGGL(k_bn_finalize, dim3(8), dim3(256), 0, c->stream, (const double*)part, nblk, 8, (double)B * H * W, c->d.bn_eps, mi, mi + 8,
+                                        (float*)nullptr, (float*)nullptr, 0.f);
+  else hipLaunchKernelGGL(k_stem_state, dim3(1), dim3(64), 0, c->stream, bn_state, c->d.bn_eps, mi, mi + 8);
+  CHK(c, hipGetLastError());
+  return LRNDE_OK;
+}
+
+int lrnde_cifar_stem_forward(lrnde_conv* c, const float* x, int32_t B, const float* ps, const float* bn_state, float* u0) {
+  if (!c || !x || !ps || !u0 || B <= 0) return LRNDE_BADARG;
+  CHK(c, hipSetDevice(c->device));
+  const int H = c->d.height, W = c->d.width;
+  const long plane = (long)H * W, total = (long)B * 8 * plane;
+  const int nblk = (int)(((long)B * plane + SH_T - 1) / SH_T);
+  float *a0 = nullptr, *mi = nullptr; double* part = nullptr;
+  CHK(c, hipMalloc(&a0, sizeof(float) * total)); CHK(c, hipMalloc(&mi, sizeof(float) * 16)); CHK(c, hipMalloc(&part, sizeof(double) * nblk * 16));
+  int rc = stem_common(c, x, B, ps, bn_state, a0, mi, part, nblk);
+  if (!rc) {
+    hipLaunchKernelGGL(k_stem_norm, dim3(2048), dim3(256), 0, c->stream, (const float*)a0, (const float*)mi, (const float*)(mi + 8), ps, plane, total, u0);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = cfail(c, LRNDE_HIP_ERROR, "stem kernels failed");
+  }
+  hipFree(a0); hipFree(mi); hipFree(part);
+  return rc;
+}
+
+int lrnde_cifar_stem_backward(lrnde_conv* c, const float* x, int32_t B, const float* ps, const float* bn_state, const float* du0, float* dps) {
+  if (!c || !x || !ps || !du0 || !dps || B <= 0) return LRNDE_BADARG;
+  CHK(c, hipSetDevice(c->device));
+  const int H = c->d.height, W = c->d.width;
+  const long plane = (long)H * W, total = (long)B * 8 * plane;
+  const int nblk = (int)(((long)B * plane + SH_T - 1) / SH_T);
+  float *a0 = nullptr, *mi = nullptr, *mm = nullptr, *partw = nullptr; double* part = nullptr;
+  CHK(c, hipMalloc(&a0, sizeof(float) * total)); CHK(c, hipMalloc(&mi, sizeof(float) * 16)); CHK(c, hipMalloc(&mm, sizeof(float) * 16));
+  CHK(c, hipMalloc(&part, sizeof(double) * nblk * 16)); CHK(c, hipMalloc(&partw, sizeof(float) * (size_t)nblk * 140));
+  int rc = stem_common(c, x, B, ps, bn_state, a0, mi, part, nblk);
+  if (!rc) {
+    hipLaunchKernelGGL(k_stem_bwd1, dim3(nblk), dim3(SH_T), 0, c->stream, (const float*)a0, du0, (const float*)mi, (const float*)(mi + 8), B, plane, part);
+    hipLaunchKernelGGL(k_stem_bwd_finalize, dim3(1), dim3(64), 0, c->stream, (const double*)part, nblk, (double)B * plane, c->d.bn_train ? 1 : 0, mm, mm + 8, dps);
+    hipLaunchKernelGGL(k_stem_bwd2, dim3(nblk), dim3(SH_T), 0, c->stream, x, (const float*)a0, du0, (const float*)mi, (const float*)(mi + 8), ps,
+                       (const float*)mm, (const float*)(mm + 8), B, H, W, partw);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, (const float*)partw, nblk, 140, dps);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) rc = cfail(c, LRNDE_HIP_ERROR, "stem backward kernels failed");
+  }
+  hipFree(a0); hipFree(mi); hipFree(mm); hipFree(part); hipFree(partw);
+  return rc;
+}
+
+int lrnde_cifar_head_ce(lrnde_conv* c, const float* u, int32_t B, const float* ph, int32_t K, const int32_t* labels, float* loss_host,
+                        float* logits, float* du, float* dph) {
+  if (!c || !u || !ph || !labels || !loss_host || B <= 0 || K <= 0 || K > 16) return LRNDE_BADARG;
+  CHK(c, hipSetDevice(c->device));
+  const int H = c->d.height, W = c->d.width, D = H * W;
+  const long plane = D, npx = (long)B * plane;
+  const int nblk = (int)((npx + SH_T - 1) / SH_T);
+  const float* pd = ph + 73;
+  float *z = nullptr, *v = nullptr, *dl = nullptr, *lb = nullptr, *dv = nullptr, *partw = nullptr;
+  CHK(c, hipMalloc(&z, sizeof(float) * npx)); CHK(c, hipMalloc(&v, sizeof(float) * npx)); CHK(c, hipMalloc(&dl, sizeof(float) * (size_t)B * K));
+  CHK(c, hipMalloc(&lb, sizeof(float) * B)); CHK(c, hipMalloc(&dv, sizeof(float) * npx)); CHK(c, hipMalloc(&partw, sizeof(float) * (size_t)nblk * 73));
+  hipLaunchKernelGGL(k_head_conv, dim3(nblk), dim3(SH_T), 0, c->stream, u, ph, B, H, W, z, v);
+  hipLaunchKernelGGL(k_cls_fwd, dim3((B + 3) / 4), dim3(256), 0, c->stream, (const float*)v, pd, labels, B, D, K, logits, dl, lb);
+  if (du || dph) {
+    hipLaunchKernelGGL(k_cls_bwd_x, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, (const float*)dl, pd, B, D, K, dv);
+    if (dph) hipLaunchKernelGGL(k_cls_bwd_w, dim3((K * (D + 1) + 255) / 256), dim3(256), 0, c->stream, (const float*)dl, (const float*)v, B, D, K, dph + 73);
+    hipLaunchKernelGGL(k_head_dz, dim3(1024), dim3(256), 0, c->stream, (const float*)z, dv, npx);
+    hipLaunchKernelGGL(k_head_bwd, dim3(nblk), dim3(SH_T), 0, c->stream, u, (const float*)dv, ph, B, H, W, du, dph ? partw : (float*)nullptr);
+    if (dph) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, (const float*)partw, nblk, 73, dph);
+  }
+  std::vector<float> hl(B);
+  hipError_t e = hipMemcpyAsync(hl.data(), lb, sizeof(float) * B, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(z); hipFree(v); hipFree(dl); hipFree(lb); hipFree(dv); hipFree(partw);
+  if (e != hipSuccess) return cfail(c, LRNDE_HIP_ERROR, "head kernels failed: %s", hipGetErrorString(e));
+  double acc = 0.0;
+  for (int b = 0; b < B; ++b) acc += (double)hl[b];
+  *loss_host = (float)(acc / (double)B);
+  return LRNDE_OK;
+}
+
+}  // extern "C"

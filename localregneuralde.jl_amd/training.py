@@ -39,3 +39,41 @@ def run_training_step(node, ps, pc, st, x, labels, w_reg, num_classes=10):
     stats = dict(y_pred=head["logits"], nfe=fw["nfe"], ce_loss=head["loss"], reg_val=fw["reg_val"])
     grads = dict(neural_ode=bw["dp"], classifier=head["dpc"], x=bw["dx"])
     return loss, st_, stats, grads, dict(fwd_time=fwd_time, bwd_time=bwd_time, adjoint=bw["stats_bwd"], forward=fw["stats"])
+
+
+def run_cifar_training_step(node, params, st, x, labels, w_reg, num_classes=10):
+    """The CIFAR10 model's forward + pullback (experiments/src/construct.jl:213-227):
+    Chain(augment, bn, neural_ode, sol_to_arr, classifier) with loss = logitcrossentropy + w_reg * reg_val.
+    params: dict(stem=(156,), neural_ode=(47560,), head=(72+1+K*H*W+K,)) CUDA float32; x (B,3,H,W); labels CUDA int32.
+    Returns (loss, st_, stats, grads, times).  The NeuralODE pullback re-solves the forward with its dense record
+    (one extra forward solve inside bwd_time)."""
+    h = node._bind(params["neural_ode"], torch.empty((x.shape[0], 8, x.shape[2], x.shape[3]), device=x.device))
+    node._model_state_in(h, st)
+    t0, t2 = node.tspan
+    kw = node.kwargs
+    abstol, reltol = kw.get("abstol", 1e-6), kw.get("reltol", 1e-3)
+    mode = node.regularize if st["training"] else "none"
+    rng = copy.deepcopy(st["rng"])
+    r01 = np.float32(rng.random(dtype=np.float32))
+    t1_or_rand = np.float32(r01 * (t2 - t0) + t0) if mode == "unbiased" else r01
+    torch.cuda.synchronize()
+    tic = time.perf_counter()
+    u0 = h.cifar_stem_forward(x, params["stem"])
+    fw = h.node_forward(u0, t0, t2, abstol, reltol, mode=mode, reg_type=node.regularize_type, t1_or_rand=t1_or_rand,
+                        maxiters=node.maxiters, save_start=kw.get("save_start", True))
+    bn_after = h.get_bn_state()
+    head = h.cifar_head_ce(fw["u_end"], params["head"], num_classes, labels)
+    loss = np.float32(head["loss"] + np.float32(w_reg) * fw["reg_val"])
+    torch.cuda.synchronize()
+    fwd_time = time.perf_counter() - tic
+    tic = time.perf_counter()
+    bw = h.node_backward(u0, t0, t2, abstol, reltol, head["du"], mode=mode, reg_type=node.regularize_type,
+                         t1_or_rand=t1_or_rand, w_reg=w_reg, maxiters=node.maxiters, save_start=kw.get("save_start", True))
+    h.set_bn_state(bn_after)  # the pullback's forward re-solve must not advance the model state a second time
+    dstem = h.cifar_stem_backward(x, params["stem"], bw["dx"])
+    torch.cuda.synchronize()
+    bwd_time = time.perf_counter() - tic
+    st_ = dict(model=dict(bn_state=bn_after), nfe=fw["nfe"], reg_val=fw["reg_val"], rng=rng, training=st["training"])
+    stats = dict(y_pred=head["logits"], nfe=fw["nfe"], ce_loss=head["loss"], reg_val=fw["reg_val"])
+    grads = dict(stem=dstem, neural_ode=bw["dp"], head=head["dph"])
+    return loss, st_, stats, grads, dict(fwd_time=fwd_time, bwd_time=bwd_time, adjoint=bw["stats_bwd"], forward=fw["stats"])

@@ -305,3 +305,75 @@ def test_conv_running_statistics_match_oracle():
     h2.node_forward(ud, 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.41)
     h3.solve(ud, 0.0, 1.0, 1e-3, 1e-3, saveat=[0.41, 1.0])
     assert np.array_equal(h2.get_bn_state().cpu().numpy(), h3.get_bn_state().cpu().numpy())
+
+
+# ---- layers around the CIFAR10 NeuralODE ----
+@pytest.mark.parametrize("W,H,B,train", [(8, 8, 5, True), (32, 32, 3, True), (16, 16, 4, False)])
+def test_cifar_stem_matches_oracle(W, H, B, train):
+    P, O = _mods()
+    rng = np.random.default_rng(W + B)
+    x = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    ps = (rng.standard_normal(156) * 0.3).astype(np.float32); ps[140:148] = rng.uniform(0.5, 1.5, 8)
+    st = None if train else np.concatenate([rng.normal(0, 0.2, 8), rng.uniform(0.5, 2, 8)]).astype(np.float32)
+    g = rng.standard_normal((B, 8, H, W)).astype(np.float32)
+    h = P.ConvHandle(W, H, 8, 64, bn_train=train)
+    xd, pd = torch.from_numpy(x).cuda(), torch.from_numpy(ps).cuda()
+    std = None if st is None else torch.from_numpy(st).cuda()
+    _close(h.cifar_stem_forward(xd, pd, std), O.cifar_stem_forward(x, ps, bn_train=train, bn_state=st), rtol=1e-5)
+    got = h.cifar_stem_backward(xd, pd, torch.from_numpy(g).cuda(), std).cpu().numpy()
+    ref = O.cifar_stem_backward(x, ps, g, bn_train=train, bn_state=st)
+    assert np.abs(got - ref).max() <= 5e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("W,H,B", [(8, 8, 6), (32, 32, 4)])
+def test_cifar_head_matches_oracle(W, H, B):
+    P, O = _mods()
+    rng = np.random.default_rng(W)
+    K = 10
+    u = rng.standard_normal((B, 8, H, W)).astype(np.float32)
+    ph = (rng.standard_normal(73 + K * H * W + K) * 0.1).astype(np.float32)
+    lab = rng.integers(0, K, B).astype(np.int32)
+    lo, lg, du, dph = O.cifar_head_ce(u, ph, K, lab)
+    h = P.ConvHandle(W, H, 8, 64)
+    r = h.cifar_head_ce(torch.from_numpy(u).cuda(), torch.from_numpy(ph).cuda(), K, torch.from_numpy(lab).cuda())
+    assert abs(float(r["loss"]) - float(lo)) <= 2e-5 * max(1.0, abs(float(lo)))
+    _close(r["logits"], lg, rtol=2e-5)
+    _close(r["du"], du, rtol=5e-5)
+    got = r["dph"].cpu().numpy()
+    assert np.abs(got - dph).max() <= 5e-5 * np.abs(dph).max()
+
+
+def test_cifar_training_step_runs_and_is_consistent():
+    """run_cifar_training_step: loss = CE + w_reg*reg_val, gradients for all three parameter groups; the NeuralODE part
+    equals lrnde_conv_node_backward with the head's cotangent (checked against the oracle on the same inputs)"""
+    P, O = _mods()
+    W = H = 8; B = 4; K = 10
+    rng = np.random.default_rng(12)
+    core = P.TDChain(P.Chain(P.Chain(P.Conv((3, 3), 9, 64), P.BatchNorm(64, "gelu")),
+                             P.Chain(P.Conv((3, 3), 65, 64), P.BatchNorm(64, "gelu")), P.Conv((3, 3), 65, 8)))
+    node = P.NeuralODE(core, regularize="unbiased", abstol=1e-3, reltol=1e-3, save_start=False, maxiters=2000)
+    pn = P.glorot_conv_params(8, 64, seed=0)
+    ps = (rng.standard_normal(156) * 0.3).astype(np.float32); ps[140:148] = 1.0; ps[148:156] = 0.0
+    ph = (rng.standard_normal(73 + K * H * W + K) * 0.1).astype(np.float32)
+    x = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    lab = rng.integers(0, K, B).astype(np.int32)
+    params = dict(stem=torch.from_numpy(ps).cuda(), neural_ode=torch.from_numpy(pn).cuda(), head=torch.from_numpy(ph).cuda())
+    st = node.initialstates(np.random.default_rng(0))
+    loss, st_, stats, grads, times = P.run_cifar_training_step(node, params, st, torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda(), 2.5)
+    assert np.isfinite(loss) and times["fwd_time"] > 0 and times["bwd_time"] > 0
+    assert grads["stem"].shape == (156,) and grads["neural_ode"].shape == (47560,) and grads["head"].shape == ph.shape
+    assert all(torch.isfinite(g).all() and g.abs().max() > 0 for g in grads.values())
+    # oracle chain on the same inputs
+    import copy
+    t1 = np.float32(copy.deepcopy(st["rng"]).random(dtype=np.float32))
+    u0 = O.cifar_stem_forward(x, ps)
+    fld = O.ConvField(W, H, 8, 64, pn, nthreads=8)
+    fo = O.node_forward(fld, u0.reshape(B, -1), 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=t1, maxiters=2000)
+    lo, lg, du, dph = O.cifar_head_ce(fo["u_end"].reshape(B, 8, H, W), ph, K, lab)
+    assert abs(float(stats["ce_loss"]) - float(lo)) <= 1e-4 * abs(float(lo))
+    bo = O.node_backward(fld, u0.reshape(B, -1), 0.0, 1.0, 1e-3, 1e-3, du.reshape(B, -1), mode="unbiased", t1_or_rand=t1, w_reg=2.5,
+                         maxiters=2000)
+    dstem = O.cifar_stem_backward(x, ps, bo["dx"].reshape(B, 8, H, W))
+    assert _rel(grads["neural_ode"].cpu().numpy(), bo["dp"]) <= 1e-2
+    assert _rel(grads["head"].cpu().numpy(), dph) <= 1e-3
+    assert _rel(grads["stem"].cpu().numpy(), dstem) <= 1e-2
