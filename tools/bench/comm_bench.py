@@ -1,6 +1,6 @@
 # per-pass cost of the per-step RCCL all-reduce on one rank (LRNDE_FORCE_COMM=1 vs unset)
 import os, sys, time, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import lrnde_amd as P
 from localregneuralde_jl_amd.layers import Handle, _mlp_desc
 D, H, B = 784, 100, 512

@@ -1,5 +1,5 @@
 import sys, os, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import lrnde_amd as P
 shapes = [(32, 32, 256)] if os.environ.get("LRNDE_CONV_DBG") else [(32, 32, 256), (28, 28, 512), (32, 32, 32)]
 for dt in ("f32", "bf16"):

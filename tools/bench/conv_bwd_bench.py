@@ -1,5 +1,5 @@
 import os, sys, time, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import lrnde_amd as P
 W = H = 32; B = 256
 h = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=True)

@@ -1,6 +1,6 @@
 """Scratch timing helper for gpurun (not a test)."""
 import sys, time, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lrnde_amd as P
