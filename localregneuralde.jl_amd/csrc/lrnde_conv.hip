@@ -1717,10 +1717,24 @@ int lrnde_conv_node_forward(lrnde_conv* c, const float* x, int32_t B, float t0, 
     hipMemcpy(u_end, us + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice);
   } else {  // :88-100 biased, saveat = [] => every accepted step
     oo.save_everystep = 1;
-    int cap = oo.maxiters + 2; if (cap > 512) cap = 512;
-    if (hipMalloc(&us, sizeof(float) * n * cap) != hipSuccess) return done2(cfail(c, LRNDE_HIP_ERROR, "allocation failed"));
-    std::vector<float> ts(cap);
-    if ((rc = lrnde_conv_solve(c, x, B, t0, t2, &oo, nullptr, 0, us, ts.data(), cap, st, nullptr, 0))) return done2(rc);
+    // every accepted step is kept: start with room for 32 and re-solve with more if that overflows (a state is
+    // 8 MB at the CIFAR shape, B=256; the running statistics are rewound so the retry does not count twice)
+    std::vector<float> ts;
+    float* bn0 = nullptr;
+    const int Hc4b = 4 * c->d.hidden;
+    if (hipMalloc(&bn0, sizeof(float) * Hc4b) != hipSuccess) return done2(cfail(c, LRNDE_HIP_ERROR, "allocation failed"));
+    hipMemcpyAsync(bn0, c->bn_state, sizeof(float) * Hc4b, hipMemcpyDeviceToDevice, c->stream);
+    for (int cap = 32;; cap *= 4) {
+      if (cap > oo.maxiters + 2) cap = oo.maxiters + 2;
+      if (us) { hipFree(us); us = nullptr; }
+      if (hipMalloc(&us, sizeof(float) * n * cap) != hipSuccess) { hipFree(bn0); return done2(cfail(c, LRNDE_HIP_ERROR, "allocation failed")); }
+      ts.assign(cap, 0.f);
+      rc = lrnde_conv_solve(c, x, B, t0, t2, &oo, nullptr, 0, us, ts.data(), cap, st, nullptr, 0);
+      if (rc == LRNDE_CAPACITY && cap < oo.maxiters + 2) { hipMemcpyAsync(c->bn_state, bn0, sizeof(float) * Hc4b, hipMemcpyDeviceToDevice, c->stream); continue; }
+      break;
+    }
+    hipFree(bn0);
+    if (rc) return done2(rc);
     if (st->nsaved < 2) return done2(cfail(c, LRNDE_BADARG, "biased mode needs at least two saved steps"));
     const int m = st->nsaved - 1;
     int idx = (int)(t1_or_rand * (float)m);
