@@ -398,7 +398,7 @@ struct StreamV {
   __amdgpu_buffer_rsrc_t rs1, rsv, rsu;
   int v1[2], v2[2], s1[2], s2[2];
   int kq2_real;
-  f32x4 ring[QRING][QSQ][2];
+  f32x4 ring[VRING][QSQ][2];
 };
 
 template <int B, int SLOT>
@@ -449,7 +449,7 @@ __device__ __forceinline__ void vq_phase_ksplit(const ModelDev& m, const SmemQ& 
   const f32x4* xp = tile + (size_t)((wave < nseg1 ? wave : 0) * QSEG) * 4 + sidx;
   static_for<0, QSB1>([&](auto Bc) {
     constexpr int B = decltype(Bc)::value;
-    constexpr int SL = (BASE + B) % QRING, NSL = (BASE + B + 2) % QRING;
+    constexpr int SL = (BASE + B) % VRING, NSL = (BASE + B + 2) % VRING;
     vq_stream_load<BASE + B + 2, NSL>(st);
     f32x4 b_[QSQ];
 #pragma unroll
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(QNT) void k_vjp_q(VjpQArgs a) {
     f32x4 acc0 = zero4, acc1 = zero4;
     static_for<0, QSB2>([&](auto Bc) {
       constexpr int B = decltype(Bc)::value;
-      constexpr int SL = (2 * QSB1 + B) % QRING, NSL = (2 * QSB1 + B + 2) % QRING;
+      constexpr int SL = (2 * QSB1 + B) % VRING, NSL = (2 * QSB1 + B + 2) % VRING;
       vq_stream_load<2 * QSB1 + B + 2, NSL>(st);
       f32x4 b_[QSQ];
 #pragma unroll

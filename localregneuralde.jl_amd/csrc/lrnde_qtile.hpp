@@ -201,7 +201,12 @@ constexpr int QSQ = 4;            // k-quads per stream block
 constexpr int QSB1 = QSEG / QSQ;  // 7 Dense-1 blocks (one canonical segment)
 constexpr int QSB2 = 7;           // Dense-2 blocks (KQ2p = 28 k-quads)
 constexpr int QSB = QSB1 + QSB2;
-constexpr int QRING = 3;
+#ifndef LRNDE_QRING
+#define LRNDE_QRING 3
+#endif
+constexpr int QRING = LRNDE_QRING;   // ring slots; QRING - 1 blocks are in flight
+constexpr int QAHEAD = QRING - 1;
+constexpr int VRING = 3;             // ring of the VJP kernel's stream (lrnde_backward.hpp)
 
 template <int I> struct IC { static constexpr int value = I; };
 template <int I0, int I1, class F> __device__ __forceinline__ void static_for(F&& f) {
@@ -257,8 +262,7 @@ __device__ __forceinline__ void stream_init_q(const ModelDev& m, StreamQ& st) {
     st.s2[c] = (g < m.RG2 ? g : 0) * m.KQ2p * 1024;
   }
   st.kq2_real = (m.H + 3) / 4;
-  q_stream_load<0, 0>(st);
-  q_stream_load<1, 1>(st);
+  static_for<0, QAHEAD>([&](auto Bc) { constexpr int B = decltype(Bc)::value; q_stream_load<B, B>(st); });
 }
 
 template <class Epi, int SLOT0>
@@ -278,8 +282,8 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
     const f32x4* xp = sm.xl + (size_t)((wave < nseg1 ? wave : 0) * QSEG) * 4 + sidx;
     static_for<0, QSB1>([&](auto Bc) {
       constexpr int B = decltype(Bc)::value;
-      constexpr int SL = (SLOT0 + B) % QRING, NSL = (SLOT0 + B + 2) % QRING;
-      q_stream_load<(B + 2) % QSB, NSL>(st);
+      constexpr int SL = (SLOT0 + B) % QRING, NSL = (SLOT0 + B + QAHEAD) % QRING;
+      q_stream_load<(B + QAHEAD) % QSB, NSL>(st);
       f32x4 b_[QSQ];
 #pragma unroll
       for (int j = 0; j < QSQ; ++j) b_[j] = xp[(B * QSQ + j) * 4];
@@ -332,8 +336,8 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
     f32x4 pb0[Epi::NPRE], pb1[Epi::NPRE];
     static_for<0, QSB2>([&](auto Bc) {
       constexpr int B = decltype(Bc)::value;
-      constexpr int SL = (SLOT0 + QSB1 + B) % QRING, NSL = (SLOT0 + QSB1 + B + 2) % QRING;
-      q_stream_load<(QSB1 + B + 2) % QSB, NSL>(st);  // wraps into the next f-eval's Dense-1 blocks
+      constexpr int SL = (SLOT0 + QSB1 + B) % QRING, NSL = (SLOT0 + QSB1 + B + QAHEAD) % QRING;
+      q_stream_load<(QSB1 + B + QAHEAD) % QSB, NSL>(st);  // wraps into the next f-eval's Dense-1 blocks
       if constexpr (B == QSB2 - 3) {  // epilogue operands: issued ~3 blocks before they are needed
         if (g0 < m.RG2) epi.pre(g0, pb0);
         if (g1 < m.RG2) epi.pre(g1, pb1);
@@ -616,7 +620,7 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
     e.off_out = arr_off(a, 4 + (S - 2));                                                \
     e.off_x = (S == 6) ? o_un : ((S == 5 && a.want_stiff) ? o_g6 : -1);                 \
     e.dt = dt; e.xl = s.xl; e.KQ1 = KQ1;                                                \
-    feval_qs<EpiStageQ<S>, (2 * (S - 2)) % QRING>(a.m, s, fc, (TS), e);                 \
+    feval_qs<EpiStageQ<S>, (QSB * (S - 2)) % QRING>(a.m, s, fc, (TS), e);                 \
     STAMP(11 + S);                                                                      \
   } while (0)
   LRNDE_QSTAGE(2, t + c1 * dt);
@@ -633,7 +637,7 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
   ef.dt = dt; ef.abstol = a.abstol; ef.reltol = a.reltol; ef.want_stiff = a.want_stiff; ef.nvalid = nvalid;
   ef.D = a.m.D;
   ef.aerr = &aerr; ef.anum = &anum; ef.aden = &aden;
-  feval_qs<EpiFinalQ, (2 * 5) % QRING>(a.m, s, fc, t + dt, ef);
+  feval_qs<EpiFinalQ, (QSB * 5) % QRING>(a.m, s, fc, t + dt, ef);
   STAMP(18);
   block_sum3_q(s.red, aerr, anum, aden);
   STAMP(19);
