@@ -274,7 +274,9 @@ def conv_measure(args, workload, brief=False):
                    "rk_steps_per_sec": steps_total / el, "fwd_ms_per_batch": el / steps * 1e3,
                    "fwd_plus_adjoint_ms_per_batch": fwd_adj_ms, "adjoint": bwd},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": None, "kernel": "one f-eval = k_conv_wide(conv1) + k_bn_finalize + k_conv_wide(conv2) + "
+                     # HBM/fabric bytes per f-eval from separate rocprofv3 --pmc passes (profiles/r1/conv/pmc_summary.txt:
+                     # 2 x FETCH_SIZE + WRITE_SIZE over the five launches), measured offline for this shape only
+                     "traffic": 429.4e6 if (workload == "cifar_conv_f32" and B == 256) else None, "kernel": "one f-eval = k_conv_wide(conv1) + k_bn_finalize + k_conv_wide(conv2) + "
                                                 "k_bn_finalize + k_conv_out(conv3)",
                      "us_per_launch": us, "flop_per_launch": flop},
     }
