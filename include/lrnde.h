@@ -219,6 +219,8 @@ int lrnde_conv_set_bn_state(lrnde_conv* c, const float* mean_var, size_t n);    
  * what the reference's dudt closure does to its captured st_ (src/layers/neural_ode.jl:44-48); the backward
  * pass's recomputations do not.  Initial value: mean 0, var 1 (Lux initialstates). */
 int lrnde_conv_get_bn_state(lrnde_conv* c, float* mean_var, size_t n);            /* device */
+/* Lux.trainmode / Lux.testmode for the field's BatchNorm layers after creation (overrides desc.bn_train) */
+int lrnde_conv_set_bn_mode(lrnde_conv* c, int32_t bn_train);
 int lrnde_conv_rhs(lrnde_conv* c, const float* u, float t, int32_t B, float* du);
 int lrnde_conv_init_dt(lrnde_conv* c, const float* u0, int32_t B, float t0, float t1, float abstol,
                        float reltol, float* k1, float* dt_host);

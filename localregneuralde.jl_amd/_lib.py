@@ -83,6 +83,7 @@ SYMBOLS = [
     ("lrnde_conv_set_params", C.c_int, [_vp, _vp, C.c_size_t]),
     ("lrnde_conv_set_bn_state", C.c_int, [_vp, _vp, C.c_size_t]),
     ("lrnde_conv_get_bn_state", C.c_int, [_vp, _vp, C.c_size_t]),
+    ("lrnde_conv_set_bn_mode", C.c_int, [_vp, _i32]),
     ("lrnde_conv_rhs", C.c_int, [_vp, _vp, _f, _i32, _vp]),
     ("lrnde_conv_init_dt", C.c_int, [_vp, _vp, _i32, _f, _f, _f, _f, _vp, _fp]),
     ("lrnde_conv_perform_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _vp, _vp, _fp, _fp, _fp]),

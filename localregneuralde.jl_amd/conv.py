@@ -123,6 +123,10 @@ class ConvHandle:
         self._keep.append(mv)
         self._chk(L.lib.lrnde_conv_set_bn_state(self._ctx, C.c_void_p(mv.data_ptr()), mv.numel()))
 
+    def set_bn_mode(self, train):
+        """Lux.trainmode / Lux.testmode of the BatchNorm layers"""
+        self._chk(L.lib.lrnde_conv_set_bn_mode(self._ctx, int(bool(train))))
+
     def get_bn_state(self):
         """running [mean1 var1 mean2 var2] (st.model of the layer), advanced by every training-mode f-eval"""
         out = torch.empty(4 * self.desc.hidden, dtype=torch.float32, device=f"cuda:{self.device}")

@@ -1523,6 +1523,21 @@ int lrnde_conv_set_bn_state(lrnde_conv* c, const float* mean_var, size_t n) {
   return LRNDE_OK;
 }
 
+// Lux.trainmode / Lux.testmode of the field's BatchNorm layers: batch statistics (and advancing running statistics)
+// versus the running statistics as they are now
+int lrnde_conv_set_bn_mode(lrnde_conv* c, int32_t bn_train) {
+  if (!c) return LRNDE_BADARG;
+  CHK(c, hipSetDevice(c->device));
+  c->d.bn_train = bn_train ? 1 : 0;
+  if (!c->d.bn_train) {
+    const int Hc = c->d.hidden;
+    hipLaunchKernelGGL(k_bn_from_state, dim3(1), dim3(64), 0, c->stream, (const float*)c->bn_state, Hc, c->d.bn_eps, c->stat, c->stat + Hc);
+    hipLaunchKernelGGL(k_bn_from_state, dim3(1), dim3(64), 0, c->stream, (const float*)(c->bn_state + 2 * Hc), Hc, c->d.bn_eps, c->stat + 2 * Hc, c->stat + 3 * Hc);
+    CHK(c, hipGetLastError());
+  }
+  return LRNDE_OK;
+}
+
 int lrnde_conv_get_bn_state(lrnde_conv* c, float* mean_var, size_t n) {
   if (!c || !mean_var) return LRNDE_BADARG;
   const int Hc = c->d.hidden;

@@ -366,8 +366,10 @@ class NeuralODE:
 
     def _model_state_in(self, h, st):
         """conv field: the BatchNorm running statistics are the layer's model state (src/layers/neural_ode.jl:44-48)"""
-        if self._conv and isinstance(st.get("model"), dict) and st["model"].get("bn_state") is not None:
-            h.set_bn_state(st["model"]["bn_state"])
+        if self._conv:
+            if isinstance(st.get("model"), dict) and st["model"].get("bn_state") is not None:
+                h.set_bn_state(st["model"]["bn_state"])
+            h.set_bn_mode(bool(st["training"]))  # Lux.testmode flips every nested layer: running statistics, no update
 
     def _model_state_out(self, h, st):
         if self._conv:

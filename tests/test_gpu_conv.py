@@ -164,8 +164,12 @@ def test_conv_layer_surface_runs_the_cifar_block():
     assert bn.shape == (256,) and not torch.allclose(bn[64:128], torch.ones(64, device=bn.device))
     sol_b, st2b = node(x, ps, st2)
     assert not torch.equal(st2b["model"]["bn_state"], bn)
-    st_test = dict(st, training=False)
+    st_test = dict(st2, training=False)  # Lux.testmode: running statistics are used and left alone
     sol_t, st3 = node(x, ps, st_test)
+    assert torch.equal(st3["model"]["bn_state"], bn)
+    h = node.handle()
+    ref = O.ConvField(16, 16, 8, 64, ps.cpu().numpy(), bn_train=False, bn_state=bn.cpu().numpy(), nthreads=8)
+    _close(h.rhs(x, 0.2), ref.rhs(x.cpu().numpy().reshape(2, -1), 0.2))
     assert st3["reg_val"] == 0.0 and st3["nfe"] == sol_t.destats.nf
 
 
