@@ -82,8 +82,10 @@ class NeuralDSDE:
                  regularize="unbiased", maxiters=1000, nsteps=20, delta=1.0 / 6.0, **kwargs):
         regularize = _sym(regularize)
         _check_valid_regularize(regularize)
-        if solver not in ("EulerHeun", "LambaEulerHeun"):
-            raise NotImplementedError("only the Euler-Heun step (src/perform_step.jl:172-206) is on the device")
+        if solver not in ("EulerHeun", "LambaEulerHeun", "RKMil", "RKMilCommute"):
+            raise NotImplementedError("on the device: the Euler-Heun step (src/perform_step.jl:172-206) and the Milstein step "
+                                      "(:108-170); SOSRI's tableau lives in un-vendored StochasticDiffEq")
+        self.solver = "RKMil" if solver.startswith("RKMil") else "EulerHeun"
         if not isinstance(diffusion, Dense) or diffusion.in_dims != diffusion.out_dims:
             raise NotImplementedError("diffusion must be Dense(D => D) (experiments/src/construct.jl:205)")
         self.drift, self.diffusion = drift, diffusion
@@ -116,14 +118,19 @@ class NeuralDSDE:
         if noise is None:  # W.dW ~ sqrt(dt) N(0,1), drawn on the host stream
             noise = (rng.standard_normal((n + 1,) + tuple(x.shape)).astype(np.float32) * np.float32(np.sqrt(dt)))
         noise = torch.as_tensor(noise, dtype=torch.float32).to(x.device)
+        if self.solver == "RKMil":
+            step = lambda uu, dw, tt: h.rkmil_step(uu, dw, tt, dt, abstol, reltol)
+        else:
+            step = lambda uu, dw, tt: h.euler_heun_step(uu, dw, tt, dt, abstol, reltol, self.delta)
         us, ts = [], []
         u, t = x, t0
         for i in range(n):
-            r = h.euler_heun_step(u, noise[i].contiguous(), t, dt, abstol, reltol, self.delta)
+            r = step(u, noise[i].contiguous(), t)
             u = r["u"]
             t = np.float32(t0 + np.float32(i + 1) * dt) if i + 1 < n else t2
             us.append(u); ts.append(t)
-        nfe = 3 * n
+        per_step = (1, 2) if self.solver == "RKMil" else (3, 3)  # (drift, diffusion) evaluations of one step
+        nfe, nfe_g = per_step[0] * n, per_step[1] * n
         mode = self.regularize if st["training"] else "none"
         reg_val = np.float32(0.0)
         if mode != "none":
@@ -137,9 +144,9 @@ class NeuralDSDE:
             else:  # :109-123: a saved time other than the last
                 j = int(rng.integers(0, max(n - 1, 1)))
                 t1, u1 = ts[j], us[j]
-            r = h.euler_heun_step(u1, noise[n].contiguous(), t1, dt, abstol, reltol, self.delta)  # :98,118
+            r = step(u1, noise[n].contiguous(), t1)  # :98,118
             reg_val = r["reg_val"]
-            nfe += 3
+            nfe += per_step[0]; nfe_g += per_step[1]
         sol = ODESolution([us[-1]], [t2], nfe)
-        return sol, dict(drift=st["drift"], diffusion=st["diffusion"], nfe_drift=nfe, nfe_diffusion=nfe,
+        return sol, dict(drift=st["drift"], diffusion=st["diffusion"], nfe_drift=nfe, nfe_diffusion=nfe_g,
                          reg_val=reg_val, rng=rng, training=st["training"])

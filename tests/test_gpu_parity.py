@@ -251,3 +251,21 @@ def test_sixteen_column_family_at_mnist_shape(oracle, gpu_pkg):
     _eq(rg["u_end"].cpu().numpy(), ro["u_end"], "u_end")
     # and the 4-column family on a slice of the same batch gives the same columns
     _eq(h.rhs(xd[:64].contiguous(), 0.1).cpu().numpy(), k1[:64], "rhs (4-column family)")
+
+
+def test_neural_dsde_rkmil_solver(oracle, gpu_pkg):
+    """NeuralDSDE(solver="RKMil"): the fixed-grid loop over lrnde_sde_rkmil_step equals the same loop over the oracle's step"""
+    import torch
+    D, H, B, n = 32, 64, 16, 5
+    pd, pg, drift, diff = _sde_fields(oracle, D, H, seed=4)
+    x = np.random.default_rng(1).standard_normal((B, D)).astype(np.float32)
+    node = gpu_pkg.NeuralDSDE(gpu_pkg.Chain(gpu_pkg.Dense(D, H, "tanh"), gpu_pkg.Dense(H, D)), gpu_pkg.Dense(D, D), solver="RKMil",
+                              regularize="none", nsteps=n, abstol=0.14, reltol=0.14)
+    noise = (np.random.default_rng(2).standard_normal((n + 1, B, D)) * np.sqrt(1.0 / n)).astype(np.float32)
+    st = node.initialstates(np.random.default_rng(0))
+    sol, st2 = node(torch.from_numpy(x).cuda(), dict(drift=pd, diffusion=pg), st, noise=noise)
+    u, dt = x, np.float32(1.0 / n)
+    for i in range(n):
+        u = oracle.rkmil_step(drift, diff, u, noise[i], np.float32(i) * dt, dt, 0.14, 0.14)["u"]
+    _eq(sol.u[-1].cpu().numpy(), u, "u_end")
+    assert st2["nfe_drift"] == n and st2["nfe_diffusion"] == 2 * n and st2["reg_val"] == 0.0
