@@ -1103,6 +1103,17 @@ int cfail(lrnde_conv* c, int code, const char* fmt, ...) {
       return cfail(c, LRNDE_HIP_ERROR, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// scoped device allocation for per-call temporaries (freed on every return path)
+struct DevBuf {
+  void* p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 inline size_t state_n(const lrnde_conv* c, int B) { return (size_t)B * c->d.width * c->d.height * c->d.channels; }
 inline int strip_rows(const lrnde_conv* c) {
   // largest TR dividing H with TR*W <= 128 pixels (8 M tiles)
@@ -2242,14 +2253,14 @@ int lrnde_cifar_stem_forward(lrnde_conv* c, const float* x, int32_t B, const flo
   const int H = c->d.height, W = c->d.width;
   const long plane = (long)H * W, total = (long)B * 8 * plane;
   const int nblk = (int)(((long)B * plane + SH_T - 1) / SH_T);
-  float *a0 = nullptr, *mi = nullptr; double* part = nullptr;
-  CHK(c, hipMalloc(&a0, sizeof(float) * total)); CHK(c, hipMalloc(&mi, sizeof(float) * 16)); CHK(c, hipMalloc(&part, sizeof(double) * nblk * 16));
+  DevBuf ba0, bmi, bpart;
+  CHK(c, ba0.alloc(sizeof(float) * total)); CHK(c, bmi.alloc(sizeof(float) * 16)); CHK(c, bpart.alloc(sizeof(double) * nblk * 16));
+  float *a0 = ba0.as<float>(), *mi = bmi.as<float>(); double* part = bpart.as<double>();
   int rc = stem_common(c, x, B, ps, bn_state, a0, mi, part, nblk);
   if (!rc) {
     hipLaunchKernelGGL(k_stem_norm, dim3(2048), dim3(256), 0, c->stream, (const float*)a0, (const float*)mi, (const float*)(mi + 8), ps, plane, total, u0);
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = cfail(c, LRNDE_HIP_ERROR, "stem kernels failed");
   }
-  hipFree(a0); hipFree(mi); hipFree(part);
   return rc;
 }
 
@@ -2259,9 +2270,10 @@ int lrnde_cifar_stem_backward(lrnde_conv* c, const float* x, int32_t B, const fl
   const int H = c->d.height, W = c->d.width;
   const long plane = (long)H * W, total = (long)B * 8 * plane;
   const int nblk = (int)(((long)B * plane + SH_T - 1) / SH_T);
-  float *a0 = nullptr, *mi = nullptr, *mm = nullptr, *partw = nullptr; double* part = nullptr;
-  CHK(c, hipMalloc(&a0, sizeof(float) * total)); CHK(c, hipMalloc(&mi, sizeof(float) * 16)); CHK(c, hipMalloc(&mm, sizeof(float) * 16));
-  CHK(c, hipMalloc(&part, sizeof(double) * nblk * 16)); CHK(c, hipMalloc(&partw, sizeof(float) * (size_t)nblk * 140));
+  DevBuf ba0, bmi, bmm, bpart, bpartw;
+  CHK(c, ba0.alloc(sizeof(float) * total)); CHK(c, bmi.alloc(sizeof(float) * 16)); CHK(c, bmm.alloc(sizeof(float) * 16));
+  CHK(c, bpart.alloc(sizeof(double) * nblk * 16)); CHK(c, bpartw.alloc(sizeof(float) * (size_t)nblk * 140));
+  float *a0 = ba0.as<float>(), *mi = bmi.as<float>(), *mm = bmm.as<float>(), *partw = bpartw.as<float>(); double* part = bpart.as<double>();
   int rc = stem_common(c, x, B, ps, bn_state, a0, mi, part, nblk);
   if (!rc) {
     hipLaunchKernelGGL(k_stem_bwd1, dim3(nblk), dim3(SH_T), 0, c->stream, (const float*)a0, du0, (const float*)mi, (const float*)(mi + 8), B, plane, part);
@@ -2271,7 +2283,6 @@ int lrnde_cifar_stem_backward(lrnde_conv* c, const float* x, int32_t B, const fl
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, (const float*)partw, nblk, 140, dps);
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = cfail(c, LRNDE_HIP_ERROR, "stem backward kernels failed");
   }
-  hipFree(a0); hipFree(mi); hipFree(mm); hipFree(part); hipFree(partw);
   return rc;
 }
 
@@ -2283,9 +2294,10 @@ int lrnde_cifar_head_ce(lrnde_conv* c, const float* u, int32_t B, const float* p
   const long plane = D, npx = (long)B * plane;
   const int nblk = (int)((npx + SH_T - 1) / SH_T);
   const float* pd = ph + 73;
-  float *z = nullptr, *v = nullptr, *dl = nullptr, *lb = nullptr, *dv = nullptr, *partw = nullptr;
-  CHK(c, hipMalloc(&z, sizeof(float) * npx)); CHK(c, hipMalloc(&v, sizeof(float) * npx)); CHK(c, hipMalloc(&dl, sizeof(float) * (size_t)B * K));
-  CHK(c, hipMalloc(&lb, sizeof(float) * B)); CHK(c, hipMalloc(&dv, sizeof(float) * npx)); CHK(c, hipMalloc(&partw, sizeof(float) * (size_t)nblk * 73));
+  DevBuf bz, bv, bdl, blb, bdv, bpartw;
+  CHK(c, bz.alloc(sizeof(float) * npx)); CHK(c, bv.alloc(sizeof(float) * npx)); CHK(c, bdl.alloc(sizeof(float) * (size_t)B * K));
+  CHK(c, blb.alloc(sizeof(float) * B)); CHK(c, bdv.alloc(sizeof(float) * npx)); CHK(c, bpartw.alloc(sizeof(float) * (size_t)nblk * 73));
+  float *z = bz.as<float>(), *v = bv.as<float>(), *dl = bdl.as<float>(), *lb = blb.as<float>(), *dv = bdv.as<float>(), *partw = bpartw.as<float>();
   hipLaunchKernelGGL(k_head_conv, dim3(nblk), dim3(SH_T), 0, c->stream, u, ph, B, H, W, z, v);
   hipLaunchKernelGGL(k_cls_fwd, dim3((B + 3) / 4), dim3(256), 0, c->stream, (const float*)v, pd, labels, B, D, K, logits, dl, lb);
   if (du || dph) {
@@ -2298,7 +2310,6 @@ int lrnde_cifar_head_ce(lrnde_conv* c, const float* u, int32_t B, const float* p
   std::vector<float> hl(B);
   hipError_t e = hipMemcpyAsync(hl.data(), lb, sizeof(float) * B, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(z); hipFree(v); hipFree(dl); hipFree(lb); hipFree(dv); hipFree(partw);
   if (e != hipSuccess) return cfail(c, LRNDE_HIP_ERROR, "head kernels failed: %s", hipGetErrorString(e));
   double acc = 0.0;
   for (int b = 0; b < B; ++b) acc += (double)hl[b];
