@@ -157,3 +157,26 @@ def test_vjp_sixteen_column_family_at_mnist_shape(oracle, gpu_pkg):
     dy, gp = h.vjp(torch.from_numpy(x).cuda(), 0.3, torch.from_numpy(lam).cuda())
     assert _rel(dy.cpu().numpy(), dy_ref) < 2e-5
     assert _rel(gp.cpu().numpy(), gp_ref) < 2e-5
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_backward_random_shapes(oracle, gpu_pkg, seed):
+    """shape sweep of the VJP and of the full layer pullback (both tile families, ragged batches)"""
+    import torch
+    rng = np.random.default_rng(2000 + seed)
+    D = int(rng.choice([3, 4, 16, 33, 64, 100, 113, 225]))
+    H = int(rng.choice([5, 16, 31, 64, 100, 112, 113, 130]))
+    B = int(rng.choice([1, 3, 4, 5, 17, 63]))
+    act = str(rng.choice(["tanh", "gelu"]))
+    td = bool(rng.integers(0, 2))
+    fld, h, p, x = _mk(oracle, gpu_pkg, D, H, B, act, td, scale=1.5, seed=seed)
+    lam = rng.standard_normal(x.shape).astype(np.float32)
+    dy_ref, gp_ref = oracle.mlp_vjp(fld, x, 0.3, lam)
+    dy, gp = h.vjp(torch.from_numpy(x).cuda(), 0.3, torch.from_numpy(lam).cuda())
+    assert _rel(dy.cpu().numpy(), dy_ref) < 3e-5, (D, H, B, act, td)
+    assert _rel(gp.cpu().numpy(), gp_ref) < 3e-5, (D, H, B, act, td)
+    bo = oracle.node_backward(fld, x, 0.0, 1.0, 1e-5, 1e-5, lam, mode="unbiased", t1_or_rand=0.37, w_reg=1.0, maxiters=5000)
+    bg = h.node_backward(torch.from_numpy(x).cuda(), 0.0, 1.0, 1e-5, 1e-5, torch.from_numpy(lam).cuda(), mode="unbiased",
+                         t1_or_rand=0.37, w_reg=1.0, maxiters=5000)
+    assert bg["stats_fwd"]["naccept"] == bo["stats_fwd"]["naccept"]
+    assert _rel(bg["dx"].cpu().numpy(), bo["dx"]) < 5e-4 and _rel(bg["dp"].cpu().numpy(), bo["dp"]) < 5e-4, (D, H, B, act, td)

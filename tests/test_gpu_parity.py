@@ -269,3 +269,29 @@ def test_neural_dsde_rkmil_solver(oracle, gpu_pkg):
         u = oracle.rkmil_step(drift, diff, u, noise[i], np.float32(i) * dt, dt, 0.14, 0.14)["u"]
     _eq(sol.u[-1].cpu().numpy(), u, "u_end")
     assert st2["nfe_drift"] == n and st2["nfe_diffusion"] == 2 * n and st2["reg_val"] == 0.0
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_shapes_bit_exact(oracle, gpu_pkg, seed):
+    """shape sweep: state/hidden sizes on and off the tile and segment boundaries, ragged batches, both tile families
+    (D % 4 != 0 or H > 112 run the 16-column kernels), all activations, with and without the time column"""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.choice([1, 3, 4, 7, 16, 33, 64, 100, 112, 113, 225, 448, 452, 900]))
+    H = int(rng.choice([1, 5, 16, 31, 64, 100, 112, 113, 130, 240]))
+    B = int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 63, 130]))
+    act = str(rng.choice(["tanh", "gelu", "identity"]))
+    td = bool(rng.integers(0, 2))
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, D, H, B, act, td, scale=1.5, seed=seed)
+    xd = torch.from_numpy(x).cuda()
+    k1 = fld.rhs(x, 0.3)
+    _eq(h.rhs(xd, 0.3).cpu().numpy(), k1, f"rhs D={D} H={H} B={B} {act} td={td}")
+    ref = oracle.tsit5_step(fld, x, k1, 0.3, 0.07, 1e-4, 1e-4)
+    got = h.perform_step(xd, torch.from_numpy(k1).cuda(), 0.3, 0.07, 1e-4, 1e-4)
+    _eq(got["u"].cpu().numpy(), ref["u"], "u"); _eq(got["k7"].cpu().numpy(), ref["k7"], "k7")
+    for k in ("eest", "reg_error", "reg_stiff"):
+        assert got[k] == ref[k], (k, got[k], ref[k], D, H, B, act, td)
+    ro = oracle.node_forward(fld, x, 0.0, 1.0, 1e-4, 1e-4, mode="unbiased", t1_or_rand=0.37)
+    rg = h.node_forward(xd, 0.0, 1.0, 1e-4, 1e-4, mode="unbiased", t1_or_rand=0.37)
+    assert rg["nfe"] == ro["nfe"] and rg["reg_val"] == ro["reg_val"], (D, H, B, act, td)
+    _eq(rg["u_end"].cpu().numpy(), ro["u_end"], "u_end")
