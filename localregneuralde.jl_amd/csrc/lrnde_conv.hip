@@ -67,6 +67,7 @@ struct ConvArgs {
   const float* in;              // planar state (B,CIN,H,W) or NHWC raw (B,H,W,CIN)
   float* out;                   // NHWC raw (B,H,W,COUT) or planar (B,COUT,H,W)
   const void* wpk;              // packed weights [NG][NT][64][4] f32 or [NG][NT][64][8] bf16
+  const void* wpk2;             // conv1 only: the bf16 pack (bf16 mode), or null
   const float* tsum;            // [9 classes][NT*16]  sum of the in-image t-channel taps
   float t;
   // BatchNorm of the INPUT (y = act(((x-mean)*inv)*scale + bias)), NHWC inputs only
@@ -617,6 +618,55 @@ __global__ __launch_bounds__(CNT) void k_conv_wide_bf16(ConvArgs a) {
   }
 }
 
+// conv1 in bf16: planar fp32 state (8 channels) -> 64 channels.  The halo tile is bf16 [pos][8] (one tap's 8 channels = one
+// 16-byte A fragment), K = 72 -> three k-groups of 32 with lane group kg reading tap 4g + kg (taps >= 9 carry zero weights).
+template <int MT>
+__global__ __launch_bounds__(CNT) void k_conv_in_bf16(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __hip_bfloat16* tileh = reinterpret_cast<__hip_bfloat16*>(smem);
+  const __bf16* tile = reinterpret_cast<const __bf16*>(smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int strips = a.H / a.TR;
+  const int n = blockIdx.x / strips, y0 = (blockIdx.x % strips) * a.TR;
+  constexpr int NT = 4, NG = 3;
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * NT * 1024, 0x00020000);
+  const int wv = lane * 16;
+  bf16x8 wq[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) wq[g] = wload8(rsW, wv, (g * NT + wave) * 1024);
+  stage_planar<__hip_bfloat16>(a, n, y0, tileh);  // a.CINP == 8
+  int ab[MAXMT];
+  pixel_bases(a, ab, 8);
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    int tap = 4 * g + kg;
+    if (tap > 8) tap = 8;
+    const int to = tap_pos(a, tap) * 8;
+    bf16x8 av[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const bf16x8*>(tile + ab[mt] + to);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mt], wq[g], acc[mt], 0, 0, 0);
+  }
+  const int co = wave * 16 + li;
+  float ts[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) ts[c] = a.tsum[c * NT * 16 + co];
+  double s1 = 0.0, s2 = 0.0;
+  wide_epilogue<MT, true>(a, acc, ts, n, y0, co, kg, s1, s2, reinterpret_cast<float*>(smem));
+  if (a.part) {
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (kg == 0) { double* pp = a.part + ((size_t)blockIdx.x * a.COUT + co) * 2; pp[0] = s1; pp[1] = s2; }
+  }
+}
+
 // conv3 in bf16: 64 -> COUT <= 16 channels, planar fp32 output; waves split the M tiles
 template <int MT>
 __global__ __launch_bounds__(CNT) void k_conv_out_bf16(ConvArgs a) {
@@ -1057,7 +1107,7 @@ struct lrnde_conv {
   bool have_params = false;
   int NG1 = 0, NG2 = 0;
   // parameters
-  void *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
+  void *w1 = nullptr, *w2 = nullptr, *w3 = nullptr, *w1b = nullptr;  // w1b: conv1 in bf16 fragments (bf16 mode)
   float *ts1 = nullptr, *ts2 = nullptr, *ts3 = nullptr;
   float *bn = nullptr;       // scale1 bias1 scale2 bias2 (4*Hc)
   float *stat = nullptr;     // mean1 inv1 mean2 inv2 (4*Hc)
@@ -1159,7 +1209,11 @@ ConvArgs base_args(const lrnde_conv* c, int B) {
 // the conv kernels are instantiated per number of M tiles of the strip (1..8)
 template <int MT> void launch_one(lrnde_conv* c, int which, const ConvArgs& a, size_t sm) {
   if (c->d.compute_dtype == LRNDE_BF16) {
-    if (which == 0) hipLaunchKernelGGL((k_conv_wide_f32<8, MT, true>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+    if (which == 0) {
+      static const bool f32in = getenv("LRNDE_CONV_BF16_F32IN") != nullptr;  // conv1 in fp32 math (bf16 output) instead
+      if (f32in || !a.wpk2) hipLaunchKernelGGL((k_conv_wide_f32<8, MT, true>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+      else { ConvArgs b = a; b.wpk = a.wpk2; b.CINP = 8; hipLaunchKernelGGL(k_conv_in_bf16<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, b); }
+    }
     else if (which == 1) hipLaunchKernelGGL(k_conv_wide_bf16<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
     else hipLaunchKernelGGL(k_conv_out_bf16<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
     return;
@@ -1196,6 +1250,7 @@ int launch_rhs_ex(lrnde_conv* c, const float* u, float t, int B, float* du, bool
   const int rows = a.TR + 2, WP = a.W + 2;
   // conv1: state -> y1
   a.CIN = C; a.CINP = cinp_of(C); a.COUT = Hc; a.in = u; a.out = c->y1; a.wpk = c->w1; a.tsum = c->ts1; a.t = t;
+  a.wpk2 = c->d.compute_dtype == LRNDE_BF16 ? c->w1b : nullptr;
   a.part = train ? c->part : nullptr;
   const size_t stg_bytes = sizeof(float) * (size_t)a.TP * 68;  // epilogue transpose buffer (aliases the tile)
   launch_mt(c, 0, a, std::max(sizeof(float) * rows * WP * a.CINP, stg_bytes));
@@ -1458,7 +1513,7 @@ int lrnde_conv_create(lrnde_conv** out, const lrnde_conv_desc* d, int device, vo
   const int C = d->channels, Hc = d->hidden;
   c->NG1 = (9 * C + 15) / 16;
   c->NG2 = d->compute_dtype == LRNDE_BF16 ? (9 * Hc + 31) / 32 : (9 * Hc + 15) / 16;
-  bool ok = hipMalloc(&c->w1, (size_t)c->NG1 * 4 * 1024) == hipSuccess &&
+  bool ok = hipMalloc(&c->w1, (size_t)c->NG1 * 4 * 1024) == hipSuccess && hipMalloc(&c->w1b, (size_t)3 * 4 * 1024) == hipSuccess &&
             hipMalloc(&c->w2, (size_t)c->NG2 * 4 * 1024) == hipSuccess &&
             hipMalloc(&c->w3, (size_t)c->NG2 * 1 * 1024) == hipSuccess &&
             hipMalloc(&c->ts1, sizeof(float) * 9 * 64) == hipSuccess && hipMalloc(&c->ts2, sizeof(float) * 9 * 64) == hipSuccess &&
@@ -1478,7 +1533,7 @@ int lrnde_conv_destroy(lrnde_conv* c) {
   if (!c) return LRNDE_OK;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
-  void* ptrs[] = {c->params, c->w1t, c->w2t, c->w3t, c->zeros, c->bwm, c->g1, c->g2, c->part_bw, c->pw, c->pt, c->w1, c->w2, c->w3, c->ts1, c->ts2, c->ts3, c->bn, c->stat, c->bn_state, c->y1, c->y2, c->part, c->vec, c->sums};
+  void* ptrs[] = {c->params, c->w1t, c->w2t, c->w3t, c->zeros, c->bwm, c->g1, c->g2, c->part_bw, c->pw, c->pt, c->w1, c->w1b, c->w2, c->w3, c->ts1, c->ts2, c->ts3, c->bn, c->stat, c->bn_state, c->y1, c->y2, c->part, c->vec, c->sums};
   for (void* p : ptrs) if (p) hipFree(p);
   for (float* d : c->dense) if (d) hipFree(d);
   if (c->rec_u1) hipFree(c->rec_u1);
@@ -1501,6 +1556,7 @@ int lrnde_conv_set_params(lrnde_conv* c, const float* p, size_t n) {
   const float* w2 = g1 + 2 * Hc; const float* g2 = w2 + 9 * (Hc + 1) * Hc;
   const float* w3 = g2 + 2 * Hc;
   hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w1, C, Hc, c->NG1, 4, 0, c->w1, c->ts1);
+  hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w1, C, Hc, 3, 4, 1, c->w1b, c->ts1);
   const int bf = c->d.compute_dtype == LRNDE_BF16 ? 1 : 0;
   hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w2, Hc, Hc, c->NG2, 4, bf, c->w2, c->ts2);
   hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w3, Hc, C, c->NG2, 1, bf, c->w3, c->ts3);

@@ -371,9 +371,13 @@ void lro_conv_rhs(const lro_conv* m, const float* u, float t, int B, float* du) 
   float* run = m->bn_train ? m->bn_run : NULL; /* running statistics advance on every training-mode call */
   if (m->bf16) {
     /* statistics come from the fp32 conv output, the normalised copy is the bf16-rounded one */
+    float* w1r = bf16_weights(w1, C, Hc);
     float* w2r = bf16_weights(w2, Hc, Hc);
     float* w3r = bf16_weights(w3, Hc, C);
-    conv3x3_t(u, B, C, Hc, H, W, w1, t, y1, nth);
+    float* ur = (float*)malloc(sizeof(float) * (size_t)B * C * plane);
+    for (long i = 0; i < (long)B * C * plane; ++i) ur[i] = bf16_round(u[i]);
+    conv3x3_t(ur, B, C, Hc, H, W, w1r, t, y1, nth);
+    free(ur); free(w1r);
     batchnorm_act_ex(y1, B, Hc, plane, g1, b1, m->bn_train, st ? st : NULL, st ? st + Hc : NULL, m->eps, m->act, nth, 1, run, run ? run + Hc : NULL);
     bf16_round_array(y1, ny);
     conv3x3_t(y1, B, Hc, Hc, H, W, w2r, t, y2, nth);

@@ -106,8 +106,8 @@ typedef struct {
                             what the reference's dudt closure does to its captured st_ (src/layers/neural_ode.jl:44-48);
                             lro_conv_vjp's recomputation leaves it alone */
   int bf16;              /* 1: emulate the bf16 compute mode of the HIP path: y1, y2 and the activated
-                            conv2/conv3 inputs rounded to bf16 (RNE), conv2/conv3 weights (not the t
-                            plane's) rounded to bf16, fp32 accumulation; conv1 stays fp32 */
+                            conv inputs (the state too) rounded to bf16 (RNE), conv weights (not the t
+                            plane's) rounded to bf16, fp32 accumulation, statistics and t-plane term */
 } lro_conv;
 
 typedef struct {
