@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=512)
     ap.add_argument("--no-conv", action="store_true", help="skip the 28x28 conv-field side measurement of the default run")
     ap.add_argument("--adjoint-steps", type=int, default=5, help="timed forward+adjoint passes (single GPU)")
-    ap.add_argument("--workload", default="mlp", choices=["mlp", "cifar_conv_bf16", "cifar_conv_f32", "mnist_conv_f32"],
+    ap.add_argument("--workload", default="mlp", choices=["mlp", "cifar_conv_bf16", "cifar_conv_f32", "cifar_conv_f32_split", "mnist_conv_f32", "mnist_conv_f32_split"],
                     help="mlp: the headline MNIST-ODE MLP field (default).  The conv workloads time the CIFAR10 node_core "
                          "(BASELINE.json configs 4 and 2-ii); single GPU.")
     args = ap.parse_args()
@@ -184,6 +184,7 @@ def main():
         # 28x28x8 state (not a model of the reference) — measured alongside, `--workload
         # mnist_conv_f32` gives its full line
         out["config"]["conv_field_28x28_b512"] = conv_measure(args, "mnist_conv_f32", brief=True)
+        out["config"]["conv_field_28x28_b512_f32_split"] = conv_measure(args, "mnist_conv_f32_split", brief=True)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the GPU box gives one GPU's share of the host: 16 cores (os.cpu_count() reports the whole host)
         cores = int(os.environ.get("LRNDE_CPU_CORES", min(len(os.sched_getaffinity(0)), 16)))
@@ -218,7 +219,9 @@ def conv_measure(args, workload, brief=False):
     import lrnde_amd as P
     W, H, B, dt, tol, train = {"cifar_conv_bf16": (32, 32, 256, "bf16", 1e-4, True),
                                "cifar_conv_f32": (32, 32, 256, "f32", 1e-4, True),
-                               "mnist_conv_f32": (28, 28, 512, "f32", 1e-4, False)}[workload]
+                               "cifar_conv_f32_split": (32, 32, 256, "f32_split", 1e-4, True),
+                               "mnist_conv_f32": (28, 28, 512, "f32", 1e-4, False),
+                               "mnist_conv_f32_split": (28, 28, 512, "f32_split", 1e-4, False)}[workload]
     if args.batch != 512 and not brief:
         B = args.batch
     steps, warmup = (3, 1) if brief else (min(args.steps, 10), min(args.warmup, 2))
@@ -245,7 +248,7 @@ def conv_measure(args, workload, brief=False):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     fwd_adj_ms, bwd = None, None
-    if dt == "f32" and args.adjoint_steps > 0 and not brief:  # pullback of <g, sol.u[end]> + 2.5*reg_val, g ~ 1e-3*N(0,1) (a mean-loss cotangent's size)
+    if dt in ("f32", "f32_split") and args.adjoint_steps > 0 and not brief:  # pullback of <g, sol.u[end]> + 2.5*reg_val, g ~ 1e-3*N(0,1) (a mean-loss cotangent's size)
         g = torch.from_numpy((np.random.default_rng(2).standard_normal(xh.shape) * 1e-3).astype(np.float32)).cuda()
         nb = min(args.adjoint_steps, 3)
         h.node_backward(x, 0.0, 1.0, tol, tol, g, mode="unbiased", t1_or_rand=float(t1s[0]), w_reg=2.5, maxiters=10000)
@@ -260,7 +263,8 @@ def conv_measure(args, workload, brief=False):
                "adjoint_nf": rb["stats_bwd"]["nf"]}
     us = h.bench_rhs(x, 0.3, reps=20)  # HIP events on the handle's stream around 20 f-evals
     flop = CONV_FLOP_PER_PIXEL * W * H * B
-    peak = PEAK_BF16_MFMA_TFLOPS if dt == "bf16" else PEAK_F32_MFMA_TFLOPS
+    # f32_split: three fp16 MFMAs per product -> a third of the fp16 (= bf16) dense rate bounds conv2/conv3
+    peak = {"bf16": PEAK_BF16_MFMA_TFLOPS, "f32_split": PEAK_BF16_MFMA_TFLOPS / 3.0}.get(dt, PEAK_F32_MFMA_TFLOPS)
     achieved = flop / (us * 1e-6) / 1e12
     out = {
         "metric": f"NFE/s (vector-field evals/s inside the adaptive Tsit5 NeuralODE forward, conv field {W}x{W}x8, B={B})",
@@ -289,7 +293,7 @@ def conv_measure(args, workload, brief=False):
         import oracle as O
         cores = int(os.environ.get("LRNDE_CPU_CORES", min(len(os.sched_getaffinity(0)), 16)))
         cb = min(B, 16)  # bounded sample: f-evals of a 16-sample slice (batch statistics of the slice)
-        fld = O.ConvField(W, H, 8, 64, params, act="gelu", bn_train=train, nthreads=cores, bf16=(dt == "bf16"))
+        fld = O.ConvField(W, H, 8, 64, params, act="gelu", bn_train=train, nthreads=cores, bf16=(dt == "bf16"))  # f32_split: the fp32 oracle
         tc = time.time()
         n = 0
         while time.time() - tc < 10.0:

@@ -11,7 +11,7 @@ STATUS = {0: "Success", 1: "MaxIters", 2: "DtLessThanMin", 3: "DtNaN", 4: "BadAr
 ACT = {"identity": 0, "tanh": 1, "gelu": 2}
 REG_TYPE = {"error_estimate": 0, "stiffness_estimate": 1}
 MODE = {"none": 0, "unbiased": 1, "biased": 2}
-DTYPE = {"f32": 0, "bf16": 1}
+DTYPE = {"f32": 0, "bf16": 1, "f32_split": 2}
 
 
 class ModelDesc(C.Structure):

@@ -723,6 +723,231 @@ __global__ __launch_bounds__(CNT) void k_conv_out_bf16(ConvArgs a) {
   }
 }
 
+// ===== fp32 results on the fp16 MFMA pipe: two-term split ("f32 split") =====================================
+// conv2 / conv3 inputs are BatchNorm + activation outputs (bounded, O(1)) and their weights are O(0.1): both are
+// written as hi + lo with hi = fp16(v), lo = fp16(v - hi) (22 significant bits; both pre-scaled by 2^8 so that
+// the lo parts stay normal fp16 numbers, undone exactly in the epilogue), and a product is hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation: three 16-cycle MFMAs per 32 k instead of eight 32-cycle
+// v_mfma_f32_16x16x4_f32, at a relative error of ~2^-21 per product (the dropped lo*lo term and the subnormal tail of
+// lo) — inside the 1e-5 parity bar of the fp32 path (tests/test_gpu_conv.py runs the same assertions on it).
+// conv1 keeps the fp32 MFMA (its input is the raw ODE state, unbounded), and so does the backward pass (cotangents
+// have no fixed scale).  LDS: two fp16 planes [pos][64] = the footprint of the fp32 tile.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float SPLIT_WSCALE = 256.0f;   // weights: |w| 2^8 < 65504, lo parts normal down to |w| ~ 2^-14
+constexpr float SPLIT_ASCALE = 256.0f;   // activations (|h| <~ 16 after BatchNorm + activation): lo parts normal down to |h| ~ 5e-4
+constexpr float SPLIT_UNSCALE = 1.0f / (SPLIT_WSCALE * SPLIT_ASCALE);
+
+__global__ void k_pack_conv_split(const float* w, int CIN, int COUT, int NG, int NT, _Float16* hi, _Float16* lo) {
+  const size_t total = (size_t)NG * NT * 64 * 8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i % 8, l = (i / 8) % 64;
+    const size_t blk = i / 512;
+    const int nt = blk % NT, g = blk / NT;
+    const int k = g * 32 + 8 * (l >> 4) + j, co = nt * 16 + (l & 15);
+    const int tap = k / CIN, ci = k % CIN;
+    float v = 0.f;
+    if (tap < 9 && co < COUT) { const int ky = tap / 3, kx = tap % 3; v = w[kx + 3 * (ky + 3 * (ci + (size_t)(CIN + 1) * co))] * SPLIT_WSCALE; }
+    const _Float16 h = (_Float16)v;
+    hi[i] = h; lo[i] = (_Float16)(v - (float)h);
+  }
+}
+
+template <int ACT>
+__device__ __forceinline__ void stage_nhwc_bn_split(const ConvArgs& a, int n, int y0, _Float16* thi, _Float16* tlo) {
+  constexpr int CQ = 8, PSTEP = CNT / CQ, UN = 2;
+  const int WP = a.W + 2, npos = (a.TR + 2) * WP;
+  const int q = threadIdx.x % CQ;
+  const float* src = a.in + (size_t)n * a.H * a.W * 64 + q * 8;
+  float mu[8], iv[8], sc[8], bi[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) { mu[h] = a.mean[q * 8 + h]; iv[h] = a.inv[q * 8 + h]; sc[h] = a.scale[q * 8 + h]; bi[h] = a.bias[q * 8 + h]; }
+  for (int pos0 = threadIdx.x / CQ; pos0 < npos; pos0 += UN * PSTEP) {
+    f32x4 r0[UN], r1[UN];
+    bool ok[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int pos = pos0 + u * PSTEP;
+      const int cc = pos % WP, rr = pos / WP;
+      const int y = y0 - 1 + rr, x = cc - 1;
+      ok[u] = pos < npos && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      r0[u] = r1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok[u]) { const float* p = src + ((size_t)y * a.W + x) * 64; r0[u] = *reinterpret_cast<const f32x4*>(p); r1[u] = *reinterpret_cast<const f32x4*>(p + 4); }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int pos = pos0 + u * PSTEP;
+      if (pos >= npos) break;
+      f16x8 vh, vl;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        float o = 0.f;
+        if (ok[u]) {
+          const float raw = h < 4 ? r0[u][h] : r1[u][h - 4];
+          const float xn = (raw - mu[h]) * iv[h];
+          o = act_fast<ACT>(xn * sc[h] + bi[h]) * SPLIT_ASCALE;
+        }
+        const _Float16 hh = (_Float16)o;
+        vh[h] = hh; vl[h] = (_Float16)(o - (float)hh);
+      }
+      const int off = pos * 64 + (((q ^ (pos >> 1)) & 7) << 3);
+      *reinterpret_cast<f16x8*>(thi + off) = vh;
+      *reinterpret_cast<f16x8*>(tlo + off) = vl;
+    }
+  }
+}
+__device__ __forceinline__ void stage_nhwc_bn_split(const ConvArgs& a, int n, int y0, _Float16* thi, _Float16* tlo) {
+  if (a.act == 2) stage_nhwc_bn_split<2>(a, n, y0, thi, tlo);
+  else if (a.act == 1) stage_nhwc_bn_split<1>(a, n, y0, thi, tlo);
+  else stage_nhwc_bn_split<0>(a, n, y0, thi, tlo);
+}
+__device__ __forceinline__ f16x8 wloadh(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+
+// conv2, f32 split: 64 -> 64 channels, wave w owns output channels 16w..16w+15.  a.wpk = hi pack, a.wpk2 = lo pack.
+template <int MT>
+__global__ __launch_bounds__(CNT) void k_conv_wide_split(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tsz = (a.TR + 2) * (a.W + 2) * 64;
+  _Float16* thi = reinterpret_cast<_Float16*>(smem);
+  _Float16* tlo = thi + tsz;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int strips = a.H / a.TR;
+  const int n = blockIdx.x / strips, y0 = (blockIdx.x % strips) * a.TR;
+  constexpr int NT = 4, NG = 18;
+  const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * NT * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk2, 0, NG * NT * 1024, 0x00020000);
+  const int wv = lane * 16;
+  stage_nhwc_bn_split(a, n, y0, thi, tlo);
+  int ab[MAXMT];
+  pixel_bases(a, ab, 1);
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  f16x8 wh[2], wl[2], whn[2], wln[2];
+#pragma unroll
+  for (int g2 = 0; g2 < 2; ++g2) { wh[g2] = wloadh(rsH, wv, (g2 * NT + wave) * 1024); wl[g2] = wloadh(rsL, wv, (g2 * NT + wave) * 1024); }
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int tn = tap < 8 ? tap + 1 : 8;
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) { whn[g2] = wloadh(rsH, wv, ((tn * 2 + g2) * NT + wave) * 1024); wln[g2] = wloadh(rsL, wv, ((tn * 2 + g2) * NT + wave) * 1024); }
+    const int tp = tap_pos(a, tap);
+    int pb[MT], hi[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int pos = ab[mt] + tp, sw = pos >> 1;
+      pb[mt] = pos * 64 + (((kg ^ sw) & 3) << 3);
+      hi[mt] = (sw & 4) << 3;
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      f16x8 ah[MT], al[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int o = pb[mt] + ((32 * g2) ^ hi[mt]);
+        ah[mt] = *reinterpret_cast<const f16x8*>(thi + o);
+        al[mt] = *reinterpret_cast<const f16x8*>(tlo + o);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], wl[g2], acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], wh[g2], acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], wh[g2], acc[mt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) { wh[g2] = whn[g2]; wl[g2] = wln[g2]; }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = acc[mt] * SPLIT_UNSCALE;
+  const int co = wave * 16 + li;
+  float ts[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) ts[c] = a.tsum[c * NT * 16 + co];
+  double s1 = 0.0, s2 = 0.0;
+  wide_epilogue<MT, false>(a, acc, ts, n, y0, co, kg, s1, s2, reinterpret_cast<float*>(smem));
+  if (a.part) {
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (kg == 0) { double* pp = a.part + ((size_t)blockIdx.x * a.COUT + co) * 2; pp[0] = s1; pp[1] = s2; }
+  }
+}
+
+// conv3, f32 split: 64 -> COUT <= 16 channels, planar fp32 output; waves split the M tiles
+template <int MT>
+__global__ __launch_bounds__(CNT) void k_conv_out_split(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tsz = (a.TR + 2) * (a.W + 2) * 64;
+  _Float16* thi = reinterpret_cast<_Float16*>(smem);
+  _Float16* tlo = thi + tsz;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int strips = a.H / a.TR;
+  const int n = blockIdx.x / strips, y0 = (blockIdx.x % strips) * a.TR;
+  constexpr int NG = 18;
+  const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk2, 0, NG * 1024, 0x00020000);
+  const int wv = lane * 16;
+  stage_nhwc_bn_split(a, n, y0, thi, tlo);
+  int ab[MAXMT];
+  pixel_bases(a, ab, 1);
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int m0 = wave, m1 = wave + 4;
+  const int ab0 = (m0 == 0) ? ab[0] : (m0 == 1) ? ab[1] : (m0 == 2) ? ab[2] : ab[3];
+  const int ab1 = (m1 == 4) ? ab[4] : (m1 == 5) ? ab[5] : (m1 == 6) ? ab[6] : ab[7];
+  __syncthreads();
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    f16x8 wh[2], wl[2];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) { wh[g2] = wloadh(rsH, wv, (tap * 2 + g2) * 1024); wl[g2] = wloadh(rsL, wv, (tap * 2 + g2) * 1024); }
+    const int tp = tap_pos(a, tap);
+    const int pos0 = ab0 + tp, pos1 = ab1 + tp;
+    const int pb0 = pos0 * 64 + (((kg ^ (pos0 >> 1)) & 3) << 3), hi0 = ((pos0 >> 1) & 4) << 3;
+    const int pb1 = pos1 * 64 + (((kg ^ (pos1 >> 1)) & 3) << 3), hi1 = ((pos1 >> 1) & 4) << 3;
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      if (m0 < MT) {
+        const int o = pb0 + ((32 * g2) ^ hi0);
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(thi + o), al = *reinterpret_cast<const f16x8*>(tlo + o);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g2], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g2], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g2], acc[0], 0, 0, 0);
+      }
+      if (MT > 4 && m1 < MT) {
+        const int o = pb1 + ((32 * g2) ^ hi1);
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(thi + o), al = *reinterpret_cast<const f16x8*>(tlo + o);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g2], acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g2], acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g2], acc[1], 0, 0, 0);
+      }
+    }
+  }
+  if (li < a.COUT) {
+    float ts[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) ts[c] = a.tsum[c * 16 + li];
+    float* dst = a.out + ((size_t)n * a.COUT + li) * a.H * a.W;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int mt = h == 0 ? m0 : m1;
+      const int p = mt * 16 + kg * 4;
+      if (mt < MT && p < a.TP) {
+        const int y = y0 + p / a.W, x = p % a.W;
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fma_(ts[border_class(y, x + r, a.H, a.W)], a.t, acc[h][r] * SPLIT_UNSCALE);
+        *reinterpret_cast<f32x4*>(dst + (size_t)y * a.W + x) = v;
+      }
+    }
+  }
+}
+
 // ---- batch statistics: fixed-order reduction of the per-workgroup partials --------------------
 // run_mean / run_var (may be null): Lux's running statistics, updated as its training-mode BatchNorm does on every
 // call (momentum m: mean <- (1-m) mean + m batch_mean; var <- (1-m) var + m n/(n-1) batch_var; UPSTREAM-RECALL)
@@ -1107,6 +1332,7 @@ struct lrnde_conv {
   bool have_params = false;
   int NG1 = 0, NG2 = 0;
   // parameters
+  void *w2h = nullptr, *w2l = nullptr, *w3h = nullptr, *w3l = nullptr; bool split = false;  // f32 split packs (fp16 hi / lo)
   void *w1 = nullptr, *w2 = nullptr, *w3 = nullptr, *w1b = nullptr;  // w1b: conv1 in bf16 fragments (bf16 mode)
   float *ts1 = nullptr, *ts2 = nullptr, *ts3 = nullptr;
   float *bn = nullptr;       // scale1 bias1 scale2 bias2 (4*Hc)
@@ -1218,9 +1444,15 @@ template <int MT> void launch_one(lrnde_conv* c, int which, const ConvArgs& a, s
     else hipLaunchKernelGGL(k_conv_out_bf16<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
     return;
   }
+  const bool split = c->split && a.smode == 0 && a.wpk2 != nullptr;  // forward conv2 / conv3 only
   if (which == 0) hipLaunchKernelGGL((k_conv_wide_f32<8, MT, false>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
-  else if (which == 1) hipLaunchKernelGGL((k_conv_wide_f32<64, MT, false>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
-  else hipLaunchKernelGGL(k_conv_out_f32<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+  else if (which == 1) {
+    if (split) hipLaunchKernelGGL(k_conv_wide_split<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+    else hipLaunchKernelGGL((k_conv_wide_f32<64, MT, false>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+  } else {
+    if (split) hipLaunchKernelGGL(k_conv_out_split<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+    else hipLaunchKernelGGL(k_conv_out_f32<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+  }
 }
 void launch_mt(lrnde_conv* c, int which, const ConvArgs& a, size_t sm) {
   static const size_t lds_min = getenv("LRNDE_CONV_LDS_MIN") ? (size_t)atoi(getenv("LRNDE_CONV_LDS_MIN")) : 0;  // occupancy experiments
@@ -1259,7 +1491,8 @@ int launch_rhs_ex(lrnde_conv* c, const float* u, float t, int B, float* du, bool
   if (train) hipLaunchKernelGGL(k_bn_finalize, dim3(Hc), dim3(256), 0, c->stream, c->part, c->nwg, Hc, count, c->d.bn_eps, c->stat, c->stat + Hc,
                                 rs, rs ? rs + Hc : nullptr, 0.1f);
   // conv2: BN1+act(y1) -> y2
-  a.CIN = Hc; a.CINP = cinp_of(Hc); a.in = c->y1; a.out = c->y2; a.wpk = c->w2; a.tsum = c->ts2;
+  a.CIN = Hc; a.CINP = cinp_of(Hc); a.in = c->y1; a.out = c->y2; a.wpk = c->w2; a.tsum = c->ts2; a.wpk2 = nullptr;
+  if (c->split) { a.wpk = c->w2h; a.wpk2 = c->w2l; }
   a.mean = c->stat; a.inv = c->stat + Hc; a.scale = c->bn; a.bias = c->bn + Hc;
   const size_t esz = c->d.compute_dtype == LRNDE_BF16 ? 2 : 4;
   launch_mt(c, 1, a, std::max(esz * rows * WP * a.CINP, stg_bytes));
@@ -1268,7 +1501,8 @@ int launch_rhs_ex(lrnde_conv* c, const float* u, float t, int B, float* du, bool
                                 rs ? rs + 2 * Hc : nullptr, rs ? rs + 3 * Hc : nullptr, 0.1f);
   if (!last) return LRNDE_OK;
   // conv3: BN2+act(y2) -> du (planar)
-  a.COUT = C; a.in = c->y2; a.out = du; a.wpk = c->w3; a.tsum = c->ts3; a.part = nullptr;
+  a.COUT = C; a.in = c->y2; a.out = du; a.wpk = c->w3; a.tsum = c->ts3; a.part = nullptr; a.wpk2 = nullptr;
+  if (c->split) { a.wpk = c->w3h; a.wpk2 = c->w3l; }
   a.mean = c->stat + 2 * Hc; a.inv = c->stat + 3 * Hc; a.scale = c->bn + 2 * Hc; a.bias = c->bn + 3 * Hc;
   launch_mt(c, 2, a, esz * rows * WP * a.CINP);
   CHK(c, hipGetLastError());
@@ -1319,7 +1553,7 @@ int ensure_bw(lrnde_conv* c, int B) {
 
 // dy = (df/dy)^T lam, gp (optional, device, flat layout) = (df/dp)^T lam at (y, t)
 int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, float* dy, float* gp) {
-  if (c->d.compute_dtype != LRNDE_F32) return cfail(c, LRNDE_UNSUPPORTED, "the conv backward pass is fp32 only");
+  if (c->d.compute_dtype == LRNDE_BF16) return cfail(c, LRNDE_UNSUPPORTED, "the conv backward pass is fp32 only");
   int rc;
   if ((rc = ensure_bw(c, B))) return rc;
   const int Hc = c->d.hidden, C = c->d.channels, W = c->d.width, H = c->d.height;
@@ -1502,7 +1736,7 @@ int lrnde_conv_create(lrnde_conv** out, const lrnde_conv_desc* d, int device, vo
   if (d->channels != 8 || d->hidden != 64 || d->width % 4 != 0 || d->width < 4 || d->width > 16 * MAXMT ||
       d->height < 2 || d->act < 0 || d->act > 2)
     return LRNDE_UNSUPPORTED;
-  if (d->compute_dtype != LRNDE_F32 && d->compute_dtype != LRNDE_BF16) return LRNDE_UNSUPPORTED;
+  if (d->compute_dtype != LRNDE_F32 && d->compute_dtype != LRNDE_BF16 && d->compute_dtype != LRNDE_F32_SPLIT) return LRNDE_UNSUPPORTED;
   lrnde_conv* c = new lrnde_conv();
   c->d = *d;
   if (!(c->d.bn_eps > 0.f)) c->d.bn_eps = 1e-5f;
@@ -1523,6 +1757,11 @@ int lrnde_conv_create(lrnde_conv** out, const lrnde_conv_desc* d, int device, vo
             hipMalloc(&c->sums, sizeof(double) * NSUMB * 3) == hipSuccess &&
             hipHostMalloc(&c->sums_host, sizeof(double) * NSUMB * 3) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+  if (ok && d->compute_dtype == LRNDE_F32_SPLIT) {
+    ok = hipMalloc(&c->w2h, (size_t)18 * 4 * 1024) == hipSuccess && hipMalloc(&c->w2l, (size_t)18 * 4 * 1024) == hipSuccess &&
+         hipMalloc(&c->w3h, (size_t)18 * 1024) == hipSuccess && hipMalloc(&c->w3l, (size_t)18 * 1024) == hipSuccess;
+    c->split = ok;
+  }
   if (!ok) { lrnde_conv_destroy(c); return LRNDE_HIP_ERROR; }
   hipLaunchKernelGGL(k_bn_state_default, dim3(1), dim3(256), 0, c->stream, c->bn_state, Hc);
   *out = c;
@@ -1533,7 +1772,7 @@ int lrnde_conv_destroy(lrnde_conv* c) {
   if (!c) return LRNDE_OK;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
-  void* ptrs[] = {c->params, c->w1t, c->w2t, c->w3t, c->zeros, c->bwm, c->g1, c->g2, c->part_bw, c->pw, c->pt, c->w1, c->w1b, c->w2, c->w3, c->ts1, c->ts2, c->ts3, c->bn, c->stat, c->bn_state, c->y1, c->y2, c->part, c->vec, c->sums};
+  void* ptrs[] = {c->params, c->w1t, c->w2t, c->w3t, c->zeros, c->bwm, c->g1, c->g2, c->part_bw, c->pw, c->pt, c->w2h, c->w2l, c->w3h, c->w3l, c->w1, c->w1b, c->w2, c->w3, c->ts1, c->ts2, c->ts3, c->bn, c->stat, c->bn_state, c->y1, c->y2, c->part, c->vec, c->sums};
   for (void* p : ptrs) if (p) hipFree(p);
   for (float* d : c->dense) if (d) hipFree(d);
   if (c->rec_u1) hipFree(c->rec_u1);
@@ -1560,6 +1799,10 @@ int lrnde_conv_set_params(lrnde_conv* c, const float* p, size_t n) {
   const int bf = c->d.compute_dtype == LRNDE_BF16 ? 1 : 0;
   hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w2, Hc, Hc, c->NG2, 4, bf, c->w2, c->ts2);
   hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w3, Hc, C, c->NG2, 1, bf, c->w3, c->ts3);
+  if (c->split) {
+    hipLaunchKernelGGL(k_pack_conv_split, dim3(64), dim3(256), 0, c->stream, w2, Hc, Hc, 18, 4, (_Float16*)c->w2h, (_Float16*)c->w2l);
+    hipLaunchKernelGGL(k_pack_conv_split, dim3(64), dim3(256), 0, c->stream, w3, Hc, C, 18, 1, (_Float16*)c->w3h, (_Float16*)c->w3l);
+  }
   CHK(c, hipGetLastError());
   CHK(c, hipMemcpyAsync(c->bn, g1, sizeof(float) * 2 * Hc, hipMemcpyDeviceToDevice, c->stream));
   CHK(c, hipMemcpyAsync(c->bn + 2 * Hc, g2, sizeof(float) * 2 * Hc, hipMemcpyDeviceToDevice, c->stream));
@@ -2017,7 +2260,7 @@ int lrnde_conv_node_backward(lrnde_conv* c, const float* x, int32_t B, float t0,
   int rc = check_ready(c, B);
   if (rc) return rc;
   if (!x || !o || !du_end || !dx || !dp || !st_fwd || !st_bwd) return cfail(c, LRNDE_BADARG, "null pointer");
-  if (c->d.compute_dtype != LRNDE_F32) return cfail(c, LRNDE_UNSUPPORTED, "the conv backward pass is fp32 only");
+  if (c->d.compute_dtype == LRNDE_BF16) return cfail(c, LRNDE_UNSUPPORTED, "the conv backward pass is fp32 only");
   const size_t n = state_n(c, B), P = lrnde_conv_param_count(&c->d), N = n + P;
   // 1. forward with the dense record
   float* u_end = nullptr;

@@ -381,3 +381,43 @@ def test_cifar_training_step_runs_and_is_consistent():
     assert _rel(grads["neural_ode"].cpu().numpy(), bo["dp"]) <= 1e-2
     assert _rel(grads["head"].cpu().numpy(), dph) <= 1e-3
     assert _rel(grads["stem"].cpu().numpy(), dstem) <= 1e-2
+
+
+# ---- LRNDE_F32_SPLIT: fp32 results for conv2/conv3 on the fp16 MFMA pipe (hi + lo operand pairs) ----
+def _split_case(W, H, B, seed, train=True, scale=1.0):
+    P, O = _mods()
+    fld, _h32, p, u = _case(W, H, B, seed=seed, train=train, scale=scale)
+    h = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=train, compute_dtype="f32_split")
+    if fld.bn_state is not None:
+        h.set_bn_state(fld.bn_state)
+    h.set_params(p)
+    return fld, h, p, u
+
+
+@pytest.mark.parametrize("W,H,B,train", [(8, 8, 3, True), (16, 16, 2, True), (28, 28, 2, False), (32, 32, 2, True), (12, 8, 5, True)])
+def test_conv_f32_split_rhs_meets_the_fp32_bar(W, H, B, train):
+    """the same rtol = 1e-5 of the output scale as the native fp32 path"""
+    fld, h, p, u = _split_case(W, H, B, seed=W + B, train=train)
+    for t in (0.0, 0.613):
+        _close(h.rhs(torch.from_numpy(u).cuda(), t), fld.rhs(u.reshape(B, -1), t))
+
+
+def test_conv_f32_split_solve_and_backward():
+    """equal accepted / rejected step counts; dt follows the oracle's within 10 % (its rounding errors are less correlated
+    between the RK stages than the native path's, so a small EEst carries more noise); the backward pass (fp32 transposed
+    convs on the split forward's activations) keeps its tolerance"""
+    P, O = _mods()
+    W = H = 16; B = 2
+    fld, h, p, u = _split_case(W, H, B, seed=5, scale=1.5)
+    ro = O.solve(fld, u.reshape(B, -1), 0.0, 1.0, 1e-4, 1e-4, saveat=[0.37, 1.0])
+    rg = h.solve(torch.from_numpy(u).cuda(), 0.0, 1.0, 1e-4, 1e-4, saveat=[0.37, 1.0], trace=True)
+    so, sg = ro["stats"], rg["stats"]
+    assert (sg["naccept"], sg["nreject"], sg["nf"]) == (so["naccept"], so["nreject"], so["nf"])
+    np.testing.assert_allclose(rg["trace"]["dt"], ro["trace"]["dt"][:len(rg["trace"])], rtol=1e-1)
+    for i in range(2):
+        _close(rg["u"][i], ro["u"][i], rtol=2e-5)
+    lam = np.random.default_rng(17).standard_normal(u.shape).astype(np.float32)
+    dy_ref, gp_ref = O.conv_vjp(fld, u.reshape(B, -1), 0.41, lam.reshape(B, -1))
+    dy, gp = h.vjp(torch.from_numpy(u).cuda(), 0.41, torch.from_numpy(lam).cuda())
+    _close(dy, dy_ref, rtol=5e-5)
+    assert _rel(gp.cpu().numpy(), gp_ref) <= 5e-5
