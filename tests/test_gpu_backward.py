@@ -180,3 +180,23 @@ def test_backward_random_shapes(oracle, gpu_pkg, seed):
                          t1_or_rand=0.37, w_reg=1.0, maxiters=5000)
     assert bg["stats_fwd"]["naccept"] == bo["stats_fwd"]["naccept"]
     assert _rel(bg["dx"].cpu().numpy(), bo["dx"]) < 5e-4 and _rel(bg["dp"].cpu().numpy(), bo["dp"]) < 5e-4, (D, H, B, act, td)
+
+
+def test_training_step_is_run_to_run_deterministic(oracle, gpu_pkg):
+    """no atomics on the path: two identical training steps return identical bits"""
+    import torch
+    P = gpu_pkg
+    D, H, B, K = 784, 100, 64, 10
+    model = P.TDChain(P.Chain(P.Dense(D + 1, H, "tanh"), P.Dense(H + 1, D)))
+    node = P.NeuralODE(model, regularize="unbiased", abstol=1e-5, reltol=1e-5, save_start=False, maxiters=2000)
+    rng = np.random.default_rng(8)
+    ps = torch.from_numpy(P.glorot_params(model, seed=2)).cuda()
+    pc = torch.from_numpy((rng.standard_normal(K * (D + 1)) * 0.05).astype(np.float32)).cuda()
+    x = torch.from_numpy(rng.random((B, D), dtype=np.float32)).cuda()
+    lab = torch.from_numpy(rng.integers(0, K, B).astype(np.int32)).cuda()
+    st = node.initialstates(np.random.default_rng(0))
+    l1, _, _, g1, _ = P.run_training_step(node, ps, pc, st, x, lab, 2.5)
+    l2, _, _, g2, _ = P.run_training_step(node, ps, pc, st, x, lab, 2.5)
+    assert l1 == l2
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k

@@ -421,3 +421,22 @@ def test_conv_f32_split_solve_and_backward():
     dy, gp = h.vjp(torch.from_numpy(u).cuda(), 0.41, torch.from_numpy(lam).cuda())
     _close(dy, dy_ref, rtol=5e-5)
     assert _rel(gp.cpu().numpy(), gp_ref) <= 5e-5
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f32_split", "bf16"])
+def test_conv_feval_and_vjp_are_run_to_run_deterministic(dtype):
+    """fixed-order reductions everywhere (batch statistics, weight gradients, norms): repeated calls give the same bits"""
+    P, O = _mods()
+    W = H = 16; B = 3
+    h = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=True, compute_dtype=dtype)
+    h.set_params(P.glorot_conv_params(8, 64, seed=1))
+    u = torch.from_numpy(np.random.default_rng(0).standard_normal((B, 8, H, W)).astype(np.float32)).cuda()
+    a = h.rhs(u, 0.3); b = h.rhs(u, 0.3)
+    assert torch.equal(a, b)
+    r1 = h.node_forward(u, 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.4)
+    r2 = h.node_forward(u, 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.4)
+    assert torch.equal(r1["u_end"], r2["u_end"]) and r1["reg_val"] == r2["reg_val"] and r1["nfe"] == r2["nfe"]
+    if dtype != "bf16":
+        lam = torch.ones_like(u)
+        d1, g1 = h.vjp(u, 0.3, lam); d2, g2 = h.vjp(u, 0.3, lam)
+        assert torch.equal(d1, d2) and torch.equal(g1, g2)
