@@ -730,8 +730,8 @@ __global__ __launch_bounds__(CNT) void k_conv_out_bf16(ConvArgs a) {
 // v_mfma_f32_16x16x32_f16 with fp32 accumulation: three 16-cycle MFMAs per 32 k instead of eight 32-cycle
 // v_mfma_f32_16x16x4_f32, at a relative error of ~2^-21 per product (the dropped lo*lo term and the subnormal tail of
 // lo) — inside the 1e-5 parity bar of the fp32 path (tests/test_gpu_conv.py runs the same assertions on it).
-// conv1 keeps the fp32 MFMA (its input is the raw ODE state, unbounded), and so does the backward pass (cotangents
-// have no fixed scale).  LDS: two fp16 planes [pos][64] = the footprint of the fp32 tile.
+// conv1's input is the raw ODE state (scaled by 2^4 only, see k_conv_in_split); the backward pass keeps the fp32 MFMA
+// (cotangents have no fixed scale).  LDS: two fp16 planes [pos][64] = the footprint of the fp32 tile.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float SPLIT_WSCALE = 256.0f;   // weights: |w| 2^8 < 65504, lo parts normal down to |w| ~ 2^-14
 constexpr float SPLIT_ASCALE = 256.0f;   // activations (|h| <~ 16 after BatchNorm + activation): lo parts normal down to |h| ~ 5e-4
@@ -864,6 +864,76 @@ __global__ __launch_bounds__(CNT) void k_conv_wide_split(ConvArgs a) {
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = acc[mt] * SPLIT_UNSCALE;
+  const int co = wave * 16 + li;
+  float ts[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) ts[c] = a.tsum[c * NT * 16 + co];
+  double s1 = 0.0, s2 = 0.0;
+  wide_epilogue<MT, false>(a, acc, ts, n, y0, co, kg, s1, s2, reinterpret_cast<float*>(smem));
+  if (a.part) {
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (kg == 0) { double* pp = a.part + ((size_t)blockIdx.x * a.COUT + co) * 2; pp[0] = s1; pp[1] = s2; }
+  }
+}
+
+// conv1, f32 split: planar fp32 state (8 channels) -> 64 channels.  The state is not bounded by a BatchNorm, so its
+// pair is scaled by 2^4 only: exact for |u| < 4094 (beyond that the hi part overflows to inf and the solve stops with a
+// NaN retcode — loudly), lo parts normal down to |u| ~ 8e-3.
+constexpr float SPLIT_USCALE = 16.0f;
+template <int MT>
+__global__ __launch_bounds__(CNT) void k_conv_in_split(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int WP = a.W + 2, rows = a.TR + 2, npos = rows * WP;
+  _Float16* thi = reinterpret_cast<_Float16*>(smem);
+  _Float16* tlo = thi + (size_t)npos * 8;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const int strips = a.H / a.TR;
+  const int n = blockIdx.x / strips, y0 = (blockIdx.x % strips) * a.TR;
+  constexpr int NT = 4, NG = 3;
+  const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * NT * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk2, 0, NG * NT * 1024, 0x00020000);
+  const int wv = lane * 16;
+  f16x8 wh[NG], wl[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) { wh[g] = wloadh(rsH, wv, (g * NT + wave) * 1024); wl[g] = wloadh(rsL, wv, (g * NT + wave) * 1024); }
+  {  // stage the planar halo tile as hi / lo fp16 planes [pos][8]
+    const float* src = a.in + (size_t)n * 8 * a.H * a.W;
+    for (int i = threadIdx.x; i < 8 * npos; i += CNT) {
+      const int cc = i % WP, rr = (i / WP) % rows, c = i / (WP * rows);
+      const int y = y0 - 1 + rr, x = cc - 1;
+      float v = 0.f;
+      if (y >= 0 && y < a.H && x >= 0 && x < a.W) v = src[((size_t)c * a.H + y) * a.W + x] * SPLIT_USCALE;
+      const _Float16 hh = (_Float16)v;
+      thi[(size_t)(rr * WP + cc) * 8 + c] = hh;
+      tlo[(size_t)(rr * WP + cc) * 8 + c] = (_Float16)(v - (float)hh);
+    }
+  }
+  int ab[MAXMT];
+  pixel_bases(a, ab, 8);
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    int tap = 4 * g + kg;
+    if (tap > 8) tap = 8;
+    const int to = tap_pos(a, tap) * 8;
+    f16x8 ah[MT], al[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { ah[mt] = *reinterpret_cast<const f16x8*>(thi + ab[mt] + to); al[mt] = *reinterpret_cast<const f16x8*>(tlo + ab[mt] + to); }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], wl[g], acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], wh[g], acc[mt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], wh[g], acc[mt], 0, 0, 0);
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = acc[mt] * (1.0f / (SPLIT_WSCALE * SPLIT_USCALE));
   const int co = wave * 16 + li;
   float ts[9];
 #pragma unroll
@@ -1332,7 +1402,7 @@ struct lrnde_conv {
   bool have_params = false;
   int NG1 = 0, NG2 = 0;
   // parameters
-  void *w2h = nullptr, *w2l = nullptr, *w3h = nullptr, *w3l = nullptr; bool split = false;  // f32 split packs (fp16 hi / lo)
+  void *w1h = nullptr, *w1l = nullptr, *w2h = nullptr, *w2l = nullptr, *w3h = nullptr, *w3l = nullptr; bool split = false;  // f32 split packs (fp16 hi / lo)
   void *w1 = nullptr, *w2 = nullptr, *w3 = nullptr, *w1b = nullptr;  // w1b: conv1 in bf16 fragments (bf16 mode)
   float *ts1 = nullptr, *ts2 = nullptr, *ts3 = nullptr;
   float *bn = nullptr;       // scale1 bias1 scale2 bias2 (4*Hc)
@@ -1445,8 +1515,10 @@ template <int MT> void launch_one(lrnde_conv* c, int which, const ConvArgs& a, s
     return;
   }
   const bool split = c->split && a.smode == 0 && a.wpk2 != nullptr;  // forward conv2 / conv3 only
-  if (which == 0) hipLaunchKernelGGL((k_conv_wide_f32<8, MT, false>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
-  else if (which == 1) {
+  if (which == 0) {
+    if (split) hipLaunchKernelGGL(k_conv_in_split<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+    else hipLaunchKernelGGL((k_conv_wide_f32<8, MT, false>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+  } else if (which == 1) {
     if (split) hipLaunchKernelGGL(k_conv_wide_split<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
     else hipLaunchKernelGGL((k_conv_wide_f32<64, MT, false>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
   } else {
@@ -1483,6 +1555,7 @@ int launch_rhs_ex(lrnde_conv* c, const float* u, float t, int B, float* du, bool
   // conv1: state -> y1
   a.CIN = C; a.CINP = cinp_of(C); a.COUT = Hc; a.in = u; a.out = c->y1; a.wpk = c->w1; a.tsum = c->ts1; a.t = t;
   a.wpk2 = c->d.compute_dtype == LRNDE_BF16 ? c->w1b : nullptr;
+  if (c->split) { a.wpk = c->w1h; a.wpk2 = c->w1l; }
   a.part = train ? c->part : nullptr;
   const size_t stg_bytes = sizeof(float) * (size_t)a.TP * 68;  // epilogue transpose buffer (aliases the tile)
   launch_mt(c, 0, a, std::max(sizeof(float) * rows * WP * a.CINP, stg_bytes));
@@ -1758,7 +1831,8 @@ int lrnde_conv_create(lrnde_conv** out, const lrnde_conv_desc* d, int device, vo
             hipHostMalloc(&c->sums_host, sizeof(double) * NSUMB * 3) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
   if (ok && d->compute_dtype == LRNDE_F32_SPLIT) {
-    ok = hipMalloc(&c->w2h, (size_t)18 * 4 * 1024) == hipSuccess && hipMalloc(&c->w2l, (size_t)18 * 4 * 1024) == hipSuccess &&
+    ok = hipMalloc(&c->w1h, (size_t)3 * 4 * 1024) == hipSuccess && hipMalloc(&c->w1l, (size_t)3 * 4 * 1024) == hipSuccess &&
+         hipMalloc(&c->w2h, (size_t)18 * 4 * 1024) == hipSuccess && hipMalloc(&c->w2l, (size_t)18 * 4 * 1024) == hipSuccess &&
          hipMalloc(&c->w3h, (size_t)18 * 1024) == hipSuccess && hipMalloc(&c->w3l, (size_t)18 * 1024) == hipSuccess;
     c->split = ok;
   }
@@ -1772,7 +1846,7 @@ int lrnde_conv_destroy(lrnde_conv* c) {
   if (!c) return LRNDE_OK;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
-  void* ptrs[] = {c->params, c->w1t, c->w2t, c->w3t, c->zeros, c->bwm, c->g1, c->g2, c->part_bw, c->pw, c->pt, c->w2h, c->w2l, c->w3h, c->w3l, c->w1, c->w1b, c->w2, c->w3, c->ts1, c->ts2, c->ts3, c->bn, c->stat, c->bn_state, c->y1, c->y2, c->part, c->vec, c->sums};
+  void* ptrs[] = {c->params, c->w1t, c->w2t, c->w3t, c->zeros, c->bwm, c->g1, c->g2, c->part_bw, c->pw, c->pt, c->w1h, c->w1l, c->w2h, c->w2l, c->w3h, c->w3l, c->w1, c->w1b, c->w2, c->w3, c->ts1, c->ts2, c->ts3, c->bn, c->stat, c->bn_state, c->y1, c->y2, c->part, c->vec, c->sums};
   for (void* p : ptrs) if (p) hipFree(p);
   for (float* d : c->dense) if (d) hipFree(d);
   if (c->rec_u1) hipFree(c->rec_u1);
@@ -1800,6 +1874,7 @@ int lrnde_conv_set_params(lrnde_conv* c, const float* p, size_t n) {
   hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w2, Hc, Hc, c->NG2, 4, bf, c->w2, c->ts2);
   hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w3, Hc, C, c->NG2, 1, bf, c->w3, c->ts3);
   if (c->split) {
+    hipLaunchKernelGGL(k_pack_conv_split, dim3(64), dim3(256), 0, c->stream, w1, C, Hc, 3, 4, (_Float16*)c->w1h, (_Float16*)c->w1l);
     hipLaunchKernelGGL(k_pack_conv_split, dim3(64), dim3(256), 0, c->stream, w2, Hc, Hc, 18, 4, (_Float16*)c->w2h, (_Float16*)c->w2l);
     hipLaunchKernelGGL(k_pack_conv_split, dim3(64), dim3(256), 0, c->stream, w3, Hc, C, 18, 1, (_Float16*)c->w3h, (_Float16*)c->w3l);
   }

@@ -8,12 +8,13 @@ rng = np.random.default_rng(5)
 p = (O.glorot_conv_params(C, Hc, seed=5) * np.float32(1.5)).astype(np.float32)
 u = rng.standard_normal((B, C, H, W)).astype(np.float32)
 fld = O.ConvField(W, H, C, Hc, p, nthreads=8)
-h = P.ConvHandle(W, H, C, Hc); h.set_params(p)
+dtype = sys.argv[1] if len(sys.argv) > 1 else "f32_split"
+h = P.ConvHandle(W, H, C, Hc, compute_dtype=dtype); h.set_params(p)
 ud = torch.from_numpy(u).cuda()
 ref = fld.rhs(u.reshape(B, -1), 0.3).reshape(u.shape)
 got = h.rhs(ud, 0.3).cpu().numpy()
 sc = np.abs(ref).max()
-print("mode", "NO_SPLIT" if os.environ.get("LRNDE_CONV_NO_SPLIT") else "split", " rhs max err / scale %.3e  rms err / rms %.3e" % (np.abs(got - ref).max() / sc, np.sqrt(np.mean((got - ref) ** 2)) / np.sqrt(np.mean(ref ** 2))))
+print("dtype", dtype, " rhs max err / scale %.3e  rms err / rms %.3e" % (np.abs(got - ref).max() / sc, np.sqrt(np.mean((got - ref) ** 2)) / np.sqrt(np.mean(ref ** 2))))
 dt0, k1 = O.init_dt(fld, u.reshape(B, -1), 0.0, 1.0, 1e-4, 1e-4)
 so = O.tsit5_step(fld, u.reshape(B, -1), k1, 0.0, dt0, 1e-4, 1e-4)
 dtg, k1g = h.init_dt(ud, 0.0, 1.0, 1e-4, 1e-4)
