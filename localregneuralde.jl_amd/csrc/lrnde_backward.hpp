@@ -390,6 +390,9 @@ struct VjpQArgs {
   const float* y; const float* dense; float theta, dense_dt;
   const float* lam;
   float* dy; float* ysc; float* hsc; float* dpsc;
+  // optional fused stage combination of the adjoint's Tsit5 loop: lambda = base + dt*(c0 k0 + c1 k1 + ...) (the
+  // arithmetic of k_axpy) formed while the tile is staged and written to lam_out for the parameter-gradient GEMM
+  const float* lbase; const float* lk[6]; float lc[6]; int lnk; float ldt; float* lam_out;
 };
 
 constexpr int VQB = 3 * QSB1;  // stream blocks of one VJP (QSB2 == QSB1)
@@ -526,7 +529,23 @@ __global__ __launch_bounds__(QNT) void k_vjp_q(VjpQArgs a) {
         }
       }
       st4(a.ysc + g, x);
-      lv = ld4(a.lam + g);
+      if (a.lnk > 0) {
+        const f32x4 bs = ld4(a.lbase + g);
+        f32x4 sacc;
+        { const f32x4 k0 = ld4(a.lk[0] + g);
+#pragma unroll
+          for (int h = 0; h < 4; ++h) sacc[h] = a.lc[0] * k0[h]; }
+        for (int j = 1; j < a.lnk; ++j) {
+          const f32x4 kj = ld4(a.lk[j] + g);
+#pragma unroll
+          for (int h = 0; h < 4; ++h) sacc[h] = sacc[h] + a.lc[j] * kj[h];
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) lv[h] = bs[h] + a.ldt * sacc[h];
+        st4(a.lam_out + g, lv);
+      } else {
+        lv = ld4(a.lam + g);
+      }
     }
     s.xl[kq * 4 + sx] = x;
     ll[kq * 4 + sx] = lv;

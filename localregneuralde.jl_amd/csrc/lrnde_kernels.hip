@@ -2297,22 +2297,32 @@ static int launch_pgrad(lrnde_ctx* c, int B, float t, const float* lam, float* g
   return LRNDE_OK;
 }
 
+// fused stage combination handed to the 4-column VJP kernel (lambda part of z_stage = z + dt * sum c_j K_j)
+struct StageIn { const float* base; float dt; int nk; const float* k[6]; float c[6]; float* lam_out; };
+
 // dy = J^T lam at (y or the interpolated dense step, t);  gp (optional) = (df/dp)^T lam
+static bool vjp_uses_qtile(const lrnde_ctx* c, int B) { return use_qtile(c, B) && !getenv("LRNDE_NO_QVJP"); }
 static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float theta, float dense_dt, float t,
-                      const float* lam, int B, float* dy, float* gp) {
+                      const float* lam, int B, float* dy, float* gp, const StageIn* sin = nullptr) {
   int rc = ensure_bw(c, B);
   if (rc) return rc;
-  if (use_qtile(c, B) && !getenv("LRNDE_NO_QVJP")) {
+  if (vjp_uses_qtile(c, B)) {
     VjpQArgs a;
     memset(&a, 0, sizeof(a));
     a.m = c->m; a.V1q = c->V1q; a.U2q = c->U2q;
     a.B = B; a.t = t; a.y = y; a.dense = dense; a.theta = theta; a.dense_dt = dense_dt; a.lam = lam; a.dy = dy;
     a.ysc = c->bw_y; a.hsc = c->bw_h; a.dpsc = c->bw_dp;
+    if (sin) {
+      a.lbase = sin->base; a.ldt = sin->dt; a.lnk = sin->nk; a.lam_out = sin->lam_out;
+      for (int j = 0; j < sin->nk; ++j) { a.lk[j] = sin->k[j]; a.lc[j] = sin->c[j]; }
+      lam = sin->lam_out;  // what the parameter-gradient GEMM reads
+    }
     const size_t smq = smem_bytes_vq(c->m.KQ1p, c->m.KQ2p, c->m.RG1, c->m.RG2);
     hipLaunchKernelGGL(k_vjp_q, dim3((B + QNB - 1) / QNB), dim3(QNT), smq, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return launch_pgrad(c, B, t, lam, gp);
   }
+  if (sin) return fail(c, LRNDE_BADARG, "fused stage input needs the 4-column VJP kernel");
   VjpArgs a;
   memset(&a, 0, sizeof(a));
   a.m = c->m; a.V1p = reinterpret_cast<const f32x4*>(c->V1p); a.U2p = reinterpret_cast<const f32x4*>(c->U2p);
@@ -2402,19 +2412,19 @@ int vec_norm(lrnde_ctx* c, const float* num, const float* num2, const float* sa,
 
 // adjoint RHS in reversed time s = -t: K = [J^T lambda; (df/dp)^T lambda] at y(t) from the dense record
 int adj_rhs(lrnde_ctx* c, const std::vector<float>& dt_, const std::vector<float>& dd_, int B, size_t n,
-            const float* zs, float sgt, float* K) {
+            const float* zs, float sgt, float* K, const StageIn* sin = nullptr) {
   const float t = -sgt;
   int lo = 0, hi = (int)dt_.size() - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (dt_[mid] <= t) lo = mid; else hi = mid - 1; }
   const float theta = (t - dt_[lo]) / dd_[lo];
-  return launch_vjp(c, nullptr, c->dense + (size_t)lo * 8 * n, theta, dd_[lo], t, zs, B, K, K + n);
+  return launch_vjp(c, nullptr, c->dense + (size_t)lo * 8 * n, theta, dd_[lo], t, zs, B, K, K + n, sin);
 }
 
 // adaptive Tsit5 on device vectors, host-side controller (mirror of the forward loop / the oracle's
 // lro_solve_ex), integrating s from s0 to s1 with tstops; only the end state is kept
-template <class RHS>
-int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, float s0, float s1, float abstol, float reltol, int maxiters,
-                    int exact_pow, const std::vector<float>& tstops, lrnde_stats* st) {
+template <class RHS, class RHSF>
+int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, RHSF rhs_fused, bool fuse_stage, float s0, float s1, float abstol,
+                    float reltol, int maxiters, int exact_pow, const std::vector<float>& tstops, lrnde_stats* st) {
   const size_t N = v.N;
   const float gamma = 0.9f, qmin = 0.2f, qmax = 10.0f, qoldinit = 1e-4f;
   const float beta1 = (float)(7.0 / 50.0), beta2 = (float)(2.0 / 25.0);
@@ -2471,6 +2481,15 @@ int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, float s0, float s1, float 
     for (int sidx = 2; sidx <= 7; ++sidx) {
       const int off = (sidx - 2) * (sidx - 1) / 2;
       float* out = (sidx == 7) ? zn : v.zs;
+      if (fuse_stage && sidx < 7) {
+        // the RHS only reads the lambda part of the stage state: it is formed inside the VJP kernel (same arithmetic as
+        // k_axpy) and left in v.zs for the parameter-gradient GEMM; the mu part of a stage state is never needed
+        StageIn sin;
+        sin.base = z; sin.dt = dt; sin.nk = sidx - 1; sin.lam_out = v.zs;
+        for (int j = 0; j < sidx - 1; ++j) { sin.k[j] = K[j]; sin.c[j] = A[off + j]; }
+        if ((rc = rhs_fused(sin, t + cs[sidx - 2] * dt, K[sidx - 1]))) return rc;
+        continue;
+      }
       if ((rc = vec_axpy(c, out, z, dt, sidx - 1, K, A + off, N))) return rc;
       if ((rc = rhs(out, t + cs[sidx - 2] * dt, K[sidx - 1]))) return rc;
     }
@@ -2631,7 +2650,9 @@ int lrnde_node_backward_recorded(lrnde_ctx* c, int32_t B, const float* du_end, f
       if (tv > t0 && tv < t2) stops.push_back(-tv);
     }
   auto rhs = [&](const float* zs, float sg, float* K) { return adj_rhs(c, dts, dds, B, n, zs, sg, K); };
-  rc = vec_tsit5_solve(c, v, rhs, -t2, -t0, o->abstol, o->reltol, o->maxiters, o->exact_pow, stops, st_bwd);
+  auto rhs_fused = [&](const StageIn& sin, float sg, float* K) { return adj_rhs(c, dts, dds, B, n, nullptr, sg, K, &sin); };
+  rc = vec_tsit5_solve(c, v, rhs, rhs_fused, vjp_uses_qtile(c, B), -t2, -t0, o->abstol, o->reltol, o->maxiters, o->exact_pow,
+                       stops, st_bwd);
   if (rc) return fail(c, rc, "adjoint solve stopped with retcode %d", rc);
   HIPCHK(c, hipMemcpyAsync(dx, v.z, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dp, v.z + n, sizeof(float) * P, hipMemcpyDeviceToDevice, c->stream));
