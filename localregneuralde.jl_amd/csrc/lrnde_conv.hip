@@ -359,6 +359,19 @@ __device__ __forceinline__ void wide_epilogue(const ConvArgs& a, const f32x4 (&a
   }
 }
 
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), every lane gets the total: four v_add_f32 with DPP
+// operands (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror) instead of ds_bpermute shuffles
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<0xB1>(v);
+  v += dpp_f32<0x4E>(v);
+  v += dpp_f32<0x141>(v);
+  v += dpp_f32<0x140>(v);
+  return v;
+}
+
 // Direct epilogue (bf16 kernels): the MFMA is issued with the weight fragment as A and the pixel fragment as B, so a
 // lane's accumulator holds 4 consecutive CHANNELS (16 wave + 4 kg + r) of ONE pixel (16 mt + li) — already the NHWC
 // order.  No LDS transpose and no barrier: + t * tsum[class] (table [9][64] in LDS at `tsl`), the statistics, and an
@@ -401,9 +414,14 @@ __device__ __forceinline__ void direct_epilogue(const ConvArgs& a, const f32x4 (
   if (a.part) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      double s1 = OBF ? (double)f1[r] : d1[r], s2 = OBF ? (double)f2[r] : d2[r];
+      double s1, s2;
+      if constexpr (OBF) {  // bf16 mode: the strip's 128 values per channel are summed in fp32 (the shuffles of a double
+        s1 = (double)row16_sum(f1[r]); s2 = (double)row16_sum(f2[r]);  // reduction cost more than the stores)
+      } else {
+        s1 = d1[r]; s2 = d2[r];
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      }
       if (li == 0) { double* pp = a.part + ((size_t)(cb + r) * gridDim.x + blockIdx.x) * 2; pp[0] = s1; pp[1] = s2; }
     }
   }
@@ -754,7 +772,10 @@ __global__ __launch_bounds__(CNT) void k_conv_in_bf16(ConvArgs a) {
   direct_epilogue<MT, true>(a, acc, tsl, n, y0, wave, li, kg);
 }
 
-// conv3 in bf16: 64 -> COUT <= 16 channels, planar fp32 output; waves split the M tiles
+// conv3 in bf16: 64 -> COUT <= 16 channels, planar fp32 output.  The waves split K: wave w runs k-groups
+// {0-4, 5-9, 10-13, 14-17}[w] over all M tiles, so it needs 5 weight fragments (loaded before the staging, their
+// latency hidden behind it) instead of all 18 after it, and the four partial accumulators are added in wave order
+// through LDS (aliasing the tile).  The fifth group of waves 2, 3 carries zero weights.
 template <int MT>
 __global__ __launch_bounds__(CNT) void k_conv_out_bf16(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -764,48 +785,58 @@ __global__ __launch_bounds__(CNT) void k_conv_out_bf16(ConvArgs a) {
   const int li = lane & 15, kg = lane >> 4;
   const int strips = a.H / a.TR;
   const int n = blockIdx.x / strips, y0 = (blockIdx.x % strips) * a.TR;
-  constexpr int NG = 18;
+  constexpr int NG = 18, GW = 5;
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * 1024, 0x00020000);
   const int wv = lane * 16;
+  const int gs = wave < 2 ? wave * 5 : 10 + (wave - 2) * 4;
+  bf16x8 wq[GW];
+#pragma unroll
+  for (int j = 0; j < GW; ++j) wq[j] = wload8(rsW, wv, min(gs + j, NG - 1) * 1024);
+  if (wave >= 2) wq[GW - 1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};  // waves 2, 3 own four groups
   if (!(a.dbg & 4)) stage_nhwc_bn_bf16(a, n, y0, tile);
   int ab[MAXMT];
   pixel_bases(a, ab, 1);
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  const int m0 = wave, m1 = wave + 4;
-  const int ab0 = (m0 == 0) ? ab[0] : (m0 == 1) ? ab[1] : (m0 == 2) ? ab[2] : ab[3];
-  const int ab1 = (m1 == 4) ? ab[4] : (m1 == 5) ? ab[5] : (m1 == 6) ? ab[6] : ab[7];
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  bf16x8 wq[NG];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) wq[g] = wload8(rsW, wv, g * 1024);
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
+  for (int j = 0; j < GW; ++j) {
     if (a.dbg & 1) break;
+    const int g = min(gs + j, NG - 1), tap = g >> 1, g2 = g & 1;
     const int tp = tap_pos(a, tap);
-    const int pos0 = ab0 + tp, pos1 = ab1 + tp;
-    const int pb0 = pos0 * 64 + (((kg ^ (pos0 >> 1)) & 3) << 3), hi0 = ((pos0 >> 1) & 4) << 3;
-    const int pb1 = pos1 * 64 + (((kg ^ (pos1 >> 1)) & 3) << 3), hi1 = ((pos1 >> 1) & 4) << 3;
+    bf16x8 av[MT];
 #pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2) {
-      if (m0 < MT) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(tile + pb0 + ((32 * g2) ^ hi0)), wq[tap * 2 + g2], acc[0], 0, 0, 0);
-      if (MT > 4 && m1 < MT) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(tile + pb1 + ((32 * g2) ^ hi1)), wq[tap * 2 + g2], acc[1], 0, 0, 0);
+    for (int mt = 0; mt < MT; ++mt) {
+      const int pos = ab[mt] + tp, sw = pos >> 1;
+      av[mt] = *reinterpret_cast<const bf16x8*>(tile + pos * 64 + ((((kg ^ sw) & 3) << 3) | ((32 * g2) ^ ((sw & 4) << 3))));
     }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[mt], wq[j], acc[mt], 0, 0, 0);
   }
   if (a.dbg & 2) { if (acc[0][0] == 123.f) a.out[0] = 1.f; return; }
-  if (li < a.COUT) {
-    float ts[9];
+  __syncthreads();  // every wave is done with the tile
+  f32x4* red = reinterpret_cast<f32x4*>(smem);  // [wave][mt][lane]
 #pragma unroll
-    for (int c = 0; c < 9; ++c) ts[c] = a.tsum[c * 16 + li];
-    float* dst = a.out + ((size_t)n * a.COUT + li) * a.H * a.W;
+  for (int mt = 0; mt < MT; ++mt) red[(wave * MT + mt) * 64 + lane] = acc[mt];
+  __syncthreads();
+  float ts[9];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int mt = h == 0 ? m0 : m1;
-      const int p = mt * 16 + kg * 4;
-      if (mt < MT && p < a.TP) {
+  for (int c = 0; c < 9; ++c) ts[c] = li < a.COUT ? a.tsum[c * 16 + li] : 0.f;
+  float* dst = a.out + ((size_t)n * a.COUT + li) * a.H * a.W;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int mt = wave + 4 * h;
+    const int p = mt * 16 + kg * 4;
+    if (mt < MT && p < a.TP) {
+      f32x4 sum = red[(0 * MT + mt) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { const f32x4 o = red[(w * MT + mt) * 64 + lane]; sum = sum + o; }
+      if (li < a.COUT) {
         const int y = y0 + p / a.W, x = p % a.W;
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fma_(ts[border_class(y, x + r, a.H, a.W)], a.t, acc[h][r]);
+        for (int r = 0; r < 4; ++r) v[r] = fma_(ts[border_class(y, x + r, a.H, a.W)], a.t, sum[r]);
         *reinterpret_cast<f32x4*>(dst + (size_t)y * a.W + x) = v;
       }
     }
@@ -1703,7 +1734,8 @@ int launch_rhs_ex(lrnde_conv* c, const float* u, float t, int B, float* du, bool
   a.COUT = C; a.in = c->y2; a.out = du; a.wpk = c->w3; a.tsum = c->ts3; a.part = nullptr; a.wpk2 = nullptr;
   if (c->split) { a.wpk = c->w3h; a.wpk2 = c->w3l; }
   a.mean = c->stat + 2 * Hc; a.inv = c->stat + 3 * Hc; a.scale = c->bn + 2 * Hc; a.bias = c->bn + 3 * Hc;
-  launch_mt(c, 2, a, esz * rows * WP * a.CINP);
+  // bf16 conv3 adds its four K-split partial accumulators through LDS: [4 waves][MT][64 lanes] float4
+  launch_mt(c, 2, a, bf ? std::max(esz * rows * WP * a.CINP, (size_t)4 * a.MT * 64 * 16) : esz * rows * WP * a.CINP);
   CHK(c, hipGetLastError());
   return LRNDE_OK;
 }
