@@ -251,13 +251,17 @@ int lrnde_conv_node_backward(lrnde_conv* c, const float* x, int32_t B, float t0,
  * stem: AugmenterLayer(Conv((3,3), 3=>5; pad=1), 3) (src/layers/common.jl:80-92: cat(x, conv(x); dims=3)) + BatchNorm(8);
  * ps (device, 156) = [conv.weight 3x3x3x5 column-major; conv.bias 5; bn.scale 8; bn.bias 8]; x (B,3,H,W) -> u0 (B,8,H,W).
  * BatchNorm(8) follows the handle's bn_train; in test mode bn_state (device, [mean 8; var 8], may be NULL = 0/1) is used.
+ * In training mode bn_state_out (device, 16 floats, may be NULL) receives the running statistics Lux's BatchNorm
+ * returns in its state: bn_state advanced by this batch (momentum 0.1, n/(n-1) variance correction, as the field's
+ * layers, lrnde_conv_get_bn_state); in test mode it receives a copy of bn_state.
  * head: Chain(Conv((3,3), 8=>1, gelu; pad=1), FlattenLayer(), Dense(H*W=>K)) + logitcrossentropy
  * (experiments/src/utils.jl:88); ph (device) = [conv.weight 3x3x8x1; conv.bias 1; dense.weight K x H*W column-major;
  * dense.bias K]; returns the mean loss on the host and, where non-NULL, logits (B,K), du (B,8,H,W), dph.
  * H, W are the handle's image size.  Run once per batch: simple direct kernels. */
 size_t lrnde_cifar_stem_param_count(void);
 size_t lrnde_cifar_head_param_count(int32_t H, int32_t W, int32_t K);
-int lrnde_cifar_stem_forward(lrnde_conv* c, const float* x, int32_t B, const float* ps, const float* bn_state, float* u0);
+int lrnde_cifar_stem_forward(lrnde_conv* c, const float* x, int32_t B, const float* ps, const float* bn_state, float* u0,
+                             float* bn_state_out);
 int lrnde_cifar_stem_backward(lrnde_conv* c, const float* x, int32_t B, const float* ps, const float* bn_state,
                               const float* du0, float* dps);
 int lrnde_cifar_head_ce(lrnde_conv* c, const float* u, int32_t B, const float* ph, int32_t K, const int32_t* labels,

@@ -97,7 +97,7 @@ SYMBOLS = [
                                            C.POINTER(Stats), C.POINTER(Stats)]),
     ("lrnde_cifar_stem_param_count", C.c_size_t, []),
     ("lrnde_cifar_head_param_count", C.c_size_t, [_i32, _i32, _i32]),
-    ("lrnde_cifar_stem_forward", C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    ("lrnde_cifar_stem_forward", C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     ("lrnde_cifar_stem_backward", C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     ("lrnde_cifar_head_ce", C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _fp, _vp, _vp, _vp]),
     ("lrnde_conv_bench_rhs", C.c_int, [_vp, _vp, _f, _i32, _i32, _fp]),

@@ -223,13 +223,16 @@ class ConvHandle:
         return dict(dx=dx, dp=dp, stats_fwd=sf.asdict(), stats_bwd=sb.asdict())
 
     # ---- layers around the CIFAR10 NeuralODE (experiments/src/construct.jl:224-227) ----
-    def cifar_stem_forward(self, x, ps, bn_state=None):
-        """AugmenterLayer(Conv 3=>5) + BatchNorm(8): x (B,3,H,W) -> u0 (B,8,H,W)"""
+    def cifar_stem_forward(self, x, ps, bn_state=None, return_state=False):
+        """AugmenterLayer(Conv 3=>5) + BatchNorm(8): x (B,3,H,W) -> u0 (B,8,H,W); with return_state also the layer's
+        running statistics [mean 8; var 8] after this call (advanced in training mode, as Lux returns them in `st`)"""
         B = x.shape[0]
         u0 = torch.empty((B, 8, self.desc.height, self.desc.width), dtype=torch.float32, device=x.device)
+        st_out = torch.empty(16, dtype=torch.float32, device=x.device) if return_state else None
         self._chk(L.lib.lrnde_cifar_stem_forward(self._ctx, _ptr(x, "x"), B, _ptr(ps, "ps"),
-                                                 _ptr(bn_state, "bn_state") if bn_state is not None else None, _ptr(u0, "u0")))
-        return u0
+                                                 _ptr(bn_state, "bn_state") if bn_state is not None else None, _ptr(u0, "u0"),
+                                                 _ptr(st_out, "bn_state_out") if return_state else None))
+        return (u0, st_out) if return_state else u0
 
     def cifar_stem_backward(self, x, ps, du0, bn_state=None):
         dps = torch.empty(156, dtype=torch.float32, device=x.device)

@@ -2768,18 +2768,22 @@ extern "C" {
 size_t lrnde_cifar_stem_param_count(void) { return 135 + 5 + 8 + 8; }
 size_t lrnde_cifar_head_param_count(int32_t H, int32_t W, int32_t K) { return (size_t)72 + 1 + (size_t)K * H * W + K; }
 
+__global__ void k_stem_state_copy(const float* st, float* out) {  // running [mean 8; var 8], NULL = 0 / 1
+  const int i = threadIdx.x;
+  if (i < 16) out[i] = st ? st[i] : (i < 8 ? 0.f : 1.f);
+}
 static int stem_common(lrnde_conv* c, const float* x, int B, const float* ps, const float* bn_state, float* a0, float* mi /* mean[8] inv[8] */,
-                       double* part, int nblk) {
+                       double* part, int nblk, float* run = nullptr /* running statistics to advance (already holding bn_state) */) {
   const int H = c->d.height, W = c->d.width;
   hipLaunchKernelGGL(k_stem_raw, dim3(nblk), dim3(SH_T), 0, c->stream, x, ps, B, H, W, a0, part);
   if (c->d.bn_train) hipLaunchKernelGGL(k_bn_finalize, dim3(8), dim3(256), 0, c->stream, (const double*)part, nblk, 8, (double)B * H * W, c->d.bn_eps, mi, mi + 8,
-                                        (float*)nullptr, (float*)nullptr, 0.f);
+                                        run, run ? run + 8 : (float*)nullptr, 0.1f);
   else hipLaunchKernelGGL(k_stem_state, dim3(1), dim3(64), 0, c->stream, bn_state, c->d.bn_eps, mi, mi + 8);
   CHK(c, hipGetLastError());
   return LRNDE_OK;
 }
 
-int lrnde_cifar_stem_forward(lrnde_conv* c, const float* x, int32_t B, const float* ps, const float* bn_state, float* u0) {
+int lrnde_cifar_stem_forward(lrnde_conv* c, const float* x, int32_t B, const float* ps, const float* bn_state, float* u0, float* bn_state_out) {
   if (!c || !x || !ps || !u0 || B <= 0) return LRNDE_BADARG;
   CHK(c, hipSetDevice(c->device));
   const int H = c->d.height, W = c->d.width;
@@ -2788,7 +2792,8 @@ int lrnde_cifar_stem_forward(lrnde_conv* c, const float* x, int32_t B, const flo
   DevBuf ba0, bmi, bpart;
   CHK(c, ba0.alloc(sizeof(float) * total)); CHK(c, bmi.alloc(sizeof(float) * 16)); CHK(c, bpart.alloc(sizeof(double) * nblk * 16));
   float *a0 = ba0.as<float>(), *mi = bmi.as<float>(); double* part = bpart.as<double>();
-  int rc = stem_common(c, x, B, ps, bn_state, a0, mi, part, nblk);
+  if (bn_state_out) hipLaunchKernelGGL(k_stem_state_copy, dim3(1), dim3(64), 0, c->stream, bn_state, bn_state_out);
+  int rc = stem_common(c, x, B, ps, bn_state, a0, mi, part, nblk, bn_state_out);
   if (!rc) {
     hipLaunchKernelGGL(k_stem_norm, dim3(2048), dim3(256), 0, c->stream, (const float*)a0, (const float*)mi, (const float*)(mi + 8), ps, plane, total, u0);
     if (hipStreamSynchronize(c->stream) != hipSuccess) rc = cfail(c, LRNDE_HIP_ERROR, "stem kernels failed");

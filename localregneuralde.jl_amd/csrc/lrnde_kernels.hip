@@ -479,7 +479,7 @@ __device__ __forceinline__ void feval_tile(const ModelDev& m, const Smem& sm, co
                                            float ts, const Epi& epi) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
-  const int n = lane & 15, rq = lane >> 4;
+  const int rq = lane >> 4;
   const int voff = lane * 16;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const float* w1t = sm.bias; const float* b1 = w1t + m.Hp;

@@ -58,7 +58,8 @@ def run_cifar_training_step(node, params, st, x, labels, w_reg, num_classes=10):
     t1_or_rand = np.float32(r01 * (t2 - t0) + t0) if mode == "unbiased" else r01
     torch.cuda.synchronize()
     tic = time.perf_counter()
-    u0 = h.cifar_stem_forward(x, params["stem"])
+    stem_in = st.get("stem_bn_state") if isinstance(st, dict) else None
+    u0, stem_bn = h.cifar_stem_forward(x, params["stem"], stem_in, return_state=True)  # BatchNorm(8)'s state advances too
     fw = h.node_forward(u0, t0, t2, abstol, reltol, mode=mode, reg_type=node.regularize_type, t1_or_rand=t1_or_rand,
                         maxiters=node.maxiters, save_start=kw.get("save_start", True))
     bn_after = h.get_bn_state()
@@ -70,10 +71,10 @@ def run_cifar_training_step(node, params, st, x, labels, w_reg, num_classes=10):
     bw = h.node_backward(u0, t0, t2, abstol, reltol, head["du"], mode=mode, reg_type=node.regularize_type,
                          t1_or_rand=t1_or_rand, w_reg=w_reg, maxiters=node.maxiters, save_start=kw.get("save_start", True))
     h.set_bn_state(bn_after)  # the pullback's forward re-solve must not advance the model state a second time
-    dstem = h.cifar_stem_backward(x, params["stem"], bw["dx"])
+    dstem = h.cifar_stem_backward(x, params["stem"], bw["dx"], stem_in)
     torch.cuda.synchronize()
     bwd_time = time.perf_counter() - tic
-    st_ = dict(model=dict(bn_state=bn_after), nfe=fw["nfe"], reg_val=fw["reg_val"], rng=rng, training=st["training"])
+    st_ = dict(model=dict(bn_state=bn_after), stem_bn_state=stem_bn, nfe=fw["nfe"], reg_val=fw["reg_val"], rng=rng, training=st["training"])
     stats = dict(y_pred=head["logits"], nfe=fw["nfe"], ce_loss=head["loss"], reg_val=fw["reg_val"])
     grads = dict(stem=dstem, neural_ode=bw["dp"], head=head["dph"])
     return loss, st_, stats, grads, dict(fwd_time=fwd_time, bwd_time=bwd_time, adjoint=bw["stats_bwd"], forward=fw["stats"])

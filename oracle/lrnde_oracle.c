@@ -1471,7 +1471,8 @@ static void stem_raw(const float* x, int B, int H, int W, const float* ps, float
         }
   }
 }
-static void stem_stats(const float* a0, int B, long plane, int c, int train, const float* st, float eps, float* mean, float* inv) {
+static void stem_stats_run(const float* a0, int B, long plane, int c, int train, const float* st, float eps, float* mean, float* inv,
+                           float* run /* [mean 8; var 8] to advance, or NULL */) {
   if (train) {
     const double N = (double)B * (double)plane;
     double s = 0.0;
@@ -1480,19 +1481,29 @@ static void stem_stats(const float* a0, int B, long plane, int c, int train, con
     double v = 0.0;
     for (int n = 0; n < B; ++n) { const float* p = a0 + ((long)n * 8 + c) * plane; for (long i = 0; i < plane; ++i) { const double d = (double)p[i] - mu; v += d * d; } }
     *mean = (float)mu; *inv = (float)(1.0 / sqrt(v / N + (double)eps));
+    if (run) { /* Lux BatchNorm's training-mode update (momentum 0.1, n/(n-1) correction), as batchnorm_act_ex */
+      const float m = 0.1f, bm = (float)mu, bv = (float)(v / N);
+      const float mcorr = m * (float)N / ((float)N - 1.0f);
+      run[c] = (1.0f - m) * run[c] + m * bm;
+      run[8 + c] = (1.0f - m) * run[8 + c] + mcorr * bv;
+    }
   } else {
     *mean = st ? st[c] : 0.0f; *inv = (float)(1.0 / sqrt((double)(st ? st[8 + c] : 1.0f) + (double)eps));
   }
 }
+static void stem_stats(const float* a0, int B, long plane, int c, int train, const float* st, float eps, float* mean, float* inv) {
+  stem_stats_run(a0, B, plane, c, train, st, eps, mean, inv, NULL);
+}
 void lro_cifar_stem_forward(const float* x, int B, int H, int W, const float* ps, int bn_train, const float* bn_state, float eps,
-                            float* u0) {
+                            float* u0, float* bn_state_out) {
+  if (bn_state_out) for (int i = 0; i < 16; ++i) bn_state_out[i] = bn_state ? bn_state[i] : (i < 8 ? 0.0f : 1.0f);
   const long plane = (long)H * W;
   float* a0 = (float*)malloc(sizeof(float) * (size_t)B * 8 * plane);
   stem_raw(x, B, H, W, ps, a0);
   const float* g = ps + 140; const float* be = ps + 148;
   for (int c = 0; c < 8; ++c) {
     float mean, inv;
-    stem_stats(a0, B, plane, c, bn_train, bn_state, eps, &mean, &inv);
+    stem_stats_run(a0, B, plane, c, bn_train, bn_state, eps, &mean, &inv, bn_state_out);
     for (int n = 0; n < B; ++n)
       for (long i = 0; i < plane; ++i) {
         const long o = ((long)n * 8 + c) * plane + i;

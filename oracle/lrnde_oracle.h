@@ -214,7 +214,7 @@ int lro_node_backward(const lro_mlp* m, const float* x, int B, float t0, float t
 int lro_cifar_stem_param_count(void);
 int lro_cifar_head_param_count(int H, int W, int K);
 void lro_cifar_stem_forward(const float* x, int B, int H, int W, const float* ps, int bn_train, const float* bn_state, float eps,
-                            float* u0);
+                            float* u0, float* bn_state_out /* running statistics after the call, or NULL */);
 void lro_cifar_stem_backward(const float* x, int B, int H, int W, const float* ps, int bn_train, const float* bn_state, float eps,
                              const float* du0, float* dps);
 float lro_cifar_head_ce(const float* u, int B, int H, int W, const float* ph, int K, const int* labels, float* logits, float* du,

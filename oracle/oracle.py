@@ -84,7 +84,7 @@ def lib():
         L.lro_classifier_ce.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.POINTER(C.c_int), fp, fp, fp]
         ip = C.POINTER(C.c_int)
         L.lro_cifar_stem_forward.restype = None
-        L.lro_cifar_stem_forward.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_float, fp]
+        L.lro_cifar_stem_forward.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_float, fp, fp]
         L.lro_cifar_stem_backward.restype = None
         L.lro_cifar_stem_backward.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_float, fp, fp]
         L.lro_cifar_head_ce.restype = C.c_float
@@ -408,14 +408,15 @@ def rkmil_step(drift, diffusion, uprev, dW, t, dt, abstol, reltol):
     return dict(u=u, eest=np.float32(ee.value), reg_val=np.float32(rv.value))
 
 
-def cifar_stem_forward(x, ps, bn_train=True, bn_state=None, eps=1e-5):
-    """AugmenterLayer(Conv 3=>5) + BatchNorm(8): x (B,3,H,W) -> u0 (B,8,H,W)"""
+def cifar_stem_forward(x, ps, bn_train=True, bn_state=None, eps=1e-5, return_state=False):
+    """AugmenterLayer(Conv 3=>5) + BatchNorm(8): x (B,3,H,W) -> u0 (B,8,H,W) [, running statistics after the call]"""
     x = _f32(x); ps = _f32(ps)
     B, _, H, W = x.shape
     u0 = np.empty((B, 8, H, W), np.float32)
     st = None if bn_state is None else _f32(bn_state)
-    lib().lro_cifar_stem_forward(_fp(x), B, H, W, _fp(ps), int(bn_train), _fp(st), float(eps), _fp(u0))
-    return u0
+    st_out = np.empty(16, np.float32) if return_state else None
+    lib().lro_cifar_stem_forward(_fp(x), B, H, W, _fp(ps), int(bn_train), _fp(st), float(eps), _fp(u0), _fp(st_out))
+    return (u0, st_out) if return_state else u0
 
 
 def cifar_stem_backward(x, ps, du0, bn_train=True, bn_state=None, eps=1e-5):

@@ -324,6 +324,13 @@ def test_cifar_stem_matches_oracle(W, H, B, train):
     xd, pd = torch.from_numpy(x).cuda(), torch.from_numpy(ps).cuda()
     std = None if st is None else torch.from_numpy(st).cuda()
     _close(h.cifar_stem_forward(xd, pd, std), O.cifar_stem_forward(x, ps, bn_train=train, bn_state=st), rtol=1e-5)
+    # the BatchNorm(8) state after the call: advanced from (0, 1) and from a given state in training mode, passed through otherwise
+    for s_in in ((None, st) if not train else (None, np.concatenate([rng.normal(0, 0.2, 8), rng.uniform(0.5, 2, 8)]).astype(np.float32))):
+        sd = None if s_in is None else torch.from_numpy(s_in).cuda()
+        u_g, st_g = h.cifar_stem_forward(xd, pd, sd, return_state=True)
+        u_o, st_o = O.cifar_stem_forward(x, ps, bn_train=train, bn_state=s_in, return_state=True)
+        _close(u_g, u_o, rtol=1e-5)
+        np.testing.assert_allclose(st_g.cpu().numpy(), st_o, rtol=1e-5, atol=1e-6)
     got = h.cifar_stem_backward(xd, pd, torch.from_numpy(g).cuda(), std).cpu().numpy()
     ref = O.cifar_stem_backward(x, ps, g, bn_train=train, bn_state=st)
     assert np.abs(got - ref).max() <= 5e-5 * np.abs(ref).max()

@@ -42,6 +42,30 @@ def test_stem_matches_torch(train):
     assert np.abs(dps - ref).max() <= 2e-5 * np.abs(ref).max()
 
 
+def test_stem_running_statistics_match_torch_batch_norm():
+    """Lux's training-mode BatchNorm returns advanced running statistics in its state (UPSTREAM-RECALL: momentum 0.1,
+    n/(n-1) variance correction) — the rule torch.nn.functional.batch_norm applies to its running buffers"""
+    rng = np.random.default_rng(3)
+    B, H, W = 4, 6, 8
+    x = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    ps = (rng.standard_normal(156) * 0.3).astype(np.float32)
+    st0 = np.concatenate([rng.normal(0, 0.2, 8), rng.uniform(0.5, 2, 8)]).astype(np.float32)
+    for st in (None, st0):
+        u0, st1 = O.cifar_stem_forward(x, ps, bn_train=True, bn_state=st, return_state=True)
+        xt = torch.tensor(x.astype(np.float64)); pt = torch.tensor(ps.astype(np.float64))
+        w = torch.flip(pt[:135].reshape(5, 3, 3, 3), dims=(2, 3))
+        a0 = torch.cat([xt, torch.nn.functional.conv2d(xt, w, bias=pt[135:140], padding=1)], dim=1)
+        rm = torch.zeros(8, dtype=torch.float64) if st is None else torch.tensor(st[:8].astype(np.float64))
+        rv = torch.ones(8, dtype=torch.float64) if st is None else torch.tensor(st[8:].astype(np.float64))
+        out = torch.nn.functional.batch_norm(a0, rm, rv, pt[140:148], pt[148:156], training=True, momentum=0.1, eps=1e-5)
+        np.testing.assert_allclose(u0, out.numpy(), rtol=0, atol=2e-5 * np.abs(out.numpy()).max())
+        np.testing.assert_allclose(st1[:8], rm.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(st1[8:], rv.numpy(), rtol=1e-5, atol=1e-6)
+    # test mode: the state passes through unchanged
+    _, st2 = O.cifar_stem_forward(x, ps, bn_train=False, bn_state=st0, return_state=True)
+    np.testing.assert_array_equal(st2, st0)
+
+
 def test_head_matches_torch():
     rng = np.random.default_rng(1)
     B, H, W, K = 4, 6, 8, 10
