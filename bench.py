@@ -248,7 +248,7 @@ def conv_measure(args, workload, brief=False):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     fwd_adj_ms, bwd = None, None
-    if dt in ("f32", "f32_split") and args.adjoint_steps > 0 and not brief:  # pullback of <g, sol.u[end]> + 2.5*reg_val, g ~ 1e-3*N(0,1) (a mean-loss cotangent's size)
+    if args.adjoint_steps > 0 and not brief:  # (bf16: bf16 forward re-solve, fp32 adjoint) pullback of <g, sol.u[end]> + 2.5*reg_val, g ~ 1e-3*N(0,1) (a mean-loss cotangent's size)
         g = torch.from_numpy((np.random.default_rng(2).standard_normal(xh.shape) * 1e-3).astype(np.float32)).cuda()
         nb = min(args.adjoint_steps, 3)
         h.node_backward(x, 0.0, 1.0, tol, tol, g, mode="unbiased", t1_or_rand=float(t1s[0]), w_reg=2.5, maxiters=10000)

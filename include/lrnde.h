@@ -195,7 +195,8 @@ int lrnde_classifier_ce(lrnde_ctx* ctx, const float* u, int32_t B, const float* 
  * is zero padded at the border like any other channel.  bn_train = 1: batch statistics (Lux training
  * mode); 0: the running statistics given to lrnde_conv_set_bn_state (default mean 0 / var 1).
  * compute_dtype LRNDE_F32: fp32 MFMA; LRNDE_BF16: bf16 MFMA operands, fp32 accumulation, fp32 state,
- * stage combination and error norm (BASELINE.json config 4).  LRNDE_F32_SPLIT: fp32 results for conv2 / conv3 on the fp16
+ * stage combination and error norm (BASELINE.json config 4); derivatives (lrnde_conv_vjp, _step_reg_grad, _node_backward) of a
+ * bf16 handle are taken in fp32 at the states of its bf16 forward solve ("bf16 forward, fp32 adjoint").  LRNDE_F32_SPLIT: fp32 results for conv2 / conv3 on the fp16
  * MFMA pipe — operands written as hi + lo fp16 pairs (22 significant bits), products hi*hi + hi*lo + lo*hi accumulated in
  * fp32; the f-eval agrees with LRNDE_F32 to ~1e-6 of its scale and runs 1.6x faster, but its rounding errors are less
  * correlated between RK stages, so the embedded error estimate carries more noise when it is far below 1.

@@ -1556,6 +1556,8 @@ struct lrnde_conv {
   // parameters
   void *w1h = nullptr, *w1l = nullptr, *w2h = nullptr, *w2l = nullptr, *w3h = nullptr, *w3l = nullptr; bool split = false;  // f32 split packs (fp16 hi / lo)
   void *w1 = nullptr, *w2 = nullptr, *w3 = nullptr, *w1b = nullptr;  // w1b: conv1 in bf16 fragments (bf16 mode)
+  void *w2f = nullptr, *w3f = nullptr;  // bf16 mode: fp32 fragments of conv2 / conv3 for the backward pass (fp32 adjoint)
+  bool force_f32 = false;               // bf16 mode: run the fp32 kernels (set for the duration of a VJP)
   float *ts1 = nullptr, *ts2 = nullptr, *ts3 = nullptr;
   float *bn = nullptr;       // scale1 bias1 scale2 bias2 (4*Hc)
   float *stat = nullptr;     // mean1 inv1 mean2 inv2 (4*Hc)
@@ -1656,7 +1658,7 @@ ConvArgs base_args(const lrnde_conv* c, int B) {
 
 // the conv kernels are instantiated per number of M tiles of the strip (1..8)
 template <int MT> void launch_one(lrnde_conv* c, int which, const ConvArgs& a, size_t sm) {
-  if (c->d.compute_dtype == LRNDE_BF16) {
+  if (c->d.compute_dtype == LRNDE_BF16 && !c->force_f32) {
     if (which == 0) {
       static const bool f32in = getenv("LRNDE_CONV_BF16_F32IN") != nullptr;  // conv1 in fp32 math (bf16 output) instead
       if (f32in || !a.wpk2) hipLaunchKernelGGL((k_conv_wide_f32<8, MT, true>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
@@ -1706,11 +1708,12 @@ int launch_rhs_ex(lrnde_conv* c, const float* u, float t, int B, float* du, bool
   const int rows = a.TR + 2, WP = a.W + 2;
   // conv1: state -> y1
   a.CIN = C; a.CINP = cinp_of(C); a.COUT = Hc; a.in = u; a.out = c->y1; a.wpk = c->w1; a.tsum = c->ts1; a.t = t;
-  a.wpk2 = c->d.compute_dtype == LRNDE_BF16 ? c->w1b : nullptr;
+  const bool bf = c->d.compute_dtype == LRNDE_BF16 && !c->force_f32;
+  const bool f32_of_bf = c->d.compute_dtype == LRNDE_BF16 && c->force_f32;  // fp32 kernels on a bf16 handle (VJP recompute)
+  a.wpk2 = bf ? c->w1b : nullptr;
   if (c->split) { a.wpk = c->w1h; a.wpk2 = c->w1l; }
   a.part = train ? c->part : nullptr;
   const size_t stg_bytes = sizeof(float) * (size_t)a.TP * 68;  // epilogue transpose buffer (aliases the tile)
-  const bool bf = c->d.compute_dtype == LRNDE_BF16;
   static const bool bf_f32in = getenv("LRNDE_CONV_BF16_F32IN") != nullptr;
   // bf16 kernels: [9][64] t-plane table + tile, no transpose buffer (direct epilogue)
   if (bf && !bf_f32in && a.wpk2) launch_mt(c, 0, a, TSL_BYTES + 2 * (size_t)rows * WP * 8);
@@ -1722,16 +1725,16 @@ int launch_rhs_ex(lrnde_conv* c, const float* u, float t, int B, float* du, bool
   };
   if (train) finalize(c->stat, c->stat + Hc, rs, rs ? rs + Hc : nullptr);
   // conv2: BN1+act(y1) -> y2
-  a.CIN = Hc; a.CINP = cinp_of(Hc); a.in = c->y1; a.out = c->y2; a.wpk = c->w2; a.tsum = c->ts2; a.wpk2 = nullptr;
+  a.CIN = Hc; a.CINP = cinp_of(Hc); a.in = c->y1; a.out = c->y2; a.wpk = f32_of_bf ? c->w2f : c->w2; a.tsum = c->ts2; a.wpk2 = nullptr;
   if (c->split) { a.wpk = c->w2h; a.wpk2 = c->w2l; }
   a.mean = c->stat; a.inv = c->stat + Hc; a.scale = c->bn; a.bias = c->bn + Hc;
-  const size_t esz = c->d.compute_dtype == LRNDE_BF16 ? 2 : 4;
+  const size_t esz = bf ? 2 : 4;
   launch_mt(c, 1, a, bf ? TSL_BYTES + esz * rows * WP * a.CINP : std::max(esz * rows * WP * a.CINP, stg_bytes));
   CHK(c, hipGetLastError());
   if (train) finalize(c->stat + 2 * Hc, c->stat + 3 * Hc, rs ? rs + 2 * Hc : nullptr, rs ? rs + 3 * Hc : nullptr);
   if (!last) return LRNDE_OK;
   // conv3: BN2+act(y2) -> du (planar)
-  a.COUT = C; a.in = c->y2; a.out = du; a.wpk = c->w3; a.tsum = c->ts3; a.part = nullptr; a.wpk2 = nullptr;
+  a.COUT = C; a.in = c->y2; a.out = du; a.wpk = f32_of_bf ? c->w3f : c->w3; a.tsum = c->ts3; a.part = nullptr; a.wpk2 = nullptr;
   if (c->split) { a.wpk = c->w3h; a.wpk2 = c->w3l; }
   a.mean = c->stat + 2 * Hc; a.inv = c->stat + 3 * Hc; a.scale = c->bn + 2 * Hc; a.bias = c->bn + 3 * Hc;
   // bf16 conv3 adds its four K-split partial accumulators through LDS: [4 waves][MT][64 lanes] float4
@@ -1784,7 +1787,10 @@ int ensure_bw(lrnde_conv* c, int B) {
 
 // dy = (df/dy)^T lam, gp (optional, device, flat layout) = (df/dp)^T lam at (y, t)
 int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, float* dy, float* gp) {
-  if (c->d.compute_dtype == LRNDE_BF16) return cfail(c, LRNDE_UNSUPPORTED, "the conv backward pass is fp32 only");
+  // bf16 handles: the derivative is taken in fp32 (fp32 recompute of y1, y2 and the fp32 backward kernels below) at the
+  // states of the bf16 forward solve — "bf16 forward, fp32 adjoint".
+  struct F32Guard { lrnde_conv* c; bool prev; ~F32Guard() { c->force_f32 = prev; } } guard{c, c->force_f32};
+  if (c->d.compute_dtype == LRNDE_BF16) c->force_f32 = true;
   int rc;
   if ((rc = ensure_bw(c, B))) return rc;
   const int Hc = c->d.hidden, C = c->d.channels, W = c->d.width, H = c->d.height;
@@ -1988,6 +1994,10 @@ int lrnde_conv_create(lrnde_conv** out, const lrnde_conv_desc* d, int device, vo
             hipMalloc(&c->sums, sizeof(double) * NSUMB * 3) == hipSuccess &&
             hipHostMalloc(&c->sums_host, sizeof(double) * NSUMB * 3) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+  if (ok && d->compute_dtype == LRNDE_BF16) {
+    const size_t ng = (size_t)(9 * Hc + 15) / 16;
+    ok = hipMalloc(&c->w2f, ng * 4 * 1024) == hipSuccess && hipMalloc(&c->w3f, ng * 1 * 1024) == hipSuccess;
+  }
   if (ok && d->compute_dtype == LRNDE_F32_SPLIT) {
     ok = hipMalloc(&c->w1h, (size_t)3 * 4 * 1024) == hipSuccess && hipMalloc(&c->w1l, (size_t)3 * 4 * 1024) == hipSuccess &&
          hipMalloc(&c->w2h, (size_t)18 * 4 * 1024) == hipSuccess && hipMalloc(&c->w2l, (size_t)18 * 4 * 1024) == hipSuccess &&
@@ -2004,7 +2014,7 @@ int lrnde_conv_destroy(lrnde_conv* c) {
   if (!c) return LRNDE_OK;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
-  void* ptrs[] = {c->params, c->w1t, c->w2t, c->w3t, c->zeros, c->bwm, c->g1, c->g2, c->part_bw, c->pw, c->pt, c->w1h, c->w1l, c->w2h, c->w2l, c->w3h, c->w3l, c->w1, c->w1b, c->w2, c->w3, c->ts1, c->ts2, c->ts3, c->bn, c->stat, c->bn_state, c->y1, c->y2, c->part, c->vec, c->sums};
+  void* ptrs[] = {c->params, c->w1t, c->w2t, c->w3t, c->zeros, c->bwm, c->g1, c->g2, c->part_bw, c->pw, c->pt, c->w1h, c->w1l, c->w2h, c->w2l, c->w3h, c->w3l, c->w1, c->w1b, c->w2, c->w3, c->ts1, c->ts2, c->ts3, c->bn, c->stat, c->bn_state, c->y1, c->y2, c->part, c->vec, c->sums, c->w2f, c->w3f};
   for (void* p : ptrs) if (p) hipFree(p);
   for (float* d : c->dense) if (d) hipFree(d);
   if (c->rec_u1) hipFree(c->rec_u1);
@@ -2031,6 +2041,10 @@ int lrnde_conv_set_params(lrnde_conv* c, const float* p, size_t n) {
   const int bf = c->d.compute_dtype == LRNDE_BF16 ? 1 : 0;
   hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w2, Hc, Hc, c->NG2, 4, bf, c->w2, c->ts2);
   hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w3, Hc, C, c->NG2, 1, bf, c->w3, c->ts3);
+  if (bf) {  // fp32 fragments for the backward pass
+    hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w2, Hc, Hc, (9 * Hc + 15) / 16, 4, 0, c->w2f, c->ts2);
+    hipLaunchKernelGGL(k_pack_conv, dim3(64), dim3(256), 0, c->stream, w3, Hc, C, (9 * Hc + 15) / 16, 1, 0, c->w3f, c->ts3);
+  }
   if (c->split) {
     hipLaunchKernelGGL(k_pack_conv_split, dim3(64), dim3(256), 0, c->stream, w1, C, Hc, 3, 4, (_Float16*)c->w1h, (_Float16*)c->w1l);
     hipLaunchKernelGGL(k_pack_conv_split, dim3(64), dim3(256), 0, c->stream, w2, Hc, Hc, 18, 4, (_Float16*)c->w2h, (_Float16*)c->w2l);
@@ -2493,7 +2507,6 @@ int lrnde_conv_node_backward(lrnde_conv* c, const float* x, int32_t B, float t0,
   int rc = check_ready(c, B);
   if (rc) return rc;
   if (!x || !o || !du_end || !dx || !dp || !st_fwd || !st_bwd) return cfail(c, LRNDE_BADARG, "null pointer");
-  if (c->d.compute_dtype == LRNDE_BF16) return cfail(c, LRNDE_UNSUPPORTED, "the conv backward pass is fp32 only");
   const size_t n = state_n(c, B), P = lrnde_conv_param_count(&c->d), N = n + P;
   // 1. forward with the dense record
   float* u_end = nullptr;

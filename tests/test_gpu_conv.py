@@ -269,6 +269,32 @@ def test_conv_node_backward_matches_oracle(mode, w_reg):
     assert _rel(bg["dp"].cpu().numpy(), bo["dp"]) <= 5e-3
 
 
+def test_conv_bf16_handle_backward_is_the_fp32_adjoint():
+    """compute_dtype=bf16: the forward solve runs the bf16 kernels, derivatives are taken in fp32 (fp32 recompute of the
+    hidden activations + the fp32 backward kernels).  So the VJP of a bf16 handle IS the fp32 handle's VJP (same
+    kernels, same packs), and node_backward differs from the fp32 handle's only through the bf16 forward trajectory."""
+    P, O = _mods()
+    W = H = 8; B = 3
+    fld, h32, p, u = _case(W, H, B, seed=43, scale=1.5)
+    hb = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=True, compute_dtype="bf16")
+    hb.set_params(p)
+    ud = torch.from_numpy(u).cuda()
+    lam = torch.from_numpy(np.random.default_rng(4).standard_normal(u.shape).astype(np.float32)).cuda()
+    dy32, gp32 = h32.vjp(ud, 0.3, lam)
+    hb.rhs(ud, 0.3)  # leaves bf16 activations in the workspace: the VJP must not reuse them
+    dyb, gpb = hb.vjp(ud, 0.3, lam)
+    assert torch.equal(dyb, dy32) and torch.equal(gpb, gp32)
+    # a bf16 f-eval still runs the bf16 kernels afterwards
+    _close(hb.rhs(ud, 0.3), fld.rhs(u.reshape(B, -1), 0.3).reshape(u.shape), rtol=3e-2)
+    assert not torch.equal(hb.rhs(ud, 0.3), h32.rhs(ud, 0.3))
+    wv = torch.from_numpy(np.random.default_rng(5).standard_normal(u.shape).astype(np.float32)).cuda()
+    tol = 1e-2  # above the bf16 field's rounding noise, so both solves take comparable steps
+    b32 = h32.node_backward(ud, 0.0, 1.0, tol, tol, wv, mode="unbiased", t1_or_rand=0.41, w_reg=2.5, maxiters=5000)
+    bb = hb.node_backward(ud, 0.0, 1.0, tol, tol, wv, mode="unbiased", t1_or_rand=0.41, w_reg=2.5, maxiters=5000)
+    assert _rel(bb["dx"].cpu().numpy(), b32["dx"].cpu().numpy()) <= 5e-2
+    assert _rel(bb["dp"].cpu().numpy(), b32["dp"].cpu().numpy()) <= 5e-2
+
+
 def test_conv_golden_fixture_on_gpu():
     """the committed fixture tests/golden/conv_block_8x8_b2.npz (generated from the oracle) through the C ABI"""
     P, O = _mods()
