@@ -244,38 +244,40 @@ __device__ __forceinline__ void stage_nhwc_bnbwd_f32(const ConvArgs& a, int n, i
 }
 template <int ACT, int UN>
 __device__ __forceinline__ void stage_nhwc_bn_f32(const ConvArgs& a, int n, int y0, float* tile, int tid) {
+  // (row, col) of a position advance incrementally (no division by W+2 per position), the loads are unconditional from
+  // a clamped offset and the halo mask is applied to the result: same arithmetic per element as before, fewer instructions
   constexpr int CQ = 16, PSTEP = CNT / CQ;
   const int WP = a.W + 2, npos = (a.TR + 2) * WP;
   const int q = tid % CQ;
   const float* src = a.in + (size_t)n * a.H * a.W * 64 + q * 4;
   const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + q * 4), iv = *reinterpret_cast<const f32x4*>(a.inv + q * 4);
   const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4), bi = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
-  for (int pos0 = tid / CQ; pos0 < npos; pos0 += UN * PSTEP) {
+  const int stepr = PSTEP / WP, stepc = PSTEP % WP;
+  int pos = tid / CQ;
+  int rr = pos / WP, cc = pos - rr * WP;
+  while (pos < npos) {
     f32x4 raw[UN];
     bool ok[UN];
+    int ps[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int pos = pos0 + u * PSTEP;
-      const int cc = pos % WP, rr = pos / WP;
       const int y = y0 - 1 + rr, x = cc - 1;
+      ps[u] = pos;
       ok[u] = pos < npos && y >= 0 && y < a.H && x >= 0 && x < a.W;
-      raw[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ok[u]) raw[u] = *reinterpret_cast<const f32x4*>(src + ((size_t)y * a.W + x) * 64);
+      raw[u] = *reinterpret_cast<const f32x4*>(src + (ok[u] ? (y * a.W + x) * 64 : 0));
+      pos += PSTEP; rr += stepr; cc += stepc;
+      if (cc >= WP) { cc -= WP; ++rr; }
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int pos = pos0 + u * PSTEP;
-      if (pos >= npos) break;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok[u]) {
+      f32x4 v;
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          const float xn = (raw[u][h] - mu[h]) * iv[h];
-          const float z = xn * sc[h] + bi[h];
-          v[h] = act_fast<ACT>(z);
-        }
+      for (int h = 0; h < 4; ++h) {
+        const float xn = (raw[u][h] - mu[h]) * iv[h];
+        const float z = xn * sc[h] + bi[h];
+        v[h] = ok[u] ? act_fast<ACT>(z) : 0.f;
       }
-      *reinterpret_cast<f32x4*>(tile + swz_f32(pos, q)) = v;
+      if (ps[u] < npos) *reinterpret_cast<f32x4*>(tile + swz_f32(ps[u], q)) = v;
     }
   }
 }
@@ -543,6 +545,17 @@ __global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
   constexpr int NG = 36;
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, NG * 1024, 0x00020000);
   const int wv = lane * 16;
+  // weights: a ring of four taps, three taps ahead.  A tap is 32 MFMAs = 1024 cycles, shorter than an L2 round trip:
+  // with a one-tap-ahead prefetch this kernel waited on every tap and ran at a third of its MFMA bound.  The first
+  // three taps are requested before the staging.  (Splitting K over the waves instead would need 9 fragments per wave
+  // and no ring, but it changes the summation order of conv3 and with it the rounding noise of the embedded error
+  // estimate: the dt trace of tests/test_gpu_conv.py moved from 1 % to 3 % of the oracle's. The bf16 kernel does that.)
+  f32x4 wr[4][4];
+#pragma unroll
+  for (int tp3 = 0; tp3 < 3; ++tp3)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wr[tp3][q] = wload4(rsW, wv, (tp3 * 4 + q) * 1024);
+  __builtin_amdgcn_sched_barrier(0);
   if (!(a.dbg & 32)) stage_nhwc_bn_f32(a, n, y0, tile);
   int ab[MAXMT];
   pixel_bases(a, ab, 1);
@@ -551,15 +564,14 @@ __global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
   const int ab0 = (m0 == 0) ? ab[0] : (m0 == 1) ? ab[1] : (m0 == 2) ? ab[2] : ab[3];
   const int ab1 = (m1 == 4) ? ab[4] : (m1 == 5) ? ab[5] : (m1 == 6) ? ab[6] : ab[7];
   __syncthreads();
-  f32x4 wc[4], wn[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) wc[q] = wload4(rsW, wv, q * 1024);
-  const int ntap = (a.dbg & 8) ? 0 : 9;
-#pragma unroll 1
-  for (int tap = 0; tap < ntap; ++tap) {
-    const int tn = tap < 8 ? tap + 1 : 8;
+  for (int tap = 0; tap < 9; ++tap) {
+    if (a.dbg & 8) break;
+    if (tap + 3 < 9) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wn[q] = wload4(rsW, wv, (tn * 4 + q) * 1024);
+      for (int q = 0; q < 4; ++q) wr[(tap + 3) & 3][q] = wload4(rsW, wv, ((tap + 3) * 4 + q) * 1024);
+    }
+    const f32x4 (&wc)[4] = wr[tap & 3];
     const int tp = tap_pos(a, tap);
     const int pos0 = ab0 + tp, pos1 = ab1 + tp;
     const int pb0 = pos0 * 64 + ((kg ^ (pos0 & 3)) << 2), hi0 = (pos0 & 12) << 2;
@@ -581,8 +593,6 @@ __global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wc[q].w, acc[1], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wc[q] = wn[q];
   }
   // planar store: lane = channel li (< COUT), 4 consecutive pixels of one row (W % 4 == 0)
   if (li < a.COUT) {

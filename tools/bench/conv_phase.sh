@@ -2,7 +2,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for d in ${DBGS:-0 1 4 5 2 6 7}; do
   export LRNDE_CONV_DBG=$d
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ph$d -o ph -- python3 $R/tools/bench/conv_bf16_phase.py bf16 > $R/gpurun_out/ph$d.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ph$d -o ph -- python3 $R/tools/bench/conv_bf16_phase.py ${DT:-bf16} > $R/gpurun_out/ph$d.log 2>&1 || exit 1
   echo "== dbg=$d"; tail -1 $R/gpurun_out/ph$d.log
   python3 - <<PY
 import csv,glob
