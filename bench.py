@@ -114,8 +114,8 @@ def main():
 
     # forward + adjoint ms/batch (the second half of BASELINE.json's metric): the reference's training step
     # (experiments/src/utils.jl:104-123) = pullback of  logitcrossentropy(classifier(sol.u[end]), y) + w_reg*reg_val
-    # through Chain(neural_ode, classifier Dense(784=>10)); fwd/bwd split timed as there.  Single GPU only in this
-    # build (the adjoint's parameter cotangent is not sharded yet).
+    # through Chain(neural_ode, classifier Dense(784=>10)); fwd/bwd split timed as there.  Timed on one GPU only
+    # (the scaling metric is the forward NFE/s; the sharded adjoint is exercised by tests/ and tools/bench/sharded_check.py).
     fwd_adj_ms, bwd_stats = None, None
     if world == 1 and args.adjoint_steps > 0:
         node = P.NeuralODE(model, regularize="unbiased", regularize_type="error_estimate", abstol=args.tol, reltol=args.tol,
