@@ -242,33 +242,37 @@ __global__ __launch_bounds__(256) void k_pgrad(PgradArgs a) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const float* Ap = A + (rok ? row : 0);
   const float* Bp = Bm + (cok ? col : 0);
-  constexpr int UN = 8;  // 8 MFMA k-steps (32 samples) per batch of 16 independent loads
+  constexpr int UN = 8;   // 8 MFMA k-steps (32 samples) per block
+  constexpr int GB = 4;   // blocks whose loads are all in flight before the first MFMA (64 independent loads per lane):
+                          // at B = 512 a wave's whole share; block after block the kernel paid one L2 round trip per block
   // blocks of 32 samples go round-robin to the 4 waves (fixed, so the summation order is fixed)
   const int nblk = (a.B + 4 * UN - 1) / (4 * UN);
-  for (int blk = wave; blk < nblk; blk += 4) {
-    const int b0 = blk * 4 * UN;
-    float av[UN], bv[UN];
-    if (b0 + 4 * UN <= a.B) {
+  for (int blk0 = wave; blk0 < nblk; blk0 += 4 * GB) {
+    float av[GB][UN], bv[GB][UN];
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const size_t b = (size_t)(b0 + 4 * u + lk);
-        av[u] = Ap[b * lda];
-        bv[u] = Bp[b * ldb];
+    for (int g = 0; g < GB; ++g) {
+      const int b0 = (blk0 + 4 * g) * 4 * UN;
+      if (b0 + 4 * UN <= a.B) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const size_t b = (size_t)(b0 + 4 * u + lk);
+          av[g][u] = rok ? Ap[b * lda] : 0.f;
+          bv[g][u] = cok ? Bp[b * ldb] : cconst;
+        }
+      } else {  // the ragged last block, or no block at all (zeros add nothing)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int b = b0 + 4 * u + lk;
+          const bool bok = b < a.B;
+          av[g][u] = (rok && bok) ? Ap[(size_t)b * lda] : 0.f;
+          bv[g][u] = bok ? (cok ? Bp[(size_t)b * ldb] : cconst) : 0.f;
+        }
       }
-#pragma unroll
-      for (int u = 0; u < UN; ++u)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rok ? av[u] : 0.f, cok ? bv[u] : cconst, acc, 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int b = b0 + 4 * u + lk;
-        const bool bok = b < a.B;
-        av[u] = (rok && bok) ? Ap[(size_t)b * lda] : 0.f;
-        bv[u] = bok ? (cok ? Bp[(size_t)b * ldb] : cconst) : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
     }
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+#pragma unroll
+      for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][u], bv[g][u], acc, 0, 0, 0);
   }
   if (wave > 0) red[wave - 1][lane] = acc;
   __syncthreads();
@@ -530,16 +534,19 @@ __global__ __launch_bounds__(QNT) void k_vjp_q(VjpQArgs a) {
       }
       st4(a.ysc + g, x);
       if (a.lnk > 0) {
+        // six loads in flight at once (terms beyond lnk point at lbase with coefficient 0 and add +-0): a loop with a
+        // runtime trip count serialised one memory round trip per term
         const f32x4 bs = ld4(a.lbase + g);
+        f32x4 kv[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) kv[j] = ld4(a.lk[j] + g);
         f32x4 sacc;
-        { const f32x4 k0 = ld4(a.lk[0] + g);
 #pragma unroll
-          for (int h = 0; h < 4; ++h) sacc[h] = a.lc[0] * k0[h]; }
-        for (int j = 1; j < a.lnk; ++j) {
-          const f32x4 kj = ld4(a.lk[j] + g);
+        for (int h = 0; h < 4; ++h) sacc[h] = a.lc[0] * kv[0][h];
 #pragma unroll
-          for (int h = 0; h < 4; ++h) sacc[h] = sacc[h] + a.lc[j] * kj[h];
-        }
+        for (int j = 1; j < 6; ++j)
+#pragma unroll
+          for (int h = 0; h < 4; ++h) sacc[h] = sacc[h] + a.lc[j] * kv[j][h];
 #pragma unroll
         for (int h = 0; h < 4; ++h) lv[h] = bs[h] + a.ldt * sacc[h];
         st4(a.lam_out + g, lv);

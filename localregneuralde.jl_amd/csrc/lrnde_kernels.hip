@@ -2315,6 +2315,7 @@ static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float th
     if (sin) {
       a.lbase = sin->base; a.ldt = sin->dt; a.lnk = sin->nk; a.lam_out = sin->lam_out;
       for (int j = 0; j < sin->nk; ++j) { a.lk[j] = sin->k[j]; a.lc[j] = sin->c[j]; }
+      for (int j = sin->nk; j < 6; ++j) { a.lk[j] = sin->base; a.lc[j] = 0.0f; }  // the kernel always loads six terms (adds +-0)
       lam = sin->lam_out;  // what the parameter-gradient GEMM reads
     }
     const size_t smq = smem_bytes_vq(c->m.KQ1p, c->m.KQ2p, c->m.RG1, c->m.RG2);
