@@ -218,11 +218,10 @@ struct PgradArgs {
   int ntile1, ntile2, nt1c, nt2c;  // tiles of gW1: ceil(H/16) x ceil(D/16); gW2: ceil(D/16) x ceil(H/16)
 };
 
-__global__ __launch_bounds__(256) void k_pgrad(PgradArgs a) {
+__device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile) {  // one output tile per workgroup, the batch (K) split over its 4 waves
   __shared__ f32x4 red[3][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = blockIdx.x;  // one output tile per workgroup, the batch (K) split over its 4 waves
   const int li = lane & 15, lk = lane >> 4;
   const size_t ob1 = (size_t)a.H * (a.D + a.td), oW2 = ob1 + a.H, ob2 = oW2 + (size_t)a.D * (a.H + a.td);
   // C[i][j] = sum_b A[b][i] * Bm[b][j]:  gW1: A = dpre (rows o), Bm = [y, t, 1];  gW2: A = lam (rows i), Bm = [h, t, 1].
@@ -247,7 +246,7 @@ __global__ __launch_bounds__(256) void k_pgrad(PgradArgs a) {
                           // at B = 512 a wave's whole share; block after block the kernel paid one L2 round trip per block
   // blocks of 32 samples go round-robin to the 4 waves (fixed, so the summation order is fixed)
   const int nblk = (a.B + 4 * UN - 1) / (4 * UN);
-  for (int blk0 = wave; blk0 < nblk; blk0 += 4 * GB) {
+  for (int blk0 = wave < 4 ? wave : nblk; blk0 < nblk; blk0 += 4 * GB) {  // waves beyond the fourth (512-thread launch) only join the barrier
     float av[GB][UN], bv[GB][UN];
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
@@ -274,7 +273,7 @@ __global__ __launch_bounds__(256) void k_pgrad(PgradArgs a) {
 #pragma unroll
       for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][u], bv[g][u], acc, 0, 0, 0);
   }
-  if (wave > 0) red[wave - 1][lane] = acc;
+  if (wave > 0 && wave < 4) red[wave - 1][lane] = acc;
   __syncthreads();
   if (wave > 0) return;
   acc = acc + red[0][lane];
@@ -293,6 +292,8 @@ __global__ __launch_bounds__(256) void k_pgrad(PgradArgs a) {
     else if (c == N + 1) gb[rr] = acc[r];
   }
 }
+
+__global__ __launch_bounds__(256) void k_pgrad(PgradArgs a) { pgrad_tile(a, blockIdx.x); }
 
 // W2^T / W1^T in the forward fragment layouts (see k_pack)
 __global__ void k_pack_t(const float* p, int D, int H, int td, int Dp, int Hp, float* V1p, float* U2p) {
@@ -474,7 +475,7 @@ static size_t smem_bytes_vq(int KQ1p, int KQ2p, int RG1, int RG2) {
   return smem_bytes_q(KQ1p, KQ2p, RG1, RG2) + (size_t)KQ1p * 4 * 16 + (size_t)RG1 * 256 * 4 + 32;
 }
 
-__global__ __launch_bounds__(QNT) void k_vjp_q(VjpQArgs a) {
+__device__ __forceinline__ void vjp_q_body(const VjpQArgs& a) {
   const ModelDev& m = a.m;
   const SmemQ s = carve_q(m);
   // extra LDS behind the forward layout: the lambda tile and act'(pre)
@@ -614,4 +615,14 @@ __global__ __launch_bounds__(QNT) void k_vjp_q(VjpQArgs a) {
       if (g1 < m.RG2 && g1 * 64 + q * 4 < m.D) st4(dst + g1 * 64, acc1);
     }
   }
+}
+
+__global__ __launch_bounds__(QNT) void k_vjp_q(VjpQArgs a) { vjp_q_body(a); }
+
+// The VJP of one adjoint RHS evaluation and, on the CUs it leaves idle (it has B/4 workgroups: 128 at B = 512), the
+// parameter-gradient GEMM of the PREVIOUS evaluation (its tiles are workgroups nvjp, nvjp+1, ...).  The two touch
+// disjoint buffers: the scratch (y, h, dpre) and the stage lambda are double buffered by the host (launch_vjp).
+__global__ __launch_bounds__(QNT) void k_vjp_q_pg(VjpQArgs a, PgradArgs pg, int nvjp) {
+  if ((int)blockIdx.x >= nvjp) { pgrad_tile(pg, (int)blockIdx.x - nvjp); return; }
+  vjp_q_body(a);
 }

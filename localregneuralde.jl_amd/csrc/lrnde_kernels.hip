@@ -1479,7 +1479,10 @@ struct lrnde_ctx {
   float *W1q = nullptr, *W2q = nullptr;
   float *V1p = nullptr, *U2p = nullptr;          // transposed weights for the backward pass
   float *V1q = nullptr, *U2q = nullptr;          // the same in the 4-column layouts
-  float *bw_y = nullptr, *bw_h = nullptr, *bw_dp = nullptr;  // VJP scratch (B*D, B*Hp, B*Hp)
+  float *bw_y = nullptr, *bw_h = nullptr, *bw_dp = nullptr;  // VJP scratch (B*D, B*Hp, B*Hp), two sets each
+  // deferred parameter-gradient GEMM (adjoint Tsit5 loop): the GEMM of RHS evaluation e rides in the launch of the VJP
+  // of evaluation e+1 (k_vjp_q_pg); scratch set bw_cur is the one the next VJP writes
+  bool pg_defer = false, pg_pending = false; int bw_cur = 0; PgradArgs pg_args;
   int bwB = 0;
   // dense forward record + adjoint work vectors
   float *dense = nullptr, *dense_t = nullptr, *dense_dt = nullptr;
@@ -2273,23 +2276,41 @@ static int ensure_bw(lrnde_ctx* c, int B) {
   if (c->bw_h) HIPCHK(c, hipFree(c->bw_h));
   if (c->bw_dp) HIPCHK(c, hipFree(c->bw_dp));
   c->bw_y = c->bw_h = c->bw_dp = nullptr;
-  HIPCHK(c, hipMalloc(&c->bw_y, sizeof(float) * (size_t)B * c->desc.state_dim));
-  HIPCHK(c, hipMalloc(&c->bw_h, sizeof(float) * (size_t)B * c->m.Hp));
-  HIPCHK(c, hipMalloc(&c->bw_dp, sizeof(float) * (size_t)B * c->m.Hp));
+  HIPCHK(c, hipMalloc(&c->bw_y, sizeof(float) * 2 * (size_t)B * c->desc.state_dim));
+  HIPCHK(c, hipMalloc(&c->bw_h, sizeof(float) * 2 * (size_t)B * c->m.Hp));
+  HIPCHK(c, hipMalloc(&c->bw_dp, sizeof(float) * 2 * (size_t)B * c->m.Hp));
   c->bwB = B;
   return LRNDE_OK;
 }
 
 // (df/dp)^T lam from the scratch left by the last VJP launch (y, h, dpre); gp may be NULL
-static int launch_pgrad(lrnde_ctx* c, int B, float t, const float* lam, float* gp) {
-  if (!gp) return LRNDE_OK;
+static PgradArgs pgrad_args(const lrnde_ctx* c, int B, float t, const float* lam, float* gp, int set) {
   PgradArgs g;
   g.D = c->m.D; g.H = c->m.H; g.Hp = c->m.Hp; g.td = c->m.td; g.B = B; g.t = t;
-  g.lam = lam; g.y = c->bw_y; g.h = c->bw_h; g.dpre = c->bw_dp; g.gp = gp;
+  g.lam = lam; g.gp = gp;
+  g.y = c->bw_y + (size_t)set * B * c->desc.state_dim; g.h = c->bw_h + (size_t)set * B * c->m.Hp; g.dpre = c->bw_dp + (size_t)set * B * c->m.Hp;
   // output tiles incl. the two virtual columns (time column, bias): gW1 is H x (D+2), gW2 is D x (H+2)
   const int th = (g.H + 15) / 16, td16 = (g.D + 15) / 16;
   g.nt1c = (g.D + 2 + 15) / 16; g.nt2c = (g.H + 2 + 15) / 16;
   g.ntile1 = th * g.nt1c; g.ntile2 = td16 * g.nt2c;
+  return g;
+}
+static int launch_pgrad_args(lrnde_ctx* c, const PgradArgs& g) {
+  hipLaunchKernelGGL(k_pgrad, dim3(g.ntile1 + g.ntile2), dim3(256), 0, c->stream, g);
+  HIPCHK(c, hipGetLastError());
+  // batch-sharded run: the parameter cotangent is a sum over all samples (SURVEY.md §8e caveat 1)
+  if (c->comm) NCCLCHK(c, ncclAllReduce(g.gp, g.gp, lrnde_param_count(&c->desc), ncclFloat, ncclSum, c->comm, c->stream));
+  return LRNDE_OK;
+}
+// the deferred GEMM, if one is waiting (before anything reads the mu part of its K vector)
+static int flush_pgrad(lrnde_ctx* c) {
+  if (!c->pg_pending) return LRNDE_OK;
+  c->pg_pending = false;
+  return launch_pgrad_args(c, c->pg_args);
+}
+static int launch_pgrad(lrnde_ctx* c, int B, float t, const float* lam, float* gp) {
+  if (!gp) return LRNDE_OK;
+  const PgradArgs g = pgrad_args(c, B, t, lam, gp, 0);
   hipLaunchKernelGGL(k_pgrad, dim3(g.ntile1 + g.ntile2), dim3(256), 0, c->stream, g);
   HIPCHK(c, hipGetLastError());
   // batch-sharded run: the parameter cotangent is a sum over all samples (SURVEY.md §8e caveat 1)
@@ -2311,7 +2332,8 @@ static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float th
     memset(&a, 0, sizeof(a));
     a.m = c->m; a.V1q = c->V1q; a.U2q = c->U2q;
     a.B = B; a.t = t; a.y = y; a.dense = dense; a.theta = theta; a.dense_dt = dense_dt; a.lam = lam; a.dy = dy;
-    a.ysc = c->bw_y; a.hsc = c->bw_h; a.dpsc = c->bw_dp;
+    const int set = c->pg_defer ? c->bw_cur : 0;
+    a.ysc = c->bw_y + (size_t)set * B * c->desc.state_dim; a.hsc = c->bw_h + (size_t)set * B * c->m.Hp; a.dpsc = c->bw_dp + (size_t)set * B * c->m.Hp;
     if (sin) {
       a.lbase = sin->base; a.ldt = sin->dt; a.lnk = sin->nk; a.lam_out = sin->lam_out;
       for (int j = 0; j < sin->nk; ++j) { a.lk[j] = sin->k[j]; a.lc[j] = sin->c[j]; }
@@ -2319,7 +2341,21 @@ static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float th
       lam = sin->lam_out;  // what the parameter-gradient GEMM reads
     }
     const size_t smq = smem_bytes_vq(c->m.KQ1p, c->m.KQ2p, c->m.RG1, c->m.RG2);
-    hipLaunchKernelGGL(k_vjp_q, dim3((B + QNB - 1) / QNB), dim3(QNT), smq, c->stream, a);
+    const int nvjp = (B + QNB - 1) / QNB;
+    if (c->pg_defer) {
+      // this VJP's launch carries the GEMM of the previous evaluation; its own GEMM waits for the next launch (or flush_pgrad)
+      const bool had = c->pg_pending;
+      const PgradArgs prev = c->pg_args;
+      if (had) hipLaunchKernelGGL(k_vjp_q_pg, dim3(nvjp + prev.ntile1 + prev.ntile2), dim3(QNT), smq, c->stream, a, prev, nvjp);
+      else hipLaunchKernelGGL(k_vjp_q, dim3(nvjp), dim3(QNT), smq, c->stream, a);
+      HIPCHK(c, hipGetLastError());
+      if (had && c->comm) NCCLCHK(c, ncclAllReduce(prev.gp, prev.gp, lrnde_param_count(&c->desc), ncclFloat, ncclSum, c->comm, c->stream));
+      c->pg_pending = gp != nullptr;
+      if (gp) c->pg_args = pgrad_args(c, B, t, lam, gp, set);
+      c->bw_cur ^= 1;
+      return LRNDE_OK;
+    }
+    hipLaunchKernelGGL(k_vjp_q, dim3(nvjp), dim3(QNT), smq, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return launch_pgrad(c, B, t, lam, gp);
   }
@@ -2434,6 +2470,7 @@ int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, RHSF rhs_fused, bool fuse_
   for (int i = 0; i < 7; ++i) BT[i] = (float)Tsit5::BT[i];
   const float cs[6] = {(float)Tsit5::C[0], (float)Tsit5::C[1], (float)Tsit5::C[2], (float)Tsit5::C[3], 1.0f, 1.0f};
   memset(st, 0, sizeof(*st));
+  struct DeferGuard { lrnde_ctx* c; ~DeferGuard() { c->pg_defer = false; c->pg_pending = false; } } defer_guard{c};
   int rc;
   float t = s0;
   const float dtmax = s1 - s0;
@@ -2479,20 +2516,30 @@ int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, RHSF rhs_fused, bool fuse_
     if (dt != dt) { rc = LRNDE_DT_NAN; break; }
     if (fabsf(dt) <= fabsf(dtmin)) { rc = LRNDE_DT_LESS_THAN_MIN; break; }
     // stages 2..7 (src/perform_step.jl:11-20 on the augmented state)
+    c->pg_defer = fuse_stage;
     for (int sidx = 2; sidx <= 7; ++sidx) {
       const int off = (sidx - 2) * (sidx - 1) / 2;
       float* out = (sidx == 7) ? zn : v.zs;
-      if (fuse_stage && sidx < 7) {
+      if (fuse_stage) {
         // the RHS only reads the lambda part of the stage state: it is formed inside the VJP kernel (same arithmetic as
-        // k_axpy) and left in v.zs for the parameter-gradient GEMM; the mu part of a stage state is never needed
+        // k_axpy) and left for the parameter-gradient GEMM, which is deferred into the next stage's launch; the stage
+        // lambdas therefore alternate between v.zs and v.ut (free until the error estimate), stage 7's is zn itself.
+        // The mu part of a stage state is never needed; zn's is formed after the last GEMM.
         StageIn sin;
-        sin.base = z; sin.dt = dt; sin.nk = sidx - 1; sin.lam_out = v.zs;
+        sin.base = z; sin.dt = dt; sin.nk = sidx - 1; sin.lam_out = (sidx == 7) ? zn : ((sidx & 1) ? v.ut : v.zs);
         for (int j = 0; j < sidx - 1; ++j) { sin.k[j] = K[j]; sin.c[j] = A[off + j]; }
         if ((rc = rhs_fused(sin, t + cs[sidx - 2] * dt, K[sidx - 1]))) return rc;
         continue;
       }
       if ((rc = vec_axpy(c, out, z, dt, sidx - 1, K, A + off, N))) return rc;
       if ((rc = rhs(out, t + cs[sidx - 2] * dt, K[sidx - 1]))) return rc;
+    }
+    if (fuse_stage) {
+      if ((rc = flush_pgrad(c))) return rc;
+      c->pg_defer = false;
+      float* Kmu[7];
+      for (int j = 0; j < 7; ++j) Kmu[j] = K[j] + v.n_lam;
+      if (v.P && (rc = vec_axpy(c, zn + v.n_lam, z + v.n_lam, dt, 6, Kmu, A + 15, v.P))) return rc;  // mu part of u_{n+1}
     }
     st->nf += 6;
     if ((rc = vec_axpy(c, v.ut, nullptr, dt, 7, K, BT, N))) return rc;
