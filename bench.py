@@ -55,10 +55,12 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=512)
     ap.add_argument("--no-conv", action="store_true", help="skip the 28x28 conv-field side measurement of the default run")
     ap.add_argument("--adjoint-steps", type=int, default=5, help="timed forward+adjoint passes (single GPU)")
-    ap.add_argument("--workload", default="mlp", choices=["mlp", "cifar_conv_bf16", "cifar_conv_f32", "cifar_conv_f32_split", "mnist_conv_f32", "mnist_conv_f32_split"],
+    ap.add_argument("--workload", default="mlp", choices=["mlp", "cifar_conv_bf16", "cifar_conv_f32", "cifar_conv_f32_split", "mnist_conv_f32", "mnist_conv_f32_split", "mnist_sde"],
                     help="mlp: the headline MNIST-ODE MLP field (default).  The conv workloads time the CIFAR10 node_core "
                          "(BASELINE.json configs 4 and 2-ii); single GPU.")
     args = ap.parse_args()
+    if args.workload == "mnist_sde":
+        return sde_main(args)
     if args.workload != "mlp":
         return conv_main(args)
 
@@ -304,6 +306,75 @@ def conv_measure(args, workload, brief=False):
                                "sample": f"{n} f-evals of the C oracle (OpenMP, {cores} threads) on a {cb}-sample slice in "
                                          f"{cel:.1f} s, scaled by {cb}/{B} to whole-batch f-evals per second"}
     return out
+
+
+# ---- MNIST-SDE (BASELINE.json config 5): Euler-Heun steps with the local-regularisation residual, B=512 ----
+def sde_main(args):
+    """state 32, drift Dense(32=>64,tanh)->Dense(64=>32), diagonal diffusion Dense(32=>32), dW supplied.
+    15.7 MFLOP and 65 KB of state per step: a latency measurement (us/step), not a roofline one."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("the SDE workload is a single-GPU latency measurement")
+    torch.cuda.set_device(0)
+    import lrnde_amd as P
+    from localregneuralde_jl_amd.layers import _mlp_desc
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    D, H, B, nsteps = 32, 64, args.batch, 20
+    rng = np.random.default_rng(0)
+    lim1, lim2 = np.sqrt(6.0 / (D + H)), np.sqrt(6.0 / (H + D))
+    pd = np.concatenate([(rng.random(H * D, dtype=np.float32) * 2 - 1) * np.float32(lim1), np.zeros(H, np.float32),
+                         (rng.random(D * H, dtype=np.float32) * 2 - 1) * np.float32(lim2), np.zeros(D, np.float32)]).astype(np.float32)
+    pg = np.concatenate([(rng.random(D * D, dtype=np.float32) * 2 - 1) * np.float32(np.sqrt(6.0 / (2 * D))), np.zeros(D, np.float32)]).astype(np.float32)
+    u0 = rng.standard_normal((B, D)).astype(np.float32)
+    dt = np.float32(1.0 / nsteps)
+    dW = (rng.standard_normal((nsteps, B, D)) * np.sqrt(dt)).astype(np.float32)
+    h = P.SdeHandle(_mlp_desc(P.Chain(P.Dense(D, H, "tanh"), P.Dense(H, D))))
+    h.set_params(pd, pg)
+    ud, dWd = torch.from_numpy(u0).cuda(), torch.from_numpy(dW).cuda()
+
+    def one_pass():  # lrnde_sde_solve_fixed: the steps of the grid enqueued back to back, one host sync per solve
+        tr = h.solve_fixed(ud, dWd, 0.0, dt, 0.14, 0.14, 1.0 / 6.0)  # abstol=reltol=0.14 (mnist_sde/mlp.yml)
+        return dict(eest=tr["eest"][-1], reg_val=tr["reg_val"][-1])
+
+    for _ in range(args.warmup):
+        one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = one_pass()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    nst = args.steps * nsteps
+    flop = 3 * (2 * B * 2 * D * H) + 3 * (2 * B * D * D)
+    out = {
+        "metric": f"Euler-Heun SDE steps/s with local regularisation (MNIST-SDE, B={B})", "value": nst / el, "unit": "steps/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"mnist_sde: NeuralDSDE drift Dense(32=>64,tanh)->Dense(64=>32), diffusion Dense(32=>32), Euler-Heun "
+                               f"(src/perform_step.jl:172-206) on a fixed grid of {nsteps} steps with supplied dW, abstol=reltol=0.14, B={B}; "
+                               "one pass = one solve (lrnde_sde_solve_fixed); every step's error estimate and residual are returned to the host after it",
+                   "global_batch": B, "parallelism": "single GPU", "us_per_sde_step": el / nst * 1e6, "flop_per_step": flop,
+                   "last_eest": float(r["eest"]), "last_reg_val": float(r["reg_val"])},
+        "roofline": {"bound": "mfma", "achieved": flop / (el / nst) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flop / (el / nst) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "kernel": "k_ctrl_init + k_sde_step + k_finalize + 1 record copy per step (15.7 MFLOP: latency bound by construction)",
+                     "us_per_launch": el / nst * 1e6, "flop_per_launch": flop},
+    }
+    if not args.no_cpu_baseline:
+        import oracle as O
+        cores = int(os.environ.get("LRNDE_CPU_CORES", min(len(os.sched_getaffinity(0)), 16)))
+        p2 = np.concatenate([np.eye(D, dtype=np.float32).ravel(), np.zeros(D, np.float32), pg])
+        drift = O.MlpField(D, H, pd, time_dep=False, act="tanh", nthreads=cores)
+        diff = O.MlpField(D, D, p2, time_dep=False, act="identity", nthreads=cores)
+        tc = time.time(); n = 0
+        while time.time() - tc < 10.0:
+            u = u0
+            for i in range(nsteps):
+                u = O.euler_heun_step(drift, diff, u, dW[i], float(i) * float(dt), dt, 0.14, 0.14, 1.0 / 6.0)["u"]
+            n += nsteps
+        cel = time.time() - tc
+        out["cpu_baseline"] = {"value": n / cel, "unit": "steps/s", "cores": cores, "kind": "port",
+                               "sample": f"{n} Euler-Heun steps of the C oracle (OpenMP, {cores} threads) at B={B} in {cel:.1f} s"}
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

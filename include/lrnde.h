@@ -277,6 +277,15 @@ int lrnde_conv_bench_rhs(lrnde_conv* c, const float* u, float t, int32_t B, int3
 int lrnde_sde_rkmil_step(lrnde_sde* sde, const float* uprev, const float* dW, int32_t B, float t, float dt,
                          float abstol, float reltol, float* u, float* eest_host, float* reg_val_host);
 
+/* nsteps steps of size dt on a fixed grid, step i from t0 + i*dt with the increments dW[i] (device, nsteps x B x D):
+ * the loop a NeuralDSDE forward (src/layers/neural_sde.jl:56-86) runs with a fixed-step solver, enqueued without a
+ * host round trip per step.  which: 0 Euler-Heun (src/perform_step.jl:172-206, delta used), 1 Milstein (:108-170).
+ * u_traj (device, nsteps x B x D): every step's u; eest_host / reg_val_host (host, nsteps, may be NULL): every step's
+ * EEst and EEst*dt.  Step i is bit-identical to the corresponding single-step call. */
+int lrnde_sde_solve_fixed(lrnde_sde* sde, int32_t which, const float* u0, const float* dW, int32_t B, float t0, float dt,
+                          int32_t nsteps, float abstol, float reltol, float delta, float* u_traj, float* eest_host,
+                          float* reg_val_host);
+
 /* ---- backward pass ----
  * lrnde_vjp: the vector-Jacobian product Zygote.pullback(dudt, y, p, t) computes inside the adjoint
  * RHS (SciMLSensitivity ZygoteVJP): dy = (df/dy)^T lam, gp = (df/dp)^T lam (flat Lux layout, may be

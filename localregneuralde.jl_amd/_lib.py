@@ -68,6 +68,7 @@ SYMBOLS = [
     ("lrnde_sde_set_params", C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
     ("lrnde_sde_euler_heun_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _vp, _fp, _fp]),
     ("lrnde_sde_rkmil_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _vp, _fp, _fp]),
+    ("lrnde_sde_solve_fixed", C.c_int, [_vp, _i32, _vp, _vp, _i32, _f, _f, _i32, _f, _f, _f, _vp, _fp, _fp]),
     ("lrnde_vjp", C.c_int, [_vp, _vp, _f, _vp, _i32, _vp, _vp]),
     ("lrnde_step_reg_grad", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _vp, _fp]),
     ("lrnde_node_backward", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _i32, _i32, _f, _vp, _f, _vp, _vp,

@@ -2181,6 +2181,7 @@ struct lrnde_sde {
   lrnde_ctx* diff = nullptr;
   float* p2 = nullptr;  // expanded diffusion parameters
   int diff_bias = 1;
+  Ctrl *traj_host = nullptr, *traj_dev = nullptr; int traj_cap = 0;  // per-step records of lrnde_sde_solve_fixed (pinned / device)
 };
 
 int lrnde_sde_create(lrnde_sde** out, const lrnde_model_desc* drift, int32_t diffusion_bias, int device, void* stream) {
@@ -2204,6 +2205,8 @@ int lrnde_sde_destroy(lrnde_sde* s) {
   lrnde_destroy(s->drift);
   lrnde_destroy(s->diff);
   if (s->p2) hipFree(s->p2);
+  if (s->traj_host) hipHostFree(s->traj_host);
+  if (s->traj_dev) hipFree(s->traj_dev);
   delete s;
   return LRNDE_OK;
 }
@@ -2232,16 +2235,14 @@ int lrnde_sde_rkmil_step(lrnde_sde* s, const float* uprev, const float* dW, int3
                          float abstol, float reltol, float* u, float* eest_host, float* reg_val_host) {
   return sde_step_impl(s, 1, uprev, dW, B, t, dt, abstol, reltol, 0.f, u, eest_host, reg_val_host);
 }
-static int sde_step_impl(lrnde_sde* s, int which, const float* uprev, const float* dW, int32_t B, float t, float dt,
-                         float abstol, float reltol, float delta, float* u, float* eest_host, float* reg_val_host) {
-  if (!s) return LRNDE_BADARG;
+// one step on the stream, its Ctrl record copied to `rec` (pinned host) without waiting
+__global__ void k_ctrl_copy(const Ctrl* src, Ctrl* dst) { *dst = *src; }
+// one step on the stream; its Ctrl record goes to `rec` (pinned host, async copy) or to `rec_dev` (device slot, a
+// one-thread kernel: an async device-to-host copy per step costs more than the step)
+static int sde_step_enqueue(lrnde_sde* s, int which, const float* uprev, const float* dW, int32_t B, float t, float dt,
+                            float abstol, float reltol, float delta, float* u, Ctrl* rec, Ctrl* rec_dev = nullptr) {
   lrnde_ctx* c = s->drift;
-  int rc = check_ready(c, B);
-  if (rc) return rc;
-  if (!s->diff->have_params) return fail(c, LRNDE_BADARG, "lrnde_sde_set_params has not been called");
-  if (!uprev || !dW || !u) return fail(c, LRNDE_BADARG, "null pointer");
-  if (!(dt > 0.f)) return fail(c, LRNDE_BADARG, "dt must be positive");
-  if ((rc = ensure_workspace(c, B))) return rc;
+  int rc;
   StepArgs a;
   fill_args(c, a, B, NB);
   a.m2 = s->diff->m;
@@ -2261,11 +2262,64 @@ static int sde_step_impl(lrnde_sde* s, int which, const float* uprev, const floa
   const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
   if ((rc = exchange(c, c->part + cnt, c->part_rx + cnt, cnt))) return rc;
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, a, 1);
+  if (rec_dev) hipLaunchKernelGGL(k_ctrl_copy, dim3(1), dim3(1), 0, c->stream, (const Ctrl*)(c->ctrl + 1), rec_dev);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->ctrl_host, c->ctrl + 1, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+  if (rec) HIPCHK(c, hipMemcpyAsync(rec, c->ctrl + 1, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+  return LRNDE_OK;
+}
+static int sde_check(lrnde_sde* s, const float* uprev, const float* dW, const float* u, int32_t B, float dt) {
+  if (!s) return LRNDE_BADARG;
+  lrnde_ctx* c = s->drift;
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!s->diff->have_params) return fail(c, LRNDE_BADARG, "lrnde_sde_set_params has not been called");
+  if (!uprev || !dW || !u) return fail(c, LRNDE_BADARG, "null pointer");
+  if (!(dt > 0.f)) return fail(c, LRNDE_BADARG, "dt must be positive");
+  return ensure_workspace(c, B);
+}
+static int sde_step_impl(lrnde_sde* s, int which, const float* uprev, const float* dW, int32_t B, float t, float dt,
+                         float abstol, float reltol, float delta, float* u, float* eest_host, float* reg_val_host) {
+  int rc = sde_check(s, uprev, dW, u, B, dt);
+  if (rc) return rc;
+  lrnde_ctx* c = s->drift;
+  if ((rc = sde_step_enqueue(s, which, uprev, dW, B, t, dt, abstol, reltol, delta, u, c->ctrl_host))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (eest_host) *eest_host = c->ctrl_host[0].eest_last;
   if (reg_val_host) *reg_val_host = c->ctrl_host[0].reg_error;  // EEst * dt (src/perform_step.jl:205)
+  return LRNDE_OK;
+}
+// nsteps steps of size dt from t0 on a fixed grid, step i from t0 + i*dt with the increments dW[i]: the loop a
+// NeuralDSDE forward runs (src/layers/neural_sde.jl with a fixed-step solver), enqueued without a host round trip
+// per step.  u_traj (device, nsteps x B x D) receives every step's u; eest_host / reg_val_host (host, nsteps, may
+// be NULL) every step's EEst and EEst*dt.  which: 0 Euler-Heun (delta used), 1 Milstein.
+int lrnde_sde_solve_fixed(lrnde_sde* s, int32_t which, const float* u0, const float* dW, int32_t B, float t0, float dt,
+                          int32_t nsteps, float abstol, float reltol, float delta, float* u_traj, float* eest_host,
+                          float* reg_val_host) {
+  int rc = sde_check(s, u0, dW, u_traj, B, dt);
+  if (rc) return rc;
+  lrnde_ctx* c = s->drift;
+  if (nsteps <= 0) return fail(c, LRNDE_BADARG, "nsteps must be positive");
+  if (which != 0 && which != 1) return fail(c, LRNDE_BADARG, "which: 0 Euler-Heun, 1 Milstein");
+  if (s->traj_cap < nsteps) {
+    if (s->traj_host) hipHostFree(s->traj_host);
+    if (s->traj_dev) hipFree(s->traj_dev);
+    s->traj_host = nullptr; s->traj_dev = nullptr; s->traj_cap = 0;
+    HIPCHK(c, hipHostMalloc(&s->traj_host, sizeof(Ctrl) * (size_t)nsteps));
+    HIPCHK(c, hipMalloc(&s->traj_dev, sizeof(Ctrl) * (size_t)nsteps));
+    s->traj_cap = nsteps;
+  }
+  const size_t n = (size_t)B * c->desc.state_dim;
+  for (int i = 0; i < nsteps; ++i) {
+    const float t = t0 + (float)i * dt;
+    if ((rc = sde_step_enqueue(s, which, i == 0 ? u0 : u_traj + (size_t)(i - 1) * n, dW + (size_t)i * n, B, t, dt, abstol, reltol,
+                               delta, u_traj + (size_t)i * n, nullptr, s->traj_dev + i))) return rc;
+  }
+  HIPCHK(c, hipMemcpyAsync(s->traj_host, s->traj_dev, sizeof(Ctrl) * (size_t)nsteps, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < nsteps; ++i) {
+    if (eest_host) eest_host[i] = s->traj_host[i].eest_last;
+    if (reg_val_host) reg_val_host[i] = s->traj_host[i].reg_error;
+  }
   return LRNDE_OK;
 }
 

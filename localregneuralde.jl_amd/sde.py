@@ -74,6 +74,20 @@ class SdeHandle:
         return dict(u=u, eest=np.float32(ee.value), reg_val=np.float32(rv.value))
 
 
+    def solve_fixed(self, u0, dW, t0, dt, abstol, reltol, delta=1.0 / 6.0, solver="EulerHeun"):
+        """nsteps = dW.shape[0] steps on a fixed grid in one call (no host round trip per step): dict(u (nsteps,B,D),
+        eest (nsteps,), reg_val (nsteps,)); step i equals the single-step call from t0 + i*dt"""
+        nsteps = int(dW.shape[0])
+        B = u0.numel() // self.D
+        dW = dW.contiguous()
+        u = torch.empty((nsteps,) + tuple(u0.shape), dtype=torch.float32, device=u0.device)
+        ee = (C.c_float * nsteps)(); rv = (C.c_float * nsteps)()
+        self._chk(L.lib.lrnde_sde_solve_fixed(self._h, 1 if solver.startswith("RKMil") else 0, _dev_ptr(u0, "u0", self.D),
+                                              _dev_ptr(dW, "dW"), B, float(t0), float(dt), nsteps, float(abstol), float(reltol),
+                                              float(delta), _dev_ptr(u, "u"), ee, rv))
+        return dict(u=u, eest=np.frombuffer(ee, dtype=np.float32).copy(), reg_val=np.frombuffer(rv, dtype=np.float32).copy())
+
+
 class NeuralDSDE:
     """`(sol, st) = nsde(x, ps, st)`; ps = dict(drift=flat, diffusion=[vec(Wg); bg]).
     src/layers/neural_sde.jl:1-123 with a fixed-grid Euler-Heun integrator (see module docstring)."""
@@ -122,13 +136,9 @@ class NeuralDSDE:
             step = lambda uu, dw, tt: h.rkmil_step(uu, dw, tt, dt, abstol, reltol)
         else:
             step = lambda uu, dw, tt: h.euler_heun_step(uu, dw, tt, dt, abstol, reltol, self.delta)
-        us, ts = [], []
-        u, t = x, t0
-        for i in range(n):
-            r = step(u, noise[i].contiguous(), t)
-            u = r["u"]
-            t = np.float32(t0 + np.float32(i + 1) * dt) if i + 1 < n else t2
-            us.append(u); ts.append(t)
+        traj = h.solve_fixed(x, noise[:n], t0, dt, abstol, reltol, self.delta, self.solver)  # the n steps, one host sync
+        us = [traj["u"][i] for i in range(n)]
+        ts = [np.float32(t0 + np.float32(i + 1) * dt) if i + 1 < n else t2 for i in range(n)]
         per_step = (1, 2) if self.solver == "RKMil" else (3, 3)  # (drift, diffusion) evaluations of one step
         nfe, nfe_g = per_step[0] * n, per_step[1] * n
         mode = self.regularize if st["training"] else "none"

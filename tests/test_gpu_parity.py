@@ -180,6 +180,39 @@ def test_sde_rkmil_step_bit_exact(oracle, gpu_pkg, D, H, B):
     assert got["eest"] == ref["eest"] and got["reg_val"] == ref["reg_val"], (got, ref["eest"], ref["reg_val"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["EulerHeun", "RKMil"])
+def test_sde_solve_fixed_equals_the_step_loop(oracle, gpu_pkg, solver):
+    """lrnde_sde_solve_fixed enqueues the steps of a fixed grid without a host round trip; step i must be the
+    single-step call from t0 + i*dt, bit for bit (u, EEst, EEst*dt), and the oracle's step loop."""
+    import torch
+    from localregneuralde_jl_amd.layers import _mlp_desc
+    D, H, B, n = 32, 64, 512, 7
+    pd, pg, drift, diff = _sde_fields(oracle, D, H, seed=5)
+    rng = np.random.default_rng(13)
+    u0 = rng.standard_normal((B, D)).astype(np.float32)
+    t0, dt = np.float32(0.1), np.float32(0.05)
+    dW = (rng.standard_normal((n, B, D)) * np.sqrt(dt)).astype(np.float32)
+    h = gpu_pkg.SdeHandle(_mlp_desc(gpu_pkg.Chain(gpu_pkg.Dense(D, H, "tanh"), gpu_pkg.Dense(H, D))))
+    h.set_params(pd, pg)
+    ud, dWd = torch.from_numpy(u0).cuda(), torch.from_numpy(dW).cuda()
+    tr = h.solve_fixed(ud, dWd, t0, dt, 0.14, 0.14, 1.0 / 6.0, solver)
+    u, uo = ud, u0
+    for i in range(n):
+        t = np.float32(t0 + np.float32(i) * dt)
+        if solver == "RKMil":
+            r = h.rkmil_step(u, dWd[i].contiguous(), t, dt, 0.14, 0.14)
+            ro = oracle.rkmil_step(drift, diff, uo, dW[i], t, dt, 0.14, 0.14)
+        else:
+            r = h.euler_heun_step(u, dWd[i].contiguous(), t, dt, 0.14, 0.14, 1.0 / 6.0)
+            ro = oracle.euler_heun_step(drift, diff, uo, dW[i], t, dt, 0.14, 0.14, 1.0 / 6.0)
+        assert torch.equal(tr["u"][i], r["u"])
+        assert tr["eest"][i] == r["eest"] and tr["reg_val"][i] == r["reg_val"]
+        _eq(r["u"].cpu().numpy(), ro["u"], f"u step {i}")
+        assert r["eest"] == ro["eest"] and r["reg_val"] == ro["reg_val"]
+        u, uo = r["u"], ro["u"]
+
+
 def test_neural_dsde_forward_behaviour(oracle, gpu_pkg):
     """NeuralDSDE mirror: reg_val is zero iff regularize == :none / test mode (test/runtests.jl:340-433
     assert exactly this plus finiteness); the fixed-grid solve equals the same loop over the oracle step."""
