@@ -1337,64 +1337,111 @@ __global__ __launch_bounds__(CNT) void k_conv_wgrad(WgradArgs a) {
   for (int strip = blockIdx.x; strip < a.nstrips; strip += gridDim.x) {
     const int n = strip / strips, y0 = (strip % strips) * a.TR;
     __syncthreads();  // previous strip's tiles are no longer read
+    // Staging: every loop below keeps a batch of independent loads in flight and advances (row, col) incrementally.
+    // (One dependent load and two integer divisions per trip made these loops — 13 trips for the halo of a
+    // 64-channel tile — the bulk of the kernel's time: each trip paid a memory round trip.)
     // ---- stage G (no halo) ----
     if constexpr (GM == 0) {
-      for (int i = threadIdx.x; i < a.TP * 16; i += CNT) {
-        const int p = i % a.TP, c = i / a.TP;
-        float v = 0.f;
-        if (c < 8) v = a.g[((size_t)n * 8 + c) * a.H * a.W + (size_t)y0 * a.W + p];
-        gt[p * GS + c] = v;
+      // planar 8-channel cotangent -> [p][16] with channels 8..15 zero: 32 threads per channel, pixels 32 apart
+      const int c = threadIdx.x >> 5, l = threadIdx.x & 31;
+      const float* src = a.g + ((size_t)n * 8 + c) * a.H * a.W + (size_t)y0 * a.W;
+      constexpr int UN = 4;
+      for (int p0 = l; p0 < a.TP; p0 += 32 * UN) {
+        float v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { const int p = p0 + 32 * u; v[u] = src[p < a.TP ? p : 0]; }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { const int p = p0 + 32 * u; if (p < a.TP) { gt[p * GS + c] = v[u]; gt[p * GS + 8 + c] = 0.f; } }
       }
     } else {
       const int q = threadIdx.x & 15;
       const f32x4 mu = *reinterpret_cast<const f32x4*>(a.gmean + q * 4), iv = *reinterpret_cast<const f32x4*>(a.ginv + q * 4);
       const f32x4 sc = *reinterpret_cast<const f32x4*>(a.gscale + q * 4);
       const f32x4 m1 = *reinterpret_cast<const f32x4*>(a.gm1 + q * 4), m2 = *reinterpret_cast<const f32x4*>(a.gm2 + q * 4);
-      for (int p = threadIdx.x >> 4; p < a.TP; p += CNT / 16) {
-        const size_t o = ((size_t)n * a.H * a.W + (size_t)y0 * a.W + p) * 64 + q * 4;
-        const f32x4 dz = *reinterpret_cast<const f32x4*>(a.g + o), ar = *reinterpret_cast<const f32x4*>(a.g2 + o);
-        f32x4 v;
+      const size_t base = ((size_t)n * a.H * a.W + (size_t)y0 * a.W) * 64 + q * 4;
+      constexpr int UN = 8, PS = CNT / 16;
+      for (int p0 = threadIdx.x >> 4; p0 < a.TP; p0 += PS * UN) {
+        f32x4 dz[UN], ar[UN];
 #pragma unroll
-        for (int h = 0; h < 4; ++h) { const float xn = (ar[h] - mu[h]) * iv[h]; v[h] = (iv[h] * sc[h]) * ((dz[h] - m1[h]) - xn * m2[h]); }
-        *reinterpret_cast<f32x4*>(gt + p * GS + q * 4) = v;
+        for (int u = 0; u < UN; ++u) {
+          const int p = p0 + PS * u;
+          const size_t o = base + (size_t)(p < a.TP ? p : 0) * 64;
+          dz[u] = *reinterpret_cast<const f32x4*>(a.g + o); ar[u] = *reinterpret_cast<const f32x4*>(a.g2 + o);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int p = p0 + PS * u;
+          f32x4 v;
+#pragma unroll
+          for (int h = 0; h < 4; ++h) { const float xn = (ar[u][h] - mu[h]) * iv[h]; v[h] = (iv[h] * sc[h]) * ((dz[u][h] - m1[h]) - xn * m2[h]); }
+          if (p < a.TP) *reinterpret_cast<f32x4*>(gt + p * GS + q * 4) = v;
+        }
       }
     }
     // ---- stage IN (halo, zero outside the image) ----
     if constexpr (IM == 0) {
-      for (int i = threadIdx.x; i < npos * 16; i += CNT) {
-        const int pos = i % npos, c = i / npos;
-        const int cc = pos % WP, rr = pos / WP;
-        const int y = y0 - 1 + rr, x = cc - 1;
-        float v = 0.f;
-        if (c < 8 && y >= 0 && y < a.H && x >= 0 && x < a.W) v = a.in[((size_t)n * 8 + c) * a.H * a.W + (size_t)y * a.W + x];
-        it[pos * IS + c] = v;
+      const int c = threadIdx.x >> 5, l = threadIdx.x & 31;
+      const float* src = a.in + ((size_t)n * 8 + c) * a.H * a.W;
+      constexpr int UN = 7;
+      const int stepr = 32 / WP, stepc = 32 % WP;
+      int pos = l, rr = l / WP, cc = l - rr * WP;
+      while (pos < npos) {
+        float v[UN]; bool ok[UN]; int ps[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int y = y0 - 1 + rr, x = cc - 1;
+          ps[u] = pos;
+          ok[u] = pos < npos && y >= 0 && y < a.H && x >= 0 && x < a.W;
+          v[u] = src[ok[u] ? y * a.W + x : 0];
+          pos += 32; rr += stepr; cc += stepc;
+          if (cc >= WP) { cc -= WP; ++rr; }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+          if (ps[u] < npos) { it[ps[u] * IS + c] = ok[u] ? v[u] : 0.f; it[ps[u] * IS + 8 + c] = 0.f; }
       }
     } else {
       const int q = threadIdx.x & 15;
       const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + q * 4), iv = *reinterpret_cast<const f32x4*>(a.inv + q * 4);
       const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4), bi = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
-      for (int pos = threadIdx.x >> 4; pos < npos; pos += CNT / 16) {
-        const int cc = pos % WP, rr = pos / WP;
-        const int y = y0 - 1 + rr, x = cc - 1;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
-          const f32x4 raw = *reinterpret_cast<const f32x4*>(a.in + ((size_t)n * a.H * a.W + (size_t)y * a.W + x) * 64 + q * 4);
+      const float* src = a.in + (size_t)n * a.H * a.W * 64 + q * 4;
+      constexpr int UN = 7, PS = CNT / 16;
+      const int stepr = PS / WP, stepc = PS % WP;
+      int pos = threadIdx.x >> 4, rr = pos / WP, cc = pos - rr * WP;
+      while (pos < npos) {
+        f32x4 raw[UN]; bool ok[UN]; int ps[UN];
 #pragma unroll
-          for (int h = 0; h < 4; ++h) { const float xn = (raw[h] - mu[h]) * iv[h]; v[h] = act_fast_rt(a.act, xn * sc[h] + bi[h]); }
+        for (int u = 0; u < UN; ++u) {
+          const int y = y0 - 1 + rr, x = cc - 1;
+          ps[u] = pos;
+          ok[u] = pos < npos && y >= 0 && y < a.H && x >= 0 && x < a.W;
+          raw[u] = *reinterpret_cast<const f32x4*>(src + (ok[u] ? (y * a.W + x) * 64 : 0));
+          pos += PS; rr += stepr; cc += stepc;
+          if (cc >= WP) { cc -= WP; ++rr; }
         }
-        *reinterpret_cast<f32x4*>(it + pos * IS + q * 4) = v;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          f32x4 v;
+#pragma unroll
+          for (int h = 0; h < 4; ++h) { const float xn = (raw[u][h] - mu[h]) * iv[h]; v[h] = ok[u] ? act_fast_rt(a.act, xn * sc[h] + bi[h]) : 0.f; }
+          if (ps[u] < npos) *reinterpret_cast<f32x4*>(it + ps[u] * IS + q * 4) = v;
+        }
       }
     }
     __syncthreads();
     // ---- border-class sums of G (t plane weights) ----
     {
-      const int co = threadIdx.x % GC, grp = threadIdx.x / GC, ngrp = CNT / GC;
+      const int co = threadIdx.x % GC, grp = threadIdx.x / GC;
+      constexpr int ngrp = CNT / GC;
+      const int stepr = ngrp / a.W, stepc = ngrp % a.W;
+      int rw = grp / a.W, x = grp - rw * a.W;
       for (int p = grp; p < a.TP; p += ngrp) {
-        const int y = y0 + p / a.W, x = p % a.W;
         const float v = gt[p * GS + co];
-        const int k = border_class(y, x, a.H, a.W);
+        const int k = border_class(y0 + rw, x, a.H, a.W);
 #pragma unroll
         for (int c = 0; c < 9; ++c) cls[c] += (c == k) ? v : 0.f;
+        x += stepc; rw += stepr;
+        if (x >= a.W) { x -= a.W; ++rw; }
       }
     }
     // ---- MFMA over the strip's pixels, 4 per k-step ----
@@ -1443,7 +1490,15 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* pw, int nwg, 
   double s = 0.0;
   if (e < E) {
     const int w0 = (nwg * pg) / 4, w1 = (nwg * (pg + 1)) / 4;
-    for (int w = w0; w < w1; ++w) s += (double)pw[(size_t)w * E + e];
+    int w = w0;
+    for (; w + 8 <= w1; w += 8) {  // eight independent loads in flight, added in index order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pw[(size_t)(w + u) * E + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; w < w1; ++w) s += (double)pw[(size_t)w * E + e];
   }
   red[pg][el] = s;
   __syncthreads();
@@ -1831,7 +1886,11 @@ int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, 
     int trw = 1;
     for (int tr = 1; tr <= H; ++tr) if (H % tr == 0 && tr * W <= wpx) trw = tr;
     const int nstrips_w = B * (H / trw);
-    const int maxwg = (trw * W <= 64) ? 2 * NWGW : NWGW;
+    const int GS = GM ? 80 : 16, IS = IM ? 80 : 16, GC = GM ? 64 : 16, IC = IM ? 64 : 16;
+    size_t sm = sizeof(float) * ((size_t)trw * W * GS + (size_t)(trw + 2) * WP * IS);
+    if (sm < sizeof(float) * CNT * 9) sm = sizeof(float) * CNT * 9;
+    // two persistent workgroups per CU where their tiles fit (the 8-channel layers): one stages while the other runs its MFMAs
+    const int maxwg = (sm <= 80 * 1024) ? 2 * NWGW : NWGW;
     const int nwgw = nstrips_w < maxwg ? nstrips_w : maxwg;
     w.W = W; w.H = H; w.B = B; w.TR = trw; w.TP = trw * W; w.nstrips = nstrips_w;
     w.g = g; w.g2 = graw;
@@ -1841,9 +1900,6 @@ int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, 
     if (IM) { w.mean = c->stat + 2 * ilayer * Hc; w.inv = c->stat + (2 * ilayer + 1) * Hc; w.scale = c->bn + 2 * ilayer * Hc;
               w.bias = c->bn + (2 * ilayer + 1) * Hc; }
     w.act = c->d.act; w.pw = c->pw; w.pt = c->pt;
-    const int GS = GM ? 80 : 16, IS = IM ? 80 : 16, GC = GM ? 64 : 16, IC = IM ? 64 : 16;
-    size_t sm = sizeof(float) * ((size_t)w.TP * GS + (size_t)(trw + 2) * WP * IS);
-    if (sm < sizeof(float) * CNT * 9) sm = sizeof(float) * CNT * 9;
     if (GM && IM) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
     else if (GM) hipLaunchKernelGGL((k_conv_wgrad<1, 0>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
     else hipLaunchKernelGGL((k_conv_wgrad<0, 1>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
