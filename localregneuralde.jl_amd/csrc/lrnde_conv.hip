@@ -210,35 +210,33 @@ __device__ __forceinline__ void stage_nhwc_bnbwd_f32(const ConvArgs& a, int n, i
   const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + q * 4), iv = *reinterpret_cast<const f32x4*>(a.inv + q * 4);
   const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4);
   const f32x4 m1 = *reinterpret_cast<const f32x4*>(a.m1 + q * 4), m2 = *reinterpret_cast<const f32x4*>(a.m2 + q * 4);
-  for (int pos0 = tid / CQ; pos0 < npos; pos0 += UN * PSTEP) {
+  const int stepr = PSTEP / WP, stepc = PSTEP % WP;  // (row, col) advance incrementally, as in stage_nhwc_bn_f32
+  int pos = tid / CQ;
+  int rr = pos / WP, cc = pos - rr * WP;
+  while (pos < npos) {
     f32x4 dz[UN], ar[UN];
     bool ok[UN];
+    int ps[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int pos = pos0 + u * PSTEP;
-      const int cc = pos % WP, rr = pos / WP;
       const int y = y0 - 1 + rr, x = cc - 1;
+      ps[u] = pos;
       ok[u] = pos < npos && y >= 0 && y < a.H && x >= 0 && x < a.W;
-      dz[u] = ar[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ok[u]) {
-        const size_t o = base + ((size_t)y * a.W + x) * 64;
-        dz[u] = *reinterpret_cast<const f32x4*>(a.in + o);
-        ar[u] = *reinterpret_cast<const f32x4*>(a.in2 + o);
-      }
+      const size_t o = base + (ok[u] ? (size_t)(y * a.W + x) * 64 : 0);
+      dz[u] = *reinterpret_cast<const f32x4*>(a.in + o);
+      ar[u] = *reinterpret_cast<const f32x4*>(a.in2 + o);
+      pos += PSTEP; rr += stepr; cc += stepc;
+      if (cc >= WP) { cc -= WP; ++rr; }
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int pos = pos0 + u * PSTEP;
-      if (pos >= npos) break;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok[u]) {
+      f32x4 v;
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          const float xn = (ar[u][h] - mu[h]) * iv[h];
-          v[h] = (iv[h] * sc[h]) * ((dz[u][h] - m1[h]) - xn * m2[h]);
-        }
+      for (int h = 0; h < 4; ++h) {
+        const float xn = (ar[u][h] - mu[h]) * iv[h];
+        v[h] = ok[u] ? (iv[h] * sc[h]) * ((dz[u][h] - m1[h]) - xn * m2[h]) : 0.f;
       }
-      *reinterpret_cast<f32x4*>(tile + swz_f32(pos, q)) = v;
+      if (ps[u] < npos) *reinterpret_cast<f32x4*>(tile + swz_f32(ps[u], q)) = v;
     }
   }
 }
