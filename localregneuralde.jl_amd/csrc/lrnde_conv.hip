@@ -1305,11 +1305,15 @@ struct WgradArgs {
   const float* mean; const float* inv; const float* scale; const float* bias; int act;
   float* pw; float* pt;
 };
-template <int GM, int IM>
-__global__ __launch_bounds__(CNT) void k_conv_wgrad(WgradArgs a) {
+// NTHR: 256, or 512 for the 64 x 64 layer (two waves per SIMD: waves w and w + 4 share output-channel tile w & 3 and
+// take two of its four input-channel tiles each — one MFMA wave per SIMD sustained only ~2/3 of the pipe rate, and
+// twice the threads halve the staging's share)
+template <int GM, int IM, int NTHR>
+__global__ __launch_bounds__(NTHR) void k_conv_wgrad(WgradArgs a) {
   constexpr int GC = GM ? 64 : 16, GS = GM ? 80 : 16;   // channels held / stride of the G tile
   constexpr int IC = IM ? 64 : 16, IS = IM ? 80 : 16;
-  constexpr int NCIT = (GM && IM) ? 4 : 1;               // ci tiles per wave
+  static_assert(NTHR == 256 || (NTHR == 512 && GM && IM), "512 threads: the 64 x 64 layer only");
+  constexpr int NCIT = (GM && IM) ? (NTHR == 512 ? 2 : 4) : 1;  // ci tiles per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* gt = reinterpret_cast<float*>(smem);
   float* it = gt + (size_t)a.TP * GS;
@@ -1318,8 +1322,8 @@ __global__ __launch_bounds__(CNT) void k_conv_wgrad(WgradArgs a) {
   const int li = lane & 15, kg = lane >> 4;
   const int WP = a.W + 2, npos = (a.TR + 2) * WP;
   const int strips = a.H / a.TR;
-  const int cot = GM ? wave : 0;                 // output-channel tile of this wave
-  const int cit0 = (GM && IM) ? 0 : (GM ? 0 : wave);
+  const int cot = GM ? (wave & 3) : 0;           // output-channel tile of this wave
+  const int cit0 = (GM && IM) ? (wave >> 2) * NCIT : (GM ? 0 : wave);
   f32x4 acc[9][NCIT];
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
@@ -1357,7 +1361,7 @@ __global__ __launch_bounds__(CNT) void k_conv_wgrad(WgradArgs a) {
       const f32x4 sc = *reinterpret_cast<const f32x4*>(a.gscale + q * 4);
       const f32x4 m1 = *reinterpret_cast<const f32x4*>(a.gm1 + q * 4), m2 = *reinterpret_cast<const f32x4*>(a.gm2 + q * 4);
       const size_t base = ((size_t)n * a.H * a.W + (size_t)y0 * a.W) * 64 + q * 4;
-      constexpr int UN = 8, PS = CNT / 16;
+      constexpr int UN = 8 * 256 / NTHR, PS = NTHR / 16;
       for (int p0 = threadIdx.x >> 4; p0 < a.TP; p0 += PS * UN) {
         f32x4 dz[UN], ar[UN];
 #pragma unroll
@@ -1403,7 +1407,7 @@ __global__ __launch_bounds__(CNT) void k_conv_wgrad(WgradArgs a) {
       const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + q * 4), iv = *reinterpret_cast<const f32x4*>(a.inv + q * 4);
       const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + q * 4), bi = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
       const float* src = a.in + (size_t)n * a.H * a.W * 64 + q * 4;
-      constexpr int UN = 7, PS = CNT / 16;
+      constexpr int UN = NTHR == 512 ? 4 : 7, PS = NTHR / 16;
       const int stepr = PS / WP, stepc = PS % WP;
       int pos = threadIdx.x >> 4, rr = pos / WP, cc = pos - rr * WP;
       while (pos < npos) {
@@ -1430,7 +1434,7 @@ __global__ __launch_bounds__(CNT) void k_conv_wgrad(WgradArgs a) {
     // ---- border-class sums of G (t plane weights) ----
     {
       const int co = threadIdx.x % GC, grp = threadIdx.x / GC;
-      constexpr int ngrp = CNT / GC;
+      constexpr int ngrp = NTHR / GC;
       const int stepr = ngrp / a.W, stepc = ngrp % a.W;
       int rw = grp / a.W, x = grp - rw * a.W;
       for (int p = grp; p < a.TP; p += ngrp) {
@@ -1467,14 +1471,14 @@ __global__ __launch_bounds__(CNT) void k_conv_wgrad(WgradArgs a) {
       for (int r = 0; r < 4; ++r) pw[((size_t)tp * GC + cot * 16 + kg * 4 + r) * IC + (cit0 + c) * 16 + li] = acc[tp][c][r];
   // class sums: reduce the thread groups through LDS
   __syncthreads();
-  float* red = gt;  // [CNT][9]
+  float* red = gt;  // [NTHR][9]
 #pragma unroll
   for (int c = 0; c < 9; ++c) red[threadIdx.x * 9 + c] = cls[c];
   __syncthreads();
-  for (int i = threadIdx.x; i < 9 * GC; i += CNT) {
+  for (int i = threadIdx.x; i < 9 * GC; i += NTHR) {
     const int co = i % GC, c = i / GC;
     float t = 0.f;
-    for (int grp = 0; grp < CNT / GC; ++grp) t += red[(grp * GC + co) * 9 + c];
+    for (int grp = 0; grp < NTHR / GC; ++grp) t += red[(grp * GC + co) * 9 + c];
     a.pt[((size_t)blockIdx.x * 9 + c) * GC + co] = t;
   }
 }
@@ -1821,9 +1825,9 @@ int ensure_bw(lrnde_conv* c, int B) {
     CHK(c, hipMalloc(&c->part_bw, sizeof(double) * NBW1 * 64 * 2));
     CHK(c, hipMalloc(&c->pw, sizeof(float) * (size_t)2 * NWGW * 9 * 64 * 64));
     CHK(c, hipMalloc(&c->pt, sizeof(float) * (size_t)2 * NWGW * 9 * 64));
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<1, 1, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<1, 0, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad<0, 1, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     c->w_t_valid = false;
   }
   if (!c->w_t_valid) {  // transposed packs of the current parameters
@@ -1886,7 +1890,8 @@ int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, 
     const int nstrips_w = B * (H / trw);
     const int GS = GM ? 80 : 16, IS = IM ? 80 : 16, GC = GM ? 64 : 16, IC = IM ? 64 : 16;
     size_t sm = sizeof(float) * ((size_t)trw * W * GS + (size_t)(trw + 2) * WP * IS);
-    if (sm < sizeof(float) * CNT * 9) sm = sizeof(float) * CNT * 9;
+    const int nthr = (GM && IM) ? 512 : CNT;
+    if (sm < sizeof(float) * nthr * 9) sm = sizeof(float) * nthr * 9;
     // two persistent workgroups per CU where their tiles fit (the 8-channel layers): one stages while the other runs its MFMAs
     const int maxwg = (sm <= 80 * 1024) ? 2 * NWGW : NWGW;
     const int nwgw = nstrips_w < maxwg ? nstrips_w : maxwg;
@@ -1898,9 +1903,9 @@ int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, 
     if (IM) { w.mean = c->stat + 2 * ilayer * Hc; w.inv = c->stat + (2 * ilayer + 1) * Hc; w.scale = c->bn + 2 * ilayer * Hc;
               w.bias = c->bn + (2 * ilayer + 1) * Hc; }
     w.act = c->d.act; w.pw = c->pw; w.pt = c->pt;
-    if (GM && IM) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
-    else if (GM) hipLaunchKernelGGL((k_conv_wgrad<1, 0>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
-    else hipLaunchKernelGGL((k_conv_wgrad<0, 1>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
+    if (GM && IM) hipLaunchKernelGGL((k_conv_wgrad<1, 1, 512>), dim3(nwgw), dim3(512), sm, c->stream, w);
+    else if (GM) hipLaunchKernelGGL((k_conv_wgrad<1, 0, 256>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
+    else hipLaunchKernelGGL((k_conv_wgrad<0, 1, 256>), dim3(nwgw), dim3(CNT), sm, c->stream, w);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((9 * GC * IC + 63) / 64), dim3(256), 0, c->stream, (const float*)c->pw, nwgw, GC, IC, CINr, COUTr, gw);
     hipLaunchKernelGGL(k_wgrad_reduce_t, dim3(GC), dim3(256), 0, c->stream, (const float*)c->pt, nwgw, GC, CINr, COUTr, t, gw);
     CHK(c, hipGetLastError());
