@@ -248,6 +248,14 @@ int lrnde_conv_step_reg_grad(lrnde_conv* c, const float* uprev, const float* k1,
 int lrnde_conv_node_backward(lrnde_conv* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
                              int32_t mode, int32_t reg_type, float t1_or_rand, const float* du_end, float w_reg,
                              float* dx, float* dp, lrnde_stats* st_fwd, lrnde_stats* st_bwd);
+/* The same in two calls, for a training step that runs the forward once (experiments/src/utils.jl:104-123):
+ * lrnde_conv_node_forward_record = lrnde_conv_node_forward that keeps the dense record of the main solve and u(t1);
+ * lrnde_conv_node_backward_recorded = the backward pass from that record (invalidated by any later solve on the handle). */
+int lrnde_conv_node_forward_record(lrnde_conv* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
+                                   int32_t mode, int32_t reg_type, float t1_or_rand, float* u_end, float* reg_val_host,
+                                   int32_t* nfe_host, lrnde_stats* st, float* t1_used_host);
+int lrnde_conv_node_backward_recorded(lrnde_conv* c, int32_t B, const float* du_end, float w_reg, float* dx, float* dp,
+                                      lrnde_stats* st_bwd);
 /* ---- layers around the CIFAR10 NeuralODE (experiments/src/construct.jl:224-227) ----
  * stem: AugmenterLayer(Conv((3,3), 3=>5; pad=1), 3) (src/layers/common.jl:80-92: cat(x, conv(x); dims=3)) + BatchNorm(8);
  * ps (device, 156) = [conv.weight 3x3x3x5 column-major; conv.bias 5; bn.scale 8; bn.bias 8]; x (B,3,H,W) -> u0 (B,8,H,W).

@@ -96,6 +96,9 @@ SYMBOLS = [
     ("lrnde_conv_step_reg_grad", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _vp, _fp]),
     ("lrnde_conv_node_backward", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _i32, _i32, _f, _vp, _f, _vp, _vp,
                                            C.POINTER(Stats), C.POINTER(Stats)]),
+    ("lrnde_conv_node_forward_record", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _i32, _i32, _f, _vp,
+                                                 _fp, C.POINTER(_i32), C.POINTER(Stats), _fp]),
+    ("lrnde_conv_node_backward_recorded", C.c_int, [_vp, _i32, _vp, _f, _vp, _vp, C.POINTER(Stats)]),
     ("lrnde_cifar_stem_param_count", C.c_size_t, []),
     ("lrnde_cifar_head_param_count", C.c_size_t, [_i32, _i32, _i32]),
     ("lrnde_cifar_stem_forward", C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),

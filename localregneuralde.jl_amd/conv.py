@@ -222,6 +222,28 @@ class ConvHandle:
                                                  C.byref(sb)))
         return dict(dx=dx, dp=dp, stats_fwd=sf.asdict(), stats_bwd=sb.asdict())
 
+    def node_forward_record(self, x, t0, t2, abstol, reltol, mode="unbiased", reg_type="error_estimate", t1_or_rand=0.5,
+                            maxiters=1000, save_start=False, exact_pow=False):
+        """node_forward that keeps the record node_backward_recorded pulls back through (one forward per training step)"""
+        o = L.SolveOpts(float(abstol), float(reltol), int(maxiters), int(save_start), 0, int(exact_pow))
+        u_end = torch.empty_like(x)
+        reg, nfe, st, t1u = C.c_float(), C.c_int32(), L.Stats(), C.c_float()
+        self._chk(L.lib.lrnde_conv_node_forward_record(self._ctx, _ptr(x, "x"), self._B(x), float(t0), float(t2), C.byref(o),
+                                                       L.MODE[mode], L.REG_TYPE[reg_type], float(t1_or_rand),
+                                                       _ptr(u_end, "u_end"), C.byref(reg), C.byref(nfe), C.byref(st),
+                                                       C.byref(t1u)))
+        return dict(u_end=u_end, reg_val=np.float32(reg.value), nfe=int(nfe.value), stats=st.asdict(),
+                    t1=np.float32(t1u.value))
+
+    def node_backward_recorded(self, B, du_end, w_reg=0.0):
+        """(dx, dp) of <du_end, sol.u[end]> + w_reg*reg_val from the record of the last node_forward_record"""
+        dx = torch.empty_like(du_end)
+        dp = torch.empty(self.param_count(), dtype=torch.float32, device=du_end.device)
+        sb = L.Stats()
+        self._chk(L.lib.lrnde_conv_node_backward_recorded(self._ctx, int(B), _ptr(du_end, "du_end"), float(w_reg), _ptr(dx, "dx"),
+                                                          C.c_void_p(dp.data_ptr()), C.byref(sb)))
+        return dict(dx=dx, dp=dp, stats_bwd=sb.asdict())
+
     # ---- layers around the CIFAR10 NeuralODE (experiments/src/construct.jl:224-227) ----
     def cifar_stem_forward(self, x, ps, bn_state=None, return_state=False):
         """AugmenterLayer(Conv 3=>5) + BatchNorm(8): x (B,3,H,W) -> u0 (B,8,H,W); with return_state also the layer's

@@ -1649,6 +1649,7 @@ struct lrnde_conv {
   bool dense_on = false; size_t dense_n = 0;
   std::vector<float*> dense; std::vector<float> dense_t, dense_dt;
   float* rec_u1 = nullptr; size_t rec_n = 0;
+  bool rec_valid = false; int rec_B = 0, rec_mode = 0, rec_reg_type = 0; float rec_t0 = 0.f, rec_t2 = 0.f, rec_t1 = 0.f; lrnde_solve_opts rec_opts;
   float* adj = nullptr; size_t adj_elems = 0;
 };
 
@@ -2235,6 +2236,7 @@ int lrnde_conv_solve(lrnde_conv* c, const float* u0, int32_t B, float t0, float 
   int nsaved = 0, isave = 0, ntrace = 0;
   c->last_ts.clear();
   if (c->dense_on) { c->dense_t.clear(); c->dense_dt.clear(); }
+  else c->rec_valid = false;  // a plain solve overwrites the saved times the recorded backward pass reads
   auto push = [&](float tt, const float* uu) -> int {
     if (nsaved >= cap_saved || !u_saved) return cfail(c, LRNDE_CAPACITY, "u_saved capacity %d exhausted", cap_saved);
     CHK(c, hipMemcpyAsync(u_saved + (size_t)nsaved * n, uu, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
@@ -2570,22 +2572,57 @@ int lrnde_conv_step_reg_grad(lrnde_conv* c, const float* uprev, const float* k1,
 }
 
 // backward of  loss = <du_end, sol.u[end]> + w_reg * reg_val  through the NeuralODE layer over the conv field
+// forward of the layer that keeps what the backward pass needs (dense record of the main solve, u(t1) of the local
+// step): lrnde_node_forward_record's counterpart for the conv field (experiments/src/utils.jl:104-123 runs the
+// forward once and pulls back through it)
+int lrnde_conv_node_forward_record(lrnde_conv* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
+                                   int32_t mode, int32_t reg_type, float t1_or_rand, float* u_end, float* reg_val_host,
+                                   int32_t* nfe_host, lrnde_stats* st, float* t1_used_host) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!x || !o || !u_end || !st) return cfail(c, LRNDE_BADARG, "null pointer");
+  c->rec_valid = false;
+  float t1 = t2;
+  c->dense_on = true;
+  rc = lrnde_conv_node_forward(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, u_end, reg_val_host, nfe_host, st, &t1);
+  c->dense_on = false;
+  if (rc) return rc;
+  if (t1_used_host) *t1_used_host = t1;
+  c->rec_valid = true; c->rec_B = B; c->rec_t0 = t0; c->rec_t2 = t2; c->rec_t1 = t1; c->rec_opts = *o; c->rec_mode = mode;
+  c->rec_reg_type = reg_type;
+  return LRNDE_OK;
+}
+
+int lrnde_conv_node_backward_recorded(lrnde_conv* c, int32_t B, const float* du_end, float w_reg, float* dx, float* dp,
+                                      lrnde_stats* st_bwd);
+
 int lrnde_conv_node_backward(lrnde_conv* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
                              int32_t mode, int32_t reg_type, float t1_or_rand, const float* du_end, float w_reg,
                              float* dx, float* dp, lrnde_stats* st_fwd, lrnde_stats* st_bwd) {
   int rc = check_ready(c, B);
   if (rc) return rc;
   if (!x || !o || !du_end || !dx || !dp || !st_fwd || !st_bwd) return cfail(c, LRNDE_BADARG, "null pointer");
-  const size_t n = state_n(c, B), P = lrnde_conv_param_count(&c->d), N = n + P;
   // 1. forward with the dense record
   float* u_end = nullptr;
-  CHK(c, hipMalloc(&u_end, sizeof(float) * n));
-  float regv = 0.f, t1 = t2; int nfe = 0;
-  c->dense_on = true;
-  rc = lrnde_conv_node_forward(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, u_end, &regv, &nfe, st_fwd, &t1);
-  c->dense_on = false;
+  CHK(c, hipMalloc(&u_end, sizeof(float) * state_n(c, B)));
+  float regv = 0.f; int nfe = 0;
+  rc = lrnde_conv_node_forward_record(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, u_end, &regv, &nfe, st_fwd, nullptr);
   hipFree(u_end);
   if (rc) return rc;
+  return lrnde_conv_node_backward_recorded(c, B, du_end, w_reg, dx, dp, st_bwd);
+}
+
+// backward of  loss = <du_end, sol.u[end]> + w_reg * reg_val  from the record of the last lrnde_conv_node_forward_record
+int lrnde_conv_node_backward_recorded(lrnde_conv* c, int32_t B, const float* du_end, float w_reg, float* dx, float* dp,
+                                      lrnde_stats* st_bwd) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!du_end || !dx || !dp || !st_bwd) return cfail(c, LRNDE_BADARG, "null pointer");
+  if (!c->rec_valid || c->rec_B != B) return cfail(c, LRNDE_BADARG, "no forward record for this batch (call lrnde_conv_node_forward_record first)");
+  const lrnde_solve_opts* o = &c->rec_opts;
+  const float t0 = c->rec_t0, t2 = c->rec_t2, t1 = c->rec_t1;
+  const int mode = c->rec_mode, reg_type = c->rec_reg_type;
+  const size_t n = state_n(c, B), P = lrnde_conv_param_count(&c->d), N = n + P;
   // the local step of node_forward re-solved nothing: last_ts / dense_t describe the main solve (dense record is
   // only appended inside lrnde_conv_solve)
   const std::vector<float> dts = c->dense_t, dds = c->dense_dt;

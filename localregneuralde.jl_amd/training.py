@@ -45,8 +45,8 @@ def run_cifar_training_step(node, params, st, x, labels, w_reg, num_classes=10):
     """The CIFAR10 model's forward + pullback (experiments/src/construct.jl:213-227):
     Chain(augment, bn, neural_ode, sol_to_arr, classifier) with loss = logitcrossentropy + w_reg * reg_val.
     params: dict(stem=(156,), neural_ode=(47560,), head=(72+1+K*H*W+K,)) CUDA float32; x (B,3,H,W); labels CUDA int32.
-    Returns (loss, st_, stats, grads, times).  The NeuralODE pullback re-solves the forward with its dense record
-    (one extra forward solve inside bwd_time)."""
+    Returns (loss, st_, stats, grads, times).  The forward keeps its dense record (lrnde_conv_node_forward_record) and the
+    pullback runs from it (lrnde_conv_node_backward_recorded), as the reference's training step runs one forward."""
     h = node._bind(params["neural_ode"], torch.empty((x.shape[0], 8, x.shape[2], x.shape[3]), device=x.device))
     node._model_state_in(h, st)
     t0, t2 = node.tspan
@@ -60,17 +60,16 @@ def run_cifar_training_step(node, params, st, x, labels, w_reg, num_classes=10):
     tic = time.perf_counter()
     stem_in = st.get("stem_bn_state") if isinstance(st, dict) else None
     u0, stem_bn = h.cifar_stem_forward(x, params["stem"], stem_in, return_state=True)  # BatchNorm(8)'s state advances too
-    fw = h.node_forward(u0, t0, t2, abstol, reltol, mode=mode, reg_type=node.regularize_type, t1_or_rand=t1_or_rand,
-                        maxiters=node.maxiters, save_start=kw.get("save_start", True))
+    fw = h.node_forward_record(u0, t0, t2, abstol, reltol, mode=mode, reg_type=node.regularize_type, t1_or_rand=t1_or_rand,
+                               maxiters=node.maxiters, save_start=kw.get("save_start", True))
     bn_after = h.get_bn_state()
     head = h.cifar_head_ce(fw["u_end"], params["head"], num_classes, labels)
     loss = np.float32(head["loss"] + np.float32(w_reg) * fw["reg_val"])
     torch.cuda.synchronize()
     fwd_time = time.perf_counter() - tic
     tic = time.perf_counter()
-    bw = h.node_backward(u0, t0, t2, abstol, reltol, head["du"], mode=mode, reg_type=node.regularize_type,
-                         t1_or_rand=t1_or_rand, w_reg=w_reg, maxiters=node.maxiters, save_start=kw.get("save_start", True))
-    h.set_bn_state(bn_after)  # the pullback's forward re-solve must not advance the model state a second time
+    bw = h.node_backward_recorded(x.shape[0], head["du"], w_reg=w_reg)  # from the forward's record: no second forward solve
+    h.set_bn_state(bn_after)  # (the local step's gradient sweep re-evaluates the field; the model state stays the forward's)
     dstem = h.cifar_stem_backward(x, params["stem"], bw["dx"], stem_in)
     torch.cuda.synchronize()
     bwd_time = time.perf_counter() - tic

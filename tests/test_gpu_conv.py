@@ -269,6 +269,30 @@ def test_conv_node_backward_matches_oracle(mode, w_reg):
     assert _rel(bg["dp"].cpu().numpy(), bo["dp"]) <= 5e-3
 
 
+def test_conv_recorded_backward_equals_the_one_call_form():
+    """lrnde_conv_node_forward_record + lrnde_conv_node_backward_recorded (one forward per training step) give the
+    bits of lrnde_conv_node_backward; a plain solve in between invalidates the record (BADARG, not stale data)."""
+    P, O = _mods()
+    W = H = 8; B = 3
+    fld, h, p, u = _case(W, H, B, seed=45, scale=1.5)
+    ud = torch.from_numpy(u).cuda()
+    wv = torch.from_numpy(np.random.default_rng(6).standard_normal(u.shape).astype(np.float32)).cuda()
+    tol = 1e-3
+    st0 = h.get_bn_state().clone()
+    one = h.node_backward(ud, 0.0, 1.0, tol, tol, wv, mode="unbiased", t1_or_rand=0.37, w_reg=2.5, maxiters=5000)
+    h.set_bn_state(st0)
+    fw_plain = h.node_forward(ud, 0.0, 1.0, tol, tol, mode="unbiased", t1_or_rand=0.37, maxiters=5000)
+    h.set_bn_state(st0)
+    fw = h.node_forward_record(ud, 0.0, 1.0, tol, tol, mode="unbiased", t1_or_rand=0.37, maxiters=5000)
+    assert torch.equal(fw["u_end"], fw_plain["u_end"]) and fw["reg_val"] == fw_plain["reg_val"] and fw["nfe"] == fw_plain["nfe"]
+    two = h.node_backward_recorded(B, wv, w_reg=2.5)
+    assert torch.equal(two["dx"], one["dx"]) and torch.equal(two["dp"], one["dp"])
+    assert two["stats_bwd"] == one["stats_bwd"]
+    h.solve(ud, 0.0, 1.0, tol, tol, saveat=[1.0])
+    with pytest.raises(P.LrndeError):
+        h.node_backward_recorded(B, wv, w_reg=2.5)
+
+
 def test_conv_bf16_handle_backward_is_the_fp32_adjoint():
     """compute_dtype=bf16: the forward solve runs the bf16 kernels, derivatives are taken in fp32 (fp32 recompute of the
     hidden activations + the fp32 backward kernels).  So the VJP of a bf16 handle IS the fp32 handle's VJP (same
