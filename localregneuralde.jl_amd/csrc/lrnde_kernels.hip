@@ -1630,8 +1630,9 @@ template <class K> int launch_tile_kernel(lrnde_ctx* c, K kern, int B, const Ste
 int launch_step(lrnde_ctx* c, int B, const StepArgs& a, int j, bool spec = false) {
   if (use_qtile(c, B)) {
     const int nq = (B + QNB - 1) / QNB;
-    if (spec) hipLaunchKernelGGL(k_step_q<true>, dim3(nq), dim3(QNT), smem_q(c), c->stream, a, j);
-    else hipLaunchKernelGGL(k_step_q<false>, dim3(nq), dim3(QNT), smem_q(c), c->stream, a, j);
+    const size_t smq = smem_q(c) + (size_t)7 * c->m.KQ1p * 4 * 16 + 16;  // + the LDS-resident stage operands (uprev, k1..k6)
+    if (spec) hipLaunchKernelGGL(k_step_q<true>, dim3(nq), dim3(QNT), smq, c->stream, a, j);
+    else hipLaunchKernelGGL(k_step_q<false>, dim3(nq), dim3(QNT), smq, c->stream, a, j);
     HIPCHK(c, hipGetLastError());
     return LRNDE_OK;
   }

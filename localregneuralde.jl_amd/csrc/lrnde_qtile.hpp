@@ -104,23 +104,29 @@ struct EpiStoreKQ {
   }
 };
 
+// The stage operands (uprev, k1 .. k_{S-1}) of a workgroup's tile stay in LDS for the whole launch: kl[slot][rg*64+lane],
+// slot 0 = uprev, slot j = k_j.  The wave that owns row groups w and w+8 in Dense-2 is the one that wrote those quads
+// (the x2 tile load walks the tile in the same order), so no barrier orders these accesses.  Re-reading them from
+// global memory went through the same L2->L1 path as the weight stream (Dense-2 streamed at 36 B/clk against
+// Dense-1's 56); the k vectors are still stored to global memory for the next launch and the dense record.
 template <int S> struct EpiStageQ {
   static constexpr int NPRE = S;
   TileIOQ io;
   int off_up, off_k[6], off_out, off_x;
   float dt;
   f32x4* xl; int KQ1;
+  f32x4* kl; int KL;
   __device__ __forceinline__ void pre(int rg, f32x4 (&pb)[NPRE]) const {
-    const int vo = q_voff(io, rg);
-    pb[0] = qload(io, vo, off_up);
+    const int li = rg * 64 + (threadIdx.x & 63);
 #pragma unroll
-    for (int j = 0; j < S - 1; ++j) pb[1 + j] = qload(io, vo, off_k[j]);
+    for (int j = 0; j < S; ++j) pb[j] = kl[(size_t)j * KL + li];
   }
   __device__ __forceinline__ void post(int rg, const f32x4& kv, f32x4 (&pb)[NPRE]) const {
     const int lane = threadIdx.x & 63, sidx = lane & 3, q = lane >> 2;
     constexpr int off = (S - 1) * S / 2;
     const int vo = q_voff(io, rg);
     qstore(io, vo, off_out, kv);
+    kl[(size_t)S * KL + rg * 64 + lane] = kv;
     f32x4 x;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -146,13 +152,14 @@ struct EpiFinalQ {
   float dt, abstol, reltol;
   int want_stiff, nvalid, D;
   double *aerr, *anum, *aden;
+  const f32x4* xl; const f32x4* kl; int KL;  // u is the x tile of this (last) f-eval; uprev, k1..k6 as in EpiStageQ
   __device__ __forceinline__ void pre(int rg, f32x4 (&pb)[NPRE]) const {
-    const int vo = q_voff(io, rg);
-    pb[0] = qload(io, vo, off_up);
-    pb[1] = qload(io, vo, off_u);
+    const int li = rg * 64 + (threadIdx.x & 63);
+    pb[0] = kl[li];
+    pb[1] = xl[li];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) pb[2 + j] = qload(io, vo, off_k[j]);
-    if (want_stiff) pb[8] = qload(io, vo, off_g6);
+    for (int j = 0; j < 6; ++j) pb[2 + j] = kl[(size_t)(1 + j) * KL + li];
+    if (want_stiff) pb[8] = qload(io, q_voff(io, rg), off_g6);
   }
   __device__ __forceinline__ void post(int rg, const f32x4& kv, f32x4 (&pb)[NPRE]) const {
     const int lane = threadIdx.x & 63, sidx = lane & 3, q = lane >> 2;
@@ -594,6 +601,8 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
               c4 = (float)Tsit5::C[3];
   double aerr = 0.0, anum = 0.0, aden = 0.0;
   const TileIOQ io = make_tile_io_q(a, b0, nvalid);
+  f32x4* kl = reinterpret_cast<f32x4*>((reinterpret_cast<uintptr_t>(s.bc + 1) + 15) & ~(uintptr_t)15);  // [7][KL] stage operands
+  const int KL = a.m.KQ1p * 4;
   const int o_up = arr_off(a, bc.cur), o_un = arr_off(a, bc.cur ^ 1);
   const int o_k1 = arr_off(a, 2 + bc.cur), o_k7 = arr_off(a, 2 + (bc.cur ^ 1));
   const int o_g6 = arr_off(a, 9);
@@ -601,13 +610,15 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
   {  // x2 = uprev + (dt*a21)*k1   (src/perform_step.jl:11-12)
     const float a21dt = dt * (float)Tsit5::A[0];
     q_tile_foreach(a.m, b0, nvalid, KQ1, [&](int kq, int sidx, bool valid, size_t g) {
-      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      f32x4 x = {0.f, 0.f, 0.f, 0.f}, u = x, f = x;
       if (valid) {
-        const f32x4 u = ld4(uprev + g), f = ld4(k1 + g);
+        u = ld4(uprev + g); f = ld4(k1 + g);
 #pragma unroll
         for (int h = 0; h < 4; ++h) x[h] = u[h] + a21dt * f[h];
       }
       s.xl[kq * 4 + sidx] = x;
+      kl[kq * 4 + sidx] = u;
+      kl[KL + kq * 4 + sidx] = f;
     });
   }
   __syncthreads();
@@ -619,7 +630,7 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
     _Pragma("unroll") for (int qq = 0; qq < 5; ++qq) e.off_k[1 + qq] = arr_off(a, 4 + qq); \
     e.off_out = arr_off(a, 4 + (S - 2));                                                \
     e.off_x = (S == 6) ? o_un : ((S == 5 && a.want_stiff) ? o_g6 : -1);                 \
-    e.dt = dt; e.xl = s.xl; e.KQ1 = KQ1;                                                \
+    e.dt = dt; e.xl = s.xl; e.KQ1 = KQ1; e.kl = kl; e.KL = KL;                          \
     feval_qs<EpiStageQ<S>, (QSB * (S - 2)) % QRING>(a.m, s, fc, (TS), e);                 \
     STAMP(11 + S);                                                                      \
   } while (0)
@@ -637,6 +648,7 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
   ef.dt = dt; ef.abstol = a.abstol; ef.reltol = a.reltol; ef.want_stiff = a.want_stiff; ef.nvalid = nvalid;
   ef.D = a.m.D;
   ef.aerr = &aerr; ef.anum = &anum; ef.aden = &aden;
+  ef.xl = s.xl; ef.kl = kl; ef.KL = KL;
   feval_qs<EpiFinalQ, (QSB * 5) % QRING>(a.m, s, fc, t + dt, ef);
   STAMP(18);
   block_sum3_q(s.red, aerr, anum, aden);
