@@ -572,8 +572,7 @@ __device__ __forceinline__ void vjp_q_body(const VjpQArgs& a) {
     const int r = e & 3, l = (e >> 2) & 63, rg = e >> 8;
     const int o = rg * 64 + (l >> 2) * 4 + r, sx = l & 3;
     if ((o >> 2) >= m.KQ2p) continue;
-    float v = plf[e];
-    for (int sgi = 1; sgi < nseg1; ++sgi) v = v + plf[(size_t)sgi * ne + e];
+    const float v = q_segment_sum(plf, ne, e, nseg1);
     float pre = m.td ? fma_(w1t[o], a.t, v) : v;
     pre = pre + b1[o];
     const float h = act_apply(m.act, pre);
@@ -588,8 +587,7 @@ __device__ __forceinline__ void vjp_q_body(const VjpQArgs& a) {
     const int r = e & 3, l = (e >> 2) & 63, rg = e >> 8;
     const int o = rg * 64 + (l >> 2) * 4 + r, sx = l & 3;
     if ((o >> 2) >= m.KQ2p) continue;
-    float v = plf[e];
-    for (int sgi = 1; sgi < nseg1; ++sgi) v = v + plf[(size_t)sgi * ne + e];
+    const float v = q_segment_sum(plf, ne, e, nseg1);
     const float dpre = (o < m.H) ? v * dact[e] : 0.f;
     hlf[((o >> 2) * 4 + sx) * 4 + r] = dpre;
     if (sx < nvalid && o < m.Hp) a.dpsc[(size_t)(b0 + sx) * m.Hp + o] = dpre;

@@ -34,6 +34,19 @@ struct SmemQ {
 
 __device__ __forceinline__ int q_nseg1(const ModelDev& m) { return (m.KQ1p + QSEG - 1) / QSEG; }
 
+// sum of the nseg (<= QNW) K-segment partials of C-fragment element e, in segment order (the canonical order), with all
+// LDS reads issued before the first add: a loop with the runtime trip count read, waited and added one segment at a time
+__device__ __forceinline__ float q_segment_sum(const float* plf, int ne, int e, int nseg) {
+  float vals[QNW];
+#pragma unroll
+  for (int sgi = 0; sgi < QNW; ++sgi) vals[sgi] = plf[(size_t)(sgi < nseg ? sgi : nseg - 1) * ne + e];
+  float v = vals[0];
+#pragma unroll
+  for (int sgi = 1; sgi < QNW; ++sgi) v = sgi < nseg ? v + vals[sgi] : v;
+  return v;
+}
+
+
 __device__ __forceinline__ SmemQ carve_q(const ModelDev& m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SmemQ s;
@@ -325,8 +338,7 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
       const int r = e & 3, l = (e >> 2) & 63, rg = e >> 8;
       const int o = rg * 64 + (l >> 2) * 4 + r;
       if ((o >> 2) >= m.KQ2p) continue;
-      float v = plf[e];
-      for (int sgi = 1; sgi < nseg1; ++sgi) v = v + plf[(size_t)sgi * ne + e];
+      const float v = q_segment_sum(plf, ne, e, nseg1);
       float pre = m.td ? fma_(w1t[o], ts, v) : v;
       pre = pre + b1[o];
       hlf[((o >> 2) * 4 + (l & 3)) * 4 + r] = act_apply(m.act, pre);
