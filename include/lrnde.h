@@ -294,6 +294,21 @@ int lrnde_sde_solve_fixed(lrnde_sde* sde, int32_t which, const float* u0, const 
                           int32_t nsteps, float abstol, float reltol, float delta, float* u_traj, float* eest_host,
                           float* reg_val_host);
 
+/* `_perform_step(integrator, cache::FourStageSRIConstantCache, p)`, src/perform_step.jl:49-106 — the step the
+ * reference's default SDE solver SOSRI runs — diagonal noise: four drift and four diffusion evaluations, the
+ * increments dW and dZ of the caller's noise process (device, B x D each), u, EEst from the 7-argument
+ * _calculate_residuals (:214-216) and EEst*dt.  The tableau is NOT part of this library: SOSRI's coefficients live in
+ * un-vendored StochasticDiffEq; the caller passes the cache's fields in the order the reference unpacks them (:51-55). */
+typedef struct lrnde_sri_tableau {
+  float a021, a031, a032, a041, a042, a043, a121, a131, a132, a141, a142, a143;
+  float b021, b031, b032, b041, b042, b043, b121, b131, b132, b141, b142, b143;
+  float c02, c03, c04, c11, c12, c13, c14, alpha1, alpha2, alpha3, alpha4;
+  float beta11, beta12, beta13, beta14, beta21, beta22, beta23, beta24, beta31, beta32, beta33, beta34, beta41, beta42, beta43, beta44;
+} lrnde_sri_tableau;
+int lrnde_sde_sri_step(lrnde_sde* sde, const lrnde_sri_tableau* tab, const float* uprev, const float* dW, const float* dZ,
+                       int32_t B, float t, float dt, float abstol, float reltol, float delta, float* u, float* eest_host,
+                       float* reg_val_host);
+
 /* ---- backward pass ----
  * lrnde_vjp: the vector-Jacobian product Zygote.pullback(dudt, y, p, t) computes inside the adjoint
  * RHS (SciMLSensitivity ZygoteVJP): dy = (df/dy)^T lam, gp = (df/dp)^T lam (flat Lux layout, may be

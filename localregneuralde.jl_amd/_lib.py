@@ -19,6 +19,17 @@ class ModelDesc(C.Structure):
                 ("act", C.c_int32)]
 
 
+SRI_FIELDS = ("a021 a031 a032 a041 a042 a043 a121 a131 a132 a141 a142 a143 "
+              "b021 b031 b032 b041 b042 b043 b121 b131 b132 b141 b142 b143 "
+              "c02 c03 c04 c11 c12 c13 c14 alpha1 alpha2 alpha3 alpha4 "
+              "beta11 beta12 beta13 beta14 beta21 beta22 beta23 beta24 beta31 beta32 beta33 beta34 beta41 beta42 beta43 beta44").split()
+
+
+class SriTableau(C.Structure):
+    """lrnde_sri_tableau: the fields of StochasticDiffEq's FourStageSRIConstantCache in the order src/perform_step.jl:51-55 unpacks them"""
+    _fields_ = [(n, C.c_float) for n in SRI_FIELDS]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32), ("hidden", C.c_int32),
                 ("act", C.c_int32), ("bn_train", C.c_int32), ("compute_dtype", C.c_int32), ("bn_eps", C.c_float)]
@@ -69,6 +80,7 @@ SYMBOLS = [
     ("lrnde_sde_euler_heun_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _vp, _fp, _fp]),
     ("lrnde_sde_rkmil_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _vp, _fp, _fp]),
     ("lrnde_sde_solve_fixed", C.c_int, [_vp, _i32, _vp, _vp, _i32, _f, _f, _i32, _f, _f, _f, _vp, _fp, _fp]),
+    ("lrnde_sde_sri_step", C.c_int, [_vp, C.POINTER(SriTableau), _vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _vp, _fp, _fp]),
     ("lrnde_vjp", C.c_int, [_vp, _vp, _f, _vp, _i32, _vp, _vp]),
     ("lrnde_step_reg_grad", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _vp, _fp]),
     ("lrnde_node_backward", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _i32, _i32, _f, _vp, _f, _vp, _vp,

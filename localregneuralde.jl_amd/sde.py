@@ -3,8 +3,9 @@
 What is built: the adaptive Euler-Heun local step with its error estimate
 (`_perform_step(::LambaEulerHeunConstantCache)`, src/perform_step.jl:172-206) on the device, and a
 NeuralDSDE-shaped forward that integrates with that step on a FIXED grid with caller-visible
-Brownian increments (BASELINE config 5).  Not built: the reference's default SOSRI solver with
-RSWM adaptive noise (un-vendored StochasticDiffEq) — `solver="SOSRI"` raises.
+Brownian increments (BASELINE config 5).  The four-stage SRI step SOSRI runs (`_perform_step(::FourStageSRIConstantCache)`, :49-106) is on
+the device too (`SdeHandle.sri_step`) with a caller-supplied tableau: SOSRI's coefficients and its RSWM adaptive
+noise process live in un-vendored StochasticDiffEq and are not restated, so `solver="SOSRI"` still raises.
 """
 import copy
 import ctypes as C
@@ -73,6 +74,19 @@ class SdeHandle:
                                              C.byref(ee), C.byref(rv)))
         return dict(u=u, eest=np.float32(ee.value), reg_val=np.float32(rv.value))
 
+
+    def sri_step(self, tableau, uprev, dW, dZ, t, dt, abstol, reltol, delta):
+        """`_perform_step(integrator, ::FourStageSRIConstantCache, p)` (src/perform_step.jl:49-106), diagonal noise;
+        tableau: dict / sequence with the 51 coefficients named as the reference unpacks them (L.SRI_FIELDS) — SOSRI's
+        values live in StochasticDiffEq and are the caller's to supply."""
+        tab = L.SriTableau(*[float(tableau[k]) for k in L.SRI_FIELDS]) if isinstance(tableau, dict) else L.SriTableau(*[float(v) for v in tableau])
+        B = uprev.numel() // self.D
+        u = torch.empty_like(uprev)
+        ee, rv = C.c_float(), C.c_float()
+        self._chk(L.lib.lrnde_sde_sri_step(self._h, C.byref(tab), _dev_ptr(uprev, "uprev", self.D), _dev_ptr(dW, "dW", self.D),
+                                           _dev_ptr(dZ, "dZ", self.D), B, float(t), float(dt), float(abstol), float(reltol),
+                                           float(delta), _dev_ptr(u, "u"), C.byref(ee), C.byref(rv)))
+        return dict(u=u, eest=np.float32(ee.value), reg_val=np.float32(rv.value))
 
     def solve_fixed(self, u0, dW, t0, dt, abstol, reltol, delta=1.0 / 6.0, solver="EulerHeun"):
         """nsteps = dW.shape[0] steps on a fixed grid in one call (no host round trip per step): dict(u (nsteps,B,D),

@@ -946,6 +946,71 @@ int lro_rkmil_step(const lro_field* fd, const lro_field* gd, const float* uprev,
   return LRO_OK;
 }
 
+/* ------------------------------------------------------------------------- */
+/* four-stage SRI step, diagonal noise (src/perform_step.jl:49-106).           */
+/* Every line below is the reference's expression evaluated elementwise in its  */
+/* own association order (Julia: left to right, scalar * scalar first in        */
+/* `dt * a021 * k1`, `x^3` = (x*x)*x); the tableau is the caller's.             */
+/* ------------------------------------------------------------------------- */
+int lro_sri_step(const lro_field* fd, const lro_field* gd, const lro_sri_tableau* T, const float* uprev, const float* dW,
+                 const float* dZ, float t, float dt, float abstol, float reltol, float delta, int B, float* u,
+                 float* eest, float* reg_val) {
+  const long n = (long)fd->D * B;
+  float* w = (float*)malloc(sizeof(float) * (size_t)n * 13);
+  float *k1 = w, *k2 = w + n, *k3 = w + 2 * n, *k4 = w + 3 * n, *g1 = w + 4 * n, *g2 = w + 5 * n, *g3 = w + 6 * n,
+        *g4 = w + 7 * n, *H0 = w + 8 * n, *H1 = w + 9 * n, *chi1 = w + 10 * n, *chi2 = w + 11 * n, *chi3 = w + 12 * n;
+  const float sqdt = sqrtf(fabsf(dt)), sqrt3 = sqrtf(3.0f);
+  const float two_sqdt = 2.0f * sqdt, six_dt = 6.0f * dt;
+  for (long i = 0; i < n; ++i) {                                                      /* :57-60 */
+    chi1[i] = (dW[i] * dW[i] - fabsf(dt)) / two_sqdt;
+    chi2[i] = (dW[i] + dZ[i] / sqrt3) / 2.0f;
+    chi3[i] = ((dW[i] * dW[i]) * dW[i] - (3.0f * dW[i]) * dt) / six_dt;
+  }
+  fd->fn(fd->ctx, uprev, t, B, k1);                                                   /* :62 */
+  gd->fn(gd->ctx, uprev, t + T->c11 * dt, B, g1);                                     /* :63 */
+  { const float da = dt * T->a021, db = dt * T->a121, sb = sqdt * T->b121;
+    for (long i = 0; i < n; ++i) {                                                    /* :65-66 */
+      H0[i] = (uprev[i] + da * k1[i]) + (T->b021 * chi2[i]) * g1[i];
+      H1[i] = (uprev[i] + db * k1[i]) + sb * g1[i];
+    } }
+  fd->fn(fd->ctx, H0, t + T->c02 * dt, B, k2);                                        /* :68 */
+  gd->fn(gd->ctx, H1, t + T->c12 * dt, B, g2);                                        /* :69 */
+  for (long i = 0; i < n; ++i) {                                                      /* :71-72 */
+    H0[i] = (uprev[i] + dt * (T->a031 * k1[i] + T->a032 * k2[i])) + chi2[i] * (T->b031 * g1[i] + T->b032 * g2[i]);
+    H1[i] = (uprev[i] + dt * (T->a131 * k1[i] + T->a132 * k2[i])) + sqdt * (T->b131 * g1[i] + T->b132 * g2[i]);
+  }
+  fd->fn(fd->ctx, H0, t + T->c03 * dt, B, k3);                                        /* :74 */
+  gd->fn(gd->ctx, H1, t + T->c13 * dt, B, g3);                                        /* :75 */
+  for (long i = 0; i < n; ++i) {                                                      /* :77-82 */
+    H0[i] = (uprev[i] + dt * ((T->a041 * k1[i] + T->a042 * k2[i]) + T->a043 * k3[i])) +
+            chi2[i] * ((T->b041 * g1[i] + T->b042 * g2[i]) + T->b043 * g3[i]);
+    H1[i] = (uprev[i] + dt * ((T->a141 * k1[i] + T->a142 * k2[i]) + T->a143 * k3[i])) +
+            sqdt * ((T->b141 * g1[i] + T->b142 * g2[i]) + T->b143 * g3[i]);
+  }
+  fd->fn(fd->ctx, H0, t + T->c04 * dt, B, k4);                                        /* :84 */
+  gd->fn(gd->ctx, H1, t + T->c14 * dt, B, g4);                                        /* :85 */
+  double acc = 0.0;
+  for (long i = 0; i < n; ++i) {
+    const float s3 = ((T->beta31 * g1[i] + T->beta32 * g2[i]) + T->beta33 * g3[i]) + T->beta34 * g4[i];
+    const float s4 = ((T->beta41 * g1[i] + T->beta42 * g2[i]) + T->beta43 * g3[i]) + T->beta44 * g4[i];
+    const float E2 = chi2[i] * s3 + chi3[i] * s4;                                     /* :87-88 */
+    const float sa = ((T->alpha1 * k1[i] + T->alpha2 * k2[i]) + T->alpha3 * k3[i]) + T->alpha4 * k4[i];
+    const float s1 = ((T->beta11 * g1[i] + T->beta12 * g2[i]) + T->beta13 * g3[i]) + T->beta14 * g4[i];
+    const float s2 = ((T->beta21 * g1[i] + T->beta22 * g2[i]) + T->beta23 * g3[i]) + T->beta24 * g4[i];
+    u[i] = (((uprev[i] + dt * sa) + E2) + dW[i] * s1) + chi1[i] * s2;                 /* :90-94 */
+    const float E1 = dt * (((k1[i] + k2[i]) + k3[i]) + k4[i]);                        /* :98 */
+    const float sc = abstol + fmaxf(fabsf(uprev[i]), fabsf(u[i])) * reltol;
+    const float r = (delta * E1 + E2) / sc;                                           /* :100-103, :214-216 */
+    const float sq = r * r;
+    acc += (double)sq;
+  }
+  const float ee = rms_from_sumsq(acc, n);
+  if (eest) *eest = ee;
+  if (reg_val) *reg_val = ee * dt;                                                    /* :105 */
+  free(w);
+  return LRO_OK;
+}
+
 /* ========================================================================= */
 /* Backward pass: continuous adjoint of the solve            */
 /* (SciMLSensitivity InterpolatingAdjoint(autojacvec=ZygoteVJP()), un-vendored) */

@@ -221,6 +221,19 @@ float lro_cifar_head_ce(const float* u, int B, int H, int W, const float* ph, in
                         float* dph);
 int lro_rkmil_step(const lro_field* drift, const lro_field* diffusion, const float* uprev, const float* dW, float t,
                    float dt, float abstol, float reltol, int B, float* u, float* eest, float* reg_val);
+
+/* four-stage SRI step (src/perform_step.jl:49-106, `FourStageSRIConstantCache`: the step SOSRI runs), diagonal noise.
+ * The tableau lives in un-vendored StochasticDiffEq (its SOSRI constructor) and is NOT restated here: the caller
+ * supplies it, in the order the reference unpacks the cache (:51-55). */
+typedef struct lro_sri_tableau {
+  float a021, a031, a032, a041, a042, a043, a121, a131, a132, a141, a142, a143;
+  float b021, b031, b032, b041, b042, b043, b121, b131, b132, b141, b142, b143;
+  float c02, c03, c04, c11, c12, c13, c14, alpha1, alpha2, alpha3, alpha4;
+  float beta11, beta12, beta13, beta14, beta21, beta22, beta23, beta24, beta31, beta32, beta33, beta34, beta41, beta42, beta43, beta44;
+} lro_sri_tableau;
+int lro_sri_step(const lro_field* drift, const lro_field* diffusion, const lro_sri_tableau* tab, const float* uprev,
+                 const float* dW, const float* dZ, float t, float dt, float abstol, float reltol, float delta, int B,
+                 float* u, float* eest, float* reg_val);
 /* classifier head + logitcrossentropy (experiments/src/construct.jl:199, experiments/src/utils.jl:88):
  * pc = [vec(W) (K x D column-major); b]; returns mean CE; optional logits (B,K), du (B,D), dpc (K*(D+1)) */
 float lro_classifier_ce(const float* u, int B, int D, const float* pc, int K, const int* labels, float* logits,

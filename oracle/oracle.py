@@ -408,6 +408,34 @@ def rkmil_step(drift, diffusion, uprev, dW, t, dt, abstol, reltol):
     return dict(u=u, eest=np.float32(ee.value), reg_val=np.float32(rv.value))
 
 
+SRI_FIELDS = ("a021 a031 a032 a041 a042 a043 a121 a131 a132 a141 a142 a143 "
+              "b021 b031 b032 b041 b042 b043 b121 b131 b132 b141 b142 b143 "
+              "c02 c03 c04 c11 c12 c13 c14 alpha1 alpha2 alpha3 alpha4 "
+              "beta11 beta12 beta13 beta14 beta21 beta22 beta23 beta24 beta31 beta32 beta33 beta34 beta41 beta42 beta43 beta44").split()
+
+
+class SriTableau(C.Structure):
+    _fields_ = [(n, C.c_float) for n in SRI_FIELDS]
+
+
+def sri_step(drift, diffusion, tableau, uprev, dW, dZ, t, dt, abstol, reltol, delta):
+    """src/perform_step.jl:49-106 with a caller-supplied tableau (dict keyed by SRI_FIELDS)"""
+    uprev = _f32(uprev); dW = _f32(dW); dZ = _f32(dZ)
+    B = uprev.size // drift.D
+    u = np.empty_like(uprev)
+    ee, rv = C.c_float(), C.c_float()
+    tab = SriTableau(*[float(tableau[k]) for k in SRI_FIELDS])
+    L = lib()
+    L.lro_sri_step.restype = C.c_int
+    L.lro_sri_step.argtypes = [C.POINTER(Field), C.POINTER(Field), C.POINTER(SriTableau), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                               C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                               C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    rc = L.lro_sri_step(C.byref(drift.field), C.byref(diffusion.field), C.byref(tab), _fp(uprev), _fp(dW), _fp(dZ), float(t),
+                        float(dt), float(abstol), float(reltol), float(delta), B, _fp(u), C.byref(ee), C.byref(rv))
+    assert rc == 0
+    return dict(u=u, eest=np.float32(ee.value), reg_val=np.float32(rv.value))
+
+
 def cifar_stem_forward(x, ps, bn_train=True, bn_state=None, eps=1e-5, return_state=False):
     """AugmenterLayer(Conv 3=>5) + BatchNorm(8): x (B,3,H,W) -> u0 (B,8,H,W) [, running statistics after the call]"""
     x = _f32(x); ps = _f32(ps)

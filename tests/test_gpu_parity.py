@@ -180,6 +180,28 @@ def test_sde_rkmil_step_bit_exact(oracle, gpu_pkg, D, H, B):
     assert got["eest"] == ref["eest"] and got["reg_val"] == ref["reg_val"], (got, ref["eest"], ref["reg_val"])
 
 
+@pytest.mark.parametrize("D,H,B", [(32, 64, 512), (32, 64, 37), (16, 16, 5)])
+def test_sde_sri_step_bit_exact(oracle, gpu_pkg, D, H, B):
+    """src/perform_step.jl:49-106 (FourStageSRIConstantCache, the step SOSRI runs) with a caller-supplied tableau: u bit
+    for bit, EEst and EEst*dt equal, against lro_sri_step on random coefficients (every term of every stage exercised)."""
+    import torch
+    from localregneuralde_jl_amd.layers import _mlp_desc
+    pd, pg, drift, diff = _sde_fields(oracle, D, H, seed=2)
+    rng = np.random.default_rng(17)
+    T = {k: float(v) for k, v in zip(oracle.SRI_FIELDS, rng.uniform(-0.8, 0.8, len(oracle.SRI_FIELDS)))}
+    u = rng.standard_normal((B, D)).astype(np.float32)
+    dt = np.float32(0.05)
+    dW = (rng.standard_normal((B, D)) * np.sqrt(dt)).astype(np.float32)
+    dZ = (rng.standard_normal((B, D)) * np.sqrt(dt)).astype(np.float32)
+    ref = oracle.sri_step(drift, diff, T, u, dW, dZ, 0.2, dt, 0.14, 0.14, 1.0 / 6.0)
+    h = gpu_pkg.SdeHandle(_mlp_desc(gpu_pkg.Chain(gpu_pkg.Dense(D, H, "tanh"), gpu_pkg.Dense(H, D))))
+    h.set_params(pd, pg)
+    got = h.sri_step(T, torch.from_numpy(u).cuda(), torch.from_numpy(dW).cuda(), torch.from_numpy(dZ).cuda(), 0.2, dt, 0.14, 0.14,
+                     1.0 / 6.0)
+    _eq(got["u"].cpu().numpy(), ref["u"], "u")
+    assert got["eest"] == ref["eest"] and got["reg_val"] == ref["reg_val"], (got["eest"], ref["eest"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("solver", ["EulerHeun", "RKMil"])
 def test_sde_solve_fixed_equals_the_step_loop(oracle, gpu_pkg, solver):

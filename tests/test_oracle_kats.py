@@ -217,3 +217,59 @@ def test_rkmil_step_is_milstein_for_linear_noise(oracle):
     res = (r["u"].astype(np.float64) - u) / (1e-2 + np.maximum(np.abs(u), np.abs(r["u"])) * 1e-2)
     assert abs(float(r["eest"]) - np.sqrt(np.mean(res ** 2))) <= 1e-5 * float(r["eest"])
     assert r["reg_val"] == np.float32(r["eest"] * dt)
+
+
+def _sri_zero_tableau():
+    return {k: 0.0 for k in "a021 a031 a032 a041 a042 a043 a121 a131 a132 a141 a142 a143 b021 b031 b032 b041 b042 b043 b121 b131 b132 "
+            "b141 b142 b143 c02 c03 c04 c11 c12 c13 c14 alpha1 alpha2 alpha3 alpha4 beta11 beta12 beta13 beta14 beta21 beta22 "
+            "beta23 beta24 beta31 beta32 beta33 beta34 beta41 beta42 beta43 beta44".split()}
+
+
+def test_sri_step_structure(oracle):
+    """src/perform_step.jl:49-106 with caller-supplied coefficients.  (1) alpha1 = beta11 = 1, everything else 0 is
+    Euler-Maruyama: u = uprev + dt f(uprev) + dW g(uprev), E2 = 0, E1 = dt (k1+k2+k3+k4).  (2) A random tableau against
+    a float64 numpy transcription of the reference's lines on a linear field (every H, E and chi term exercised)."""
+    O = oracle
+    a, b = -0.7, 0.4
+    drift = O.PyField(3, lambda u, t: np.float32(a) * u + np.float32(0.1 * t))
+    diff = O.PyField(3, lambda u, t: np.float32(b) * u)
+    rng = np.random.default_rng(1)
+    u = rng.uniform(0.5, 2.0, (5, 3)).astype(np.float32)
+    t, dt = np.float32(0.2), np.float32(0.01)
+    dW = (rng.standard_normal((5, 3)) * np.sqrt(dt)).astype(np.float32)
+    dZ = (rng.standard_normal((5, 3)) * np.sqrt(dt)).astype(np.float32)
+    T = _sri_zero_tableau(); T["alpha1"] = 1.0; T["beta11"] = 1.0
+    r = O.sri_step(drift, diff, T, u, dW, dZ, t, dt, 1e-2, 1e-2, 1.0 / 6.0)
+    em = u + dt * (np.float32(a) * u + np.float32(0.1 * t)) + dW * (np.float32(b) * u)
+    np.testing.assert_allclose(r["u"], em, rtol=2e-7)
+    f0 = a * u.astype(np.float64) + 0.1 * float(t)
+    E1 = float(dt) * 4 * f0  # all stages sit at uprev and time t (every a, b, c is zero)
+    res = (E1 / 6.0) / (1e-2 + np.maximum(np.abs(u), np.abs(r["u"])) * 1e-2)
+    assert abs(float(r["eest"]) - np.sqrt(np.mean(res ** 2))) <= 2e-6 * float(r["eest"])
+    assert r["reg_val"] == np.float32(r["eest"] * dt)
+    # random tableau vs a float64 transcription
+    T = {k: float(v) for k, v in zip(T.keys(), rng.uniform(-0.8, 0.8, len(T)))}
+    r = O.sri_step(drift, diff, T, u, dW, dZ, t, dt, 1e-2, 1e-2, 1.0 / 6.0)
+    U, W, Z, h, tt = u.astype(np.float64), dW.astype(np.float64), dZ.astype(np.float64), float(dt), float(t)
+    f = lambda x, s: a * x + 0.1 * s
+    g = lambda x, s: b * x
+    sq = np.sqrt(h)
+    chi1 = (W ** 2 - h) / (2 * sq); chi2 = (W + Z / np.sqrt(3.0)) / 2; chi3 = (W ** 3 - 3 * W * h) / (6 * h)
+    k1 = f(U, tt); g1 = g(U, tt + T["c11"] * h)
+    H01 = U + h * T["a021"] * k1 + T["b021"] * chi2 * g1; H11 = U + h * T["a121"] * k1 + sq * T["b121"] * g1
+    k2 = f(H01, tt + T["c02"] * h); g2 = g(H11, tt + T["c12"] * h)
+    H02 = U + h * (T["a031"] * k1 + T["a032"] * k2) + chi2 * (T["b031"] * g1 + T["b032"] * g2)
+    H12 = U + h * (T["a131"] * k1 + T["a132"] * k2) + sq * (T["b131"] * g1 + T["b132"] * g2)
+    k3 = f(H02, tt + T["c03"] * h); g3 = g(H12, tt + T["c13"] * h)
+    H03 = U + h * (T["a041"] * k1 + T["a042"] * k2 + T["a043"] * k3) + chi2 * (T["b041"] * g1 + T["b042"] * g2 + T["b043"] * g3)
+    H13 = U + h * (T["a141"] * k1 + T["a142"] * k2 + T["a143"] * k3) + sq * (T["b141"] * g1 + T["b142"] * g2 + T["b143"] * g3)
+    k4 = f(H03, tt + T["c04"] * h); g4 = g(H13, tt + T["c14"] * h)
+    E2 = chi2 * (T["beta31"] * g1 + T["beta32"] * g2 + T["beta33"] * g3 + T["beta34"] * g4) + \
+        chi3 * (T["beta41"] * g1 + T["beta42"] * g2 + T["beta43"] * g3 + T["beta44"] * g4)
+    un = U + h * (T["alpha1"] * k1 + T["alpha2"] * k2 + T["alpha3"] * k3 + T["alpha4"] * k4) + E2 + \
+        W * (T["beta11"] * g1 + T["beta12"] * g2 + T["beta13"] * g3 + T["beta14"] * g4) + \
+        chi1 * (T["beta21"] * g1 + T["beta22"] * g2 + T["beta23"] * g3 + T["beta24"] * g4)
+    np.testing.assert_allclose(r["u"], un, rtol=3e-6)
+    E1 = h * (k1 + k2 + k3 + k4)
+    res = (E1 / 6.0 + E2) / (1e-2 + np.maximum(np.abs(U), np.abs(un)) * 1e-2)
+    assert abs(float(r["eest"]) - np.sqrt(np.mean(res ** 2))) <= 1e-4 * float(r["eest"])
