@@ -1557,6 +1557,32 @@ __global__ void k_lincomb(LinArgs a) {
   }
 }
 
+// the same on four consecutive elements per thread, with all nk (+ base) 16-byte loads issued before the first use: the
+// scalar kernel's loop over the terms has a runtime trip count, so it read, waited and added one term at a time.
+// Unused term slots point at k[0] (host) and are skipped in the arithmetic, which is element for element the scalar one.
+__global__ void k_lincomb4(LinArgs a) {
+  const size_t n4 = a.n / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 kv[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) kv[j] = reinterpret_cast<const f32x4*>(a.k[j])[i];
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+    if (a.base) bs = reinterpret_cast<const f32x4*>(a.base)[i];
+    f32x4 r;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      if (a.nk == 1) r[h] = bs[h] + a.c[0] * kv[0][h];
+      else {
+        float s = a.c[0] * kv[0][h] + a.c[1] * kv[1][h];
+#pragma unroll
+        for (int j = 2; j < 7; ++j) s = j < a.nk ? s + a.c[j] * kv[j][h] : s;
+        r[h] = a.base ? bs[h] + a.dt * s : a.dt * s;
+      }
+    }
+    reinterpret_cast<f32x4*>(a.out)[i] = r;
+  }
+}
+
 __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* out3) {
   __shared__ double red[3][4];
 #pragma unroll
@@ -1584,26 +1610,41 @@ __global__ __launch_bounds__(256) void k_sums_init(const float* u0, const float*
   block_sum3(a0, a1, a2, part + (size_t)blockIdx.x * 3);
 }
 // error residual (src/perform_step.jl:21-27, 210-212) and the two stiffness sums (:40-47)
-struct ErrArgs { const float* uprev; const float* u; const float* k[7]; const float* g6; float dt, abstol, reltol; size_t n; double* part; };
+struct ErrArgs { const float* uprev; const float* u; const float* k[7]; const float* g6; float dt, abstol, reltol; size_t n; double* part; int vec4; };
 __global__ __launch_bounds__(256) void k_sums_err(ErrArgs a) {
   double e0 = 0.0, e1 = 0.0, e2 = 0.0;
   const float b0 = (float)Tsit5::BT[0], b1 = (float)Tsit5::BT[1], b2 = (float)Tsit5::BT[2], b3 = (float)Tsit5::BT[3],
               b4 = (float)Tsit5::BT[4], b5 = (float)Tsit5::BT[5], b6 = (float)Tsit5::BT[6];
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
-    float s = b0 * a.k[0][i] + b1 * a.k[1][i];
-    s = s + b2 * a.k[2][i];
-    s = s + b3 * a.k[3][i];
-    s = s + b4 * a.k[4][i];
-    s = s + b5 * a.k[5][i];
-    s = s + b6 * a.k[6][i];
+  auto one = [&](float k0, float k1, float k2, float k3, float k4, float k5, float k6, float up, float un, float g6v) {
+    float s = b0 * k0 + b1 * k1;
+    s = s + b2 * k2;
+    s = s + b3 * k3;
+    s = s + b4 * k4;
+    s = s + b5 * k5;
+    s = s + b6 * k6;
     const float ut = a.dt * s;
-    const float sc = a.abstol + fmaxf_(__builtin_fabsf(a.uprev[i]), __builtin_fabsf(a.u[i])) * a.reltol;
+    const float sc = a.abstol + fmaxf_(__builtin_fabsf(up), __builtin_fabsf(un)) * a.reltol;
     const float r = ut / sc;
     const float q = r * r;
     e0 += (double)q;
-    const float d1 = a.k[6][i] - a.k[5][i], d2 = a.u[i] - a.g6[i];
+    const float d1 = k6 - k5, d2 = un - g6v;
     const float q1 = d1 * d1, q2 = d2 * d2;
     e1 += (double)q1; e2 += (double)q2;
+  };
+  if (a.vec4) {  // 16-byte loads, ten of them in flight per thread (n % 4 == 0, 16-byte aligned vectors)
+    const size_t n4 = a.n / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+      f32x4 kv[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) kv[j] = reinterpret_cast<const f32x4*>(a.k[j])[i];
+      const f32x4 up = reinterpret_cast<const f32x4*>(a.uprev)[i], un = reinterpret_cast<const f32x4*>(a.u)[i],
+                  g6 = reinterpret_cast<const f32x4*>(a.g6)[i];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) one(kv[0][h], kv[1][h], kv[2][h], kv[3][h], kv[4][h], kv[5][h], kv[6][h], up[h], un[h], g6[h]);
+    }
+  } else {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x)
+      one(a.k[0][i], a.k[1][i], a.k[2][i], a.k[3][i], a.k[4][i], a.k[5][i], a.k[6][i], a.uprev[i], a.u[i], a.g6[i]);
   }
   block_sum3(e0, e1, e2, a.part + (size_t)blockIdx.x * 3);
 }
@@ -1938,6 +1979,15 @@ int lincomb(lrnde_conv* c, float* out, const float* base, float dt, int nk, cons
   LinArgs a;
   a.out = out; a.base = base; a.dt = dt; a.nk = nk; a.n = n;
   for (int j = 0; j < 7; ++j) { a.k[j] = j < nk ? k[j] : nullptr; a.c[j] = j < nk ? coef[j] : 0.f; }
+  bool vec = n % 4 == 0 && ((uintptr_t)out % 16) == 0 && (!base || ((uintptr_t)base % 16) == 0);
+  for (int j = 0; j < nk; ++j) vec = vec && ((uintptr_t)k[j] % 16) == 0;
+  if (vec) {
+    for (int j = nk; j < 7; ++j) a.k[j] = k[0];  // loaded, not used
+    int nb4 = (int)((n / 4 + 255) / 256); if (nb4 > 2048) nb4 = 2048;
+    hipLaunchKernelGGL(k_lincomb4, dim3(nb4), dim3(256), 0, c->stream, a);
+    CHK(c, hipGetLastError());
+    return LRNDE_OK;
+  }
   int nb = (int)((n + 255) / 256); if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(k_lincomb, dim3(nb), dim3(256), 0, c->stream, a);
   CHK(c, hipGetLastError());
@@ -2005,6 +2055,9 @@ int tsit5_step_g(lrnde_conv* c, size_t n, RHS&& rhs, const float* uprev, const f
   ErrArgs e;
   e.uprev = uprev; e.u = u; for (int j = 0; j < 7; ++j) e.k[j] = K[j];
   e.g6 = g6; e.dt = dt; e.abstol = abstol; e.reltol = reltol; e.n = n; e.part = c->sums;
+  bool v4 = n % 4 == 0 && ((uintptr_t)uprev % 16) == 0 && ((uintptr_t)u % 16) == 0 && ((uintptr_t)g6 % 16) == 0;
+  for (int j = 0; j < 7; ++j) v4 = v4 && ((uintptr_t)K[j] % 16) == 0;
+  e.vec4 = v4 ? 1 : 0;
   hipLaunchKernelGGL(k_sums_err, dim3(NSUMB), dim3(256), 0, c->stream, e);
   CHK(c, hipGetLastError());
   return fetch_sums(c, sums3);
