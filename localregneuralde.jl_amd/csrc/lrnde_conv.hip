@@ -1813,7 +1813,8 @@ int launch_rhs_ex(lrnde_conv* c, const float* u, float t, int B, float* du, bool
   const bool train = c->d.bn_train != 0;
   const double count = (double)B * c->d.width * c->d.height;
   ConvArgs a = base_args(c, B);
-  a.dbg = getenv("LRNDE_CONV_DBG") ? atoi(getenv("LRNDE_CONV_DBG")) : 0;
+  static const int conv_dbg = getenv("LRNDE_CONV_DBG") ? atoi(getenv("LRNDE_CONV_DBG")) : 0;  // phase switches of the timing experiments
+  a.dbg = conv_dbg;
   const int rows = a.TR + 2, WP = a.W + 2;
   // conv1: state -> y1
   a.CIN = C; a.CINP = cinp_of(C); a.COUT = Hc; a.in = u; a.out = c->y1; a.wpk = c->w1; a.tsum = c->ts1; a.t = t;

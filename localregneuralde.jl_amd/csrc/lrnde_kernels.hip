@@ -1560,7 +1560,8 @@ bool use_qtile(const lrnde_ctx* c, int B) {
   // streaming path shape limits: one Dense-1 segment and one Dense-2 pass per wave
   const bool shape_ok = (D % 4 == 0) && (H <= 112) && (c->m.KQ1p / QSEG <= QNW) && (c->m.RG1 <= 2) &&
                         (c->m.RG2 <= 2 * QNW);
-  return shape_ok && ((double)B * D * 40.0 < 2147483000.0) && B <= qmax && !getenv("LRNDE_NO_QTILE");
+  static const bool no_qtile = getenv("LRNDE_NO_QTILE") != nullptr;
+  return shape_ok && ((double)B * D * 40.0 < 2147483000.0) && B <= qmax && !no_qtile;
 }
 inline int tile_nb(const lrnde_ctx* c, int B) { return use_qtile(c, B) ? QNB : NB; }
 
@@ -1601,7 +1602,8 @@ void fill_args(lrnde_ctx* c, StepArgs& a, int B, int force_nb = 0) {
   const int nwg = (B + nb - 1) / nb;
   a.m = c->m;
   a.state = c->state; a.n_local = (long)n;
-  a.fused = (c->desc.state_dim % 16 == 0) && ((double)n * 40.0 < 2147483000.0) && !getenv("LRNDE_NO_FUSE");
+  static const bool no_fuse = getenv("LRNDE_NO_FUSE") != nullptr;
+  a.fused = (c->desc.state_dim % 16 == 0) && ((double)n * 40.0 < 2147483000.0) && !no_fuse;
   a.ubuf[0] = c->state; a.ubuf[1] = c->state + n;
   a.kfsal[0] = c->state + 2 * n; a.kfsal[1] = c->state + 3 * n;
   for (int i = 0; i < 5; ++i) a.ks[i] = c->state + (4 + i) * n;
@@ -2494,7 +2496,10 @@ static int launch_pgrad(lrnde_ctx* c, int B, float t, const float* lam, float* g
 struct StageIn { const float* base; float dt; int nk; const float* k[6]; float c[6]; float* lam_out; };
 
 // dy = J^T lam at (y or the interpolated dense step, t);  gp (optional) = (df/dp)^T lam
-static bool vjp_uses_qtile(const lrnde_ctx* c, int B) { return use_qtile(c, B) && !getenv("LRNDE_NO_QVJP"); }
+static bool vjp_uses_qtile(const lrnde_ctx* c, int B) {
+  static const bool no_qvjp = getenv("LRNDE_NO_QVJP") != nullptr;
+  return use_qtile(c, B) && !no_qvjp;
+}
 static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float theta, float dense_dt, float t,
                       const float* lam, int B, float* dy, float* gp, const StageIn* sin = nullptr) {
   int rc = ensure_bw(c, B);
