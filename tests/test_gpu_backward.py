@@ -91,6 +91,22 @@ def test_classifier_ce_matches_oracle(oracle, gpu_pkg):
     np.testing.assert_allclose(r["dpc"].cpu().numpy(), dpc, rtol=0, atol=2e-5 * np.abs(dpc).max())
 
 
+def test_full_size_mnist_b512_backward(oracle, gpu_pkg):
+    """The metric's configuration (MNIST-ODE MLP field, B=512): continuous adjoint + regulariser sweep against the oracle
+    at abstol=reltol=1e-5 with a unit-scale cotangent; the fused stage combination and the deferred parameter-gradient
+    GEMMs run here on all 128 workgroups."""
+    import torch
+    fld, h, p, x = _mk(oracle, gpu_pkg, 784, 100, 512, "tanh", True, scale=1.5)
+    g = np.random.default_rng(14).standard_normal(x.shape).astype(np.float32)
+    ref = oracle.node_backward(fld, x, 0.0, 1.0, 1e-5, 1e-5, g, mode="unbiased", t1_or_rand=0.43, w_reg=2.5)
+    got = h.node_backward(torch.from_numpy(x).cuda(), 0.0, 1.0, 1e-5, 1e-5, torch.from_numpy(g).cuda(), mode="unbiased",
+                          t1_or_rand=0.43, w_reg=2.5, maxiters=10000)
+    assert ref["retcode"] == 0 and got["stats_fwd"]["naccept"] == ref["stats_fwd"]["naccept"]   # the forward is bit-exact
+    # the two adjoint solves are adaptive on summation-order-dependent norms: their step sequences may differ by a few steps
+    assert abs(got["stats_bwd"]["naccept"] - ref["stats_bwd"]["naccept"]) <= 4
+    assert _rel(got["dx"].cpu().numpy(), ref["dx"]) < 2e-4 and _rel(got["dp"].cpu().numpy(), ref["dp"]) < 2e-4
+
+
 def test_training_step_matches_oracle_and_one_call_backward(oracle, gpu_pkg):
     """run_training_step (experiments/src/utils.jl:104-123): forward with record, classifier + CE, recorded backward
     == the one-call lrnde_node_backward with the same du_end, and == the oracle's gradients."""
