@@ -497,3 +497,35 @@ def test_conv_feval_and_vjp_are_run_to_run_deterministic(dtype):
         lam = torch.ones_like(u)
         d1, g1 = h.vjp(u, 0.3, lam); d2, g2 = h.vjp(u, 0.3, lam)
         assert torch.equal(d1, d2) and torch.equal(g1, g2)
+
+
+# ---- size-independent properties at BASELINE's full conv shapes (the oracle needs minutes there) ----
+def test_conv_full_size_properties():
+    """CIFAR10 block 32x32x8, B=256 (BASELINE config 4) and the 28x28 B=512 field (config 2-ii):
+    (1) with running statistics the field is per-sample: f(u)[rows] == f(u[rows]) bit for bit, whatever else is in the batch;
+    (2) the VJP is linear in the cotangent and satisfies <w, J v> = <J^T w, v> against a central difference of the field;
+    (3) with batch statistics a permutation of the batch permutes the output (to the summation-order tolerance)."""
+    P, O = _mods()
+    rng = np.random.default_rng(21)
+    for (W, H, B) in ((32, 32, 256), (28, 28, 512)):
+        p = P.glorot_conv_params(8, 64, seed=1)
+        u = torch.from_numpy(rng.standard_normal((B, 8, H, W)).astype(np.float32)).cuda()
+        he = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=False)
+        he.set_params(p)
+        full = he.rhs(u, 0.3)
+        rows = torch.tensor([0, 3, B // 2, B - 1], device="cuda")
+        assert torch.equal(full[rows], he.rhs(u[rows].contiguous(), 0.3))
+        ht = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=True)
+        ht.set_params(p)
+        w1 = torch.from_numpy(rng.standard_normal(u.shape).astype(np.float32)).cuda()
+        w2 = torch.from_numpy(rng.standard_normal(u.shape).astype(np.float32)).cuda()
+        d1, g1 = ht.vjp(u, 0.3, w1); d2, g2 = ht.vjp(u, 0.3, w2); d12, g12 = ht.vjp(u, 0.3, w1 + w2)
+        assert _rel((d1 + d2).cpu().numpy(), d12.cpu().numpy()) <= 2e-5 and _rel((g1 + g2).cpu().numpy(), g12.cpu().numpy()) <= 2e-5
+        v = torch.from_numpy(rng.standard_normal(u.shape).astype(np.float32)).cuda()
+        eps = 1e-2
+        jv = (ht.rhs(u + eps * v, 0.3).double() - ht.rhs(u - eps * v, 0.3).double()) / (2 * eps)
+        lhs = float((w1.double() * jv).sum()); rhs = float((d1.double() * v.double()).sum())
+        assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs)), (lhs, rhs)
+        perm = torch.from_numpy(rng.permutation(B)).cuda()
+        fa = ht.rhs(u, 0.3); fb = ht.rhs(u[perm].contiguous(), 0.3)
+        assert _rel(fb.cpu().numpy(), fa[perm].cpu().numpy()) <= 1e-5
