@@ -1402,6 +1402,20 @@ __global__ void k_finalize(StepArgs a, int j) {
   }
 }
 
+// the SDE steps' own footer for lrnde_sde_solve_fixed: EEst and EEst*dt of the step just run into a record slot (no
+// integrator state is involved: the step kernels take t and dt as arguments)
+__global__ void k_sde_record(StepArgs a, float dt, Ctrl* rec) {
+  if (threadIdx.x >= 64) return;
+  double s[3];
+  reduce_partials(a.part_recv + (size_t)a.nwg_global * PSTRIDE, a.nwg_global, s);
+  if (threadIdx.x == 0) {
+    const float eest = rms_from(s[0], a.n_global);
+    rec->eest_last = eest;
+    rec->reg_error = eest * dt;
+    rec->status = ST_DONE;
+  }
+}
+
 __global__ void k_ctrl_init(Ctrl* ctrl, float t0, float dt, int cur, int nsaved) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   Ctrl c;
@@ -2243,9 +2257,8 @@ int lrnde_sde_rkmil_step(lrnde_sde* s, const float* uprev, const float* dW, int3
   return sde_step_impl(s, 1, uprev, dW, B, t, dt, abstol, reltol, 0.f, u, eest_host, reg_val_host);
 }
 // one step on the stream, its Ctrl record copied to `rec` (pinned host) without waiting
-__global__ void k_ctrl_copy(const Ctrl* src, Ctrl* dst) { *dst = *src; }
-// one step on the stream; its Ctrl record goes to `rec` (pinned host, async copy) or to `rec_dev` (device slot, a
-// one-thread kernel: an async device-to-host copy per step costs more than the step)
+// one step on the stream; its record goes to `rec` (pinned host: integrator-state footer k_finalize + async copy) or to
+// the device slot `rec_dev` (k_sde_record: two launches per step, no copy)
 static int sde_step_enqueue(lrnde_sde* s, int which, const float* uprev, const float* dW, int32_t B, float t, float dt,
                             float abstol, float reltol, float delta, float* u, Ctrl* rec, Ctrl* rec_dev = nullptr) {
   lrnde_ctx* c = s->drift;
@@ -2259,7 +2272,7 @@ static int sde_step_enqueue(lrnde_sde* s, int which, const float* uprev, const f
   size_t sm = smem_bytes(c->m.Dp, c->m.Hp);
   const size_t sm2 = smem_bytes(s->diff->m.Dp, s->diff->m.Hp);
   if (sm2 > sm) sm = sm2;
-  hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t, dt, 0, 0);
+  if (!rec_dev) hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t, dt, 0, 0);
   if (which == 1) {
     if (vecw(c) == 4) hipLaunchKernelGGL(k_sde_rkmil<4>, dim3(nwg), dim3(NT), sm, c->stream, a);
     else hipLaunchKernelGGL(k_sde_rkmil<1>, dim3(nwg), dim3(NT), sm, c->stream, a);
@@ -2268,8 +2281,8 @@ static int sde_step_enqueue(lrnde_sde* s, int which, const float* uprev, const f
   HIPCHK(c, hipGetLastError());
   const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
   if ((rc = exchange(c, c->part + cnt, c->part_rx + cnt, cnt))) return rc;
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, a, 1);
-  if (rec_dev) hipLaunchKernelGGL(k_ctrl_copy, dim3(1), dim3(1), 0, c->stream, (const Ctrl*)(c->ctrl + 1), rec_dev);
+  if (rec_dev) hipLaunchKernelGGL(k_sde_record, dim3(1), dim3(64), 0, c->stream, a, dt, rec_dev);  // two launches per step
+  else hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, a, 1);
   HIPCHK(c, hipGetLastError());
   if (rec) HIPCHK(c, hipMemcpyAsync(rec, c->ctrl + 1, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
   return LRNDE_OK;
