@@ -347,6 +347,26 @@ __global__ __launch_bounds__(256) void k_norm(NormArgs a) {
   if (threadIdx.x == 0) a.part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// both parts of the augmented vector in one launch: blocks 0..255 the lambda part (a), blocks 256..511 the mu part (b)
+__global__ __launch_bounds__(256) void k_norm2(NormArgs a, NormArgs b) {
+  __shared__ double red[4];
+  const bool second = blockIdx.x >= 256;
+  const NormArgs& g = second ? b : a;
+  const unsigned bx = second ? blockIdx.x - 256 : blockIdx.x;
+  double acc = 0.0;
+  for (size_t i = bx * (size_t)blockDim.x + threadIdx.x; i < g.n; i += (size_t)256 * blockDim.x) {
+    const float v = g.num2 ? g.num[i] - g.num2[i] : g.num[i];
+    const float sa = __builtin_fabsf(g.sa[i]), sb = g.sb ? __builtin_fabsf(g.sb[i]) : sa;
+    const float sc = g.abstol + fmaxf_(sa, sb) * g.reltol;
+    const float r = v / sc;
+    acc += (double)(r * r);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) g.part[bx] = red[0] + red[1] + red[2] + red[3];
+}
+
 // the rank's own fp64 sum (256 block partials, fixed order) into slot[rank] of a zeroed per-rank vector: the
 // all-reduce (sum) of that vector is the exact gather
 __global__ void k_rank_slot(const double* part, double* slots, int rank, int nranks) {

@@ -1526,6 +1526,7 @@ struct lrnde_ctx {
   float* usave = nullptr;  // internal save slots for node_forward
   size_t usave_slots = 0, usave_slot_elems = 0;
   Ctrl* ctrl_host = nullptr;  // pinned [2]
+  hipEvent_t ev_norm = nullptr;  // vec_norm's read-back
   // comm
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
@@ -1808,6 +1809,7 @@ int lrnde_destroy(lrnde_ctx* c) {
                   c->usave};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ctrl_host) hipHostFree(c->ctrl_host);
+  if (c->ev_norm) hipEventDestroy(c->ev_norm);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->evp[0]) hipEventDestroy(c->evp[0]);
@@ -2613,12 +2615,13 @@ int vec_norm(lrnde_ctx* c, const float* num, const float* num2, const float* sa,
              float reltol, size_t n_lam, size_t P, float* out) {
   NormArgs a;
   a.num = num; a.num2 = num2; a.sa = sa; a.sb = sb; a.abstol = abstol; a.reltol = reltol; a.n = n_lam; a.part = c->adj_part;
-  hipLaunchKernelGGL(k_norm, dim3(256), dim3(256), 0, c->stream, a);
-  if (P) {
+  if (P) {  // one launch for both parts (same per-block sums as two k_norm launches)
     NormArgs b = a;
     b.num = num + n_lam; b.num2 = num2 ? num2 + n_lam : nullptr; b.sa = sa + n_lam; b.sb = sb ? sb + n_lam : nullptr;
     b.n = P; b.part = c->adj_part + 256;
-    hipLaunchKernelGGL(k_norm, dim3(256), dim3(256), 0, c->stream, b);
+    hipLaunchKernelGGL(k_norm2, dim3(512), dim3(256), 0, c->stream, a, b);
+  } else {
+    hipLaunchKernelGGL(k_norm, dim3(256), dim3(256), 0, c->stream, a);
   }
   HIPCHK(c, hipGetLastError());
   const int nr = c->comm ? c->nranks : 1;
@@ -2628,7 +2631,14 @@ int vec_norm(lrnde_ctx* c, const float* num, const float* num2, const float* sa,
     NCCLCHK(c, ncclAllReduce(c->adj_part + 512, c->adj_part + 512, nr, ncclDouble, ncclSum, c->comm, c->stream));
   }
   HIPCHK(c, hipMemcpyAsync(c->adj_part_host, c->adj_part, sizeof(double) * (512 + 64), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // the controller waits for this read-back once per adjoint step: poll an event instead of a blocking stream wait
+  if (!c->ev_norm) HIPCHK(c, hipEventCreateWithFlags(&c->ev_norm, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->ev_norm, c->stream));
+  for (;;) {
+    const hipError_t q = hipEventQuery(c->ev_norm);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) return fail(c, LRNDE_HIP_ERROR, "waiting for the norm read-back: %s", hipGetErrorString(q));
+  }
   double s = 0.0;
   if (c->comm) { for (int r = 0; r < nr; ++r) s += c->adj_part_host[512 + r]; }
   else { for (int i = 0; i < 256; ++i) s += c->adj_part_host[i]; }
