@@ -367,6 +367,49 @@ __global__ __launch_bounds__(256) void k_norm2(NormArgs a, NormArgs b) {
   if (threadIdx.x == 0) g.part[bx] = red[0] + red[1] + red[2] + red[3];
 }
 
+// End of an adjoint Tsit5 step in one launch: utilde = dt * sum btilde_j K_j is formed on the fly (the arithmetic of
+// k_axpy without a base) and goes straight into the error norm's per-block sums (those of k_norm2) without being stored;
+// the mu part of u_{n+1} (its lambda part is stage 7's input, already written by the VJP) is formed here too.
+struct AdjErrArgs {
+  const float* K[7]; float BT[7], A7[6]; float dt;
+  const float* z; float* zn; size_t n_lam, P; float abstol, reltol; double* part;
+};
+__global__ __launch_bounds__(256) void k_adj_err(AdjErrArgs a) {
+  __shared__ double red[4];
+  const bool second = blockIdx.x >= 256;
+  const unsigned bx = second ? blockIdx.x - 256 : blockIdx.x;
+  const size_t off = second ? a.n_lam : 0, cnt = second ? a.P : a.n_lam;
+  double acc = 0.0;
+  for (size_t j = bx * (size_t)blockDim.x + threadIdx.x; j < cnt; j += (size_t)256 * blockDim.x) {
+    const size_t i = off + j;
+    float kv[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) kv[q] = a.K[q][i];
+    const float zv = a.z[i];
+    float znv;
+    if (second) {
+      float s = a.A7[0] * kv[0];
+#pragma unroll
+      for (int q = 1; q < 6; ++q) s = s + a.A7[q] * kv[q];
+      znv = zv + a.dt * s;
+      a.zn[i] = znv;
+    } else {
+      znv = a.zn[i];
+    }
+    float s = a.BT[0] * kv[0];
+#pragma unroll
+    for (int q = 1; q < 7; ++q) s = s + a.BT[q] * kv[q];
+    const float ut = 0.f + a.dt * s;
+    const float sc = a.abstol + fmaxf_(__builtin_fabsf(zv), __builtin_fabsf(znv)) * a.reltol;
+    const float r = ut / sc;
+    acc += (double)(r * r);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) a.part[(second ? 256 : 0) + bx] = red[0] + red[1] + red[2] + red[3];
+}
+
 // the rank's own fp64 sum (256 block partials, fixed order) into slot[rank] of a zeroed per-rank vector: the
 // all-reduce (sum) of that vector is the exact gather
 __global__ void k_rank_slot(const double* part, double* slots, int rank, int nranks) {

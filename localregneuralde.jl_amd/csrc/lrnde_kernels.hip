@@ -2611,6 +2611,7 @@ int vec_axpy(lrnde_ctx* c, float* out, const float* base, float dt, int nk, cons
 // sqrt(sum(((num[-num2]) / (abstol + max(|sa|,|sb|)*reltol))^2) / n_total), fp64 accumulation, over the augmented
 // vector [lambda; mu]: the lambda part is summed over all ranks (exact gather of one fp64 sum per rank, added in
 // rank order), the replicated mu part is counted once; n_total = n_lam * nranks + P.
+int norm_readback(lrnde_ctx* c, size_t n_lam, size_t P, float* out);
 int vec_norm(lrnde_ctx* c, const float* num, const float* num2, const float* sa, const float* sb, float abstol,
              float reltol, size_t n_lam, size_t P, float* out) {
   NormArgs a;
@@ -2624,6 +2625,10 @@ int vec_norm(lrnde_ctx* c, const float* num, const float* num2, const float* sa,
     hipLaunchKernelGGL(k_norm, dim3(256), dim3(256), 0, c->stream, a);
   }
   HIPCHK(c, hipGetLastError());
+  return norm_readback(c, n_lam, P, out);
+}
+// the per-block sums in c->adj_part (lambda part [0,256), mu part [256,512)) -> the rms over [lambda of all ranks; mu]
+int norm_readback(lrnde_ctx* c, size_t n_lam, size_t P, float* out) {
   const int nr = c->comm ? c->nranks : 1;
   if (c->comm) {
     if (nr > 64) return fail(c, LRNDE_UNSUPPORTED, "more than 64 ranks");
@@ -2734,17 +2739,24 @@ int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, RHSF rhs_fused, bool fuse_
       if ((rc = vec_axpy(c, out, z, dt, sidx - 1, K, A + off, N))) return rc;
       if ((rc = rhs(out, t + cs[sidx - 2] * dt, K[sidx - 1]))) return rc;
     }
-    if (fuse_stage) {
+    st->nf += 6;
+    float eest;
+    if (fuse_stage && v.P) {
       if ((rc = flush_pgrad(c))) return rc;
       c->pg_defer = false;
-      float* Kmu[7];
-      for (int j = 0; j < 7; ++j) Kmu[j] = K[j] + v.n_lam;
-      if (v.P && (rc = vec_axpy(c, zn + v.n_lam, z + v.n_lam, dt, 6, Kmu, A + 15, v.P))) return rc;  // mu part of u_{n+1}
+      // mu part of u_{n+1}, utilde and the error norm's sums in one launch (k_adj_err: the values of k_axpy + k_norm2)
+      AdjErrArgs e;
+      for (int j = 0; j < 7; ++j) { e.K[j] = K[j]; e.BT[j] = BT[j]; }
+      for (int j = 0; j < 6; ++j) e.A7[j] = A[15 + j];
+      e.dt = dt; e.z = z; e.zn = zn; e.n_lam = v.n_lam; e.P = v.P; e.abstol = abstol; e.reltol = reltol; e.part = c->adj_part;
+      hipLaunchKernelGGL(k_adj_err, dim3(512), dim3(256), 0, c->stream, e);
+      HIPCHK(c, hipGetLastError());
+      if ((rc = norm_readback(c, v.n_lam, v.P, &eest))) return rc;
+    } else {
+      if (fuse_stage) { if ((rc = flush_pgrad(c))) return rc; c->pg_defer = false; }
+      if ((rc = vec_axpy(c, v.ut, nullptr, dt, 7, K, BT, N))) return rc;
+      if ((rc = vec_norm(c, v.ut, nullptr, z, zn, abstol, reltol, v.n_lam, v.P, &eest))) return rc;
     }
-    st->nf += 6;
-    if ((rc = vec_axpy(c, v.ut, nullptr, dt, 7, K, BT, N))) return rc;
-    float eest;
-    if ((rc = vec_norm(c, v.ut, nullptr, z, zn, abstol, reltol, v.n_lam, v.P, &eest))) return rc;
     st->eest_last = eest;
     if (eest != eest) { rc = LRNDE_DT_NAN; break; }
     const float ttmp = t + dt;
