@@ -228,11 +228,21 @@ __device__ __forceinline__ void block_sum3(double* red, double& a, double& b, do
 __device__ __forceinline__ void reduce_partials(const double* p, int nwg, double out[3]) {
   const int lane = threadIdx.x & 63;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int i = lane; i < nwg; i += 64) {
-    // agent-scope loads: the vector was written by the previous launch / by RCCL
-    s0 += __hip_atomic_load(p + (size_t)i * PSTRIDE + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s1 += __hip_atomic_load(p + (size_t)i * PSTRIDE + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s2 += __hip_atomic_load(p + (size_t)i * PSTRIDE + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // agent-scope loads (the vector was written by the previous launch / by RCCL), four workgroups' triples per lane in
+  // flight at once: this reduction opens every step launch, one round trip per loop trip was on its critical path.
+  // The adds run in the same order as a plain loop over i = lane, lane + 64, ...
+  for (int i0 = lane; i0 < nwg; i0 += 256) {
+    double v[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 64 * u;
+      const size_t o = (size_t)(i < nwg ? i : i0) * PSTRIDE;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) v[u][q] = __hip_atomic_load(p + o + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + 64 * u < nwg) { s0 += v[u][0]; s1 += v[u][1]; s2 += v[u][2]; }
   }
   s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
   out[0] = __shfl(s0, 0, 64); out[1] = __shfl(s1, 0, 64); out[2] = __shfl(s2, 0, 64);
