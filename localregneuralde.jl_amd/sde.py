@@ -107,13 +107,19 @@ class NeuralDSDE:
     src/layers/neural_sde.jl:1-123 with a fixed-grid Euler-Heun integrator (see module docstring)."""
 
     def __init__(self, drift, diffusion, *, solver="EulerHeun", sensealg=None, tspan=(0.0, 1.0),
-                 regularize="unbiased", maxiters=1000, nsteps=20, delta=1.0 / 6.0, **kwargs):
+                 regularize="unbiased", maxiters=1000, nsteps=20, delta=1.0 / 6.0, tableau=None, **kwargs):
         regularize = _sym(regularize)
         _check_valid_regularize(regularize)
-        if solver not in ("EulerHeun", "LambaEulerHeun", "RKMil", "RKMilCommute"):
-            raise NotImplementedError("on the device: the Euler-Heun step (src/perform_step.jl:172-206) and the Milstein step "
-                                      "(:108-170); SOSRI's tableau lives in un-vendored StochasticDiffEq")
-        self.solver = "RKMil" if solver.startswith("RKMil") else "EulerHeun"
+        if solver in ("SRI", "FourStageSRI"):
+            if tableau is None:
+                raise ValueError("solver='SRI' (src/perform_step.jl:49-106) needs tableau=: the 51 coefficients of the "
+                                 "FourStageSRIConstantCache (SOSRI's live in un-vendored StochasticDiffEq)")
+        elif solver not in ("EulerHeun", "LambaEulerHeun", "RKMil", "RKMilCommute"):
+            raise NotImplementedError("on the device: the Euler-Heun step (src/perform_step.jl:172-206), the Milstein step "
+                                      "(:108-170) and the four-stage SRI step (:49-106, solver='SRI' with tableau=); SOSRI's own "
+                                      "tableau and adaptive noise process live in un-vendored StochasticDiffEq")
+        self.solver = "SRI" if solver in ("SRI", "FourStageSRI") else ("RKMil" if solver.startswith("RKMil") else "EulerHeun")
+        self.tableau = tableau
         if not isinstance(diffusion, Dense) or diffusion.in_dims != diffusion.out_dims:
             raise NotImplementedError("diffusion must be Dense(D => D) (experiments/src/construct.jl:205)")
         self.drift, self.diffusion = drift, diffusion
@@ -146,14 +152,23 @@ class NeuralDSDE:
         if noise is None:  # W.dW ~ sqrt(dt) N(0,1), drawn on the host stream
             noise = (rng.standard_normal((n + 1,) + tuple(x.shape)).astype(np.float32) * np.float32(np.sqrt(dt)))
         noise = torch.as_tensor(noise, dtype=torch.float32).to(x.device)
-        if self.solver == "RKMil":
-            step = lambda uu, dw, tt: h.rkmil_step(uu, dw, tt, dt, abstol, reltol)
+        # step(u, i, t): one step with the i-th increments of the noise process
+        if self.solver == "SRI":  # second increment dZ (W.dZ), drawn after dW from the same host stream
+            dz = torch.as_tensor(rng.standard_normal((n + 1,) + tuple(x.shape)).astype(np.float32) * np.float32(np.sqrt(dt))).to(x.device)
+            step = lambda uu, i, tt: h.sri_step(self.tableau, uu, noise[i].contiguous(), dz[i].contiguous(), tt, dt, abstol, reltol, self.delta)
+            us, u = [], x
+            for i in range(n):
+                u = step(u, i, np.float32(t0 + np.float32(i) * dt))["u"]
+                us.append(u)
         else:
-            step = lambda uu, dw, tt: h.euler_heun_step(uu, dw, tt, dt, abstol, reltol, self.delta)
-        traj = h.solve_fixed(x, noise[:n], t0, dt, abstol, reltol, self.delta, self.solver)  # the n steps, one host sync
-        us = [traj["u"][i] for i in range(n)]
+            if self.solver == "RKMil":
+                step = lambda uu, i, tt: h.rkmil_step(uu, noise[i].contiguous(), tt, dt, abstol, reltol)
+            else:
+                step = lambda uu, i, tt: h.euler_heun_step(uu, noise[i].contiguous(), tt, dt, abstol, reltol, self.delta)
+            traj = h.solve_fixed(x, noise[:n], t0, dt, abstol, reltol, self.delta, self.solver)  # the n steps, one host sync
+            us = [traj["u"][i] for i in range(n)]
         ts = [np.float32(t0 + np.float32(i + 1) * dt) if i + 1 < n else t2 for i in range(n)]
-        per_step = (1, 2) if self.solver == "RKMil" else (3, 3)  # (drift, diffusion) evaluations of one step
+        per_step = {"RKMil": (1, 2), "SRI": (4, 4)}.get(self.solver, (3, 3))  # (drift, diffusion) evaluations of one step
         nfe, nfe_g = per_step[0] * n, per_step[1] * n
         mode = self.regularize if st["training"] else "none"
         reg_val = np.float32(0.0)
@@ -168,7 +183,7 @@ class NeuralDSDE:
             else:  # :109-123: a saved time other than the last
                 j = int(rng.integers(0, max(n - 1, 1)))
                 t1, u1 = ts[j], us[j]
-            r = step(u1, noise[n].contiguous(), t1)  # :98,118
+            r = step(u1, n, t1)  # :98,118
             reg_val = r["reg_val"]
             nfe += per_step[0]; nfe_g += per_step[1]
         sol = ODESolution([us[-1]], [t2], nfe)

@@ -290,6 +290,15 @@ def test_neural_dsde_forward_behaviour(oracle, gpu_pkg):
     _eq(outs["none"][0], u, "NeuralDSDE end state")
     with pytest.raises(NotImplementedError):
         gpu_pkg.NeuralDSDE(gpu_pkg.Chain(gpu_pkg.Dense(D, H), gpu_pkg.Dense(H, D)), gpu_pkg.Dense(D, D), solver="SOSRI")
+    # the four-stage SRI step with a caller-supplied tableau: same layer behaviour, 4 + 4 evaluations per step
+    T = {k: float(v) for k, v in zip(oracle.SRI_FIELDS, np.random.default_rng(5).uniform(-0.5, 0.5, len(oracle.SRI_FIELDS)))}
+    node = gpu_pkg.NeuralDSDE(gpu_pkg.Chain(gpu_pkg.Dense(D, H, "tanh"), gpu_pkg.Dense(H, D)), gpu_pkg.Dense(D, D), solver="SRI",
+                              tableau=T, regularize="unbiased", nsteps=n, abstol=0.14, reltol=0.14)
+    sol, st2 = node(torch.from_numpy(x).cuda(), ps, node.initialstates(np.random.default_rng(0)), noise=noise)
+    assert np.isfinite(gpu_pkg.diffeqsol_to_array(sol).cpu().numpy()).all() and st2["reg_val"] != 0
+    assert st2["nfe_drift"] == 4 * n + 4 and st2["nfe_diffusion"] == 4 * n + 4
+    with pytest.raises(ValueError):
+        gpu_pkg.NeuralDSDE(gpu_pkg.Chain(gpu_pkg.Dense(D, H), gpu_pkg.Dense(H, D)), gpu_pkg.Dense(D, D), solver="SRI")
 
 
 def test_rccl_exchange_path_on_one_rank(oracle, gpu_pkg, monkeypatch):
