@@ -40,3 +40,26 @@ np.savez_compressed(os.path.join(HERE, "conv_block_8x8_b2.npz"), params=pc, x=xc
                     vjp_gp=gpc, node_u_end=ndc["u_end"], node_nfe=ndc["nfe"], node_naccept=ndc["stats"]["naccept"],
                     node_reg_val=ndc["reg_val"])
 print("wrote", os.path.getsize(os.path.join(HERE, "conv_block_8x8_b2.npz")), "bytes")
+
+# ---- MNIST-SDE shapes (experiments/src/construct.jl:204-205): one Euler-Heun, one Milstein and one four-stage SRI step ----
+Ds, Hs, Bs = 32, 64, 16
+rngs = np.random.default_rng(3)
+pds = (O.glorot_mlp_params(Ds, Hs, time_dep=False, seed=3) + rngs.standard_normal(O.lib().lro_mlp_param_count(Ds, Hs, 0)).astype(np.float32) * np.float32(0.02)).astype(np.float32)
+Wg = ((rngs.random((Ds, Ds), dtype=np.float32) - np.float32(0.5)) * np.float32(0.6)).astype(np.float32)
+bg = (rngs.standard_normal(Ds) * 0.05).astype(np.float32)
+pgs = np.concatenate([Wg.ravel(), bg]).astype(np.float32)
+p2 = np.concatenate([np.eye(Ds, dtype=np.float32).ravel(), np.zeros(Ds, np.float32), Wg.ravel(), bg])
+drift = O.MlpField(Ds, Hs, pds, time_dep=False, act="tanh", nthreads=4)
+diff = O.MlpField(Ds, Ds, p2, time_dep=False, act="identity", nthreads=4)
+us = rngs.standard_normal((Bs, Ds)).astype(np.float32)
+dts = np.float32(0.05)
+dWs = (rngs.standard_normal((Bs, Ds)) * np.sqrt(dts)).astype(np.float32)
+dZs = (rngs.standard_normal((Bs, Ds)) * np.sqrt(dts)).astype(np.float32)
+tab = rngs.uniform(-0.8, 0.8, len(O.SRI_FIELDS)).astype(np.float32)
+eh = O.euler_heun_step(drift, diff, us, dWs, 0.2, dts, 0.14, 0.14, 1.0 / 6.0)
+rk = O.rkmil_step(drift, diff, us, dWs, 0.2, dts, 0.14, 0.14)
+sr = O.sri_step(drift, diff, dict(zip(O.SRI_FIELDS, tab.tolist())), us, dWs, dZs, 0.2, dts, 0.14, 0.14, 1.0 / 6.0)
+np.savez_compressed(os.path.join(HERE, "mnist_sde_b16.npz"), p_drift=pds, p_diffusion=pgs, u=us, dW=dWs, dZ=dZs, t=np.float32(0.2), dt=dts,
+                    tableau=tab, eh_u=eh["u"], eh_eest=eh["eest"], eh_reg=eh["reg_val"], rk_u=rk["u"], rk_eest=rk["eest"],
+                    rk_reg=rk["reg_val"], sri_u=sr["u"], sri_eest=sr["eest"], sri_reg=sr["reg_val"])
+print("wrote", os.path.getsize(os.path.join(HERE, "mnist_sde_b16.npz")), "bytes")

@@ -158,6 +158,40 @@ def test_full_size_mnist_b512_and_b2048_bit_exact(oracle, gpu_pkg):
     assert g2["eest"] == r2["eest"] and g2["reg_error"] == r2["reg_error"]
 
 
+def test_golden_fixtures_on_gpu(gpu_pkg):
+    """The committed fixtures (tests/golden/, generated from the oracle by make_golden.py) through the C ABI, without the
+    oracle in the loop: the MNIST-ODE MLP step / solve / layer forward and the three SDE steps, bit for bit."""
+    import os
+    import torch
+    from localregneuralde_jl_amd.layers import Handle, _mlp_desc
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gold, "mnist_mlp_b16.npz"))
+    model = gpu_pkg.TDChain(gpu_pkg.Chain(gpu_pkg.Dense(785, 100, "tanh"), gpu_pkg.Dense(101, 784)))
+    h = Handle(_mlp_desc(model))
+    h.set_params(torch.from_numpy(g["params"]))
+    x = torch.from_numpy(g["x"]).cuda()
+    tol = float(g["tol"])
+    st = h.perform_step(x, torch.from_numpy(g["k1"]).cuda(), float(g["t"]), float(g["dt"]), tol, tol)
+    _eq(st["u"].cpu().numpy(), g["step_u"], "step u"); _eq(st["k7"].cpu().numpy(), g["step_k7"], "step k7")
+    assert st["eest"] == g["step_eest"] and st["reg_error"] == g["step_reg_error"] and st["reg_stiff"] == g["step_reg_stiff"]
+    sv = h.solve(x, 0.0, 1.0, tol, tol, saveat=[0.5, 1.0], maxiters=10000)
+    _eq(sv["u"].cpu().numpy(), g["solve_u"], "saveat states")
+    assert sv["stats"]["nf"] == int(g["solve_nf"])
+    nd = h.node_forward(x, 0.0, 1.0, tol, tol, mode="unbiased", t1_or_rand=0.37, maxiters=10000)
+    assert nd["reg_val"] == g["node_reg_val"] and nd["nfe"] == int(g["node_nfe"])
+    s = np.load(os.path.join(gold, "mnist_sde_b16.npz"))
+    sh = gpu_pkg.SdeHandle(_mlp_desc(gpu_pkg.Chain(gpu_pkg.Dense(32, 64, "tanh"), gpu_pkg.Dense(64, 32))))
+    sh.set_params(s["p_drift"], s["p_diffusion"])
+    u, dW, dZ = (torch.from_numpy(s[k]).cuda() for k in ("u", "dW", "dZ"))
+    t, dt = float(s["t"]), s["dt"]
+    eh = sh.euler_heun_step(u, dW, t, dt, 0.14, 0.14, 1.0 / 6.0)
+    _eq(eh["u"].cpu().numpy(), s["eh_u"], "Euler-Heun u"); assert eh["eest"] == s["eh_eest"] and eh["reg_val"] == s["eh_reg"]
+    rk = sh.rkmil_step(u, dW, t, dt, 0.14, 0.14)
+    _eq(rk["u"].cpu().numpy(), s["rk_u"], "Milstein u"); assert rk["eest"] == s["rk_eest"] and rk["reg_val"] == s["rk_reg"]
+    sr = sh.sri_step(s["tableau"].tolist(), u, dW, dZ, t, dt, 0.14, 0.14, 1.0 / 6.0)
+    _eq(sr["u"].cpu().numpy(), s["sri_u"], "SRI u"); assert sr["eest"] == s["sri_eest"] and sr["reg_val"] == s["sri_reg"]
+
+
 def _sde_fields(O, D, H, seed=0):
     rng = np.random.default_rng(seed)
     pd = O.glorot_mlp_params(D, H, time_dep=False, seed=seed) + rng.standard_normal(O.lib().lro_mlp_param_count(D, H, 0)).astype(np.float32) * np.float32(0.02)

@@ -195,6 +195,23 @@ def test_golden_fixtures(oracle):
     assert n["reg_val"] == g["node_reg_val"] and n["nfe"] == int(g["node_nfe"])
 
 
+def test_golden_sde_fixture(oracle):
+    """tests/golden/mnist_sde_b16.npz: one Euler-Heun, one Milstein and one four-stage SRI step at the MNIST-SDE shapes"""
+    g = np.load(os.path.join(GOLD, "mnist_sde_b16.npz"))
+    D = 32
+    p2 = np.concatenate([np.eye(D, dtype=np.float32).ravel(), np.zeros(D, np.float32), g["p_diffusion"]])
+    drift = oracle.MlpField(D, 64, g["p_drift"], time_dep=False, act="tanh")
+    diff = oracle.MlpField(D, D, p2, time_dep=False, act="identity")
+    t, dt = float(g["t"]), g["dt"]
+    eh = oracle.euler_heun_step(drift, diff, g["u"], g["dW"], t, dt, 0.14, 0.14, 1.0 / 6.0)
+    assert np.array_equal(eh["u"], g["eh_u"]) and eh["eest"] == g["eh_eest"] and eh["reg_val"] == g["eh_reg"]
+    rk = oracle.rkmil_step(drift, diff, g["u"], g["dW"], t, dt, 0.14, 0.14)
+    assert np.array_equal(rk["u"], g["rk_u"]) and rk["eest"] == g["rk_eest"] and rk["reg_val"] == g["rk_reg"]
+    sr = oracle.sri_step(drift, diff, dict(zip(oracle.SRI_FIELDS, g["tableau"].tolist())), g["u"], g["dW"], g["dZ"], t, dt, 0.14, 0.14,
+                         1.0 / 6.0)
+    assert np.array_equal(sr["u"], g["sri_u"]) and sr["eest"] == g["sri_eest"] and sr["reg_val"] == g["sri_reg"]
+
+
 def test_rkmil_step_is_milstein_for_linear_noise(oracle):
     """dX = a X dt + b X dW (diagonal, Ito).  With K = X(1 + a dt), the derivative-free quotient of
     src/perform_step.jl:136-139 is Dg = (g(K + sqrt(dt) g(X)) - g(X))/sqrt(dt) = b^2 X + a b X sqrt(dt), so the step is
