@@ -204,7 +204,9 @@ int lrnde_classifier_ce(lrnde_ctx* ctx, const float* u, int32_t B, const float* 
  * the adaptive loop's controller runs on the host for this field (an f-eval is 10^2..10^3 us). */
 enum { LRNDE_F32 = 0, LRNDE_BF16 = 1, LRNDE_F32_SPLIT = 2 };
 typedef struct {
-  int32_t width, height, channels; /* state image W, H, C (CIFAR block: 32, 32, 8) */
+  int32_t width, height, channels; /* state image W, H, C (CIFAR block: 32, 32, 8).  Supported: C = 8, Hc = 64, W % 4 == 0,
+                                    * 4 <= W <= 128 (forward; the backward pass up to W = 124), H >= 2; otherwise
+                                    * lrnde_conv_create / the call returns LRNDE_UNSUPPORTED */
   int32_t hidden;                  /* Hc (64) */
   int32_t act;                     /* LRNDE_ACT_*: activation inside the BatchNorm layers (gelu) */
   int32_t bn_train;

@@ -1766,29 +1766,36 @@ ConvArgs base_args(const lrnde_conv* c, int B) {
 }
 
 // the conv kernels are instantiated per number of M tiles of the strip (1..8)
+// wide images need more than the default 64 KiB of dynamic LDS for their halo tile (W = 64 in fp32: 68 KiB)
+#define LRNDE_CONV_LAUNCH(kern, args)                                                                                   \
+  do {                                                                                                                  \
+    if (sm > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL(kern, dim3(c->nwg), dim3(CNT), sm, c->stream, args);                                             \
+  } while (0)
 template <int MT> void launch_one(lrnde_conv* c, int which, const ConvArgs& a, size_t sm) {
   if (c->d.compute_dtype == LRNDE_BF16 && !c->force_f32) {
     if (which == 0) {
       static const bool f32in = getenv("LRNDE_CONV_BF16_F32IN") != nullptr;  // conv1 in fp32 math (bf16 output) instead
-      if (f32in || !a.wpk2) hipLaunchKernelGGL((k_conv_wide_f32<8, MT, true>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
-      else { ConvArgs b = a; b.wpk = a.wpk2; b.CINP = 8; hipLaunchKernelGGL(k_conv_in_bf16<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, b); }
+      if (f32in || !a.wpk2) LRNDE_CONV_LAUNCH((k_conv_wide_f32<8, MT, true>), a);
+      else { ConvArgs b = a; b.wpk = a.wpk2; b.CINP = 8; LRNDE_CONV_LAUNCH(k_conv_in_bf16<MT>, b); }
     }
-    else if (which == 1) hipLaunchKernelGGL(k_conv_wide_bf16<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
-    else hipLaunchKernelGGL(k_conv_out_bf16<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+    else if (which == 1) LRNDE_CONV_LAUNCH(k_conv_wide_bf16<MT>, a);
+    else LRNDE_CONV_LAUNCH(k_conv_out_bf16<MT>, a);
     return;
   }
   const bool split = c->split && a.smode == 0 && a.wpk2 != nullptr;  // forward conv2 / conv3 only
   if (which == 0) {
-    if (split) hipLaunchKernelGGL(k_conv_in_split<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
-    else hipLaunchKernelGGL((k_conv_wide_f32<8, MT, false>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+    if (split) LRNDE_CONV_LAUNCH(k_conv_in_split<MT>, a);
+    else LRNDE_CONV_LAUNCH((k_conv_wide_f32<8, MT, false>), a);
   } else if (which == 1) {
-    if (split) hipLaunchKernelGGL(k_conv_wide_split<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
-    else hipLaunchKernelGGL((k_conv_wide_f32<64, MT, false>), dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+    if (split) LRNDE_CONV_LAUNCH(k_conv_wide_split<MT>, a);
+    else LRNDE_CONV_LAUNCH((k_conv_wide_f32<64, MT, false>), a);
   } else {
-    if (split) hipLaunchKernelGGL(k_conv_out_split<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
-    else hipLaunchKernelGGL(k_conv_out_f32<MT>, dim3(c->nwg), dim3(CNT), sm, c->stream, a);
+    if (split) LRNDE_CONV_LAUNCH(k_conv_out_split<MT>, a);
+    else LRNDE_CONV_LAUNCH(k_conv_out_f32<MT>, a);
   }
 }
+#undef LRNDE_CONV_LAUNCH
 void launch_mt(lrnde_conv* c, int which, const ConvArgs& a, size_t sm) {
   static const size_t lds_min = getenv("LRNDE_CONV_LDS_MIN") ? (size_t)atoi(getenv("LRNDE_CONV_LDS_MIN")) : 0;  // occupancy experiments
   if (sm < lds_min) sm = lds_min;
@@ -1935,6 +1942,7 @@ int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, 
     size_t sm = sizeof(float) * ((size_t)trw * W * GS + (size_t)(trw + 2) * WP * IS);
     const int nthr = (GM && IM) ? 512 : CNT;
     if (sm < sizeof(float) * nthr * 9) sm = sizeof(float) * nthr * 9;
+    if (sm > 160 * 1024) return cfail(c, LRNDE_UNSUPPORTED, "image width %d: the weight-gradient kernel's tiles (%zu bytes) exceed the 160 KiB of LDS", W, sm);
     // two persistent workgroups per CU where their tiles fit (the 8-channel layers): one stages while the other runs its MFMAs
     const int maxwg = (sm <= 80 * 1024) ? 2 * NWGW : NWGW;
     const int nwgw = nstrips_w < maxwg ? nstrips_w : maxwg;

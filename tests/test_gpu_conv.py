@@ -529,3 +529,24 @@ def test_conv_full_size_properties():
         perm = torch.from_numpy(rng.permutation(B)).cuda()
         fa = ht.rhs(u, 0.3); fb = ht.rhs(u[perm].contiguous(), 0.3)
         assert _rel(fb.cpu().numpy(), fa[perm].cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("W,H,B", [(64, 4, 2), (128, 2, 2)])
+def test_conv_wide_images(W, H, B):
+    """widths whose halo tile exceeds the default 64 KiB of dynamic LDS (the maximum supported width is 128)"""
+    P, O = _mods()
+    fld, h, p, u = _case(W, H, B, seed=W, scale=1.2)
+    ud = torch.from_numpy(u).cuda()
+    _close(h.rhs(ud, 0.3), fld.rhs(u.reshape(B, -1), 0.3).reshape(u.shape))
+    lam = np.random.default_rng(5).standard_normal(u.shape).astype(np.float32)
+    if W <= 124:
+        dy, gp = h.vjp(ud, 0.3, torch.from_numpy(lam).cuda())
+        dyo, gpo = O.conv_vjp(fld, u.reshape(B, -1), 0.3, lam.reshape(B, -1))
+        _close(dy, dyo.reshape(u.shape), rtol=5e-5)
+        assert _rel(gp.cpu().numpy(), gpo) <= 5e-5
+    else:  # the 64 x 64 weight-gradient kernel's tiles need 166 KB at W = 128: refused, not mis-launched
+        with pytest.raises(P.LrndeError, match="weight-gradient"):
+            h.vjp(ud, 0.3, torch.from_numpy(lam).cuda())
+    hb = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=True, compute_dtype="bf16")
+    hb.set_params(p)
+    _close(hb.rhs(ud, 0.3), fld.rhs(u.reshape(B, -1), 0.3).reshape(u.shape), rtol=3e-2)
