@@ -112,6 +112,20 @@ def test_maxiters_retcode(oracle, gpu_pkg):
     assert got["stats"]["naccept"] == ref["stats"]["naccept"]
 
 
+def test_nan_and_empty_inputs(oracle, gpu_pkg):
+    """A NaN in one column reaches the error norm: both sides stop with DtNaN (retcode 3) after the same number of
+    attempts instead of looping or returning garbage silently; an empty batch and null pointers are BADARG."""
+    import torch
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, 32, 64, 16, "tanh", True)
+    x[3, 5] = np.nan
+    ref = oracle.solve(fld, x, 0.0, 1.0, 1e-5, 1e-5, saveat=[1.0], maxiters=100)
+    got = h.solve(torch.from_numpy(x).cuda(), 0.0, 1.0, 1e-5, 1e-5, saveat=[1.0], maxiters=100, raise_on_retcode=False)
+    assert ref["retcode"] == 3 and got["retcode"] == 3
+    assert got["stats"]["naccept"] == ref["stats"]["naccept"] and got["stats"]["nreject"] == ref["stats"]["nreject"]
+    with pytest.raises((gpu_pkg.LrndeError, ValueError)):
+        h.rhs(torch.empty((0, 32), device="cuda"), 0.0)
+
+
 @pytest.mark.parametrize("mode,reg_type", [("none", "error_estimate"), ("unbiased", "error_estimate"),
                                            ("unbiased", "stiffness_estimate"), ("biased", "error_estimate"),
                                            ("biased", "stiffness_estimate")])
