@@ -36,6 +36,30 @@ def test_struct_layouts_match_header():
     assert _lib.lib.lrnde_param_count(ctypes.byref(d)) == 158568  # 158 568 fp32
 
 
+def test_julia_binding_matches_the_header():
+    """julia/LRNDEBackend.jl cannot run here (no Julia): at least every symbol it ccalls is declared in include/lrnde.h with
+    the same number of arguments, and its structs have the field counts of the C ones."""
+    from localregneuralde_jl_amd import _lib
+    src = open(os.path.join(ROOT, "julia", "LRNDEBackend.jl")).read()
+    arity = {n: len(a) for n, _, a in _lib.SYMBOLS}
+    calls = re.findall(r"ccall\(\(:?(\w+), lib\), \w+,\s*\((.*?)\),\s*\n?", src, flags=re.S)
+    seen = set()
+    for name, types in calls:
+        if name in ("last_error", "f"):   # dispatched through a variable: checked below
+            continue
+        assert name in arity, f"{name} is not declared in include/lrnde.h"
+        nargs = len([t for t in re.split(r",(?![^{]*})", types) if t.strip()])
+        assert nargs == arity[name], f"{name}: the Julia ccall passes {nargs} arguments, the header declares {arity[name]}"
+        seen.add(name)
+    for name in re.findall(r":(lrnde_\w+)", src):
+        assert name in arity, name
+    assert {"lrnde_create", "lrnde_node_forward", "lrnde_node_forward_record", "lrnde_node_backward_recorded", "lrnde_conv_create",
+            "lrnde_sde_sri_step", "lrnde_comm_init"} <= seen
+    fields = lambda name: len(re.findall(r"::(?:Int32|Float32)", re.search(r"struct %s\b(.*?)\bend\b" % name, src, re.S).group(1)))
+    assert fields("ModelDesc") == 4 and fields("SolveOpts") == 6 and fields("Stats") == 10 and fields("ConvDesc") == 8
+    assert fields("SriTableau") == len(_lib.SRI_FIELDS) == 51
+
+
 def test_bad_handle_arguments_return_status_not_crash():
     from localregneuralde_jl_amd import _lib
     assert _lib.lib.lrnde_destroy(None) == 0
