@@ -7,12 +7,24 @@ __global__ __launch_bounds__(256) void k_cls_fwd(const float* u, const float* pc
   if (b >= B) return;
   const float* ub = u + (size_t)b * D;
   float lg[16];
-  for (int c = 0; c < K; ++c) {
-    float s = 0.f;
-    for (int k = lane; k < D; k += 64) s = fma_(pc[(size_t)c + (size_t)K * k], ub[k], s);
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-    lg[c] = s + pc[(size_t)K * D + c];
+  for (int c = 0; c < 16; ++c) lg[c] = 0.f;
+  // k outermost: one trip reads u[k] and the K weights of row k (contiguous) — 13 trips of independent loads instead of
+  // K x 13 dependent ones; each class still accumulates over k = lane, lane + 64, ... in that order
+  for (int k = lane; k < D; k += 64) {
+    const float uk = ub[k];
+    const float* wk = pc + (size_t)K * k;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) if (c < K) lg[c] = fma_(wk[c], uk, lg[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    if (c < K) {
+      float s = lg[c];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+      lg[c] = s + pc[(size_t)K * D + c];
+    }
   }
   float mx = lg[0];
   for (int c = 1; c < K; ++c) mx = fmaxf_(mx, lg[c]);
@@ -45,6 +57,18 @@ __global__ void k_cls_bwd_w(const float* dl, const float* u, int B, int D, int K
   const int c = i % K, k = i / K;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int b = 0;
+  for (; b + 16 <= B; b += 16) {  // sixteen samples' loads in flight; the four accumulators take them in the same order
+    float dv[16], uv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { dv[j] = dl[(size_t)(b + j) * K + c]; uv[j] = k < D ? u[(size_t)(b + j) * D + k] : 1.f; }
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) {
+      s0 = fma_(dv[j + 0], uv[j + 0], s0);
+      s1 = fma_(dv[j + 1], uv[j + 1], s1);
+      s2 = fma_(dv[j + 2], uv[j + 2], s2);
+      s3 = fma_(dv[j + 3], uv[j + 3], s3);
+    }
+  }
   for (; b + 4 <= B; b += 4) {
     s0 = fma_(dl[(size_t)(b + 0) * K + c], k < D ? u[(size_t)(b + 0) * D + k] : 1.f, s0);
     s1 = fma_(dl[(size_t)(b + 1) * K + c], k < D ? u[(size_t)(b + 1) * D + k] : 1.f, s1);
