@@ -322,13 +322,18 @@ __device__ __forceinline__ void wide_epilogue(const ConvArgs& a, const f32x4 (&a
   const int stepr = 16 / a.W, stepc = 16 % a.W;
   int rw = (kg * 4) / a.W, x = (kg * 4) - rw * a.W;
   float f1 = 0.f, f2 = 0.f;  // OBF: per-lane fp32 partial sums (32 values), widened once
+  // The nine class sums as nine opaque registers: left as an array, hipcc turned the row selects below into an indexed
+  // load, spilled the array to scratch (48 bytes per lane) and re-read it per tile — 19 MB of scratch stores per launch
+  // on top of the 67 MB activation (rocprofv3 WRITE_SIZE 88 MB).
+  float t0 = ts[0], t1 = ts[1], t2 = ts[2], t3 = ts[3], t4 = ts[4], t5 = ts[5], t6 = ts[6], t7 = ts[7], t8 = ts[8];
+  asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7), "+v"(t8));
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int p = mt * 16 + kg * 4;
     if (p < a.TP) {
       const int y = y0 + rw;
       const bool top = y == 0, bot = y == a.H - 1;
-      const float tl = top ? ts[0] : (bot ? ts[6] : ts[3]), tm = top ? ts[1] : (bot ? ts[7] : ts[4]), tr = top ? ts[2] : (bot ? ts[8] : ts[5]);
+      const float tl = top ? t0 : (bot ? t6 : t3), tm = top ? t1 : (bot ? t7 : t4), tr = top ? t2 : (bot ? t8 : t5);
       const float tq[4] = {x == 0 ? tl : tm, tm, tm, x + 3 == a.W - 1 ? tr : tm};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

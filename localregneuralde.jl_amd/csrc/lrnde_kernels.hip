@@ -378,6 +378,11 @@ __device__ __forceinline__ void sstore(const TileIO& io, int soff, const f32x4& 
 #endif
 // byte offset of state array `idx` (0,1: ubuf; 2,3: kfsal; 4..8: ks; 9: g6)
 __device__ __forceinline__ int arr_off(const StepArgs& a, int idx) { return (int)(a.n_local * 4) * idx; }
+// ubuf[i] / kfsal[i] for a runtime i (the ping-pong parity): the two buffers of a pair are n_local floats apart
+// (fill_args), so this is arithmetic — indexing the kernel argument's pointer arrays with a runtime value made hipcc copy
+// them to scratch (40 bytes per lane in k_step_q) and fetch the pointer from there at the head of every launch
+__device__ __forceinline__ float* ubuf_at(const StepArgs& a, int i) { return a.ubuf[0] + (size_t)i * a.n_local; }
+__device__ __forceinline__ float* kfsal_at(const StepArgs& a, int i) { return a.kfsal[0] + (size_t)i * a.n_local; }
 
 // ---- Dense-2 epilogue policies -------------------------------------------------------------
 // pre(mt, pb): issue the loads this tile's epilogue needs (one tile ahead of use);
@@ -969,8 +974,8 @@ template <int W> __global__ __launch_bounds__(NT) void k_init1(StepArgs a) {
   feval_ctx_init(a.m, fc);
   const int b0 = blockIdx.x * NB, nvalid = min(NB, a.B - b0);
   const Ctrl c = a.ctrl[0];
-  const float* u0 = a.ubuf[c.cur];
-  float* f0 = a.kfsal[c.cur];
+  const float* u0 = ubuf_at(a, c.cur);
+  float* f0 = kfsal_at(a, c.cur);
   tile_foreach<W>(a.m, b0, nvalid, [&](int row, int n, bool valid, size_t g) {
     const Vec<W> x = valid ? vload<W>(u0 + g) : vzero<W>();
     lds_put<W>(s.xl, row, n, x);
@@ -1011,8 +1016,8 @@ template <int W> __global__ __launch_bounds__(NT) void k_init2(StepArgs a) {
   }
   __syncthreads();
   const float dt0 = s.bc->dt0;
-  const float* u0 = a.ubuf[c.cur];
-  const float* f0 = a.kfsal[c.cur];
+  const float* u0 = ubuf_at(a, c.cur);
+  const float* f0 = kfsal_at(a, c.cur);
   float* f1 = a.ks[0];
   tile_foreach<W>(a.m, b0, nvalid, [&](int row, int n, bool valid, size_t g) {
     Vec<W> x;
@@ -1065,10 +1070,10 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
 
   // savevalues! of the step accepted by the prologue (Tsit5 dense output / copy)
   if (bc.accepted_prev) {
-    const float* up = a.ubuf[bc.cur_prev];
-    const float* un = a.ubuf[bc.cur_prev ^ 1];
-    const float* k1 = a.kfsal[bc.cur_prev];
-    const float* k7 = a.kfsal[bc.cur_prev ^ 1];
+    const float* up = ubuf_at(a, bc.cur_prev);
+    const float* un = ubuf_at(a, bc.cur_prev ^ 1);
+    const float* k1 = kfsal_at(a, bc.cur_prev);
+    const float* k7 = kfsal_at(a, bc.cur_prev ^ 1);
     int slot = bc.nsaved0;
     for (int is = bc.isave0; is < a.nsave && a.saveat[is] <= bc.t_new; ++is, ++slot) {
       const float ts = a.saveat[is];
@@ -1124,10 +1129,10 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
   if (!bc.do_step) return;
 
   const float t = bc.t, dt = bc.dt;
-  const float* uprev = a.ubuf[bc.cur];
-  float* unew = a.ubuf[bc.cur ^ 1];
-  const float* k1 = a.kfsal[bc.cur];
-  float* k7 = a.kfsal[bc.cur ^ 1];
+  const float* uprev = ubuf_at(a, bc.cur);
+  float* unew = ubuf_at(a, bc.cur ^ 1);
+  const float* k1 = kfsal_at(a, bc.cur);
+  float* k7 = kfsal_at(a, bc.cur ^ 1);
   const float c1 = (float)Tsit5::C[0], c2 = (float)Tsit5::C[1], c3 = (float)Tsit5::C[2],
               c4 = (float)Tsit5::C[3];
 

@@ -457,8 +457,8 @@ __global__ __launch_bounds__(QNT) void k_init1_q(StepArgs a) {
   const int b0 = blockIdx.x * QNB, nvalid = min(QNB, a.B - b0);
   const int KQ1 = a.m.D / 4;
   const Ctrl c = a.ctrl[0];
-  const float* u0 = a.ubuf[c.cur];
-  float* f0 = a.kfsal[c.cur];
+  const float* u0 = ubuf_at(a, c.cur);
+  float* f0 = kfsal_at(a, c.cur);
   __syncthreads();
   q_tile_foreach(a.m, b0, nvalid, KQ1, [&](int kq, int sidx, bool valid, size_t g) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -500,8 +500,8 @@ __global__ __launch_bounds__(QNT) void k_init2_q(StepArgs a) {
   }
   __syncthreads();
   const float dt0 = s.bc->dt0;
-  const float* u0 = a.ubuf[c.cur];
-  const float* f0 = a.kfsal[c.cur];
+  const float* u0 = ubuf_at(a, c.cur);
+  const float* f0 = kfsal_at(a, c.cur);
   float* f1 = a.ks[0];
   q_tile_foreach(a.m, b0, nvalid, KQ1, [&](int kq, int sidx, bool valid, size_t g) {
     f32x4 x = {0.f, 0.f, 0.f, 0.f};
@@ -549,10 +549,10 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
   const Bcast bc = *s.bc;
 
   if (bc.accepted_prev) {  // savevalues! of the step accepted by the prologue
-    const float* up = a.ubuf[bc.cur_prev];
-    const float* un = a.ubuf[bc.cur_prev ^ 1];
-    const float* k1 = a.kfsal[bc.cur_prev];
-    const float* k7 = a.kfsal[bc.cur_prev ^ 1];
+    const float* up = ubuf_at(a, bc.cur_prev);
+    const float* un = ubuf_at(a, bc.cur_prev ^ 1);
+    const float* k1 = kfsal_at(a, bc.cur_prev);
+    const float* k7 = kfsal_at(a, bc.cur_prev ^ 1);
     int slot = bc.nsaved0;
     for (int is = bc.isave0; is < a.nsave && a.saveat[is] <= bc.t_new; ++is, ++slot) {
       const float ts = a.saveat[is];
@@ -607,8 +607,8 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
   if (!bc.do_step) return;
 
   const float t = bc.t, dt = bc.dt;
-  const float* uprev = a.ubuf[bc.cur];
-  const float* k1 = a.kfsal[bc.cur];
+  const float* uprev = ubuf_at(a, bc.cur);
+  const float* k1 = kfsal_at(a, bc.cur);
   const float c1 = (float)Tsit5::C[0], c2 = (float)Tsit5::C[1], c3 = (float)Tsit5::C[2],
               c4 = (float)Tsit5::C[3];
   double aerr = 0.0, anum = 0.0, aden = 0.0;

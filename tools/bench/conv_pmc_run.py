@@ -3,7 +3,7 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import lrnde_amd as P
 dt = sys.argv[1] if len(sys.argv) > 1 else "f32"
-h = P.ConvHandle(32, 32, 8, 64, act="gelu", bn_train=True, compute_dtype=dt)
+h = P.ConvHandle(32, 32, 8, 64, act="gelu", bn_train=(os.environ.get("LRNDE_PMC_BN_EVAL") is None), compute_dtype=dt)
 h.set_params(P.glorot_conv_params(8, 64, seed=0))
 u = torch.randn(256, 8, 32, 32, device="cuda")
 for i in range(6):
