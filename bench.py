@@ -282,7 +282,7 @@ def conv_measure(args, workload, brief=False):
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      # HBM/fabric bytes per f-eval from separate rocprofv3 --pmc passes (profiles/r1/conv/pmc_summary.txt:
                      # 2 x FETCH_SIZE + WRITE_SIZE over the five launches), measured offline for this shape only
-                     "traffic": {"cifar_conv_f32": 409.6e6, "cifar_conv_bf16": 200.6e6}.get(workload) if B == 256 else None, "kernel": "one f-eval = k_conv_wide(conv1) + k_bn_finalize + k_conv_wide(conv2) + "
+                     "traffic": {"cifar_conv_f32": 366.9e6, "cifar_conv_bf16": 200.4e6}.get(workload) if B == 256 else None, "kernel": "one f-eval = k_conv_wide(conv1) + k_bn_finalize + k_conv_wide(conv2) + "
                                                 "k_bn_finalize + k_conv_out(conv3)",
                      "us_per_launch": us, "flop_per_launch": flop},
     }
