@@ -581,14 +581,18 @@ __global__ __launch_bounds__(CNT) void k_conv_out_f32(ConvArgs a) {
     const int pb1 = pos1 * 64 + ((kg ^ (pos1 & 3)) << 2), hi1 = (pos1 & 12) << 2;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (m0 < MT) {
+      // no wave-uniform RUNTIME guard (m0 < MT, m1 < MT) around the MFMAs: each guarded group became its own basic block
+      // with the accumulators shuffled through v_accvgpr_read / _write around it (428 + 300 of them for 288 MFMAs,
+      // 274 branches) and the kernel ran at 59 % of its MFMA bound.  A tile beyond the strip reads pixel 0 (pixel_bases)
+      // and is not stored; the second tile exists only for MT > 4 (compile time).
+      {
         const f32x4 av = *reinterpret_cast<const f32x4*>(tile + pb0 + ((16 * q) ^ hi0));
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wc[q].x, acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wc[q].y, acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wc[q].z, acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wc[q].w, acc[0], 0, 0, 0);
       }
-      if (MT > 4 && m1 < MT) {
+      if constexpr (MT > 4) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(tile + pb1 + ((16 * q) ^ hi1));
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wc[q].x, acc[1], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wc[q].y, acc[1], 0, 0, 0);
@@ -1115,14 +1119,14 @@ __global__ __launch_bounds__(CNT) void k_conv_out_split(ConvArgs a) {
     const int pb1 = pos1 * 64 + (((kg ^ (pos1 >> 1)) & 3) << 3), hi1 = ((pos1 >> 1) & 4) << 3;
 #pragma unroll
     for (int g2 = 0; g2 < 2; ++g2) {
-      if (m0 < MT) {
+      {  // no runtime guards around the MFMAs (see k_conv_out_f32)
         const int o = pb0 + ((32 * g2) ^ hi0);
         const f16x8 ah = *reinterpret_cast<const f16x8*>(thi + o), al = *reinterpret_cast<const f16x8*>(tlo + o);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g2], acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[g2], acc[0], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[g2], acc[0], 0, 0, 0);
       }
-      if (MT > 4 && m1 < MT) {
+      if constexpr (MT > 4) {
         const int o = pb1 + ((32 * g2) ^ hi1);
         const f16x8 ah = *reinterpret_cast<const f16x8*>(thi + o), al = *reinterpret_cast<const f16x8*>(tlo + o);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[g2], acc[1], 0, 0, 0);
