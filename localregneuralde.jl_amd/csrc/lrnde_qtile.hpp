@@ -16,7 +16,10 @@
 // B operand: x[k][s]; D register r: out[row 64*rg + 4q + r][s].
 
 constexpr int QNB = 4;    // batch columns per workgroup
-constexpr int QNW = 8;    // waves per workgroup
+constexpr int QNW = 7;    // waves per workgroup: one per canonical K-segment of Dense-1 (784 rows = 7 segments).  With 8,
+                          // the eighth wave's 56 Dense-1 loads per f-eval and the second Dense-2 row group of waves 5..7
+                          // were out-of-range loads (they return 0 without touching memory), and those still take the
+                          // CU's address-issue slot of a real 1-KiB wave-load (tools/oor_probe.hip): 59.9 -> 56.5 us.
 constexpr int QNT = QNW * 64;
 constexpr int QB1 = 7;    // k-quads per Dense-1 block (a canonical segment = 28 quads = 4 blocks)
 constexpr int QSEG = 28;  // k-quads per canonical segment (112 rows)
