@@ -493,19 +493,45 @@ __device__ __forceinline__ void vq_stream_load(StreamV& st) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// 4 k-quads of one stream block against the B operands b_[0..3]
-__device__ __forceinline__ void vq_block_mfma(const f32x4 (&a)[QSQ][2], const f32x4 (&b_)[QSQ], f32x4& acc0, f32x4& acc1) {
-#pragma unroll
-  for (int j = 0; j < QSQ; ++j) {
-    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].x, b_[j].x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].x, b_[j].x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].y, b_[j].y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].y, b_[j].y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].z, b_[j].z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].z, b_[j].z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][0].w, b_[j].w, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[j][1].w, b_[j].w, acc1, 0, 0, 0);
+// the two loads (row groups 0 and 1) of quad J of stream block B
+template <int B, int SLOT, int J>
+__device__ __forceinline__ void vq_stream_load_quad(StreamV& st) {
+  if constexpr (B < 2 * QSB1) {
+    constexpr int BB = B % QSB1;
+    st.ring[SLOT][J][0] = wload(B < QSB1 ? st.rs1 : st.rsv, st.v1[0], st.s1[0] + (BB * QSQ + J) * 1024);
+    st.ring[SLOT][J][1] = wload(B < QSB1 ? st.rs1 : st.rsv, st.v1[1], st.s1[1] + (BB * QSQ + J) * 1024);
+  } else if constexpr (B < VQB) {
+    constexpr int kq = (B - 2 * QSB1) * QSQ;
+    const bool real = (kq + J) < st.kq2_real;  // wave-uniform
+    st.ring[SLOT][J][0] = wload(st.rsu, real ? st.v2[0] : 0x7ffffff0, st.s2[0] + (kq + J) * 1024);
+    st.ring[SLOT][J][1] = wload(st.rsu, real ? st.v2[1] : 0x7ffffff0, st.s2[1] + (kq + J) * 1024);
   }
+}
+
+// 4 k-quads of the stream block in ring slot SL against the B operands b_[0..3], with the loads of block LB (two blocks
+// ahead, into slot NSL) issued two at a time between the quads (see feval_qs)
+template <int LB, int SL, int NSL>
+__device__ __forceinline__ void vq_block_mfma(StreamV& st, const f32x4 (&b_)[QSQ], f32x4& acc0, f32x4& acc1) {
+#ifdef LRNDE_QBURST
+  vq_stream_load<LB, NSL>(st);
+#endif
+  static_for<0, QSQ>([&](auto Jc) {
+    constexpr int j = decltype(Jc)::value;
+#ifndef LRNDE_QBURST
+    vq_stream_load_quad<LB, NSL, j>(st);
+#endif
+    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].x, b_[j].x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].x, b_[j].x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].y, b_[j].y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].y, b_[j].y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].z, b_[j].z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].z, b_[j].z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].w, b_[j].w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].w, b_[j].w, acc1, 0, 0, 0);
+#ifndef LRNDE_QBURST
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  });
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -521,11 +547,10 @@ __device__ __forceinline__ void vq_phase_ksplit(const ModelDev& m, const SmemQ& 
   static_for<0, QSB1>([&](auto Bc) {
     constexpr int B = decltype(Bc)::value;
     constexpr int SL = (BASE + B) % VRING, NSL = (BASE + B + 2) % VRING;
-    vq_stream_load<BASE + B + 2, NSL>(st);
     f32x4 b_[QSQ];
 #pragma unroll
     for (int j = 0; j < QSQ; ++j) b_[j] = xp[(B * QSQ + j) * 4];
-    vq_block_mfma(st.ring[SL], b_, acc0, acc1);
+    vq_block_mfma<BASE + B + 2, SL, NSL>(st, b_, acc0, acc1);
   });
   if (wave < nseg1) {
     f32x4* pp = sm.pl + ((size_t)wave * m.RG1) * 64 + lane;
@@ -663,11 +688,10 @@ __device__ __forceinline__ void vjp_q_body(const VjpQArgs& a) {
     static_for<0, QSB2>([&](auto Bc) {
       constexpr int B = decltype(Bc)::value;
       constexpr int SL = (2 * QSB1 + B) % VRING, NSL = (2 * QSB1 + B + 2) % VRING;
-      vq_stream_load<2 * QSB1 + B + 2, NSL>(st);
       f32x4 b_[QSQ];
 #pragma unroll
       for (int j = 0; j < QSQ; ++j) b_[j] = hp[(B * QSQ + j) * 4];
-      vq_block_mfma(st.ring[SL], b_, acc0, acc1);
+      vq_block_mfma<2 * QSB1 + B + 2, SL, NSL>(st, b_, acc0, acc1);
     });
     const int g0 = wave, g1 = wave + QNW;
     if (sidx < nvalid) {

@@ -269,6 +269,20 @@ __device__ __forceinline__ void q_stream_load(StreamQ& st) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// the two loads (row groups 0 and 1) of quad J of stream block B: the pieces of q_stream_load, for interleaving with MFMAs
+template <int B, int SLOT, int J>
+__device__ __forceinline__ void q_stream_load_quad(StreamQ& st) {
+  if constexpr (B < QSB1) {
+    st.ring[SLOT][J][0] = wload(st.rs1, st.v1[0], st.s1[0] + (B * QSQ + J) * 1024);
+    st.ring[SLOT][J][1] = wload(st.rs1, st.v1[1], st.s1[1] + (B * QSQ + J) * 1024);
+  } else {
+    constexpr int kq = (B - QSB1) * QSQ;
+    const bool real = (kq + J) < st.kq2_real;  // wave-uniform
+    st.ring[SLOT][J][0] = wload(st.rs2, real ? st.v2[0] : 0x7ffffff0, st.s2[0] + (kq + J) * 1024);
+    st.ring[SLOT][J][1] = wload(st.rs2, real ? st.v2[1] : 0x7ffffff0, st.s2[1] + (kq + J) * 1024);
+  }
+}
+
 __device__ __forceinline__ void stream_init_q(const ModelDev& m, StreamQ& st) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -288,6 +302,17 @@ __device__ __forceinline__ void stream_init_q(const ModelDev& m, StreamQ& st) {
   static_for<0, QAHEAD>([&](auto Bc) { constexpr int B = decltype(Bc)::value; q_stream_load<B, B>(st); });
 }
 
+// The loads of the block two ahead are issued two at a time between the quads' MFMAs (eight MFMAs per pair of loads),
+// pinned by sched_barriers: as a burst of eight ahead of the block's 32 MFMAs a wave sat in the CU's address-issue
+// queue behind the other waves' bursts before it could start its MFMAs (56.5 -> 53.0 us per step).  -DLRNDE_QBURST
+// builds the burst form.
+#ifndef LRNDE_QBURST
+#define LRNDE_QLOAD_QUAD(BB, SS, JJ) q_stream_load_quad<BB, SS, JJ>(st)
+#define LRNDE_QPIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define LRNDE_QLOAD_QUAD(BB, SS, JJ) do {} while (0)
+#define LRNDE_QPIN() do {} while (0)
+#endif
 template <class Epi, int SLOT0>
 __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, StreamQ& st, float ts, const Epi& epi) {
   const int lane = threadIdx.x & 63;
@@ -306,12 +331,15 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
     static_for<0, QSB1>([&](auto Bc) {
       constexpr int B = decltype(Bc)::value;
       constexpr int SL = (SLOT0 + B) % QRING, NSL = (SLOT0 + B + QAHEAD) % QRING;
+#ifdef LRNDE_QBURST
       q_stream_load<(B + QAHEAD) % QSB, NSL>(st);
+#endif
       f32x4 b_[QSQ];
 #pragma unroll
       for (int j = 0; j < QSQ; ++j) b_[j] = xp[(B * QSQ + j) * 4];
-#pragma unroll
-      for (int j = 0; j < QSQ; ++j) {
+      static_for<0, QSQ>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        LRNDE_QLOAD_QUAD((B + QAHEAD) % QSB, NSL, j);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].x, b_[j].x, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].x, b_[j].x, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].y, b_[j].y, acc0, 0, 0, 0);
@@ -320,7 +348,8 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
         acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].z, b_[j].z, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].w, b_[j].w, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].w, b_[j].w, acc1, 0, 0, 0);
-      }
+        LRNDE_QPIN();
+      });
       __builtin_amdgcn_sched_barrier(0);
     });
     if (wave < nseg1) {
@@ -359,7 +388,9 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
     static_for<0, QSB2>([&](auto Bc) {
       constexpr int B = decltype(Bc)::value;
       constexpr int SL = (SLOT0 + QSB1 + B) % QRING, NSL = (SLOT0 + QSB1 + B + QAHEAD) % QRING;
+#ifdef LRNDE_QBURST
       q_stream_load<(QSB1 + B + QAHEAD) % QSB, NSL>(st);  // wraps into the next f-eval's Dense-1 blocks
+#endif
       if constexpr (B == QSB2 - 3) {  // epilogue operands: issued ~3 blocks before they are needed
         if (g0 < m.RG2) epi.pre(g0, pb0);
         if (g1 < m.RG2) epi.pre(g1, pb1);
@@ -368,8 +399,9 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
       f32x4 b_[QSQ];
 #pragma unroll
       for (int j = 0; j < QSQ; ++j) b_[j] = hp[(B * QSQ + j) * 4];
-#pragma unroll
-      for (int j = 0; j < QSQ; ++j) {
+      static_for<0, QSQ>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        LRNDE_QLOAD_QUAD((QSB1 + B + QAHEAD) % QSB, NSL, j);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].x, b_[j].x, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].x, b_[j].x, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].y, b_[j].y, acc0, 0, 0, 0);
@@ -378,7 +410,8 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
         acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].z, b_[j].z, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].w, b_[j].w, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].w, b_[j].w, acc1, 0, 0, 0);
-      }
+        LRNDE_QPIN();
+      });
       __builtin_amdgcn_sched_barrier(0);
     });
     auto finish = [&](int rg, const f32x4& tot) {
