@@ -567,7 +567,7 @@ __device__ __forceinline__ void vjp_q_body(const VjpQArgs& a) {
   const ModelDev& m = a.m;
   const SmemQ s = carve_q(m);
   // extra LDS behind the forward layout: the lambda tile and act'(pre)
-  f32x4* ll = reinterpret_cast<f32x4*>((reinterpret_cast<uintptr_t>(s.bc + 1) + 15) & ~(uintptr_t)15);
+  f32x4* ll = q_extra_smem(s);
   float* dact = reinterpret_cast<float*>(ll + (size_t)m.KQ1p * 4);
   smem_init_q(m, s);
   const int lane = threadIdx.x & 63;

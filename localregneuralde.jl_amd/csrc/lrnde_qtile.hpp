@@ -61,6 +61,14 @@ __device__ __forceinline__ SmemQ carve_q(const ModelDev& m) {
   s.bc = reinterpret_cast<Bcast*>(s.red + QNW * 3);
   return s;
 }
+// first 16-byte aligned LDS address behind the forward layout, as an LDS pointer.  (Rounding the address up through
+// uintptr_t loses the address space: every access through the result was a FLAT instruction, which counts in vmcnt
+// and lgkmcnt at once and can only be waited for with vmcnt(0) — it drained the weight stream at every stage epilogue.)
+__device__ __forceinline__ f32x4* q_extra_smem(const SmemQ& s) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned off = (unsigned)(reinterpret_cast<const char*>(s.bc + 1) - smem);
+  return reinterpret_cast<f32x4*>(smem + ((off + 15u) & ~15u));
+}
 static size_t smem_bytes_q(int KQ1p, int KQ2p, int RG1, int RG2) {
   const size_t nseg1 = (size_t)((KQ1p + QSEG - 1) / QSEG);
   return ((size_t)KQ1p * 4 + (size_t)KQ2p * 4 + nseg1 * RG1 * 64) * 16 + 128 * (size_t)(RG1 + RG2) * 4 +
@@ -272,6 +280,11 @@ __device__ __forceinline__ void q_stream_load(StreamQ& st) {
 // the two loads (row groups 0 and 1) of quad J of stream block B: the pieces of q_stream_load, for interleaving with MFMAs
 template <int B, int SLOT, int J>
 __device__ __forceinline__ void q_stream_load_quad(StreamQ& st) {
+#ifdef LRNDE_QABL_NOLOAD  // diagnostic ablation: no weight stream (results are meaningless)
+  st.ring[SLOT][J][0] = f32x4{0.f, 0.f, 0.f, 0.f}; st.ring[SLOT][J][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("" : "+v"(st.ring[SLOT][J][0]), "+v"(st.ring[SLOT][J][1]));
+  return;
+#endif
   if constexpr (B < QSB1) {
     st.ring[SLOT][J][0] = wload(st.rs1, st.v1[0], st.s1[0] + (B * QSQ + J) * 1024);
     st.ring[SLOT][J][1] = wload(st.rs1, st.v1[1], st.s1[1] + (B * QSQ + J) * 1024);
@@ -299,6 +312,9 @@ __device__ __forceinline__ void stream_init_q(const ModelDev& m, StreamQ& st) {
     st.s2[c] = (g < m.RG2 ? g : 0) * m.KQ2p * 1024;
   }
   st.kq2_real = (m.H + 3) / 4;
+#ifdef LRNDE_QPRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(LRNDE_QPRIO);  // the second wave of a SIMD
+#endif
   static_for<0, QAHEAD>([&](auto Bc) { constexpr int B = decltype(Bc)::value; q_stream_load<B, B>(st); });
 }
 
@@ -312,6 +328,13 @@ __device__ __forceinline__ void stream_init_q(const ModelDev& m, StreamQ& st) {
 #else
 #define LRNDE_QLOAD_QUAD(BB, SS, JJ) do {} while (0)
 #define LRNDE_QPIN() do {} while (0)
+#endif
+// diagnostic ablation (-DLRNDE_QABL_NOMFMA): the MFMAs of feval_qs are replaced by an empty asm that keeps their
+// operands live, so the launch time is that of the weight stream, the LDS traffic and the epilogues alone
+#ifdef LRNDE_QABL_NOMFMA
+__device__ __forceinline__ f32x4 qmfma(float a, float b, f32x4 c) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c; }
+#else
+__device__ __forceinline__ f32x4 qmfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 #endif
 template <class Epi, int SLOT0>
 __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, StreamQ& st, float ts, const Epi& epi) {
@@ -340,14 +363,14 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
       static_for<0, QSQ>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
         LRNDE_QLOAD_QUAD((B + QAHEAD) % QSB, NSL, j);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].x, b_[j].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].x, b_[j].x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].y, b_[j].y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].y, b_[j].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].z, b_[j].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].z, b_[j].z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].w, b_[j].w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].w, b_[j].w, acc1, 0, 0, 0);
+        acc0 = qmfma(st.ring[SL][j][0].x, b_[j].x, acc0);
+        acc1 = qmfma(st.ring[SL][j][1].x, b_[j].x, acc1);
+        acc0 = qmfma(st.ring[SL][j][0].y, b_[j].y, acc0);
+        acc1 = qmfma(st.ring[SL][j][1].y, b_[j].y, acc1);
+        acc0 = qmfma(st.ring[SL][j][0].z, b_[j].z, acc0);
+        acc1 = qmfma(st.ring[SL][j][1].z, b_[j].z, acc1);
+        acc0 = qmfma(st.ring[SL][j][0].w, b_[j].w, acc0);
+        acc1 = qmfma(st.ring[SL][j][1].w, b_[j].w, acc1);
         LRNDE_QPIN();
       });
       __builtin_amdgcn_sched_barrier(0);
@@ -402,14 +425,14 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
       static_for<0, QSQ>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
         LRNDE_QLOAD_QUAD((QSB1 + B + QAHEAD) % QSB, NSL, j);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].x, b_[j].x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].x, b_[j].x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].y, b_[j].y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].y, b_[j].y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].z, b_[j].z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].z, b_[j].z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].w, b_[j].w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].w, b_[j].w, acc1, 0, 0, 0);
+        acc0 = qmfma(st.ring[SL][j][0].x, b_[j].x, acc0);
+        acc1 = qmfma(st.ring[SL][j][1].x, b_[j].x, acc1);
+        acc0 = qmfma(st.ring[SL][j][0].y, b_[j].y, acc0);
+        acc1 = qmfma(st.ring[SL][j][1].y, b_[j].y, acc1);
+        acc0 = qmfma(st.ring[SL][j][0].z, b_[j].z, acc0);
+        acc1 = qmfma(st.ring[SL][j][1].z, b_[j].z, acc1);
+        acc0 = qmfma(st.ring[SL][j][0].w, b_[j].w, acc0);
+        acc1 = qmfma(st.ring[SL][j][1].w, b_[j].w, acc1);
         LRNDE_QPIN();
       });
       __builtin_amdgcn_sched_barrier(0);
@@ -649,7 +672,7 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
               c4 = (float)Tsit5::C[3];
   double aerr = 0.0, anum = 0.0, aden = 0.0;
   const TileIOQ io = make_tile_io_q(a, b0, nvalid);
-  f32x4* kl = reinterpret_cast<f32x4*>((reinterpret_cast<uintptr_t>(s.bc + 1) + 15) & ~(uintptr_t)15);  // [7][KL] stage operands
+  f32x4* kl = q_extra_smem(s);  // [7][KL] stage operands
   const int KL = a.m.KQ1p * 4;
   const int o_up = arr_off(a, bc.cur), o_un = arr_off(a, bc.cur ^ 1);
   const int o_k1 = arr_off(a, 2 + bc.cur), o_k7 = arr_off(a, 2 + (bc.cur ^ 1));
