@@ -312,9 +312,6 @@ __device__ __forceinline__ void stream_init_q(const ModelDev& m, StreamQ& st) {
     st.s2[c] = (g < m.RG2 ? g : 0) * m.KQ2p * 1024;
   }
   st.kq2_real = (m.H + 3) / 4;
-#ifdef LRNDE_QPRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(LRNDE_QPRIO);  // the second wave of a SIMD
-#endif
   static_for<0, QAHEAD>([&](auto Bc) { constexpr int B = decltype(Bc)::value; q_stream_load<B, B>(st); });
 }
 
@@ -351,15 +348,22 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
   // ---- Dense 1: stream blocks 0..6 (segment = wave, row groups 0 and 1) ----
   {
     const f32x4* xp = sm.xl + (size_t)((wave < nseg1 ? wave : 0) * QSEG) * 4 + sidx;
+    // the B operands (x quads from LDS) are read one block ahead of their MFMAs: read at the top of their own block,
+    // every block exposed the LDS round trip (~230 cycles x 14 blocks per f-eval)
+    f32x4 bq[2][QSQ];
+#pragma unroll
+    for (int j = 0; j < QSQ; ++j) bq[0][j] = xp[j * 4];
     static_for<0, QSB1>([&](auto Bc) {
       constexpr int B = decltype(Bc)::value;
       constexpr int SL = (SLOT0 + B) % QRING, NSL = (SLOT0 + B + QAHEAD) % QRING;
 #ifdef LRNDE_QBURST
       q_stream_load<(B + QAHEAD) % QSB, NSL>(st);
 #endif
-      f32x4 b_[QSQ];
+      if constexpr (B + 1 < QSB1) {
 #pragma unroll
-      for (int j = 0; j < QSQ; ++j) b_[j] = xp[(B * QSQ + j) * 4];
+        for (int j = 0; j < QSQ; ++j) bq[(B + 1) & 1][j] = xp[((B + 1) * QSQ + j) * 4];
+      }
+      const f32x4 (&b_)[QSQ] = bq[B & 1];
       static_for<0, QSQ>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
         LRNDE_QLOAD_QUAD((B + QAHEAD) % QSB, NSL, j);
@@ -408,6 +412,9 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
     acc0 = zero4; acc1 = zero4;
     const int g0 = wave, g1 = wave + QNW;
     f32x4 pb0[Epi::NPRE], pb1[Epi::NPRE];
+    f32x4 bq[2][QSQ];
+#pragma unroll
+    for (int j = 0; j < QSQ; ++j) bq[0][j] = hp[j * 4];
     static_for<0, QSB2>([&](auto Bc) {
       constexpr int B = decltype(Bc)::value;
       constexpr int SL = (SLOT0 + QSB1 + B) % QRING, NSL = (SLOT0 + QSB1 + B + QAHEAD) % QRING;
@@ -419,9 +426,11 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
         if (g1 < m.RG2) epi.pre(g1, pb1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      f32x4 b_[QSQ];
+      if constexpr (B + 1 < QSB2) {
 #pragma unroll
-      for (int j = 0; j < QSQ; ++j) b_[j] = hp[(B * QSQ + j) * 4];
+        for (int j = 0; j < QSQ; ++j) bq[(B + 1) & 1][j] = hp[((B + 1) * QSQ + j) * 4];
+      }
+      const f32x4 (&b_)[QSQ] = bq[B & 1];
       static_for<0, QSQ>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
         LRNDE_QLOAD_QUAD((QSB1 + B + QAHEAD) % QSB, NSL, j);
