@@ -10,7 +10,7 @@ from collections import defaultdict
 root = sys.argv[1]
 want = sys.argv[2] if len(sys.argv) > 2 else "k_step_q<false>"
 acc = defaultdict(list)
-for f in glob.glob(root + "/*/*/*_counter_collection.csv"):
+for f in glob.glob(root + "/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if want in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
