@@ -177,7 +177,7 @@ def main():
                      # (profiles/r1/pmc_summary.txt: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction);
                      # measured offline for the default B=512 launch only
                      "traffic": 21.2e6 if (args.batch == 512 and world == 1) else None,
-                     "kernel": "k_step_q<false> (one attempted Tsit5 step: 6 f-evals, fused stage combination, error norm)"
+                     "kernel": "k_step_q<false, 1> (one attempted Tsit5 step: 6 f-evals, fused stage combination, error norm)"
                                if args.batch <= 1024 else "k_step<4,false>",
                      "us_per_launch": us, "flop_per_launch": flop_per_launch},
     }

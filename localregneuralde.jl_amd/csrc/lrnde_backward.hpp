@@ -494,13 +494,13 @@ __device__ __forceinline__ void vq_stream_load(StreamV& st) {
 }
 
 // the two loads (row groups 0 and 1) of quad J of stream block B
-template <int B, int SLOT, int J>
+template <int B, int SLOT, int J, int KT>
 __device__ __forceinline__ void vq_stream_load_quad(StreamV& st) {
   if constexpr (B < 2 * QSB1) {
     constexpr int BB = B % QSB1;
     st.ring[SLOT][J][0] = wload(B < QSB1 ? st.rs1 : st.rsv, st.v1[0], st.s1[0] + (BB * QSQ + J) * 1024);
     st.ring[SLOT][J][1] = wload(B < QSB1 ? st.rs1 : st.rsv, st.v1[1], st.s1[1] + (BB * QSQ + J) * 1024);
-  } else if constexpr (B < VQB) {
+  } else if constexpr (B < VQB - 1 || (B == VQB - 1 && J < KT)) {  // KT: see q_stream_load_quad
     constexpr int kq = (B - 2 * QSB1) * QSQ;
     const bool real = (kq + J) < st.kq2_real;  // wave-uniform
     st.ring[SLOT][J][0] = wload(st.rsu, real ? st.v2[0] : 0x7ffffff0, st.s2[0] + (kq + J) * 1024);
@@ -510,7 +510,7 @@ __device__ __forceinline__ void vq_stream_load_quad(StreamV& st) {
 
 // 4 k-quads of the stream block in ring slot SL against the B operands b_[0..3], with the loads of block LB (two blocks
 // ahead, into slot NSL) issued two at a time between the quads (see feval_qs)
-template <int LB, int SL, int NSL>
+template <int LB, int SL, int NSL, int KT = 4, int NQ = QSQ>
 __device__ __forceinline__ void vq_block_mfma(StreamV& st, const f32x4 (&b_)[QSQ], f32x4& acc0, f32x4& acc1) {
 #ifdef LRNDE_QBURST
   vq_stream_load<LB, NSL>(st);
@@ -518,16 +518,18 @@ __device__ __forceinline__ void vq_block_mfma(StreamV& st, const f32x4 (&b_)[QSQ
   static_for<0, QSQ>([&](auto Jc) {
     constexpr int j = decltype(Jc)::value;
 #ifndef LRNDE_QBURST
-    vq_stream_load_quad<LB, NSL, j>(st);
+    vq_stream_load_quad<LB, NSL, j, KT>(st);
 #endif
-    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].x, b_[j].x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].x, b_[j].x, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].y, b_[j].y, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].y, b_[j].y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].z, b_[j].z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].z, b_[j].z, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].w, b_[j].w, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].w, b_[j].w, acc1, 0, 0, 0);
+    if constexpr (j < NQ) {  // NQ < 4: the last phase-3 block, whose quads beyond the real matrix are not loaded
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].x, b_[j].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].x, b_[j].x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].y, b_[j].y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].y, b_[j].y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].z, b_[j].z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].z, b_[j].z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][0].w, b_[j].w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(st.ring[SL][j][1].w, b_[j].w, acc1, 0, 0, 0);
+    }
 #ifndef LRNDE_QBURST
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -536,7 +538,7 @@ __device__ __forceinline__ void vq_block_mfma(StreamV& st, const f32x4 (&b_)[QSQ
 }
 
 // Dense-1-shaped phase: stream blocks BASE..BASE+6, segment = wave, both row groups; partials -> pl
-template <int BASE>
+template <int BASE, int KT>
 __device__ __forceinline__ void vq_phase_ksplit(const ModelDev& m, const SmemQ& sm, StreamV& st, const f32x4* tile) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -550,7 +552,7 @@ __device__ __forceinline__ void vq_phase_ksplit(const ModelDev& m, const SmemQ& 
     f32x4 b_[QSQ];
 #pragma unroll
     for (int j = 0; j < QSQ; ++j) b_[j] = xp[(B * QSQ + j) * 4];
-    vq_block_mfma<BASE + B + 2, SL, NSL>(st, b_, acc0, acc1);
+    vq_block_mfma<BASE + B + 2, SL, NSL, KT>(st, b_, acc0, acc1);
   });
   if (wave < nseg1) {
     f32x4* pp = sm.pl + ((size_t)wave * m.RG1) * 64 + lane;
@@ -563,7 +565,7 @@ static size_t smem_bytes_vq(int KQ1p, int KQ2p, int RG1, int RG2) {
   return smem_bytes_q(KQ1p, KQ2p, RG1, RG2) + (size_t)KQ1p * 4 * 16 + (size_t)RG1 * 256 * 4 + 32;
 }
 
-__device__ __forceinline__ void vjp_q_body(const VjpQArgs& a) {
+template <int KT> __device__ __forceinline__ void vjp_q_body(const VjpQArgs& a) {
   const ModelDev& m = a.m;
   const SmemQ s = carve_q(m);
   // extra LDS behind the forward layout: the lambda tile and act'(pre)
@@ -654,7 +656,7 @@ __device__ __forceinline__ void vjp_q_body(const VjpQArgs& a) {
   const int ne = m.RG1 * 256;
   const int nseg1 = q_nseg1(m);
   // ---- phase 1: pre = W1 [y;t] + b1 ; h, act' ----
-  vq_phase_ksplit<0>(m, s, st, s.xl);
+  vq_phase_ksplit<0, KT>(m, s, st, s.xl);
   q_barrier();
   for (int e = threadIdx.x; e < ne; e += QNT) {
     const int r = e & 3, l = (e >> 2) & 63, rg = e >> 8;
@@ -669,7 +671,7 @@ __device__ __forceinline__ void vjp_q_body(const VjpQArgs& a) {
   }
   q_barrier();
   // ---- phase 2: dh = W2^T lam ; dpre = dh .* act' -> h tile image + scratch ----
-  vq_phase_ksplit<QSB1>(m, s, st, ll);
+  vq_phase_ksplit<QSB1, KT>(m, s, st, ll);
   q_barrier();
   for (int e = threadIdx.x; e < ne; e += QNT) {
     const int r = e & 3, l = (e >> 2) & 63, rg = e >> 8;
@@ -691,7 +693,7 @@ __device__ __forceinline__ void vjp_q_body(const VjpQArgs& a) {
       f32x4 b_[QSQ];
 #pragma unroll
       for (int j = 0; j < QSQ; ++j) b_[j] = hp[(B * QSQ + j) * 4];
-      vq_block_mfma<2 * QSB1 + B + 2, SL, NSL>(st, b_, acc0, acc1);
+      vq_block_mfma<2 * QSB1 + B + 2, SL, NSL, KT, (B == QSB2 - 1 ? KT : QSQ)>(st, b_, acc0, acc1);
     });
     const int g0 = wave, g1 = wave + QNW;
     if (sidx < nvalid) {
@@ -702,12 +704,12 @@ __device__ __forceinline__ void vjp_q_body(const VjpQArgs& a) {
   }
 }
 
-__global__ __launch_bounds__(QNT) void k_vjp_q(VjpQArgs a) { vjp_q_body(a); }
+template <int KT> __global__ __launch_bounds__(QNT) void k_vjp_q(VjpQArgs a) { vjp_q_body<KT>(a); }
 
 // The VJP of one adjoint RHS evaluation and, on the CUs it leaves idle (it has B/4 workgroups: 128 at B = 512), the
 // parameter-gradient GEMM of the PREVIOUS evaluation (its tiles are workgroups nvjp, nvjp+1, ...).  The two touch
 // disjoint buffers: the scratch (y, h, dpre) and the stage lambda are double buffered by the host (launch_vjp).
-__global__ __launch_bounds__(QNT) void k_vjp_q_pg(VjpQArgs a, PgradArgs pg, int nvjp) {
+template <int KT> __global__ __launch_bounds__(QNT) void k_vjp_q_pg(VjpQArgs a, PgradArgs pg, int nvjp) {
   if ((int)blockIdx.x >= nvjp) { pgrad_tile(pg, (int)blockIdx.x - nvjp); return; }
-  vjp_q_body(a);
+  vjp_q_body<KT>(a);
 }

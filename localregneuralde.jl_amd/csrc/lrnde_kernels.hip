@@ -1663,8 +1663,15 @@ int launch_step(lrnde_ctx* c, int B, const StepArgs& a, int j, bool spec = false
   if (use_qtile(c, B)) {
     const int nq = (B + QNB - 1) / QNB;
     const size_t smq = smem_q(c) + (size_t)7 * c->m.KQ1p * 4 * 16 + 16;  // + the LDS-resident stage operands (uprev, k1..k6)
-    if (spec) hipLaunchKernelGGL(k_step_q<true>, dim3(nq), dim3(QNT), smq, c->stream, a, j);
-    else hipLaunchKernelGGL(k_step_q<false>, dim3(nq), dim3(QNT), smq, c->stream, a, j);
+    // KT: real k-quads in the last Dense-2 stream block (lrnde_qtile.hpp); 1 for H = 97..100, else the generic form
+    const bool kt1 = (c->desc.hidden_dim + 3) / 4 == (QSB2 - 1) * QSQ + 1;
+    if (kt1) {
+      if (spec) hipLaunchKernelGGL((k_step_q<true, 1>), dim3(nq), dim3(QNT), smq, c->stream, a, j);
+      else hipLaunchKernelGGL((k_step_q<false, 1>), dim3(nq), dim3(QNT), smq, c->stream, a, j);
+    } else {
+      if (spec) hipLaunchKernelGGL((k_step_q<true, 4>), dim3(nq), dim3(QNT), smq, c->stream, a, j);
+      else hipLaunchKernelGGL((k_step_q<false, 4>), dim3(nq), dim3(QNT), smq, c->stream, a, j);
+    }
     HIPCHK(c, hipGetLastError());
     return LRNDE_OK;
   }
@@ -1720,8 +1727,10 @@ int set_smem_attr() {
   hipFuncSetAttribute((const void*)k_init2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_rhs<4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_rhs<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
-  hipFuncSetAttribute((const void*)k_step_q<false>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
-  hipFuncSetAttribute((const void*)k_step_q<true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_step_q<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_step_q<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_step_q<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+  hipFuncSetAttribute((const void*)k_step_q<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_init1_q, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_init2_q, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
   hipFuncSetAttribute((const void*)k_rhs_q, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
@@ -2549,12 +2558,18 @@ static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float th
     }
     const size_t smq = smem_bytes_vq(c->m.KQ1p, c->m.KQ2p, c->m.RG1, c->m.RG2);
     const int nvjp = (B + QNB - 1) / QNB;
+    const bool kt1 = (c->desc.hidden_dim + 3) / 4 == (QSB2 - 1) * QSQ + 1;  // real k-quads in the last phase-3 block (see launch_step)
     if (c->pg_defer) {
       // this VJP's launch carries the GEMM of the previous evaluation; its own GEMM waits for the next launch (or flush_pgrad)
       const bool had = c->pg_pending;
       const PgradArgs prev = c->pg_args;
-      if (had) hipLaunchKernelGGL(k_vjp_q_pg, dim3(nvjp + prev.ntile1 + prev.ntile2), dim3(QNT), smq, c->stream, a, prev, nvjp);
-      else hipLaunchKernelGGL(k_vjp_q, dim3(nvjp), dim3(QNT), smq, c->stream, a);
+      if (kt1) {
+        if (had) hipLaunchKernelGGL(k_vjp_q_pg<1>, dim3(nvjp + prev.ntile1 + prev.ntile2), dim3(QNT), smq, c->stream, a, prev, nvjp);
+        else hipLaunchKernelGGL(k_vjp_q<1>, dim3(nvjp), dim3(QNT), smq, c->stream, a);
+      } else {
+        if (had) hipLaunchKernelGGL(k_vjp_q_pg<4>, dim3(nvjp + prev.ntile1 + prev.ntile2), dim3(QNT), smq, c->stream, a, prev, nvjp);
+        else hipLaunchKernelGGL(k_vjp_q<4>, dim3(nvjp), dim3(QNT), smq, c->stream, a);
+      }
       HIPCHK(c, hipGetLastError());
       if (had && c->comm) NCCLCHK(c, ncclAllReduce(prev.gp, prev.gp, lrnde_param_count(&c->desc), ncclFloat, ncclSum, c->comm, c->stream));
       c->pg_pending = gp != nullptr;
@@ -2562,7 +2577,8 @@ static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float th
       c->bw_cur ^= 1;
       return LRNDE_OK;
     }
-    hipLaunchKernelGGL(k_vjp_q, dim3(nvjp), dim3(QNT), smq, c->stream, a);
+    if (kt1) hipLaunchKernelGGL(k_vjp_q<1>, dim3(nvjp), dim3(QNT), smq, c->stream, a);
+    else hipLaunchKernelGGL(k_vjp_q<4>, dim3(nvjp), dim3(QNT), smq, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return launch_pgrad(c, B, t, lam, gp);
   }

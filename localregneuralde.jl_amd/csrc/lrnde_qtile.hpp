@@ -278,7 +278,11 @@ __device__ __forceinline__ void q_stream_load(StreamQ& st) {
 }
 
 // the two loads (row groups 0 and 1) of quad J of stream block B: the pieces of q_stream_load, for interleaving with MFMAs
-template <int B, int SLOT, int J>
+// KT = number of k-quads of the LAST Dense-2 block that exist (1..4; 4 = generic: quads beyond the real matrix are
+// fetched with an out-of-range offset and return 0).  With KT < 4 the missing quads are neither loaded nor multiplied:
+// an out-of-range load still costs its slot in the SIMD's return path (tools/oor_probe.hip), and for H = 100 (25 real
+// quads) 3 of the 28 loads of every Dense-2 row group were of that kind.
+template <int B, int SLOT, int J, int KT = 4>
 __device__ __forceinline__ void q_stream_load_quad(StreamQ& st) {
 #ifdef LRNDE_QABL_NOLOAD  // diagnostic ablation: no weight stream (results are meaningless)
   st.ring[SLOT][J][0] = f32x4{0.f, 0.f, 0.f, 0.f}; st.ring[SLOT][J][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -288,7 +292,7 @@ __device__ __forceinline__ void q_stream_load_quad(StreamQ& st) {
   if constexpr (B < QSB1) {
     st.ring[SLOT][J][0] = wload(st.rs1, st.v1[0], st.s1[0] + (B * QSQ + J) * 1024);
     st.ring[SLOT][J][1] = wload(st.rs1, st.v1[1], st.s1[1] + (B * QSQ + J) * 1024);
-  } else {
+  } else if constexpr (B < QSB - 1 || J < KT) {
     constexpr int kq = (B - QSB1) * QSQ;
     const bool real = (kq + J) < st.kq2_real;  // wave-uniform
     st.ring[SLOT][J][0] = wload(st.rs2, real ? st.v2[0] : 0x7ffffff0, st.s2[0] + (kq + J) * 1024);
@@ -320,7 +324,7 @@ __device__ __forceinline__ void stream_init_q(const ModelDev& m, StreamQ& st) {
 // queue behind the other waves' bursts before it could start its MFMAs (56.5 -> 53.0 us per step).  -DLRNDE_QBURST
 // builds the burst form.
 #ifndef LRNDE_QBURST
-#define LRNDE_QLOAD_QUAD(BB, SS, JJ) q_stream_load_quad<BB, SS, JJ>(st)
+#define LRNDE_QLOAD_QUAD(BB, SS, JJ) q_stream_load_quad<BB, SS, JJ, KT>(st)
 #define LRNDE_QPIN() __builtin_amdgcn_sched_barrier(0)
 #else
 #define LRNDE_QLOAD_QUAD(BB, SS, JJ) do {} while (0)
@@ -333,7 +337,7 @@ __device__ __forceinline__ f32x4 qmfma(float a, float b, f32x4 c) { asm volatile
 #else
 __device__ __forceinline__ f32x4 qmfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 #endif
-template <class Epi, int SLOT0>
+template <class Epi, int SLOT0, int KT = 4>
 __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, StreamQ& st, float ts, const Epi& epi) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -434,14 +438,16 @@ __device__ __forceinline__ void feval_qs(const ModelDev& m, const SmemQ& sm, Str
       static_for<0, QSQ>([&](auto Jc) {
         constexpr int j = decltype(Jc)::value;
         LRNDE_QLOAD_QUAD((QSB1 + B + QAHEAD) % QSB, NSL, j);
-        acc0 = qmfma(st.ring[SL][j][0].x, b_[j].x, acc0);
-        acc1 = qmfma(st.ring[SL][j][1].x, b_[j].x, acc1);
-        acc0 = qmfma(st.ring[SL][j][0].y, b_[j].y, acc0);
-        acc1 = qmfma(st.ring[SL][j][1].y, b_[j].y, acc1);
-        acc0 = qmfma(st.ring[SL][j][0].z, b_[j].z, acc0);
-        acc1 = qmfma(st.ring[SL][j][1].z, b_[j].z, acc1);
-        acc0 = qmfma(st.ring[SL][j][0].w, b_[j].w, acc0);
-        acc1 = qmfma(st.ring[SL][j][1].w, b_[j].w, acc1);
+        if constexpr (B < QSB2 - 1 || j < KT) {
+          acc0 = qmfma(st.ring[SL][j][0].x, b_[j].x, acc0);
+          acc1 = qmfma(st.ring[SL][j][1].x, b_[j].x, acc1);
+          acc0 = qmfma(st.ring[SL][j][0].y, b_[j].y, acc0);
+          acc1 = qmfma(st.ring[SL][j][1].y, b_[j].y, acc1);
+          acc0 = qmfma(st.ring[SL][j][0].z, b_[j].z, acc0);
+          acc1 = qmfma(st.ring[SL][j][1].z, b_[j].z, acc1);
+          acc0 = qmfma(st.ring[SL][j][0].w, b_[j].w, acc0);
+          acc1 = qmfma(st.ring[SL][j][1].w, b_[j].w, acc1);
+        }
         LRNDE_QPIN();
       });
       __builtin_amdgcn_sched_barrier(0);
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(QNT) void k_init2_q(StepArgs a) {
 }
 
 // one attempted Tsit5 step, 4 columns per workgroup (same flow as k_step's fused path)
-template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a, int j) {
+template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a, int j) {
   STAMP(9);
   const SmemQ s = carve_q(a.m);
   smem_init_q(a.m, s);
@@ -711,7 +717,7 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
     e.off_out = arr_off(a, 4 + (S - 2));                                                \
     e.off_x = (S == 6) ? o_un : ((S == 5 && a.want_stiff) ? o_g6 : -1);                 \
     e.dt = dt; e.xl = s.xl; e.KQ1 = KQ1; e.kl = kl; e.KL = KL;                          \
-    feval_qs<EpiStageQ<S>, (QSB * (S - 2)) % QRING>(a.m, s, fc, (TS), e);                 \
+    feval_qs<EpiStageQ<S>, (QSB * (S - 2)) % QRING, KT>(a.m, s, fc, (TS), e);                 \
     STAMP(11 + S);                                                                      \
   } while (0)
   LRNDE_QSTAGE(2, t + c1 * dt);
@@ -729,7 +735,7 @@ template <bool SPEC> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a,
   ef.D = a.m.D;
   ef.aerr = &aerr; ef.anum = &anum; ef.aden = &aden;
   ef.xl = s.xl; ef.kl = kl; ef.KL = KL;
-  feval_qs<EpiFinalQ, (QSB * 5) % QRING>(a.m, s, fc, t + dt, ef);
+  feval_qs<EpiFinalQ, (QSB * 5) % QRING, KT>(a.m, s, fc, t + dt, ef);
   STAMP(18);
   block_sum3_q(s.red, aerr, anum, aden);
   STAMP(19);

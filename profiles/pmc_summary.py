@@ -8,7 +8,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-want = sys.argv[2] if len(sys.argv) > 2 else "k_step_q<false>"
+want = sys.argv[2] if len(sys.argv) > 2 else "k_step_q<false"
 acc = defaultdict(list)
 for f in glob.glob(root + "/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):

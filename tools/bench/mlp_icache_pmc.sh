@@ -11,7 +11,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$O/*/p_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         m=re.search(r"(k_\w+(<[^>]*>)?)",r["Kernel_Name"])
-        if m and m.group(1) in ("k_step_q<false>","k_vjp_q_pg"): acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if m and m.group(1) in ("k_step_q<false, 1>","k_vjp_q_pg<1>"): acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in acc.items():
     print(k)
     for c in sorted(v):

@@ -6,4 +6,4 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_B
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/$i -o p -- python3 $R/bench.py --no-conv --no-cpu-baseline --steps 5 --warmup 1 --adjoint-steps 0 > $O/run$i.log 2>&1 || { tail -3 $O/run$i.log; exit 1; }
 done
-python3 $R/profiles/pmc_summary.py $O "k_step_q<false>"
+python3 $R/profiles/pmc_summary.py $O "k_step_q<false"
