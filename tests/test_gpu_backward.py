@@ -37,6 +37,19 @@ def test_vjp_matches_oracle(oracle, gpu_pkg, D, H, B, act, td):
     assert _rel(gp.cpu().numpy(), gp_ref) < 2e-5
 
 
+@pytest.mark.parametrize("H", [96, 97, 100, 101, 112])
+def test_vjp_around_the_phase3_tail(oracle, gpu_pkg, H):
+    """hidden sizes on both sides of the VJP kernel's ceil(H/4) == 25 specialisation (see the step kernel's)"""
+    import torch
+    D, B = 64, 9
+    fld, h, p, x = _mk(oracle, gpu_pkg, D, H, B, "tanh", True)
+    lam = np.random.default_rng(9).standard_normal((B, D)).astype(np.float32)
+    dy_ref, gp_ref = oracle.mlp_vjp(fld, x, 0.3, lam)
+    dy, gp = h.vjp(torch.from_numpy(x).cuda(), 0.3, torch.from_numpy(lam).cuda())
+    assert _rel(dy.cpu().numpy(), dy_ref) < 2e-5
+    assert _rel(gp.cpu().numpy(), gp_ref) < 2e-5
+
+
 @pytest.mark.parametrize("reg_type", ["error_estimate", "stiffness_estimate"])
 @pytest.mark.parametrize("D,H,B,act,td", [(784, 100, 32, "tanh", True), (32, 64, 20, "gelu", True)])
 def test_reg_gradient_matches_oracle(oracle, gpu_pkg, reg_type, D, H, B, act, td):

@@ -57,6 +57,21 @@ def test_perform_step_bit_exact(oracle, gpu_pkg, D, H, B, act, td):
         assert got[k] == ref[k], (k, got[k], ref[k])
 
 
+@pytest.mark.parametrize("H", [92, 96, 97, 99, 100, 101, 104, 108, 112])
+def test_perform_step_bit_exact_around_the_dense2_tail(oracle, gpu_pkg, H):
+    """the 4-column step kernel has a launch-time specialisation for ceil(H/4) == 25 (the padded k-quads of the last
+    Dense-2 stream block are neither loaded nor multiplied): hidden sizes on both sides of it, both regularisers"""
+    import torch
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, 64, H, 9, "tanh", True)
+    k1 = fld.rhs(x, 0.1)
+    ref = oracle.tsit5_step(fld, x, k1, 0.1, 0.05, 1e-4, 1e-4)
+    got = h.perform_step(torch.from_numpy(x).cuda(), torch.from_numpy(k1).cuda(), 0.1, 0.05, 1e-4, 1e-4)
+    _eq(got["u"].cpu().numpy(), ref["u"], "u")
+    _eq(got["k7"].cpu().numpy(), ref["k7"], "k7")
+    for k in ("eest", "reg_error", "reg_stiff"):
+        assert got[k] == ref[k], (k, got[k], ref[k])
+
+
 @pytest.mark.parametrize("D,H,B,act,td", CASES)
 def test_init_dt_bit_exact(oracle, gpu_pkg, D, H, B, act, td):
     import torch
