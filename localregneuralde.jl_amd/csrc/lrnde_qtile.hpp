@@ -484,10 +484,13 @@ __device__ __forceinline__ void q_tile_foreach(const ModelDev& m, int b0, int nv
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-__device__ __forceinline__ void block_sum3_q(double* red, double& a, double& b, double& c) {
+// `three` (workgroup-uniform) = false: b and c are known to be zero everywhere (no stiffness sums wanted) and their
+// shuffle reductions — 12 dependent ds_bpermute round trips each — are skipped; the sums are the same zeros
+__device__ __forceinline__ void block_sum3_q(double* red, double& a, double& b, double& c, bool three = true) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  a = wave_sum(a);
+  if (three) { b = wave_sum(b); c = wave_sum(c); }
   if (lane == 0) { red[wave * 3 + 0] = a; red[wave * 3 + 1] = b; red[wave * 3 + 2] = c; }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -737,7 +740,7 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
   ef.xl = s.xl; ef.kl = kl; ef.KL = KL;
   feval_qs<EpiFinalQ, (QSB * 5) % QRING, KT>(a.m, s, fc, t + dt, ef);
   STAMP(18);
-  block_sum3_q(s.red, aerr, anum, aden);
+  block_sum3_q(s.red, aerr, anum, aden, a.want_stiff != 0);
   STAMP(19);
   if (threadIdx.x == 0) {
     double* p = a.part_send + ((size_t)((j + 1) & 1) * a.nwg_global + a.wg_offset + blockIdx.x) * PSTRIDE;
