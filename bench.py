@@ -178,7 +178,7 @@ def main():
                      # measured offline for the default B=512 launch only
                      "traffic": 21.2e6 if (args.batch == 512 and world == 1) else None,
                      "kernel": "k_step_q<false, 1> (one attempted Tsit5 step: 6 f-evals, fused stage combination, error norm)"
-                               if args.batch <= 1024 else "k_step<4,false>",
+                               if args.batch <= 2048 else "k_step<4,false>",
                      "us_per_launch": us, "flop_per_launch": flop_per_launch},
     }
     if rank == 0 and world == 1 and not args.no_conv:

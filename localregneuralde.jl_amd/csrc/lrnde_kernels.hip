@@ -1585,7 +1585,7 @@ inline int vecw(const lrnde_ctx* c) { return (c->desc.state_dim % 4 == 0) ? 4 : 
 // Which tile shape runs this batch: the 4-column family (lrnde_qtile.hpp) when there would be too
 // few 16-column workgroups to fill the chip, the 16-column family otherwise.
 bool use_qtile(const lrnde_ctx* c, int B) {
-  static const int qmax = getenv("LRNDE_QTILE_MAX_B") ? atoi(getenv("LRNDE_QTILE_MAX_B")) : 1024;
+  static const int qmax = getenv("LRNDE_QTILE_MAX_B") ? atoi(getenv("LRNDE_QTILE_MAX_B")) : 2048;  // two rounds of 4-column workgroups (97 us at B=2048) beat one of 16-column ones (114 us)
   const int D = c->desc.state_dim, H = c->desc.hidden_dim;
   // streaming path shape limits: one Dense-1 segment and one Dense-2 pass per wave
   const bool shape_ok = (D % 4 == 0) && (H <= 112) && (c->m.KQ1p / QSEG <= QNW) && (c->m.RG1 <= 2) &&
