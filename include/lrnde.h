@@ -277,8 +277,6 @@ int lrnde_cifar_stem_backward(lrnde_conv* c, const float* x, int32_t B, const fl
                               const float* du0, float* dps);
 int lrnde_cifar_head_ce(lrnde_conv* c, const float* u, int32_t B, const float* ph, int32_t K, const int32_t* labels,
                         float* loss_host, float* logits, float* du, float* dph);
-/* average microseconds of one f-eval (3 conv + 2 batch-norm statistics launches), HIP events */
-int lrnde_conv_bench_rhs(lrnde_conv* c, const float* u, float t, int32_t B, int32_t reps, float* us_host);
 
 /* `_perform_step(integrator, cache::RKMilCommuteConstantCache, p)`, src/perform_step.jl:108-170, diagonal noise,
  * Ito interpretation: u = K + L*dW + Dgj*J with J = dW^2/2 - |dt|/2, EEst from the 4-argument
@@ -332,14 +330,6 @@ int lrnde_node_backward(lrnde_ctx* ctx, const float* x, int32_t B, float t0, flo
                         const lrnde_solve_opts* opts, int32_t mode, int32_t reg_type, float t1_or_rand,
                         const float* du_end, float w_reg, float* dx, float* dp, lrnde_stats* stats_fwd_host,
                         lrnde_stats* stats_bwd_host);
-
-/* Timing hooks for bench.py: HIP events on the handle's stream around the
- * kernels of the last solve (ms), and the number of step-kernel launches. */
-/* `reps` back-to-back launches of the full Tsit5 step kernel on fixed (uprev, k1, t, dt), timed
- * with HIP events on the handle's stream; avg_us_host = microseconds per launch (roofline leg). */
-int lrnde_bench_step(lrnde_ctx* ctx, const float* uprev, const float* k1, int32_t B, float t, float dt,
-                     float abstol, float reltol, int32_t reps, float* avg_us_host);
-int lrnde_last_solve_kernel_ms(lrnde_ctx* ctx, float* total_ms_host, int32_t* step_launches_host);
 
 #ifdef __cplusplus
 }

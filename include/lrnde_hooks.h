@@ -1,0 +1,43 @@
+/*
+ * lrnde_hooks.h — entry points of liblrnde that are NOT part of the drop-in boundary (include/lrnde.h): the timing
+ * hooks bench.py uses for its roofline leg, and the in-process local communicator that lets the batch-sharded
+ * (nranks > 1) code of the library run inside one process — several handles, one host thread each, on one GPU or
+ * on several — where RCCL cannot (it refuses two ranks on one device).  Nothing in the reference corresponds to
+ * these (it has neither a benchmark harness nor a collective: SURVEY.md §2 rows 16-18).
+ */
+#ifndef LRNDE_HOOKS_H
+#define LRNDE_HOOKS_H
+
+#include "lrnde.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- in-process local communicator ----
+ * lrnde_local_comm_create(nranks) makes the rendezvous object; every participating handle joins it with
+ * lrnde_comm_init_local(ctx, lc, rank) (instead of lrnde_comm_init) and is then driven by ITS OWN host thread: the
+ * sharded entry points (lrnde_solve, lrnde_node_forward*, lrnde_node_backward*, lrnde_vjp, lrnde_classifier_ce ...)
+ * must be called by all ranks concurrently, exactly as one process per GPU would call them.  Each collective is a
+ * SUM all-reduce done by stream-ordered kernels and events (rank-order sum, identical on every rank); a rank that
+ * does not arrive within 60 s breaks the communicator and every pending call returns LRNDE_NCCL_ERROR.  Handles
+ * must leave the communicator (lrnde_comm_destroy or lrnde_destroy) before lrnde_local_comm_destroy. */
+typedef struct lrnde_local_comm lrnde_local_comm;
+int lrnde_local_comm_create(lrnde_local_comm** out, int32_t nranks);
+int lrnde_local_comm_destroy(lrnde_local_comm* lc);
+int lrnde_comm_init_local(lrnde_ctx* ctx, lrnde_local_comm* lc, int32_t rank);
+
+/* ---- timing hooks (bench.py) ---- */
+/* `reps` back-to-back launches of the full Tsit5 step kernel on fixed (uprev, k1, t, dt), timed
+ * with HIP events on the handle's stream; avg_us_host = microseconds per launch (roofline leg). */
+int lrnde_bench_step(lrnde_ctx* ctx, const float* uprev, const float* k1, int32_t B, float t, float dt,
+                     float abstol, float reltol, int32_t reps, float* avg_us_host);
+/* HIP events on the handle's stream around the kernels of the last solve (ms), and its step-kernel launches */
+int lrnde_last_solve_kernel_ms(lrnde_ctx* ctx, float* total_ms_host, int32_t* step_launches_host);
+/* average microseconds of one f-eval (3 conv + 2 batch-norm statistics launches), HIP events */
+int lrnde_conv_bench_rhs(lrnde_conv* c, const float* u, float t, int32_t B, int32_t reps, float* us_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

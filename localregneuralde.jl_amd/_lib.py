@@ -54,7 +54,7 @@ class TraceRow(C.Structure):
     _fields_ = [("t", C.c_float), ("dt", C.c_float), ("eest", C.c_float), ("accepted", C.c_int32)]
 
 
-# every symbol include/lrnde.h declares: (name, restype, argtypes)
+# every symbol include/lrnde.h and include/lrnde_hooks.h declare: (name, restype, argtypes)
 _vp, _fp, _i32, _f = C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_float
 SYMBOLS = [
     ("lrnde_create", C.c_int, [C.POINTER(_vp), C.POINTER(ModelDesc), C.c_int, _vp]),
@@ -73,6 +73,9 @@ SYMBOLS = [
     ("lrnde_comm_unique_id", C.c_int, [_vp]),
     ("lrnde_comm_init", C.c_int, [_vp, _vp, _i32, _i32]),
     ("lrnde_comm_destroy", C.c_int, [_vp]),
+    ("lrnde_local_comm_create", C.c_int, [C.POINTER(_vp), _i32]),
+    ("lrnde_local_comm_destroy", C.c_int, [_vp]),
+    ("lrnde_comm_init_local", C.c_int, [_vp, _vp, _i32]),
     ("lrnde_sde_create", C.c_int, [C.POINTER(_vp), C.POINTER(ModelDesc), _i32, C.c_int, _vp]),
     ("lrnde_sde_destroy", C.c_int, [_vp]),
     ("lrnde_sde_last_error", C.c_char_p, [_vp]),

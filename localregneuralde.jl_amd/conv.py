@@ -85,7 +85,7 @@ class ConvHandle:
                                      C.c_void_p(self._stream.cuda_stream))
         if rc != 0:
             raise L.LrndeError(rc, "lrnde_conv_create failed (shape or dtype not supported by the kernels)")
-        self._keep = []
+        self._keep = {}  # name -> the tensor a pending async copy reads (one slot per kind: overwritten, never appended)
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -114,13 +114,13 @@ class ConvHandle:
     def set_params(self, ps):
         ps = ps if isinstance(ps, torch.Tensor) else torch.as_tensor(np.asarray(ps, dtype=np.float32))
         ps = ps.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous().reshape(-1)
-        self._keep = [ps]
+        self._keep["params"] = ps
         self._chk(L.lib.lrnde_conv_set_params(self._ctx, C.c_void_p(ps.data_ptr()), ps.numel()))
 
     def set_bn_state(self, mean_var):
         mv = mean_var if isinstance(mean_var, torch.Tensor) else torch.as_tensor(np.asarray(mean_var, dtype=np.float32))
         mv = mv.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous().reshape(-1)
-        self._keep.append(mv)
+        self._keep["bn_state"] = mv
         self._chk(L.lib.lrnde_conv_set_bn_state(self._ctx, C.c_void_p(mv.data_ptr()), mv.numel()))
 
     def set_bn_mode(self, train):

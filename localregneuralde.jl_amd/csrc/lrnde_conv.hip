@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "lrnde.h"
+#include "lrnde_hooks.h"
 #include "lrnde_math.hpp"
 
 using namespace lrnde;

@@ -39,7 +39,9 @@
 #include <vector>
 
 #include "lrnde.h"
+#include "lrnde_hooks.h"
 #include "lrnde_math.hpp"
+#include "lrnde_comm.hpp"
 
 namespace {
 
@@ -116,8 +118,15 @@ struct StepArgs {
   float* ks[5];  // k2..k6
   float* g6;
   int B;          // local batch columns
-  int wg_offset;  // index of this rank's first tile in the global partial vector
-  int nwg_global;
+  int wg_offset;  // index of this rank's first tile in the global partial vector (prered: this rank's slot)
+  int nwg_global; // entries of the exchanged partial vector: all ranks' tiles, or (prered) one slot per rank
+  // sharded handles, per-rank pre-reduction: every tile writes its partial to tile_part / tile_pinit (rank local), the
+  // LAST workgroup of the launch to arrive (arrive[] counters) reduces them in the fixed order of reduce_partials and
+  // publishes ONE triple in this rank's slot of part_send / pinit_send: the all-reduce carries nranks triples
+  int prered;
+  int* arrive;         // [4]: step parity 0/1, init phase 1/2
+  double* tile_part;   // [2][nwg_local*PSTRIDE]
+  double* tile_pinit;  // [2][nwg_local*PSTRIDE]
   double n_global;  // D * B_global, the norm's element count
   float t0, t1, abstol, reltol, bench_dt;
   int maxiters, save_everystep, exact_pow, want_stiff, mode;
@@ -248,7 +257,43 @@ __device__ __forceinline__ void reduce_partials(const double* p, int nwg, double
   out[0] = __shfl(s0, 0, 64); out[1] = __shfl(s1, 0, 64); out[2] = __shfl(s2, 0, 64);
 }
 
+// A workgroup hands in its three fp64 partial sums (valid on thread 0).  which = 0/1: the step's parity block of
+// part_send; 2/3: init phase 1/2 block of pinit_send.  Gather mode: thread 0 writes the tile's entry of the exchanged
+// vector.  prered mode: see StepArgs — the last workgroup to arrive reduces the rank's tiles and writes the rank's slot.
 __device__ __forceinline__ float rms_from(double sumsq, double n) { return (float)sqrt(sumsq / n); }
+
+__device__ __forceinline__ void publish_partial(const StepArgs& a, int which, double s0, double s1, double s2) {
+  const size_t blk = (size_t)(which & 1);
+  double* send = (which < 2 ? a.part_send : a.pinit_send) + blk * (size_t)a.nwg_global * PSTRIDE;
+  if (!a.prered) {
+    if (threadIdx.x == 0) {
+      double* p = send + (size_t)(a.wg_offset + blockIdx.x) * PSTRIDE;
+      p[0] = s0; p[1] = s1; p[2] = s2;
+    }
+    return;
+  }
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  double* tiles = (which < 2 ? a.tile_part : a.tile_pinit) + blk * (size_t)gridDim.x * PSTRIDE;
+  int last = 0;
+  if (lane == 0) {
+    double* p = tiles + (size_t)blockIdx.x * PSTRIDE;
+    __hip_atomic_store(p + 0, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 2, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int old = __hip_atomic_fetch_add(a.arrive + which, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = (old == (int)gridDim.x - 1);
+  }
+  last = __shfl(last, 0, 64);
+  if (!last) return;
+  double s[3];
+  reduce_partials(tiles, (int)gridDim.x, s);  // agent-scope loads, the fixed order every reduction here uses
+  if (lane == 0) {
+    double* q = send + (size_t)a.wg_offset * PSTRIDE;
+    q[0] = s[0]; q[1] = s[1]; q[2] = s[2];
+    __hip_atomic_store(a.arrive + which, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch of this kind
+  }
+}
 
 // ---------------------------------------------------------------------------
 // vector field on one tile:  k = W2 * act(W1 * [x; t] + b1) (+ t column) + b2
@@ -995,10 +1040,7 @@ template <int W> __global__ __launch_bounds__(NT) void k_init1(StepArgs a) {
     }
   });
   block_sum3(s.red, a0, a1, a2);
-  if (threadIdx.x == 0) {
-    double* p = a.pinit_send + (size_t)(a.wg_offset + blockIdx.x) * PSTRIDE;
-    p[0] = a0; p[1] = a1; p[2] = 0.0;
-  }
+  publish_partial(a, 2, a0, a1, 0.0);
 }
 
 // init phase 2: u1 = u0 + dt0*f0, f1 = f(u1, t0+dt0); partial sum of ((f1-f0)/sk)^2
@@ -1045,10 +1087,7 @@ template <int W> __global__ __launch_bounds__(NT) void k_init2(StepArgs a) {
     }
   });
   block_sum3(s.red, a0, a1, a2);
-  if (threadIdx.x == 0) {
-    double* p = a.pinit_send + (size_t)(a.nwg_global + a.wg_offset + blockIdx.x) * PSTRIDE;
-    p[0] = a0; p[1] = 0.0; p[2] = 0.0;
-  }
+  publish_partial(a, 3, a0, 0.0, 0.0);
 }
 
 // one attempted Tsit5 step for the whole batch (src/perform_step.jl:3-47), preceded by the
@@ -1220,10 +1259,7 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
   }
   block_sum3(s.red, aerr, anum, aden);
   STAMP(19);
-  if (threadIdx.x == 0) {
-    double* p = a.part_send + ((size_t)((j + 1) & 1) * a.nwg_global + a.wg_offset + blockIdx.x) * PSTRIDE;
-    p[0] = aerr; p[1] = anum; p[2] = aden;
-  }
+  publish_partial(a, (j + 1) & 1, aerr, anum, aden);
 }
 
 
@@ -1520,6 +1556,8 @@ struct lrnde_ctx {
   double* adj_part = nullptr; double* adj_part_host = nullptr;
   std::vector<float> last_ts;  // sol.t of the last node_forward (cotangent times of the adjoint)
   float last_t1 = 0.f; int last_i1 = 0;
+  // backward workspace kept across calls: u(t1) of the recorded forward, k1 and the regulariser's gradient
+  float *rec_u1 = nullptr, *rec_k1 = nullptr, *rec_gr = nullptr; size_t rec_n = 0;
   // arguments of the last lrnde_node_forward_record (what lrnde_node_backward_recorded differentiates)
   bool rec_valid = false; int rec_B = 0, rec_mode = 0, rec_reg_type = 0, rec_naccept = 0;
   float rec_t0 = 0.f, rec_t2 = 0.f, rec_t1 = 0.f; lrnde_solve_opts rec_opts{};
@@ -1542,9 +1580,15 @@ struct lrnde_ctx {
   size_t usave_slots = 0, usave_slot_elems = 0;
   Ctrl* ctrl_host = nullptr;  // pinned [2]
   hipEvent_t ev_norm = nullptr;  // vec_norm's read-back
+  void* cls_ws = nullptr; size_t cls_ws_bytes = 0; void* cls_host = nullptr;  // lrnde_classifier_ce workspace (device / pinned)
   // comm
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;           // RCCL communicator (one process per GPU)
+  lrnde_local_comm* lcomm = nullptr;   // or: in-process local communicator (lrnde_hooks.h), never both
   int rank = 0, nranks = 1;
+  // per-rank pre-reduction of the error-norm partial sums (StepArgs::prered): default for sharded handles; with
+  // LRNDE_GATHER_TILES=1 in the environment every tile's partial is exchanged instead (the exact gather)
+  bool prered = false;
+  int* arrive = nullptr; double* tile_part = nullptr; double* tile_pinit = nullptr;
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evp[2] = {nullptr, nullptr};
   float last_ms = 0.f;
@@ -1579,6 +1623,22 @@ int fail(lrnde_ctx* c, int code, const char* fmt, ...) {
                   __FILE__, __LINE__);                                                        \
   } while (0)
 
+// a batch-sharded handle: its collectives run (RCCL or the in-process local communicator, lrnde_comm.hpp)
+inline bool sharded(const lrnde_ctx* c) { return c->comm != nullptr || c->lcomm != nullptr; }
+// every collective of the library: SUM all-reduce of `count` doubles / floats on the handle's stream (send may equal recv)
+int comm_allreduce(lrnde_ctx* c, const void* send, void* recv, size_t count, bool is_double) {
+  if (c->comm) {
+    NCCLCHK(c, ncclAllReduce(send, recv, count, is_double ? ncclDouble : ncclFloat, ncclSum, c->comm, c->stream));
+    return LRNDE_OK;
+  }
+  if (c->lcomm) {
+    const int rc = lc_allreduce(c->lcomm, c->rank, c->stream, send, recv, count, is_double);
+    if (rc) return fail(c, rc, "local communicator all-reduce failed (rank %d of %d): %s", c->rank, c->nranks,
+                        rc == LRNDE_NCCL_ERROR ? "a peer did not arrive (timeout) or the communicator is broken" : "HIP error");
+  }
+  return LRNDE_OK;
+}
+
 inline int ceil16(int x) { return (x + 15) & ~15; }
 inline int vecw(const lrnde_ctx* c) { return (c->desc.state_dim % 4 == 0) ? 4 : 1; }
 
@@ -1605,18 +1665,27 @@ int ensure_workspace(lrnde_ctx* c, int B) {
     if (c->part_rx) HIPCHK(c, hipFree(c->part_rx));
     if (c->pinit) HIPCHK(c, hipFree(c->pinit));
     if (c->pinit_rx) HIPCHK(c, hipFree(c->pinit_rx));
-    c->state = nullptr; c->part = c->part_rx = c->pinit = c->pinit_rx = nullptr;
+    if (c->tile_part) HIPCHK(c, hipFree(c->tile_part));
+    if (c->tile_pinit) HIPCHK(c, hipFree(c->tile_pinit));
+    c->state = nullptr; c->part = c->part_rx = c->pinit = c->pinit_rx = c->tile_part = c->tile_pinit = nullptr;
     HIPCHK(c, hipMalloc(&c->state, sizeof(float) * n * 10));
     const size_t pb = sizeof(double) * 2 * (size_t)nwg_global * PSTRIDE;
     HIPCHK(c, hipMalloc(&c->part, pb));
     HIPCHK(c, hipMalloc(&c->pinit, pb));
     HIPCHK(c, hipMemsetAsync(c->part, 0, pb, c->stream));
     HIPCHK(c, hipMemsetAsync(c->pinit, 0, pb, c->stream));
-    if (c->comm) {  // nranks > 1 (or LRNDE_FORCE_COMM: the same path on one rank)
+    if (sharded(c)) {  // nranks > 1 (or LRNDE_FORCE_COMM: the same path on one rank)
       HIPCHK(c, hipMalloc(&c->part_rx, pb));
       HIPCHK(c, hipMalloc(&c->pinit_rx, pb));
       HIPCHK(c, hipMemsetAsync(c->part_rx, 0, pb, c->stream));
       HIPCHK(c, hipMemsetAsync(c->pinit_rx, 0, pb, c->stream));
+      if (c->prered) {
+        const size_t tb = sizeof(double) * 2 * (size_t)nwg * PSTRIDE;
+        HIPCHK(c, hipMalloc(&c->tile_part, tb));
+        HIPCHK(c, hipMalloc(&c->tile_pinit, tb));
+        if (!c->arrive) HIPCHK(c, hipMalloc(&c->arrive, sizeof(int) * 4));
+        HIPCHK(c, hipMemsetAsync(c->arrive, 0, sizeof(int) * 4, c->stream));
+      }
     }
     c->wsB = B;
   }
@@ -1625,6 +1694,7 @@ int ensure_workspace(lrnde_ctx* c, int B) {
   return LRNDE_OK;
 }
 
+// force_nb: the SDE kernels' fixed tile shape; they exchange per-tile partials (no pre-reduction)
 void fill_args(lrnde_ctx* c, StepArgs& a, int B, int force_nb = 0) {
   memset(&a, 0, sizeof(a));
   const size_t n = (size_t)B * c->desc.state_dim;
@@ -1641,12 +1711,16 @@ void fill_args(lrnde_ctx* c, StepArgs& a, int B, int force_nb = 0) {
   a.B = B;
   a.nwg_global = nwg * c->nranks;
   a.wg_offset = nwg * c->rank;
+  if (sharded(c) && c->prered && !force_nb) {
+    a.prered = 1; a.arrive = c->arrive; a.tile_part = c->tile_part; a.tile_pinit = c->tile_pinit;
+    a.nwg_global = c->nranks; a.wg_offset = c->rank;
+  }
   a.n_global = (double)c->desc.state_dim * (double)B * (double)c->nranks;
   a.ctrl = c->ctrl;
   a.part_send = c->part;
-  a.part_recv = c->comm ? c->part_rx : c->part;
+  a.part_recv = sharded(c) ? c->part_rx : c->part;
   a.pinit_send = c->pinit;
-  a.pinit_recv = c->comm ? c->pinit_rx : c->pinit;
+  a.pinit_recv = sharded(c) ? c->pinit_rx : c->pinit;
 }
 
 size_t smem_q(const lrnde_ctx* c) { return smem_bytes_q(c->m.KQ1p, c->m.KQ2p, c->m.RG1, c->m.RG2); }
@@ -1691,9 +1765,8 @@ int launch_step(lrnde_ctx* c, int B, const StepArgs& a, int j, bool spec = false
 // exchange of the per-tile fp64 partial sums between ranks: ONE all-reduce (sum) of a vector
 // in which every rank has zeros outside its own segment, so the result is the exact gather.
 int exchange(lrnde_ctx* c, double* send, double* recv, size_t count) {
-  if (!c->comm) return LRNDE_OK;
-  NCCLCHK(c, ncclAllReduce(send, recv, count, ncclDouble, ncclSum, c->comm, c->stream));
-  return LRNDE_OK;
+  if (!sharded(c)) return LRNDE_OK;
+  return comm_allreduce(c, send, recv, count, true);
 }
 
 int run_init(lrnde_ctx* c, int B, const StepArgs& a) {
@@ -1829,10 +1902,12 @@ int lrnde_destroy(lrnde_ctx* c) {
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->adj_part_host) hipHostFree(c->adj_part_host);
   void* ptrs[] = {c->dense, c->dense_t, c->dense_dt, c->adj, c->adj_part, c->V1p, c->U2p, c->V1q, c->U2q, c->bw_y, c->bw_h, c->bw_dp, c->W1q, c->W2q, c->W1p, c->W2p, c->w1t, c->b1, c->w2t, c->b2, c->state, c->ctrl, c->part,
-                  c->part_rx, c->pinit, c->pinit_rx, c->saveat_dev, c->tsaved_dev, c->trace_dev,
+                  c->part_rx, c->pinit, c->pinit_rx, c->arrive, c->tile_part, c->tile_pinit, c->rec_u1, c->rec_k1, c->rec_gr, c->saveat_dev, c->tsaved_dev, c->trace_dev,
                   c->usave};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ctrl_host) hipHostFree(c->ctrl_host);
+  if (c->cls_ws) hipFree(c->cls_ws);
+  if (c->cls_host) hipHostFree(c->cls_host);
   if (c->ev_norm) hipEventDestroy(c->ev_norm);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
@@ -2096,6 +2171,9 @@ int lrnde_node_forward(lrnde_ctx* c, const float* x, int32_t B, float t0, float 
   if (reg_type != LRNDE_REG_ERROR_ESTIMATE && reg_type != LRNDE_REG_STIFFNESS_ESTIMATE)
     return fail(c, LRNDE_BADARG, "regularize must be one of (:error_estimate, :stiffness_estimate)");
   const size_t n = (size_t)B * c->desc.state_dim;
+  // a plain forward overwrites what a recorded one left for lrnde_node_backward_recorded (usave, last_ts, the state
+  // workspace): the record is gone
+  if (!c->dense_on) c->rec_valid = false;
   lrnde_solve_opts oo = *o;
   size_t need = 3;
   if (mode == LRNDE_MODE_BIASED) need = (size_t)(oo.maxiters < 510 ? oo.maxiters + 2 : 512);
@@ -2178,12 +2256,14 @@ int lrnde_comm_init(lrnde_ctx* c, const void* uid, int32_t rank, int32_t nranks)
   if (!c || !uid || nranks < 1 || rank < 0 || rank >= nranks) return LRNDE_BADARG;
   HIPCHK(c, hipSetDevice(c->device));
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+  c->lcomm = nullptr;
   c->rank = rank; c->nranks = nranks;
   c->wsB = 0;  // partial vectors are sized by nranks
   if (nranks > 1 || getenv("LRNDE_FORCE_COMM")) {
     ncclUniqueId id;
     memcpy(&id, uid, sizeof(id));
     NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+    c->prered = getenv("LRNDE_GATHER_TILES") == nullptr;
   }
   return LRNDE_OK;
 }
@@ -2191,7 +2271,48 @@ int lrnde_comm_init(lrnde_ctx* c, const void* uid, int32_t rank, int32_t nranks)
 int lrnde_comm_destroy(lrnde_ctx* c) {
   if (!c) return LRNDE_BADARG;
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+  c->lcomm = nullptr;
   c->rank = 0; c->nranks = 1; c->wsB = 0;
+  return LRNDE_OK;
+}
+
+// ---- in-process local communicator (include/lrnde_hooks.h; lrnde_comm.hpp) ----
+int lrnde_local_comm_create(lrnde_local_comm** out, int32_t nranks) {
+  if (!out || nranks < 1 || nranks > LRNDE_LC_MAXR) return LRNDE_BADARG;
+  lrnde_local_comm* lc = new lrnde_local_comm();
+  lc->n = nranks;
+  *out = lc;
+  return LRNDE_OK;
+}
+
+int lrnde_local_comm_destroy(lrnde_local_comm* lc) {
+  if (!lc) return LRNDE_OK;
+  for (int r = 0; r < lc->n; ++r) {
+    if (!lc->joined[r]) continue;
+    hipSetDevice(lc->device[r]);
+    if (lc->tmp[r]) hipFree(lc->tmp[r]);
+    if (lc->ready[r]) hipEventDestroy(lc->ready[r]);
+    if (lc->done[r]) hipEventDestroy(lc->done[r]);
+  }
+  delete lc;
+  return LRNDE_OK;
+}
+
+int lrnde_comm_init_local(lrnde_ctx* c, lrnde_local_comm* lc, int32_t rank) {
+  if (!c || !lc || rank < 0 || rank >= lc->n) return LRNDE_BADARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+  {
+    std::lock_guard<std::mutex> lk(lc->mu);
+    if (lc->joined[rank]) return fail(c, LRNDE_BADARG, "rank %d has already joined this local communicator", rank);
+    HIPCHK(c, hipEventCreateWithFlags(&lc->ready[rank], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&lc->done[rank], hipEventDisableTiming));
+    lc->device[rank] = c->device;
+    lc->joined[rank] = true;
+  }
+  c->lcomm = lc; c->rank = rank; c->nranks = lc->n;
+  c->prered = getenv("LRNDE_GATHER_TILES") == nullptr;
+  c->wsB = 0;  // partial vectors are sized by nranks
   return LRNDE_OK;
 }
 
@@ -2512,7 +2633,7 @@ static int launch_pgrad_args(lrnde_ctx* c, const PgradArgs& g) {
   hipLaunchKernelGGL(k_pgrad, dim3(g.ntile1 + g.ntile2), dim3(256), 0, c->stream, g);
   HIPCHK(c, hipGetLastError());
   // batch-sharded run: the parameter cotangent is a sum over all samples (SURVEY.md §8e caveat 1)
-  if (c->comm) NCCLCHK(c, ncclAllReduce(g.gp, g.gp, lrnde_param_count(&c->desc), ncclFloat, ncclSum, c->comm, c->stream));
+  if (sharded(c)) return comm_allreduce(c, g.gp, g.gp, lrnde_param_count(&c->desc), false);
   return LRNDE_OK;
 }
 // the deferred GEMM, if one is waiting (before anything reads the mu part of its K vector)
@@ -2527,7 +2648,7 @@ static int launch_pgrad(lrnde_ctx* c, int B, float t, const float* lam, float* g
   hipLaunchKernelGGL(k_pgrad, dim3(g.ntile1 + g.ntile2), dim3(256), 0, c->stream, g);
   HIPCHK(c, hipGetLastError());
   // batch-sharded run: the parameter cotangent is a sum over all samples (SURVEY.md §8e caveat 1)
-  if (c->comm) NCCLCHK(c, ncclAllReduce(gp, gp, lrnde_param_count(&c->desc), ncclFloat, ncclSum, c->comm, c->stream));
+  if (sharded(c)) return comm_allreduce(c, gp, gp, lrnde_param_count(&c->desc), false);
   return LRNDE_OK;
 }
 
@@ -2571,7 +2692,7 @@ static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float th
         else hipLaunchKernelGGL(k_vjp_q<4>, dim3(nvjp), dim3(QNT), smq, c->stream, a);
       }
       HIPCHK(c, hipGetLastError());
-      if (had && c->comm) NCCLCHK(c, ncclAllReduce(prev.gp, prev.gp, lrnde_param_count(&c->desc), ncclFloat, ncclSum, c->comm, c->stream));
+      if (had && sharded(c)) { const int rcc = comm_allreduce(c, prev.gp, prev.gp, lrnde_param_count(&c->desc), false); if (rcc) return rcc; }
       c->pg_pending = gp != nullptr;
       if (gp) c->pg_args = pgrad_args(c, B, t, lam, gp, set);
       c->bw_cur ^= 1;
@@ -2660,11 +2781,11 @@ int vec_norm(lrnde_ctx* c, const float* num, const float* num2, const float* sa,
 }
 // the per-block sums in c->adj_part (lambda part [0,256), mu part [256,512)) -> the rms over [lambda of all ranks; mu]
 int norm_readback(lrnde_ctx* c, size_t n_lam, size_t P, float* out) {
-  const int nr = c->comm ? c->nranks : 1;
-  if (c->comm) {
+  const int nr = sharded(c) ? c->nranks : 1;
+  if (sharded(c)) {
     if (nr > 64) return fail(c, LRNDE_UNSUPPORTED, "more than 64 ranks");
     hipLaunchKernelGGL(k_rank_slot, dim3(1), dim3(64), 0, c->stream, c->adj_part, c->adj_part + 512, c->rank, nr);
-    NCCLCHK(c, ncclAllReduce(c->adj_part + 512, c->adj_part + 512, nr, ncclDouble, ncclSum, c->comm, c->stream));
+    { const int rcc = comm_allreduce(c, c->adj_part + 512, c->adj_part + 512, nr, true); if (rcc) return rcc; }
   }
   HIPCHK(c, hipMemcpyAsync(c->adj_part_host, c->adj_part, sizeof(double) * (512 + 64), hipMemcpyDeviceToHost, c->stream));
   // the controller waits for this read-back once per adjoint step: poll an event instead of a blocking stream wait
@@ -2676,7 +2797,7 @@ int norm_readback(lrnde_ctx* c, size_t n_lam, size_t P, float* out) {
     if (q != hipErrorNotReady) return fail(c, LRNDE_HIP_ERROR, "waiting for the norm read-back: %s", hipGetErrorString(q));
   }
   double s = 0.0;
-  if (c->comm) { for (int r = 0; r < nr; ++r) s += c->adj_part_host[512 + r]; }
+  if (sharded(c)) { for (int r = 0; r < nr; ++r) s += c->adj_part_host[512 + r]; }
   else { for (int i = 0; i < 256; ++i) s += c->adj_part_host[i]; }
   if (P) for (int i = 0; i < 256; ++i) s += c->adj_part_host[256 + i];
   *out = (float)sqrt(s / ((double)n_lam * (double)nr + (double)P));
@@ -2845,7 +2966,7 @@ int lrnde_step_reg_grad(lrnde_ctx* c, const float* uprev, const float* k1, int32
   HIPCHK(c, hipMemsetAsync(c->adj, 0, sizeof(float) * 8 * N, c->stream));
   HIPCHK(c, hipMemsetAsync(gp, 0, sizeof(float) * P, c->stream));
   RegSeedArgs sa;
-  sa.n = n; sa.n_norm = n * (size_t)(c->comm ? c->nranks : 1); sa.uprev = uprev; sa.u = u; sa.g6 = g6;
+  sa.n = n; sa.n_norm = n * (size_t)(sharded(c) ? c->nranks : 1); sa.uprev = uprev; sa.u = u; sa.g6 = g6;
   for (int j = 0; j < 7; ++j) sa.k[j] = kk[j];
   for (int j = 1; j < 7; ++j) sa.kb[j] = kb[j];
   sa.ub = ub; sa.g6b = g6b; sa.dt = dt; sa.abstol = abstol; sa.reltol = reltol; sa.reg_type = reg_type;
@@ -2904,6 +3025,16 @@ int lrnde_node_forward_record(lrnde_ctx* c, const float* x, int32_t B, float t0,
   }
   if (rc) return rc;
   if (t1_used_host) *t1_used_host = t1;
+  if (c->rec_n != n) {
+    if (c->rec_u1) { hipFree(c->rec_u1); hipFree(c->rec_k1); hipFree(c->rec_gr); }
+    c->rec_u1 = c->rec_k1 = c->rec_gr = nullptr; c->rec_n = 0;
+    HIPCHK(c, hipMalloc(&c->rec_u1, sizeof(float) * n));
+    HIPCHK(c, hipMalloc(&c->rec_k1, sizeof(float) * n));
+    HIPCHK(c, hipMalloc(&c->rec_gr, sizeof(float) * lrnde_param_count(&c->desc)));
+    c->rec_n = n;
+  }
+  if (mode != LRNDE_MODE_NONE)  // u(t1): the local step's uprev, kept out of the save slots a later solve may reuse
+    HIPCHK(c, hipMemcpyAsync(c->rec_u1, c->usave + (size_t)c->last_i1 * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   c->rec_valid = true; c->rec_B = B; c->rec_t0 = t0; c->rec_t2 = t2; c->rec_opts = *o; c->rec_mode = mode;
   c->rec_reg_type = reg_type; c->rec_t1 = t1; c->rec_naccept = st->naccept;
   return LRNDE_OK;
@@ -2950,17 +3081,12 @@ int lrnde_node_backward_recorded(lrnde_ctx* c, int32_t B, const float* du_end, f
   HIPCHK(c, hipStreamSynchronize(c->stream));
   // regulariser: dp += w_reg * d reg_val / d p   (no gradient w.r.t. x: test/runtests.jl:129)
   if (mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
-    float *k1 = nullptr, *gr = nullptr, *u1 = nullptr;
-    HIPCHK(c, hipMalloc(&k1, sizeof(float) * n));
-    HIPCHK(c, hipMalloc(&gr, sizeof(float) * P));
-    HIPCHK(c, hipMalloc(&u1, sizeof(float) * n));
-    HIPCHK(c, hipMemcpy(u1, c->usave + (size_t)c->last_i1 * n, sizeof(float) * n, hipMemcpyDeviceToDevice));
+    float *k1 = c->rec_k1, *gr = c->rec_gr, *u1 = c->rec_u1;
     float dtl = 0.f, rv = 0.f;
     rc = lrnde_init_dt(c, u1, B, t1, t2, o->abstol, o->reltol, k1, &dtl);
     if (!rc) rc = lrnde_step_reg_grad(c, u1, k1, B, t1, dtl, o->abstol, o->reltol, reg_type, gr, &rv);
     if (!rc) { const float* g1[2] = {dp, gr}; const float cc[2] = {1.0f, w_reg}; rc = vec_axpy(c, dp, nullptr, 1.0f, 2, g1, cc, P); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipFree(k1); hipFree(gr); hipFree(u1);
     if (rc) return rc;
   }
   c->rec_valid = false;  // the regulariser sweep reused the state workspace
@@ -2990,6 +3116,7 @@ int lrnde_node_backward(lrnde_ctx* c, const float* x, int32_t B, float t0, float
 }  // extern "C"
 namespace {
 #include "lrnde_cls.hpp"
+#include "lrnde_cls_fused.hpp"
 }  // namespace
 extern "C" {
 
@@ -2999,20 +3126,44 @@ int lrnde_classifier_ce(lrnde_ctx* c, const float* u, int32_t B, const float* pc
   if (!u || !pc || !labels || !loss_host || B <= 0 || K <= 0 || K > 16) return fail(c, LRNDE_BADARG, "bad argument (1 <= K <= 16)");
   HIPCHK(c, hipSetDevice(c->device));
   const int D = c->desc.state_dim;
-  float *dl = nullptr, *lb = nullptr;
-  HIPCHK(c, hipMalloc(&dl, sizeof(float) * (size_t)B * K));
-  HIPCHK(c, hipMalloc(&lb, sizeof(float) * (size_t)B));
-  hipLaunchKernelGGL(k_cls_fwd, dim3((B + 3) / 4), dim3(256), 0, c->stream, u, pc, labels, B, D, K, logits, dl, lb);
-  if (du) hipLaunchKernelGGL(k_cls_bwd_x, dim3((unsigned)(((size_t)B * D + 255) / 256)), dim3(256), 0, c->stream, (const float*)dl, pc, B, D, K, du);
-  if (dpc) hipLaunchKernelGGL(k_cls_bwd_w, dim3((K * (D + 1) + 255) / 256), dim3(256), 0, c->stream, (const float*)dl, u, B, D, K, dpc);
-  std::vector<float> h(B);
-  hipError_t e = hipMemcpyAsync(h.data(), lb, sizeof(float) * B, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(dl); hipFree(lb);
-  if (e != hipSuccess) return fail(c, LRNDE_HIP_ERROR, "classifier kernels failed: %s", hipGetErrorString(e));
-  double acc = 0.0;
-  for (int b = 0; b < B; ++b) acc += (double)h[b];
-  *loss_host = (float)(acc / (double)B);
+  // cached workspace: dl (B x K), per-sample losses (B), {double loss sum, int bad-label flag}
+  const size_t need = sizeof(float) * ((size_t)B * K + (size_t)B) + 64;
+  if (c->cls_ws_bytes < need) {
+    if (c->cls_ws) HIPCHK(c, hipFree(c->cls_ws));
+    c->cls_ws = nullptr; c->cls_ws_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->cls_ws, need));
+    c->cls_ws_bytes = need;
+  }
+  if (!c->cls_host) HIPCHK(c, hipHostMalloc(&c->cls_host, sizeof(ClsOut)));
+  ClsOut* out = reinterpret_cast<ClsOut*>(c->cls_ws);
+  float* dl = reinterpret_cast<float*>(reinterpret_cast<char*>(c->cls_ws) + 64);
+  float* lb = dl + (size_t)B * K;
+  // the loss is the mean over the GLOBAL batch: on a sharded handle every rank normalises by B * nranks, and the loss
+  // and the classifier cotangent (sums over all samples) are all-reduced; du stays sharded like dx
+  const int nr = sharded(c) ? c->nranks : 1;
+  const float Bnorm = (float)B * (float)nr;
+  HIPCHK(c, hipMemsetAsync(out, 0, sizeof(ClsOut), c->stream));
+  hipLaunchKernelGGL(k_cls_fwd_bwdx, dim3((B + 3) / 4), dim3(256), 0, c->stream, u, pc, labels, B, D, K, Bnorm, logits, dl, lb, du, out);
+  {  // dW = dl^T u and db = dl^T 1 as ONE batch-reduction GEMM (the parameter-gradient tiles of the adjoint, first form,
+     // H := K, no time column) + one extra workgroup that adds the per-sample losses in a fixed order
+    PgradArgs g;
+    memset(&g, 0, sizeof(g));
+    g.D = D; g.H = K; g.Hp = K; g.td = 0; g.B = B; g.t = 0.f; g.dpre = dl; g.y = u; g.gp = dpc;
+    g.nt1c = (D + 2 + 15) / 16; g.ntile1 = ((K + 15) / 16) * g.nt1c; g.ntile2 = 0; g.nt2c = 1;
+    const int nt = dpc ? g.ntile1 : 0;
+    hipLaunchKernelGGL(k_cls_bwdw_loss, dim3(nt + 1), dim3(256), 0, c->stream, g, nt, (const float*)lb, B, out);
+  }
+  HIPCHK(c, hipGetLastError());
+  if (sharded(c)) {
+    int rc;
+    if (dpc && (rc = comm_allreduce(c, dpc, dpc, (size_t)K * (D + 1), false))) return rc;
+    if ((rc = comm_allreduce(c, &out->loss_sum, &out->loss_sum, 1, true))) return rc;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->cls_host, out, sizeof(ClsOut), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const ClsOut* ho = reinterpret_cast<const ClsOut*>(c->cls_host);
+  if (ho->bad_label) return fail(c, LRNDE_BADARG, "a label is outside [0, %d)", K);
+  *loss_host = (float)(ho->loss_sum / ((double)B * (double)nr));
   return LRNDE_OK;
 }
 

@@ -556,10 +556,7 @@ __global__ __launch_bounds__(QNT) void k_init1_q(StepArgs a) {
     }
   });
   block_sum3_q(s.red, a0, a1, a2);
-  if (threadIdx.x == 0) {
-    double* p = a.pinit_send + (size_t)(a.wg_offset + blockIdx.x) * PSTRIDE;
-    p[0] = a0; p[1] = a1; p[2] = 0.0;
-  }
+  publish_partial(a, 2, a0, a1, 0.0);
 }
 
 __global__ __launch_bounds__(QNT) void k_init2_q(StepArgs a) {
@@ -604,10 +601,7 @@ __global__ __launch_bounds__(QNT) void k_init2_q(StepArgs a) {
     }
   });
   block_sum3_q(s.red, a0, a1, a2);
-  if (threadIdx.x == 0) {
-    double* p = a.pinit_send + (size_t)(a.nwg_global + a.wg_offset + blockIdx.x) * PSTRIDE;
-    p[0] = a0; p[1] = 0.0; p[2] = 0.0;
-  }
+  publish_partial(a, 3, a0, 0.0, 0.0);
 }
 
 // one attempted Tsit5 step, 4 columns per workgroup (same flow as k_step's fused path)
@@ -742,10 +736,7 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
   STAMP(18);
   block_sum3_q(s.red, aerr, anum, aden, a.want_stiff != 0);
   STAMP(19);
-  if (threadIdx.x == 0) {
-    double* p = a.part_send + ((size_t)((j + 1) & 1) * a.nwg_global + a.wg_offset + blockIdx.x) * PSTRIDE;
-    p[0] = aerr; p[1] = anum; p[2] = aden;
-  }
+  publish_partial(a, (j + 1) & 1, aerr, anum, aden);
 }
 
 // flat Lux parameter vector -> quad-tile A layouts (zero padded in k; row groups NOT padded)

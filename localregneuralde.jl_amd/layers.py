@@ -286,6 +286,12 @@ class Handle:
         return float(ms.value), int(n.value)
 
 
+def biased_index(r01, m):
+    """index into sol.t[1:end-1] (m entries) from one uniform draw: (int)(r01 * (float)m) in float32, clamped — the
+    arithmetic of lrnde_node_forward (csrc/lrnde_kernels.hip)"""
+    return max(0, min(int(np.float32(r01) * np.float32(m)), m - 1))
+
+
 # ----- solution object: the fields the reference reads (src/utils.jl:7-9,25-46) -----
 class ODESolution:
     def __init__(self, u, t, nf, naccept=0, nreject=0, retcode="Success"):
@@ -330,7 +336,7 @@ class NeuralODE:
         self._conv = conv_topology(model)  # (C, Hc, act, eps) for the CIFAR node_core, else None
         self.desc = None if self._conv else _mlp_desc(model)
         self._handle = None
-        self._ps_key = None
+        self._bound = False
 
     def initialstates(self, rng):
         """:27-31 — burns one normal draw, then replicates the rng."""
@@ -350,18 +356,21 @@ class NeuralODE:
                     Cst, Hc, act, eps = self._conv
                     self._handle = ConvHandle(hw[0], hw[1], Cst, Hc, act=act, bn_train=True, bn_eps=eps,
                                               compute_dtype=self.kwargs.get("compute_dtype", "f32"))
-                    self._hw, self._ps_key = hw, None
+                    self._hw, self._bound = hw, False
             return self._handle
         if self._handle is None:
             self._handle = Handle(self.desc)
         return self._handle
 
-    def _bind(self, ps, x=None):
+    def _bind(self, ps, x=None, changed=True):
+        """Hands `ps` to the device handle.  The parameters are repacked on EVERY call unless the caller states
+        `changed=False` (same values as the last bind): equality is never inferred from a pointer or a torch version
+        counter — an in-place numpy / ctypes / foreign-kernel update of the same storage bumps neither, and a freed
+        buffer can come back at the same address.  The repack is four small kernels (a few microseconds)."""
         h = self.handle(x)
-        key = (ps.data_ptr(), ps._version) if isinstance(ps, torch.Tensor) else None
-        if key is None or key != self._ps_key:
+        if changed or not self._bound:
             h.set_params(ps)
-            self._ps_key = key
+            self._bound = True
         return h
 
     def _model_state_in(self, h, st):
@@ -406,7 +415,10 @@ class NeuralODE:
                         save_everystep=saveat is None, cap=min(self.maxiters, 510) + 2, **common)
             ts = list(r["t"])
             needs_correction = False
-            i1 = int(rng.integers(0, len(ts) - 1))  # rand(rng, sol.t[1:end-1])
+            # rand(rng, sol.t[1:end-1]) with the ONE draw convention of this package (pullback, run_training_step and the
+            # C side's lrnde_node_forward use the same): one uniform float32 r in [0,1), index floor(r * m)
+            r01 = np.float32(rng.random(dtype=np.float32))
+            i1 = biased_index(r01, len(ts) - 1)
             t1, u1 = ts[i1], r["u"][i1]
         model_state = self._model_state_out(h, st)  # as it is when the solve returns (:52); the local step leaves no trace
         # _get_ode_integrator :33-38 + _perform_step :77
@@ -426,7 +438,8 @@ class NeuralODE:
     def pullback(self, x, ps, st, du_end, w_reg=0.0):
         """What `Zygote.pullback` returns for this layer in the reference's training step
         (experiments/src/utils.jl:104-115) for  loss = <du_end, sol.u[end]> + w_reg * reg_val:
-        (dx, dps).  The forward is re-run with the same rng draw as `__call__` would make."""
+        (dx, dps, info).  One forward with the dense record, then the backward from it; t1 comes from the same single
+        draw of st['rng'] as in `__call__` (biased_index), so info['reg_val'] / info['t1'] are `__call__`'s."""
         h = self._bind(ps, x)
         t0, t2 = self.tspan
         kw = self.kwargs
@@ -437,7 +450,8 @@ class NeuralODE:
         rng = copy.deepcopy(st["rng"])
         r01 = np.float32(rng.random(dtype=np.float32))
         t1_or_rand = np.float32(r01 * (t2 - t0) + t0) if mode == "unbiased" else r01
-        out = h.node_backward(x, t0, t2, abstol, reltol, du_end, mode=mode, reg_type=self.regularize_type,
-                              t1_or_rand=t1_or_rand, w_reg=w_reg, maxiters=self.maxiters,
-                              save_start=kw.get("save_start", True))
-        return out["dx"], out["dp"], out
+        fw = h.node_forward_record(x, t0, t2, abstol, reltol, mode=mode, reg_type=self.regularize_type,
+                                   t1_or_rand=t1_or_rand, maxiters=self.maxiters, save_start=kw.get("save_start", True))
+        bw = h.node_backward_recorded(du_end, w_reg=w_reg) if not self._conv else h.node_backward_recorded(x.shape[0], du_end, w_reg=w_reg)
+        info = dict(bw, reg_val=fw["reg_val"], t1=fw["t1"], nfe=fw["nfe"], u_end=fw["u_end"], stats_fwd=fw["stats"])
+        return bw["dx"], bw["dp"], info

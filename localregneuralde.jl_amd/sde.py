@@ -180,12 +180,22 @@ class NeuralDSDE:
                 ua = x if j == 0 else us[j - 1]
                 th = np.float32((t1 - ta) / (ts[j] - ta))
                 u1 = (ua + th * (us[j] - ua)).contiguous()
-            else:  # :109-123: a saved time other than the last
-                j = int(rng.integers(0, max(n - 1, 1)))
-                t1, u1 = ts[j], us[j]
-            r = step(u1, n, t1)  # :98,118
+            else:  # :109-123: rand(rng, sol.t[1:end-1]) — every saved time but the last, t0 included (the SDE solve saves
+                # its start); one uniform draw, index floor(r * m) (layers.biased_index: the package's one convention)
+                from .layers import biased_index
+                j = biased_index(np.float32(rng.random(dtype=np.float32)), n)
+                t1, u1 = (t0, x) if j == 0 else (ts[j - 1], us[j - 1])
+            # the local step's integrator is a fresh `init` on (t1, t2) (:96,116): its first dt is clipped to the span
+            dt_loc = np.float32(min(dt, np.float32(t2 - t1)))
+            if self.solver == "SRI":
+                r = h.sri_step(self.tableau, u1, noise[n].contiguous(), dz[n].contiguous(), t1, dt_loc, abstol, reltol, self.delta)
+            elif self.solver == "RKMil":
+                r = h.rkmil_step(u1, noise[n].contiguous(), t1, dt_loc, abstol, reltol)
+            else:
+                r = h.euler_heun_step(u1, noise[n].contiguous(), t1, dt_loc, abstol, reltol, self.delta)
             reg_val = r["reg_val"]
             nfe += per_step[0]; nfe_g += per_step[1]
+            self._last_local = dict(t1=t1, dt=dt_loc, u1=u1, dW=noise[n])
         sol = ODESolution([us[-1]], [t2], nfe)
         return sol, dict(drift=st["drift"], diffusion=st["diffusion"], nfe_drift=nfe, nfe_diffusion=nfe_g,
                          reg_val=reg_val, rng=rng, training=st["training"])

@@ -15,16 +15,16 @@ def run_training_step(node, ps, pc, st, x, labels, w_reg, num_classes=10):
     (CUDA float32), labels: CUDA int32 (B).  Returns (loss, st_, stats, grads, times) like the reference:
     stats = (y_pred, nfe, ce_loss, reg_val), grads = dict(neural_ode=dps, classifier=dpc, x=dx),
     times = dict(fwd_time, bwd_time) in seconds (wall, synchronised)."""
-    h = node._bind(ps)
     t0, t2 = node.tspan
     kw = node.kwargs
     abstol, reltol = kw.get("abstol", 1e-6), kw.get("reltol", 1e-3)
     mode = node.regularize if st["training"] else "none"
     rng = copy.deepcopy(st["rng"])
-    r01 = np.float32(rng.random(dtype=np.float32))
+    r01 = np.float32(rng.random(dtype=np.float32))  # the package's one draw convention (layers.biased_index)
     t1_or_rand = np.float32(r01 * (t2 - t0) + t0) if mode == "unbiased" else r01
     torch.cuda.synchronize()
     tic = time.perf_counter()
+    h = node._bind(ps)  # the repack of the (updated) parameters is part of the step
     fw = h.node_forward_record(x, t0, t2, abstol, reltol, mode=mode, reg_type=node.regularize_type,
                                t1_or_rand=t1_or_rand, maxiters=node.maxiters, save_start=kw.get("save_start", True))
     head = h.classifier_ce(fw["u_end"], pc, num_classes, labels)

@@ -531,6 +531,46 @@ def test_conv_full_size_properties():
         assert _rel(fb.cpu().numpy(), fa[perm].cpu().numpy()) <= 1e-5
 
 
+def test_conv_bf16_full_size_properties():
+    """BASELINE.json config 4 at its own size and dtype: the CIFAR10 block 32x32x8, B=256 with bf16 handles.
+    (1) running statistics: the bf16 field is per-sample — f(u)[rows] == f(u[rows]) bit for bit;
+    (2) the bf16 f-eval is within 3e-2 of the fp32 handle's f-eval at full size (bf16 operands, 8 mantissa bits; the same
+        bound the small-shape oracle tests use), train-mode and test-mode statistics;
+    (3) batch statistics: a permutation of the batch permutes the output (bf16 rounding + summation-order tolerance 2e-2);
+    (4) determinism: two evaluations and two adaptive forward passes at the experiment's tolerance are bitwise equal, the
+        solve finishes (retcode 0) and reports the NFE the bench line quotes for bf16."""
+    P, O = _mods()
+    rng = np.random.default_rng(22)
+    W, H, B = 32, 32, 256
+    p = P.glorot_conv_params(8, 64, seed=1)
+    u = torch.from_numpy(rng.standard_normal((B, 8, H, W)).astype(np.float32)).cuda()
+    for train in (False, True):
+        hb = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=train, compute_dtype="bf16")
+        hf = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=train)
+        hb.set_params(p); hf.set_params(p)
+        fb, ff = hb.rhs(u, 0.3), hf.rhs(u, 0.3)
+        assert torch.isfinite(fb).all()
+        err = float((fb - ff).abs().max() / ff.abs().max())
+        assert err <= 3e-2, err
+        assert torch.equal(fb, hb.rhs(u, 0.3))
+        if not train:
+            rows = torch.tensor([0, 5, B // 2, B - 1], device="cuda")
+            assert torch.equal(fb[rows], hb.rhs(u[rows].contiguous(), 0.3))
+        else:
+            perm = torch.from_numpy(rng.permutation(B)).cuda()
+            fp = hb.rhs(u[perm].contiguous(), 0.3)
+            assert _rel(fp.cpu().numpy(), fb[perm].cpu().numpy()) <= 2e-2
+            r1 = hb.node_forward(u, 0.0, 1.0, 1e-4, 1e-4, mode="unbiased", t1_or_rand=0.4, maxiters=10000)
+            hb.set_bn_state(np.concatenate([np.zeros(64), np.ones(64), np.zeros(64), np.ones(64)]).astype(np.float32))
+            r2 = hb.node_forward(u, 0.0, 1.0, 1e-4, 1e-4, mode="unbiased", t1_or_rand=0.4, maxiters=10000)
+            assert torch.equal(r1["u_end"], r2["u_end"]) and r1["nfe"] == r2["nfe"] and r1["reg_val"] == r2["reg_val"]
+            assert r1["stats"]["retcode"] == 0 and torch.isfinite(r1["u_end"]).all()
+            rf = hf.node_forward(u, 0.0, 1.0, 1e-4, 1e-4, mode="unbiased", t1_or_rand=0.4, maxiters=10000)
+            print(f"CIFAR block B=256 tol 1e-4: bf16 nfe {r1['nfe']} (accepted {r1['stats']['naccept']}), fp32 nfe {rf['nfe']}")
+            # both integrate the same ODE to the same tolerance: the end states agree to the bf16 field's accuracy
+            assert float((r1["u_end"] - rf["u_end"]).abs().max() / rf["u_end"].abs().max()) <= 5e-2
+
+
 @pytest.mark.parametrize("W,H,B", [(64, 4, 2), (128, 2, 2)])
 def test_conv_wide_images(W, H, B):
     """widths whose halo tile exceeds the default 64 KiB of dynamic LDS (the maximum supported width is 128)"""

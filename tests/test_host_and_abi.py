@@ -10,10 +10,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "lrnde.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(lrnde_[a-z0-9_]+)\s*\(", txt)))
+def _declared_symbols(headers=("lrnde.h", "lrnde_hooks.h")):
+    out = set()
+    for h in headers:
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        out |= set(re.findall(r"\b(lrnde_[a-z0-9_]+)\s*\(", txt))
+    return sorted(out)
 
 
 def test_header_symbols_are_exported_and_bound():
@@ -26,6 +29,9 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(raw, name), f"{name} declared in include/lrnde.h but not exported"
     assert sorted(n for n, _, _ in _lib.SYMBOLS) == decl, "ctypes table and header drifted apart"
     assert b"gfx950" in _lib.lib.lrnde_version()
+    # the drop-in boundary carries no bench / test hooks: those live in include/lrnde_hooks.h
+    assert not {"lrnde_bench_step", "lrnde_conv_bench_rhs", "lrnde_last_solve_kernel_ms", "lrnde_local_comm_create"} & \
+        set(_declared_symbols(("lrnde.h",)))
 
 
 def test_struct_layouts_match_header():

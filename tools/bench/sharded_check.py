@@ -22,7 +22,7 @@ try:
     P.init_comm(h, rank, world)
 except Exception as e:
     print(f"rank {rank}: init_comm failed: {e}", flush=True)
-    dist.destroy_process_group(); sys.exit(0)
+    dist.destroy_process_group(); sys.exit(2)  # a communicator that cannot be built is a FAILURE of this check
 x = torch.from_numpy(np.ascontiguousarray(P.shard_columns(xg, rank, world))).cuda()
 r = h.node_forward(x, 0.0, 1.0, 1e-5, 1e-5, mode="unbiased", t1_or_rand=0.37, maxiters=2000)
 import oracle as O
@@ -36,5 +36,10 @@ g = np.random.default_rng(4).standard_normal(xg.shape).astype(np.float32)
 bo = O.node_backward(fld, xg, 0.0, 1.0, 1e-5, 1e-5, g, mode="unbiased", t1_or_rand=0.37, w_reg=2.5, maxiters=5000)
 bg = h.node_backward(x, 0.0, 1.0, 1e-5, 1e-5, torch.from_numpy(g[rank * Bl:(rank + 1) * Bl]).cuda(), mode="unbiased", t1_or_rand=0.37, w_reg=2.5, maxiters=5000)
 rel = lambda a, b: np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64))
-print(f"rank {rank}: adjoint naccept {bg['stats_bwd']['naccept']} vs {bo['stats_bwd']['naccept']}  dx rel {rel(bg['dx'].cpu().numpy(), bo['dx'][rank*Bl:(rank+1)*Bl]):.2e}  dp rel {rel(bg['dp'].cpu().numpy(), bo['dp']):.2e}", flush=True)
+rdx, rdp = rel(bg['dx'].cpu().numpy(), bo['dx'][rank*Bl:(rank+1)*Bl]), rel(bg['dp'].cpu().numpy(), bo['dp'])
+print(f"rank {rank}: adjoint naccept {bg['stats_bwd']['naccept']} vs {bo['stats_bwd']['naccept']}  dx rel {rdx:.2e}  dp rel {rdp:.2e}", flush=True)
+ok = ok and rdx < 2e-3 and rdp < 2e-3
+flag = torch.tensor([0 if ok else 1])
+dist.all_reduce(flag)
 dist.destroy_process_group()
+sys.exit(0 if int(flag.item()) == 0 else 1)  # non-zero if ANY rank saw a mismatch
