@@ -176,6 +176,23 @@ int lrnde_node_forward_record(lrnde_ctx* ctx, const float* x, int32_t B, float t
 int lrnde_node_backward_recorded(lrnde_ctx* ctx, int32_t B, const float* du_end, float w_reg, float* dx, float* dp,
                                  lrnde_stats* stats_bwd_host);
 
+/* The recorded forward with the layer's `saveat` kwarg, and its pullback for cotangents on EVERY state of the returned
+ * solution — what the reference's time-series consumers differentiate (diffeqsol_to_timeseries, src/utils.jl:42-46;
+ * experiments/src/construct.jl:244-249).  saveat_host: nsave ascending times (nsave = 0: the default of
+ * src/layers/neural_ode.jl:102-116).  Mode unbiased appends t1 for the solve and drops every saved time equal to t1 from
+ * the result again (_CorrectedDESolution, src/utils.jl:25-33); mode biased draws t1 among the saved times but the last.
+ * u_series (device, cap_series x B x D) / t_series_host receive sol.u / sol.t as the caller of the layer sees them,
+ * *nseries_host their count.  lrnde_node_backward_recorded_ts: du_series (device, nseries x B x D), one cotangent per
+ * state of that series; each enters the reversed-time adjoint solve as an impulse on lambda at its time (SciMLSensitivity's
+ * callbacks at the saved times, with the first-same-as-last derivative re-evaluated after each), the one at the end time is
+ * lambda's start value. */
+int lrnde_node_forward_record_ts(lrnde_ctx* ctx, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* opts,
+                                 int32_t mode, int32_t reg_type, float t1_or_rand, const float* saveat_host, int32_t nsave,
+                                 float* u_series, float* t_series_host, int32_t cap_series, int32_t* nseries_host,
+                                 float* reg_val_host, int32_t* nfe_host, lrnde_stats* stats_host, float* t1_used_host);
+int lrnde_node_backward_recorded_ts(lrnde_ctx* ctx, int32_t B, const float* du_series, int32_t nseries, float w_reg,
+                                    float* dx, float* dp, lrnde_stats* stats_bwd_host);
+
 /* Classifier head + loss of the MNIST experiments: logits = Dense(D => K)(u) with flat Lux
  * parameters pc = [vec(W) (K x D, column-major); b] (experiments/src/construct.jl:199), loss =
  * logitcrossentropy(logits, onehot(labels)) = mean over the batch (experiments/src/utils.jl:88).  Returns the

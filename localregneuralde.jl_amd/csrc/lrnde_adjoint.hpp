@@ -1,0 +1,218 @@
+// lrnde_adjoint.hpp — device-side controller of the continuous adjoint's reversed-time Tsit5 solve (SURVEY.md §3.3:
+// SciMLSensitivity InterpolatingAdjoint, un-vendored; what the reference reaches through Zygote.pullback in
+// experiments/src/utils.jl:104-115).  Included by lrnde_kernels.hip inside its anonymous namespace, before
+// lrnde_backward.hpp (whose kernels resolve their per-attempt arguments through it).
+//
+// Round 1 kept this loop's controller on the host: one norm read-back per adjoint step (a stream sync and ~35 us of
+// idle GPU per 145-us step).  Here it is the forward solve's scheme (step_prologue): the integrator state AdjCtrl lives
+// on the device, double-buffered by attempt parity; the FIRST launch of attempt j (the stage-2 VJP) runs, in wave 0 of
+// every workgroup and on identical inputs, the footer of attempt j-1 (error norm from the per-block fp64 partial sums,
+// PI controller, accept/reject, FSAL swap, tstop handling) and the header of attempt j (dt, the six stage times and the
+// dense-record step / interpolation parameter each of them falls into); block 0 publishes the result, the other
+// launches of the attempt (stages 3..7, the parameter-gradient GEMMs, the end-of-step norm kernel) just read it.  The
+// host enqueues attempts in chunks and polls the status word one chunk behind; nothing waits for the host.
+//
+// z = [lambda (n_lam local columns); mu (P, replicated)], N = n_lam + P, reversed time s = -t.
+// Buffers (one allocation, c->adj): zb[2] (z / z_new ping-pong), zs, ut (stage lambdas), K[0..6] with K[0], K[6] the
+// FSAL pair that swaps with z on an accepted step.
+
+struct AdjStage { int lo; float theta, ddt, t; };  // dense-record step, interpolation parameter, that step's dt, forward time
+
+struct AdjCtrl {
+  int status, first, do_step;
+  int resume;  // 1: first attempt of a later segment (after a cotangent impulse): no footer, dt = dtpropose
+  int iter, naccept, nreject, nf;
+  int cur;     // z = zb[cur], z_new = zb[cur^1]; K1 = (cur ? K[6] : K[0]), K7 = (cur ? K[0] : K[6])
+  int istop;
+  float t, dt;  // reversed time and dt of the attempt this block describes
+  float tstop;  // end of that attempt's tstop interval (the accept snap needs it)
+  float qold, q11, dtpropose, eest_last, dt_init;
+  float dt0;    // initdt's first guess (init phase B)
+  AdjStage st[6];  // stages 2..7 (init phases use st[0])
+};
+
+struct AdjArgs {
+  AdjCtrl* ctl;  // [2]
+  float* base;   // the 11-vector allocation: zb0 zb1 zs ut K0..K6, each N floats
+  size_t N, n_lam, P;
+  const float* dense; const float* dense_t; const float* dense_dt; int nrec;  // forward record: [uprev,k1..k7] per accepted step
+  const float* stops; int nstops;  // tstops in reversed time (device, ascending)
+  float s0, s1;        // start of the whole solve; end of the CURRENT segment (the next cotangent impulse, or the end)
+  float dtmax, dtmin;  // of the whole solve (s_end - s0; eps)
+  float abstol, reltol;
+  int maxiters, exact_pow;
+  const double* part;   // [512 + 64]: per-block sums of the error norm (lambda 256, mu 256) and the per-rank lambda sums
+  const double* ipart;  // [3][512 + 64]: the same for initdt's d0, d1, d2
+  int nranks;           // > 1 (or a forced communicator): the lambda part's sum is the rank slots', added in rank order
+  int use_slots;
+};
+
+// how a backward kernel gets its per-launch arguments: from the host (round-1 path, single calls), or from AdjCtrl:
+// ADJ_FSAL = K1 := rhs(z, t) at the state of ctl[0] (init phase A; re-evaluation after an impulse), ADJ_INIT_B = initdt's
+// second evaluation at z + dt0*K1, ADJ_STAGE = stage sidx of attempt j
+enum { ADJ_HOST = 0, ADJ_FSAL = 1, ADJ_INIT_B = 2, ADJ_STAGE = 3 };
+
+__device__ __forceinline__ float* adj_zb(const AdjArgs& g, int i) { return g.base + (size_t)i * g.N; }
+__device__ __forceinline__ float* adj_zs(const AdjArgs& g) { return g.base + 2 * g.N; }
+__device__ __forceinline__ float* adj_ut(const AdjArgs& g) { return g.base + 3 * g.N; }
+// K_j of the attempt (j = 0..6) under FSAL parity cur
+__device__ __forceinline__ float* adj_K(const AdjArgs& g, int j, int cur) {
+  const int slot = (j == 0) ? (cur ? 6 : 0) : ((j == 6) ? (cur ? 0 : 6) : j);
+  return g.base + (size_t)(4 + slot) * g.N;
+}
+// lambda part of the stage state of stage sidx (2..7): the buffers the host loop of round 1 alternated between
+__device__ __forceinline__ float* adj_stage_lam(const AdjArgs& g, int sidx, int cur) {
+  return (sidx == 7) ? adj_zb(g, cur ^ 1) : ((sidx & 1) ? adj_ut(g) : adj_zs(g));
+}
+
+// sum of the norm's partial sums (wave 0, all lanes return the total): lambda part = the 256 block sums, or, on a sharded
+// handle, the per-rank sums in rank order; then the 256 mu block sums.  Fixed order: lane-strided, DPP/readlane tree.
+__device__ __forceinline__ double adj_norm_sum(const double* p, int use_slots, int nranks, bool has_mu) {
+  const int lane = threadIdx.x & 63;
+  double s = 0.0;
+  if (use_slots) {
+    if (lane < nranks) s = __hip_atomic_load(p + 512 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __hip_atomic_load(p + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s = ((v[0] + v[1]) + v[2]) + v[3];
+  }
+  if (has_mu) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __hip_atomic_load(p + 256 + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s += ((v[0] + v[1]) + v[2]) + v[3];
+  }
+  return wave_sum_dpp(s);
+}
+
+// the forward step the time tt falls into: the largest lo with dense_t[lo] <= tt (0 if none), by ballots over the
+// (ascending) start times; wave 0, uniform result
+__device__ __forceinline__ AdjStage adj_lookup(const AdjArgs& g, float tt) {
+  const int lane = threadIdx.x & 63;
+  int cnt = 0;
+  for (int base = 0; base < g.nrec; base += 64) {
+    const int i = base + lane;
+    const float v = (i < g.nrec) ? g.dense_t[i] : 3.0e38f;
+    cnt += __popcll(__ballot(v <= tt));
+  }
+  AdjStage s;
+  s.lo = cnt > 0 ? cnt - 1 : 0;
+  s.ddt = g.dense_dt[s.lo];
+  s.theta = (tt - g.dense_t[s.lo]) / s.ddt;
+  s.t = tt;
+  return s;
+}
+
+__device__ __forceinline__ float adj_dt0(float d0, float d1, float dtmax) {
+  float dt0 = ((double)d0 < 1e-5 || (double)d1 < 1e-5) ? 1e-6f : (d0 / d1) / 100.0f;
+  return fminf_(dt0, dtmax);
+}
+
+// footer of attempt j-1 + header of attempt j (wave 0 of every workgroup; identical inputs => identical results).
+// Returns the control block of attempt j; block 0 also publishes it to ctl[(j+1)&1].
+__device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
+  const int lane = threadIdx.x & 63;
+  AdjCtrl c = g.ctl[j & 1];
+  AdjCtrl* cout = g.ctl + ((j + 1) & 1);
+  c.do_step = 0;
+  if (c.status != ST_RUNNING) {
+    if (blockIdx.x == 0 && lane == 0) *cout = c;
+    return c;
+  }
+  const float gamma = 0.9f, qmin = 0.2f, qmax = 10.0f, qoldinit = 1e-4f;
+  const float beta1 = (float)(7.0 / 50.0), beta2 = (float)(2.0 / 25.0);
+  const float dtmax = g.dtmax, dtmin = g.dtmin;
+  const double ntot = (double)g.n_lam * (double)(g.use_slots ? g.nranks : 1) + (double)g.P;
+  float t = c.t, dt = c.dt;
+  int accepted = 0;
+  if (c.first) {
+    // ode_determine_initdt from the partial sums of d1 and d2; dt0 was fixed by init phase B
+    const float d1 = (float)sqrt(adj_norm_sum(g.ipart + 576, g.use_slots, g.nranks, g.P != 0) / ntot);
+    const float d2 = (float)sqrt(adj_norm_sum(g.ipart + 2 * 576, g.use_slots, g.nranks, g.P != 0) / ntot) / c.dt0;
+    const float maxd = fmaxf_(d1, d2);
+    float dt1;
+    if ((double)maxd <= 1e-15) dt1 = fmaxf_(1e-6f, c.dt0 * 1e-3f);
+    else {
+      const float l10 = (float)log10((double)maxd);
+      const float e = (-(2.0f + l10)) / 5.0f;
+      dt1 = (float)pow(10.0, (double)e);
+    }
+    dt = fminf_(fminf_(100.0f * c.dt0, dt1), dtmax);
+    c.nf = 3; c.dt_init = dt; c.dtpropose = dt;
+    c.qold = qoldinit; c.q11 = 1.0f;
+  } else if (c.resume) {
+    dt = c.dtpropose;
+    c.resume = 0;
+  } else {
+    const float eest = (float)sqrt(adj_norm_sum(g.part, g.use_slots, g.nranks, g.P != 0) / ntot);
+    c.eest_last = eest;
+    if (eest != eest) {
+      c.status = LRNDE_DT_NAN;
+    } else {
+      float q;
+      if (eest == 0.0f) q = 1.0f / qmax;
+      else {
+        if (g.exact_pow) { c.q11 = (float)pow((double)eest, (double)beta1); q = c.q11 / (float)pow((double)c.qold, (double)beta2); }
+        else { c.q11 = fastpow(eest, beta1); q = c.q11 / fastpow(c.qold, beta2); }
+        q = fmaxf_(1.0f / qmax, fminf_(1.0f / qmin, q / gamma));
+      }
+      accepted = (eest <= 1.0f);
+      if (accepted) {
+        c.naccept++;
+        const float dtnew = c.dt / q;
+        c.qold = fmaxf_(eest, qoldinit);
+        const float ttmp = c.t + c.dt;
+        t = (__builtin_fabsf(ttmp - c.tstop) < 100.0f * eps_f(fmaxf_(c.t, c.tstop))) ? c.tstop : ttmp;
+        c.dtpropose = fmaxf_(fminf_(dtmax, dtnew), fmaxf_(eps_f(t), dtmin));
+        c.cur ^= 1;  // z <- z_new, K1 <- K7 (FSAL)
+        dt = c.dtpropose;
+      } else {
+        c.nreject++;
+        dt = c.dt / fminf_(1.0f / qmin, c.q11 / gamma);
+      }
+    }
+  }
+  if (c.status == ST_RUNNING) {
+    if (!(t < g.s1)) {
+      c.status = ST_DONE;
+    } else {
+      while (c.istop < g.nstops && g.stops[c.istop] <= t) ++c.istop;
+      const float tstop = (c.istop < g.nstops && g.stops[c.istop] < g.s1) ? g.stops[c.istop] : g.s1;
+      c.iter++;
+      dt = fminf_(dtmax, dt);
+      dt = fmaxf_(dt, dtmin);
+      dt = fminf_(__builtin_fabsf(dt), __builtin_fabsf(tstop - t));
+      if (c.iter > g.maxiters) c.status = LRNDE_MAXITERS;
+      else if (dt != dt) c.status = LRNDE_DT_NAN;
+      else if (__builtin_fabsf(dt) <= __builtin_fabsf(dtmin)) c.status = LRNDE_DT_LESS_THAN_MIN;
+      else {
+        c.do_step = 1; c.nf += 6; c.tstop = tstop;
+        const float cs[6] = {(float)Tsit5::C[0], (float)Tsit5::C[1], (float)Tsit5::C[2], (float)Tsit5::C[3], 1.0f, 1.0f};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) c.st[q] = adj_lookup(g, -(t + cs[q] * dt));
+      }
+    }
+  }
+  c.t = t; c.dt = dt; c.first = 0;
+  if (blockIdx.x == 0 && lane == 0) *cout = c;
+  return c;
+}
+
+__global__ void k_adj_ctrl_init(AdjCtrl* ctl, float s0) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  AdjCtrl c;
+  memset(&c, 0, sizeof(c));
+  c.status = ST_RUNNING; c.first = 1; c.t = s0; c.qold = 1e-4f; c.q11 = 1.0f;
+  ctl[0] = c; ctl[1] = c;
+}
+
+// a later segment of the same solve (after a cotangent impulse at a saved time): the integrator goes on with its
+// proposed dt and controller memory, K1 has been re-evaluated by the host driver at the modified state
+__global__ void k_adj_ctrl_continue(AdjCtrl* ctl, int from) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  AdjCtrl c = ctl[from];
+  c.status = ST_RUNNING; c.first = 0; c.do_step = 0; c.resume = 1;
+  ctl[0] = c; ctl[1] = c;
+}

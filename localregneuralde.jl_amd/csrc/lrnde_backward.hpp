@@ -216,7 +216,29 @@ struct PgradArgs {
   const float* dpre;  // (B,Hp)
   float* gp;          // flat (P)
   int ntile1, ntile2, nt1c, nt2c;  // tiles of gW1: ceil(H/16) x ceil(D/16); gW2: ceil(D/16) x ceil(H/16)
+  // device-resolved form (lrnde_adjoint.hpp): t, lam and gp of the evaluation come from the control block
+  int adj_mode, adj_stage, adj_j;
 };
+
+// t / lam / gp of a parameter-gradient GEMM that belongs to the adjoint loop's evaluation (mode, stage) of attempt j
+__device__ __forceinline__ bool pgrad_resolve(PgradArgs& a, const AdjArgs& g) {
+  if (a.adj_mode == ADJ_HOST) return true;
+  if (a.adj_mode == ADJ_FSAL || a.adj_mode == ADJ_INIT_B) {
+    const AdjCtrl* cp = g.ctl;
+    const int cur = cp->cur;
+    if (a.adj_mode == ADJ_FSAL) { a.t = -cp->t; a.lam = adj_zb(g, cur); a.gp = adj_K(g, 0, cur) + g.n_lam; }
+    else { a.t = cp->st[0].t; a.lam = adj_zs(g); a.gp = adj_K(g, 1, cur) + g.n_lam; }
+    return true;
+  }
+  // (fields read through the pointer: a private copy of the block indexed by the runtime stage would live in scratch)
+  const AdjCtrl* cp = g.ctl + ((a.adj_j + 1) & 1);
+  if (!cp->do_step) return false;
+  const int cur = cp->cur;
+  a.t = cp->st[a.adj_stage - 2].t;
+  a.lam = adj_stage_lam(g, a.adj_stage, cur);
+  a.gp = adj_K(g, a.adj_stage - 1, cur) + g.n_lam;
+  return true;
+}
 
 __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile) {  // one output tile per workgroup, the batch (K) split over its 4 waves
   __shared__ f32x4 red[3][64];
@@ -294,6 +316,10 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile) {
 }
 
 __global__ __launch_bounds__(256) void k_pgrad(PgradArgs a) { pgrad_tile(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_pgrad_adj(PgradArgs a, AdjArgs g) {
+  if (!pgrad_resolve(a, g)) return;
+  pgrad_tile(a, blockIdx.x);
+}
 
 // W2^T / W1^T in the forward fragment layouts (see k_pack)
 __global__ void k_pack_t(const float* p, int D, int H, int td, int Dp, int Hp, float* V1p, float* U2p) {
@@ -410,6 +436,51 @@ __global__ __launch_bounds__(256) void k_adj_err(AdjErrArgs a) {
   if (threadIdx.x == 0) a.part[(second ? 256 : 0) + bx] = red[0] + red[1] + red[2] + red[3];
 }
 
+// the same with z / z_new / K_j / dt taken from the control block of attempt j (device-side controller)
+__global__ __launch_bounds__(256) void k_adj_err_dev(AdjErrArgs a, AdjArgs g, int j) {
+  const AdjCtrl c = g.ctl[(j + 1) & 1];
+  if (!c.do_step) return;
+  __shared__ double red[4];
+  const bool second = blockIdx.x >= 256;
+  const unsigned bx = second ? blockIdx.x - 256 : blockIdx.x;
+  const size_t off = second ? a.n_lam : 0, cnt = second ? a.P : a.n_lam;
+  const float* K[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) K[q] = adj_K(g, q, c.cur);
+  const float* z = adj_zb(g, c.cur);
+  float* zn = adj_zb(g, c.cur ^ 1);
+  const float dt = c.dt;
+  double acc = 0.0;
+  for (size_t jj = bx * (size_t)blockDim.x + threadIdx.x; jj < cnt; jj += (size_t)256 * blockDim.x) {
+    const size_t i = off + jj;
+    float kv[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) kv[q] = K[q][i];
+    const float zv = z[i];
+    float znv;
+    if (second) {
+      float s = a.A7[0] * kv[0];
+#pragma unroll
+      for (int q = 1; q < 6; ++q) s = s + a.A7[q] * kv[q];
+      znv = zv + dt * s;
+      zn[i] = znv;
+    } else {
+      znv = zn[i];
+    }
+    float s = a.BT[0] * kv[0];
+#pragma unroll
+    for (int q = 1; q < 7; ++q) s = s + a.BT[q] * kv[q];
+    const float ut = 0.f + dt * s;
+    const float sc = a.abstol + fmaxf_(__builtin_fabsf(zv), __builtin_fabsf(znv)) * a.reltol;
+    const float r = ut / sc;
+    acc += (double)(r * r);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) a.part[(second ? 256 : 0) + bx] = red[0] + red[1] + red[2] + red[3];
+}
+
 // the rank's own fp64 sum (256 block partials, fixed order) into slot[rank] of a zeroed per-rank vector: the
 // all-reduce (sum) of that vector is the exact gather
 __global__ void k_rank_slot(const double* part, double* slots, int rank, int nranks) {
@@ -461,6 +532,10 @@ struct VjpQArgs {
   // optional fused stage combination of the adjoint's Tsit5 loop: lambda = base + dt*(c0 k0 + c1 k1 + ...) (the
   // arithmetic of k_axpy) formed while the tile is staged and written to lam_out for the parameter-gradient GEMM
   const float* lbase; const float* lk[6]; float lc[6]; int lnk; float ldt; float* lam_out;
+  // device-resolved form: the fields above that depend on the integrator's decisions (which record step and theta, t,
+  // dt, the z / K buffers) are filled in from the control block (lrnde_adjoint.hpp) at the head of the kernel
+  int adj_mode, adj_stage, adj_j;
+  AdjArgs adj;
 };
 
 constexpr int VQB = 3 * QSB1;  // stream blocks of one VJP (QSB2 == QSB1)
@@ -565,7 +640,80 @@ static size_t smem_bytes_vq(int KQ1p, int KQ2p, int RG1, int RG2) {
   return smem_bytes_q(KQ1p, KQ2p, RG1, RG2) + (size_t)KQ1p * 4 * 16 + (size_t)RG1 * 256 * 4 + 32;
 }
 
-template <int KT> __device__ __forceinline__ void vjp_q_body(const VjpQArgs& a) {
+// fills the decision-dependent fields of `a` for a launch of the adjoint loop; false: nothing to do (solve finished)
+__device__ __forceinline__ bool vjp_q_resolve(VjpQArgs& a) {
+  if (a.adj_mode == ADJ_HOST) return true;
+  __shared__ AdjCtrl sh_c;
+  const AdjArgs& g = a.adj;
+  if (a.adj_mode == ADJ_STAGE && a.adj_stage > 2) {
+    // control block of this attempt, published by the stage-2 launch (uniform address: scalar loads)
+    const AdjCtrl* cp = g.ctl + ((a.adj_j + 1) & 1);
+    if (!cp->do_step) return false;
+    if (threadIdx.x == 0) sh_c = *cp;
+  } else if (threadIdx.x < 64) {
+    AdjCtrl c;
+    if (a.adj_mode == ADJ_STAGE) {
+      c = adj_prologue(g, a.adj_j);
+    } else {
+      c = g.ctl[0];
+      if (a.adj_mode == ADJ_FSAL) {
+        c.st[0] = adj_lookup(g, -c.t);
+      } else {  // ADJ_INIT_B: dt0 from the partial sums of d0 and d1, evaluation at z + dt0*K1, time s0 + dt0
+        const double ntot = (double)g.n_lam * (double)(g.use_slots ? g.nranks : 1) + (double)g.P;
+        const float d0 = (float)sqrt(adj_norm_sum(g.ipart, g.use_slots, g.nranks, g.P != 0) / ntot);
+        const float d1 = (float)sqrt(adj_norm_sum(g.ipart + 576, g.use_slots, g.nranks, g.P != 0) / ntot);
+        c.dt0 = adj_dt0(d0, d1, g.dtmax);
+        c.st[0] = adj_lookup(g, -(c.t + c.dt0));
+      }
+      c.do_step = 1;
+      if (blockIdx.x == 0 && threadIdx.x == 0) { g.ctl[0] = c; g.ctl[1] = c; }
+    }
+    if (threadIdx.x == 0) sh_c = c;
+  }
+  __syncthreads();
+  // (read field by field from LDS: a private copy of the block indexed by the runtime stage would live in scratch)
+  if (!sh_c.do_step) return false;
+  const int cur = sh_c.cur;
+  const size_t nst = g.n_lam;
+  a.y = nullptr;
+  const int sidx = a.adj_mode == ADJ_STAGE ? a.adj_stage : 2;
+  const AdjStage* sp = &sh_c.st[sidx - 2];
+  a.dense = g.dense + (size_t)sp->lo * 8 * nst; a.theta = sp->theta; a.dense_dt = sp->ddt; a.t = sp->t;
+  if (a.adj_mode == ADJ_STAGE) {
+    a.lbase = adj_zb(g, cur); a.ldt = sh_c.dt; a.lnk = sidx - 1;
+    // row sidx of the tableau; terms beyond the row: the base vector with coefficient 0 (adds +-0, as the host path does)
+    const float* arow = nullptr;
+    float cf[6];
+    (void)arow;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      float v = 0.0f;
+#pragma unroll
+      for (int ss = 2; ss <= 7; ++ss) if (ss == sidx && q < ss - 1) v = (float)Tsit5::A[(ss - 2) * (ss - 1) / 2 + q];
+      cf[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const bool on = q < sidx - 1;
+      a.lk[q] = on ? adj_K(g, q, cur) : a.lbase;
+      a.lc[q] = cf[q];
+    }
+    a.lam_out = adj_stage_lam(g, sidx, cur);
+    a.lam = a.lam_out;
+    a.dy = adj_K(g, sidx - 1, cur);
+  } else if (a.adj_mode == ADJ_FSAL) {
+    a.lnk = 0; a.lam = adj_zb(g, cur); a.dy = adj_K(g, 0, cur);
+  } else {
+    a.lbase = adj_zb(g, cur); a.ldt = sh_c.dt0; a.lnk = 1;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { a.lk[q] = q == 0 ? adj_K(g, 0, cur) : a.lbase; a.lc[q] = q == 0 ? 1.0f : 0.0f; }
+    a.lam_out = adj_zs(g); a.lam = a.lam_out; a.dy = adj_K(g, 1, cur);
+  }
+  return true;
+}
+
+template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
+  if (!vjp_q_resolve(a)) return;
   const ModelDev& m = a.m;
   const SmemQ s = carve_q(m);
   // extra LDS behind the forward layout: the lambda tile and act'(pre)
@@ -710,6 +858,10 @@ template <int KT> __global__ __launch_bounds__(QNT) void k_vjp_q(VjpQArgs a) { v
 // parameter-gradient GEMM of the PREVIOUS evaluation (its tiles are workgroups nvjp, nvjp+1, ...).  The two touch
 // disjoint buffers: the scratch (y, h, dpre) and the stage lambda are double buffered by the host (launch_vjp).
 template <int KT> __global__ __launch_bounds__(QNT) void k_vjp_q_pg(VjpQArgs a, PgradArgs pg, int nvjp) {
-  if ((int)blockIdx.x >= nvjp) { pgrad_tile(pg, (int)blockIdx.x - nvjp); return; }
+  if ((int)blockIdx.x >= nvjp) {
+    if (!pgrad_resolve(pg, a.adj)) return;
+    pgrad_tile(pg, (int)blockIdx.x - nvjp);
+    return;
+  }
   vjp_q_body<KT>(a);
 }

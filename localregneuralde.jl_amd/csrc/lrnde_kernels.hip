@@ -35,6 +35,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -218,6 +219,25 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// The same sum with DPP row operations instead of ds_bpermute shuffles (a double is two of them per step, six dependent
+// steps): four v_add_f64 on DPP-moved halves give every lane its 16-lane row total, the four row totals are read with
+// v_readlane and added in row order.  The total is wave-uniform.  (A different — still fixed — order of fp64 adds.)
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror
+  return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
+}
+
 // fixed-order block reduction of up to 3 doubles; result valid on thread 0
 __device__ __forceinline__ void block_sum3(double* red, double& a, double& b, double& c) {
   const int lane = threadIdx.x & 63;
@@ -234,27 +254,36 @@ __device__ __forceinline__ void block_sum3(double* red, double& a, double& b, do
 }
 
 // every workgroup reduces the global partial vector in the same fixed order (wave 0)
+struct Sum3 { double a, b, c; };
+__device__ __forceinline__ Sum3 reduce_partials3(const double* p, int nwg);
 __device__ __forceinline__ void reduce_partials(const double* p, int nwg, double out[3]) {
+  const Sum3 r = reduce_partials3(p, nwg);
+  out[0] = r.a; out[1] = r.b; out[2] = r.c;
+}
+__device__ __forceinline__ Sum3 reduce_partials3(const double* p, int nwg) {
   const int lane = threadIdx.x & 63;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   // agent-scope loads (the vector was written by the previous launch / by RCCL), four workgroups' triples per lane in
   // flight at once: this reduction opens every step launch, one round trip per loop trip was on its critical path.
   // The adds run in the same order as a plain loop over i = lane, lane + 64, ...
   for (int i0 = lane; i0 < nwg; i0 += 256) {
-    double v[4][3];
+    double va[4], vb[4], vc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + 64 * u;
       const size_t o = (size_t)(i < nwg ? i : i0) * PSTRIDE;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) v[u][q] = __hip_atomic_load(p + o + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      va[u] = __hip_atomic_load(p + o + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      vb[u] = __hip_atomic_load(p + o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      vc[u] = __hip_atomic_load(p + o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (i0 + 64 * u < nwg) { s0 += v[u][0]; s1 += v[u][1]; s2 += v[u][2]; }
+      if (i0 + 64 * u < nwg) { s0 += va[u]; s1 += vb[u]; s2 += vc[u]; }
   }
   s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
-  out[0] = __shfl(s0, 0, 64); out[1] = __shfl(s1, 0, 64); out[2] = __shfl(s2, 0, 64);
+  Sum3 r;
+  r.a = __shfl(s0, 0, 64); r.b = __shfl(s1, 0, 64); r.c = __shfl(s2, 0, 64);
+  return r;
 }
 
 // A workgroup hands in its three fp64 partial sums (valid on thread 0).  which = 0/1: the step's parity block of
@@ -286,11 +315,10 @@ __device__ __forceinline__ void publish_partial(const StepArgs& a, int which, do
   }
   last = __shfl(last, 0, 64);
   if (!last) return;
-  double s[3];
-  reduce_partials(tiles, (int)gridDim.x, s);  // agent-scope loads, the fixed order every reduction here uses
+  const Sum3 sr = reduce_partials3(tiles, (int)gridDim.x);  // agent-scope loads, the fixed order every reduction here uses
   if (lane == 0) {
     double* q = send + (size_t)a.wg_offset * PSTRIDE;
-    q[0] = s[0]; q[1] = s[1]; q[2] = s[2];
+    q[0] = sr.a; q[1] = sr.b; q[2] = sr.c;
     __hip_atomic_store(a.arrive + which, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch of this kind
   }
 }
@@ -470,7 +498,7 @@ template <int S> struct EpiStage {
   __device__ __forceinline__ void post(int mt, const f32x4& kv, f32x4 (&pb)[NPRE]) const {
     const int lane = threadIdx.x & 63, n = lane & 15, rq = lane >> 4;
     constexpr int off = (S - 1) * S / 2;  // row S+1 of the tableau
-    sstore(io, off_out + mt * 64, kv);
+    sstore(io, off_out + mt * 64, kv);  // always: this tile shape's later stages re-read k_S from global memory (Bcast::store_k is the 4-column kernel's)
     f32x4 x;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -816,6 +844,10 @@ struct Bcast {
   float t_new, tprev, dt_prev;
   float dt0;  // init phase 2
   int dense_idx;  // index of the accepted step in the dense record (-1: none)
+  // 1: this step's k2..k6 must reach global memory — the next launch's prologue reads them (dense record of the step, or
+  // a saveat point inside the step to interpolate) or the caller does (single-step entry points).  Otherwise they live in
+  // LDS for the launch only: five state-sized stores per attempted step (8 MB of 21 at B=512) that nothing would read
+  int store_k;
 };
 
 __device__ __forceinline__ float init_dt0(const double s[3], double n, float dtmax) {
@@ -843,11 +875,30 @@ __device__ __forceinline__ float init_dt_final(const double s1[3], const double 
   return fminf_(fminf_(100.0f * dt0, dt1), dtmax);
 }
 
+__device__ __forceinline__ float init_dt_final3(const Sum3& r1, const Sum3& r2, double n, float dtmax) {
+  const float d0 = rms_from(r1.a, n), d1 = rms_from(r1.b, n);
+  float dt0;
+  if ((double)d0 < 1e-5 || (double)d1 < 1e-5) dt0 = 1e-6f;
+  else dt0 = (d0 / d1) / 100.0f;
+  dt0 = fminf_(dt0, dtmax);
+  const float d2 = rms_from(r2.a, n) / dt0;
+  const float maxd = fmaxf_(d1, d2);
+  float dt1;
+  if ((double)maxd <= 1e-15) {
+    dt1 = fmaxf_(1e-6f, dt0 * 1e-3f);
+  } else {
+    const float l10 = (float)log10((double)maxd);
+    const float e = (-(2.0f + l10)) / 5.0f;
+    dt1 = (float)pow(10.0, (double)e);
+  }
+  return fminf_(fminf_(100.0f * dt0, dt1), dtmax);
+}
+
 __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* bc) {
   // wave 0 only
   const int lane = threadIdx.x & 63;
   if (a.mode == MODE_BENCH) {  // timing hook: every launch is a full step on fixed inputs
-    if (lane == 0) { bc->do_step = 1; bc->cur = 0; bc->t = a.t0; bc->dt = a.bench_dt; bc->accepted_prev = 0; }
+    if (lane == 0) { bc->do_step = 1; bc->cur = 0; bc->t = a.t0; bc->dt = a.bench_dt; bc->accepted_prev = 0; bc->store_k = 0; }
     return;
   }
   const Ctrl* cin = a.ctrl + (j & 1);
@@ -870,18 +921,16 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
 
   if (c.first) {
     if (a.mode != MODE_SINGLE_GIVEN_DT) {
-      double s1[3], s2[3];
-      reduce_partials(a.pinit_recv, a.nwg_global, s1);
-      reduce_partials(a.pinit_recv + (size_t)a.nwg_global * PSTRIDE, a.nwg_global, s2);
-      dt = init_dt_final(s1, s2, a.n_global, dtmax);
+      const Sum3 r1 = reduce_partials3(a.pinit_recv, a.nwg_global);
+      const Sum3 r2 = reduce_partials3(a.pinit_recv + (size_t)a.nwg_global * PSTRIDE, a.nwg_global);
+      dt = init_dt_final3(r1, r2, a.n_global, dtmax);
       c.nf = 3;  // initdt: 2 f-evals, initialize!: fsalfirst
     }
     c.dt_init = dt;
     c.dtpropose = dt;
   } else {
-    double s[3];
-    reduce_partials(a.part_recv + (size_t)(j & 1) * a.nwg_global * PSTRIDE, a.nwg_global, s);
-    const float eest = rms_from(s[0], a.n_global);
+    const Sum3 sr = reduce_partials3(a.part_recv + (size_t)(j & 1) * a.nwg_global * PSTRIDE, a.nwg_global);
+    const float eest = rms_from(sr.a, a.n_global);
     c.eest_last = eest;
     float q;
     if (eest == 0.0f) {
@@ -952,6 +1001,9 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
   }
   c.t = t; c.dt = dt; c.first = 0;
   b.do_step = do_step; b.cur = c.cur; b.t = t; b.dt = dt;
+  // (the margin covers the snap of t + dt onto t1 within 100 eps; a pending saveat equal to the new time is a copy of u)
+  b.store_k = (a.mode == MODE_SINGLE_GIVEN_DT) || a.dense != nullptr ||
+              (a.mode == MODE_SOLVE && c.isave < a.nsave && a.saveat[c.isave] < t + dt * 1.001f);
   if (lane == 0) {
     *bc = b;
     if (blockIdx.x == 0) *cout = c;
@@ -1190,7 +1242,7 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
 #define LRNDE_STAGE(S, TS)                                                              \
   do {                                                                                  \
     EpiStage<S> e;                                                                      \
-    e.io = io; e.off_up = o_up; e.off_k[0] = o_k1;                                      \
+    e.io = io; e.off_up = o_up; e.off_k[0] = o_k1;                                                     \
     _Pragma("unroll") for (int q = 0; q < 5; ++q) e.off_k[1 + q] = arr_off(a, 4 + q) + tb; \
     e.off_out = arr_off(a, 4 + (S - 2)) + tb;                                           \
     e.off_x = (S == 6) ? o_un : ((S == 5 && a.want_stiff) ? o_g6 : -1);                 \
@@ -1428,6 +1480,7 @@ template <int W> __global__ __launch_bounds__(NT) void k_sde_rkmil(StepArgs a) {
 }
 
 #include "lrnde_qtile.hpp"
+#include "lrnde_adjoint.hpp"
 #include "lrnde_backward.hpp"
 
 // single-step modes: EEst and the two regularisation values from the partial sums
@@ -1554,7 +1607,11 @@ struct lrnde_ctx {
   int dense_cap = 0; size_t dense_n = 0; bool dense_on = false;
   float* adj = nullptr; size_t adj_elems = 0;   // 11 vectors of N = B*D + P floats
   double* adj_part = nullptr; double* adj_part_host = nullptr;
+  // device-side adjoint controller (lrnde_adjoint.hpp): control blocks, initdt partial sums, tstops, pinned read-back slots
+  AdjCtrl* adj_ctl = nullptr; AdjCtrl* adj_ctl_host = nullptr; double* adj_ipart = nullptr; float* adj_stops = nullptr; int adj_stops_cap = 0;
+  hipEvent_t adj_ev[2] = {nullptr, nullptr};
   std::vector<float> last_ts;  // sol.t of the last node_forward (cotangent times of the adjoint)
+  std::vector<int> series_idx; std::vector<float> series_t;  // the caller's view of that solution: save slots and times
   float last_t1 = 0.f; int last_i1 = 0;
   // backward workspace kept across calls: u(t1) of the recorded forward, k1 and the regulariser's gradient
   float *rec_u1 = nullptr, *rec_k1 = nullptr, *rec_gr = nullptr; size_t rec_n = 0;
@@ -1906,6 +1963,12 @@ int lrnde_destroy(lrnde_ctx* c) {
                   c->usave};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ctrl_host) hipHostFree(c->ctrl_host);
+  if (c->adj_ctl) hipFree(c->adj_ctl);
+  if (c->adj_ctl_host) hipHostFree(c->adj_ctl_host);
+  if (c->adj_ipart) hipFree(c->adj_ipart);
+  if (c->adj_stops) hipFree(c->adj_stops);
+  if (c->adj_ev[0]) hipEventDestroy(c->adj_ev[0]);
+  if (c->adj_ev[1]) hipEventDestroy(c->adj_ev[1]);
   if (c->cls_ws) hipFree(c->cls_ws);
   if (c->cls_host) hipHostFree(c->cls_host);
   if (c->ev_norm) hipEventDestroy(c->ev_norm);
@@ -2158,10 +2221,17 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   return LRNDE_OK;
 }
 
-int lrnde_node_forward(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2,
-                       const lrnde_solve_opts* o, int32_t mode, int32_t reg_type, float t1_or_rand,
-                       float* u_end, float* reg_val_host, int32_t* nfe_host, lrnde_stats* st,
-                       float* t1_used_host) {
+}  // extern "C"
+// `(n::NeuralODE)(x, ps, st)` for every mode, with or without a user `saveat` (src/layers/neural_ode.jl:56-116).
+// user_sv / nuser: the layer's `saveat` kwarg (ascending); nuser == 0 is the default of :102-116 ([t2] / [t1, t2] / every
+// step).  With a user saveat the :unbiased mode appends t1 for the solve and the returned series leaves every saved
+// time equal to t1 out again (_CorrectedDESolution, src/utils.jl:31-33: `sol.u[t1 .!= sol.t]`); :biased draws t1 from
+// the saved times but the last.  The series (the times the caller sees as sol.t) is kept in c->series_* for the caller
+// and for lrnde_node_backward_recorded_ts.
+static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2,
+                             const lrnde_solve_opts* o, int32_t mode, int32_t reg_type, float t1_or_rand,
+                             const float* user_sv, int nuser, float* u_end, float* reg_val_host, int32_t* nfe_host,
+                             lrnde_stats* st, float* t1_used_host) {
   int rc = check_ready(c, B);
   if (rc) return rc;
   if (!x || !o || !u_end || !st) return fail(c, LRNDE_BADARG, "null pointer");
@@ -2177,6 +2247,12 @@ int lrnde_node_forward(lrnde_ctx* c, const float* x, int32_t B, float t0, float 
   lrnde_solve_opts oo = *o;
   size_t need = 3;
   if (mode == LRNDE_MODE_BIASED) need = (size_t)(oo.maxiters < 510 ? oo.maxiters + 2 : 512);
+  if (nuser > 0) {
+    if (!user_sv) return fail(c, LRNDE_BADARG, "null saveat");
+    for (int i = 1; i < nuser; ++i) if (!(user_sv[i] >= user_sv[i - 1])) return fail(c, LRNDE_BADARG, "saveat must be ascending");
+    need = (size_t)nuser + 3;
+  }
+  c->series_idx.clear(); c->series_t.clear();
   if (c->usave_slots < need || c->usave_slot_elems != n) {
     if (c->usave) HIPCHK(c, hipFree(c->usave));
     c->usave = nullptr;
@@ -2188,25 +2264,40 @@ int lrnde_node_forward(lrnde_ctx* c, const float* x, int32_t B, float t0, float 
   std::vector<float> ts(c->usave_slots);
   float t1 = t2;
   const float* u1 = nullptr;
+  auto series_all = [&](int nsaved, float drop) {  // the caller's sol: every saved entry (drop: t1 of the corrected solution)
+    for (int i = 0; i < nsaved; ++i)
+      if (!(ts[i] == drop)) { c->series_idx.push_back(i); c->series_t.push_back(ts[i]); }
+  };
+  const float no_drop = nanf("");
   if (mode == LRNDE_MODE_NONE) {  // _vanilla_node_fallback, neural_ode.jl:56-60
-    const float sv[1] = {t2};
+    const float sv1[1] = {t2};
     oo.save_everystep = 0;
-    rc = lrnde_solve(c, x, B, t0, t2, &oo, sv, 1, c->usave, ts.data(), 2, st, nullptr, 0);
+    rc = lrnde_solve(c, x, B, t0, t2, &oo, nuser ? user_sv : sv1, nuser ? nuser : 1, c->usave, ts.data(), (int)c->usave_slots, st, nullptr, 0);
     if (rc) return rc;
+    if (st->nsaved < 1) return fail(c, LRNDE_BADARG, "the solve saved nothing (saveat outside the time span)");
+    series_all(st->nsaved, no_drop);
+    c->last_ts.assign(ts.begin(), ts.begin() + st->nsaved);
     HIPCHK(c, hipMemcpyAsync(u_end, c->usave + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
     if (nfe_host) *nfe_host = st->nf;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LRNDE_OK;
-  } else if (mode == LRNDE_MODE_UNBIASED) {  // neural_ode.jl:68-84, saveat = [t1, t2]
+  } else if (mode == LRNDE_MODE_UNBIASED) {  // neural_ode.jl:68-84, saveat = [t1, t2] or vcat(user saveat, t1)
     t1 = t1_or_rand;
-    const float sv[2] = {t1, t2};
+    std::vector<float> sv;
+    if (nuser) { sv.assign(user_sv, user_sv + nuser); sv.insert(std::upper_bound(sv.begin(), sv.end(), t1), t1); }
+    else { sv.push_back(t1); sv.push_back(t2); }
     oo.save_everystep = 0;
-    rc = lrnde_solve(c, x, B, t0, t2, &oo, sv, 2, c->usave, ts.data(), 3, st, nullptr, 0);
+    rc = lrnde_solve(c, x, B, t0, t2, &oo, sv.data(), (int)sv.size(), c->usave, ts.data(), (int)c->usave_slots, st, nullptr, 0);
     if (rc) return rc;
-    u1 = c->usave + (size_t)(oo.save_start ? 1 : 0) * n;
-  } else {  // neural_ode.jl:88-100, saveat = [] => every accepted step
-    oo.save_everystep = 1;
-    rc = lrnde_solve(c, x, B, t0, t2, &oo, nullptr, 0, c->usave, ts.data(), (int)c->usave_slots, st, nullptr, 0);
+    int i1 = -1;
+    for (int i = 0; i < st->nsaved; ++i) if (ts[i] == t1) i1 = i;   // the last entry saved at t1 is sol(t1)
+    if (i1 < 0) return fail(c, LRNDE_BADARG, "t1 = %g is not inside the time span", (double)t1);
+    u1 = c->usave + (size_t)i1 * n;
+    c->last_i1 = i1;
+    series_all(st->nsaved, nuser ? t1 : no_drop);
+  } else {  // neural_ode.jl:88-100, saveat = [] => every accepted step (or the user's saveat)
+    oo.save_everystep = nuser ? 0 : 1;
+    rc = lrnde_solve(c, x, B, t0, t2, &oo, nuser ? user_sv : nullptr, nuser, c->usave, ts.data(), (int)c->usave_slots, st, nullptr, 0);
     if (rc) return rc;
     if (st->nsaved < 2) return fail(c, LRNDE_BADARG, "biased mode needs at least two saved times");
     const int mm = st->nsaved - 1;
@@ -2216,10 +2307,10 @@ int lrnde_node_forward(lrnde_ctx* c, const float* x, int32_t B, float t0, float 
     t1 = ts[idx];
     u1 = c->usave + (size_t)idx * n;
     c->last_i1 = idx;
+    series_all(st->nsaved, no_drop);
   }
   c->last_ts.assign(ts.begin(), ts.begin() + st->nsaved);
   c->last_t1 = t1;
-  if (mode == LRNDE_MODE_UNBIASED) c->last_i1 = oo.save_start ? 1 : 0;
   HIPCHK(c, hipMemcpyAsync(u_end, c->usave + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   if (t1_used_host) *t1_used_host = t1;
   // _get_ode_integrator (neural_ode.jl:33-38): fresh init on (t1, t2); then _perform_step (:77)
@@ -2241,6 +2332,14 @@ int lrnde_node_forward(lrnde_ctx* c, const float* x, int32_t B, float t0, float 
   if (reg_val_host) *reg_val_host = a.want_stiff ? k.reg_stiff : k.reg_error;
   if (nfe_host) *nfe_host = st->nf + k.nf;  // sol.destats.nf + (6 + 3), perform_step.jl:31
   return LRNDE_OK;
+}
+extern "C" {
+
+int lrnde_node_forward(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2,
+                       const lrnde_solve_opts* o, int32_t mode, int32_t reg_type, float t1_or_rand,
+                       float* u_end, float* reg_val_host, int32_t* nfe_host, lrnde_stats* st,
+                       float* t1_used_host) {
+  return node_forward_impl(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, nullptr, 0, u_end, reg_val_host, nfe_host, st, t1_used_host);
 }
 
 int lrnde_comm_unique_id(void* out) {
@@ -2814,11 +2913,14 @@ int adj_rhs(lrnde_ctx* c, const std::vector<float>& dt_, const std::vector<float
   return launch_vjp(c, nullptr, c->dense + (size_t)lo * 8 * n, theta, dd_[lo], t, zs, B, K, K + n, sin);
 }
 
+struct AdjImpulse { float s; const float* du; };  // a cotangent added to lambda when the reversed solve reaches s = -t_saved
+
 // adaptive Tsit5 on device vectors, host-side controller (mirror of the forward loop / the oracle's
 // lro_solve_ex), integrating s from s0 to s1 with tstops; only the end state is kept
 template <class RHS, class RHSF>
 int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, RHSF rhs_fused, bool fuse_stage, float s0, float s1, float abstol,
-                    float reltol, int maxiters, int exact_pow, const std::vector<float>& tstops, lrnde_stats* st) {
+                    float reltol, int maxiters, int exact_pow, const std::vector<float>& tstops,
+                    const std::vector<AdjImpulse>& impulses, lrnde_stats* st) {
   const size_t N = v.N;
   const float gamma = 0.9f, qmin = 0.2f, qmax = 10.0f, qoldinit = 1e-4f;
   const float beta1 = (float)(7.0 / 50.0), beta2 = (float)(2.0 / 25.0);
@@ -2857,14 +2959,26 @@ int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, RHSF rhs_fused, bool fuse_
   }
   float qold = qoldinit, q11 = 1.0f, dtpropose = dt;
   int accept = 0, iter = 0;
-  size_t istop = 0;
+  size_t istop = 0, iimp = 0;
+  while (iimp < impulses.size() && impulses[iimp].s <= s0) ++iimp;
   while (istop < tstops.size() && tstops[istop] <= s0) ++istop;
   rc = LRNDE_OK;
   while (t < s1) {
     while (istop < tstops.size() && tstops[istop] <= t) ++istop;
     const float tstop = (istop < tstops.size() && tstops[istop] < s1) ? tstops[istop] : s1;
     if (iter > 0) {
-      if (accept) { std::swap(z, zn); std::swap(K[0], K[6]); dt = dtpropose; }
+      if (accept) {
+        std::swap(z, zn); std::swap(K[0], K[6]); dt = dtpropose;
+        // a cotangent impulse at the saved time just reached: lambda += du, K1 re-evaluated at the modified state
+        while (iimp < impulses.size() && impulses[iimp].s < t) ++iimp;
+        bool hit = false;
+        for (; iimp < impulses.size() && impulses[iimp].s == t && t < s1; ++iimp) {
+          const float* gi[1] = {impulses[iimp].du}; const float one = 1.0f;
+          if ((rc = vec_axpy(c, z, z, 1.0f, 1, gi, &one, v.n_lam))) return rc;
+          hit = true;
+        }
+        if (hit) { if ((rc = rhs(z, t, K[0]))) return rc; st->nf += 1; }
+      }
       else dt = dt / fminf(1.0f / qmin, q11 / gamma);
     }
     ++iter;
@@ -2931,9 +3045,201 @@ int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, RHSF rhs_fused, bool fuse_
     }
   }
   if (accept && rc == LRNDE_OK) std::swap(z, zn);  // z now holds the end state
+  if (rc == LRNDE_OK)  // cotangents at the end time itself (a saved start value)
+    for (; iimp < impulses.size(); ++iimp) {
+      if (impulses[iimp].s < s1) continue;
+      const float* gi[1] = {impulses[iimp].du}; const float one = 1.0f;
+      int r2 = vec_axpy(c, z, z, 1.0f, 1, gi, &one, v.n_lam);
+      if (r2) return r2;
+    }
   if (z != v.z) HIPCHK(c, hipMemcpyAsync(v.z, z, sizeof(float) * N, hipMemcpyDeviceToDevice, c->stream));
   st->retcode = rc; st->iters = iter; st->t_final = t; st->dt_final = dt;
   return rc;
+}
+
+
+// ---- the adjoint solve with the controller on the device (lrnde_adjoint.hpp) --------------------------------------
+// One segment = s from the current time of the control block to s_end (tstops inside it are handled on the device).
+// `impulses`: cotangents added to lambda when the reversed solve reaches a saved time — (reversed time, device pointer
+// to a (B, D) cotangent) pairs in ascending s; each ends a segment: the host waits for it, adds the impulse, has K1
+// re-evaluated at the modified state (what a callback's u_modified! does upstream) and lets the integrator go on.
+int adj_enqueue_eval(lrnde_ctx* c, int B, const AdjArgs& g, int mode, int stage, int j, bool with_prev_pgrad,
+                     int prev_mode, int prev_stage) {
+  // one VJP launch in device-resolved form; with_prev_pgrad: the launch also carries the parameter-gradient GEMM of the
+  // previous evaluation (prev_mode / prev_stage of the same attempt), whose scratch set is the one written last
+  VjpQArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m = c->m; a.V1q = c->V1q; a.U2q = c->U2q; a.B = B;
+  a.adj_mode = mode; a.adj_stage = stage; a.adj_j = j; a.adj = g;
+  const int set = c->bw_cur;
+  a.ysc = c->bw_y + (size_t)set * B * c->desc.state_dim; a.hsc = c->bw_h + (size_t)set * B * c->m.Hp; a.dpsc = c->bw_dp + (size_t)set * B * c->m.Hp;
+  const size_t smq = smem_bytes_vq(c->m.KQ1p, c->m.KQ2p, c->m.RG1, c->m.RG2);
+  const int nvjp = (B + QNB - 1) / QNB;
+  const bool kt1 = (c->desc.hidden_dim + 3) / 4 == (QSB2 - 1) * QSQ + 1;
+  if (with_prev_pgrad) {
+    PgradArgs pg = pgrad_args(c, B, 0.f, nullptr, nullptr, set ^ 1);
+    pg.adj_mode = prev_mode; pg.adj_stage = prev_stage; pg.adj_j = j;
+    if (kt1) hipLaunchKernelGGL(k_vjp_q_pg<1>, dim3(nvjp + pg.ntile1 + pg.ntile2), dim3(QNT), smq, c->stream, a, pg, nvjp);
+    else hipLaunchKernelGGL(k_vjp_q_pg<4>, dim3(nvjp + pg.ntile1 + pg.ntile2), dim3(QNT), smq, c->stream, a, pg, nvjp);
+  } else {
+    if (kt1) hipLaunchKernelGGL(k_vjp_q<1>, dim3(nvjp), dim3(QNT), smq, c->stream, a);
+    else hipLaunchKernelGGL(k_vjp_q<4>, dim3(nvjp), dim3(QNT), smq, c->stream, a);
+  }
+  HIPCHK(c, hipGetLastError());
+  c->bw_cur ^= 1;
+  return LRNDE_OK;
+}
+
+// the parameter-gradient GEMM of the evaluation whose scratch was written by the LAST VJP launch, by itself; on a
+// sharded handle followed by the all-reduce of mu's slot (every rank's sum over its own columns -> the batch sum)
+int adj_enqueue_pgrad(lrnde_ctx* c, int B, const AdjArgs& g, int mode, int stage, int j) {
+  PgradArgs pg = pgrad_args(c, B, 0.f, nullptr, nullptr, c->bw_cur ^ 1);
+  pg.adj_mode = mode; pg.adj_stage = stage; pg.adj_j = j;
+  hipLaunchKernelGGL(k_pgrad_adj, dim3(pg.ntile1 + pg.ntile2), dim3(256), 0, c->stream, pg, g);
+  HIPCHK(c, hipGetLastError());
+  return LRNDE_OK;
+}
+
+// per-rank lambda sum -> rank slots, exact gather (sharded handles); the partial block `part` is [512 + 64] doubles
+int adj_enqueue_slots(lrnde_ctx* c, double* part) {
+  if (!sharded(c)) return LRNDE_OK;
+  if (c->nranks > 64) return fail(c, LRNDE_UNSUPPORTED, "more than 64 ranks");
+  hipLaunchKernelGGL(k_rank_slot, dim3(1), dim3(64), 0, c->stream, part, part + 512, c->rank, c->nranks);
+  return comm_allreduce(c, part + 512, part + 512, c->nranks, true);
+}
+
+int adj_norm_into(lrnde_ctx* c, const float* num, const float* num2, const float* sa, float abstol, float reltol, size_t n_lam,
+                  size_t P, double* part) {
+  NormArgs a;
+  a.num = num; a.num2 = num2; a.sa = sa; a.sb = nullptr; a.abstol = abstol; a.reltol = reltol; a.n = n_lam; a.part = part;
+  NormArgs b = a;
+  b.num = num + n_lam; b.num2 = num2 ? num2 + n_lam : nullptr; b.sa = sa + n_lam; b.n = P; b.part = part + 256;
+  hipLaunchKernelGGL(k_norm2, dim3(512), dim3(256), 0, c->stream, a, b);
+  HIPCHK(c, hipGetLastError());
+  return adj_enqueue_slots(c, part);
+}
+
+int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float abstol, float reltol, int maxiters, int exact_pow,
+                     const std::vector<float>& tstops, const std::vector<AdjImpulse>& impulses, int nrec, lrnde_stats* st) {
+  int rc;
+  memset(st, 0, sizeof(*st));
+  if (sharded(c)) return fail(c, LRNDE_UNSUPPORTED, "sharded handles use the host-controlled adjoint loop");
+  if ((rc = ensure_bw(c, B))) return rc;
+  if (!c->adj_ctl) {
+    HIPCHK(c, hipMalloc(&c->adj_ctl, sizeof(AdjCtrl) * 2));
+    HIPCHK(c, hipHostMalloc(&c->adj_ctl_host, sizeof(AdjCtrl) * 2));
+    HIPCHK(c, hipMalloc(&c->adj_ipart, sizeof(double) * 3 * 576));
+    HIPCHK(c, hipEventCreateWithFlags(&c->adj_ev[0], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->adj_ev[1], hipEventDisableTiming));
+  }
+  if ((int)tstops.size() > c->adj_stops_cap) {
+    if (c->adj_stops) HIPCHK(c, hipFree(c->adj_stops));
+    c->adj_stops = nullptr; c->adj_stops_cap = 0;
+    HIPCHK(c, hipMalloc(&c->adj_stops, sizeof(float) * (tstops.size() + 8)));
+    c->adj_stops_cap = (int)tstops.size() + 8;
+  }
+  if (!tstops.empty())
+    HIPCHK(c, hipMemcpyAsync(c->adj_stops, tstops.data(), sizeof(float) * tstops.size(), hipMemcpyHostToDevice, c->stream));
+  AdjArgs g;
+  memset(&g, 0, sizeof(g));
+  g.ctl = c->adj_ctl; g.base = c->adj; g.N = v.N; g.n_lam = v.n_lam; g.P = v.P;
+  g.dense = c->dense; g.dense_t = c->dense_t; g.dense_dt = c->dense_dt; g.nrec = nrec;
+  g.stops = c->adj_stops; g.nstops = (int)tstops.size();
+  g.s0 = s0; g.dtmax = s1 - s0; g.dtmin = fmaxf(eps_f(s1), eps_f(s0));
+  g.abstol = abstol; g.reltol = reltol; g.maxiters = maxiters; g.exact_pow = exact_pow;
+  g.part = c->adj_part; g.ipart = c->adj_ipart; g.nranks = 1; g.use_slots = 0;
+  const size_t N = v.N, n = v.n_lam;
+  float* const zb0 = c->adj; float* const K0 = c->adj + 4 * N; float* const K1 = c->adj + 5 * N;
+  AdjErrArgs e;
+  memset(&e, 0, sizeof(e));
+  for (int q = 0; q < 7; ++q) e.BT[q] = (float)Tsit5::BT[q];
+  for (int q = 0; q < 6; ++q) e.A7[q] = (float)Tsit5::A[15 + q];
+  e.n_lam = v.n_lam; e.P = v.P; e.abstol = abstol; e.reltol = reltol; e.part = c->adj_part;
+
+  hipLaunchKernelGGL(k_adj_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->adj_ctl, s0);
+  size_t iseg = 0;
+  while (iseg < impulses.size() && impulses[iseg].s <= s0) ++iseg;  // a cotangent at the start time is the caller's lambda(s0)
+  bool first_seg = true;
+  int extra_nf = 0;
+  AdjCtrl fin;
+  memset(&fin, 0, sizeof(fin));
+  for (;;) {
+    const bool last_seg = iseg >= impulses.size() || !(impulses[iseg].s < s1);
+    g.s1 = last_seg ? s1 : impulses[iseg].s;
+    // (re-)evaluate K1 = rhs(z, t) at the state of ctl[0]; first segment: the rest of ode_determine_initdt
+    c->bw_cur = 0;
+    if ((rc = adj_enqueue_eval(c, B, g, ADJ_FSAL, 0, 0, false, 0, 0))) return rc;
+    if ((rc = adj_enqueue_pgrad(c, B, g, ADJ_FSAL, 0, 0))) return rc;
+    if (first_seg) {
+      if ((rc = adj_norm_into(c, zb0, nullptr, zb0, abstol, reltol, v.n_lam, v.P, c->adj_ipart))) return rc;          // d0
+      if ((rc = adj_norm_into(c, K0, nullptr, zb0, abstol, reltol, v.n_lam, v.P, c->adj_ipart + 576))) return rc;     // d1
+      if ((rc = adj_enqueue_eval(c, B, g, ADJ_INIT_B, 0, 0, false, 0, 0))) return rc;
+      if ((rc = adj_enqueue_pgrad(c, B, g, ADJ_INIT_B, 0, 0))) return rc;
+      if ((rc = adj_norm_into(c, K1, K0, zb0, abstol, reltol, v.n_lam, v.P, c->adj_ipart + 2 * 576))) return rc;      // d2 * dt0
+    } else {
+      ++extra_nf;
+    }
+    first_seg = false;
+    // attempts, enqueued in chunks, status polled one chunk behind
+    int j = 0, pending = -1, target = 2, nchunk = 0;
+    bool done = false;
+    while (!done) {
+      int ch = target - j;
+      if (ch < 1) ch = 1;
+      if (ch > 8) ch = 8;
+      for (int i = 0; i < ch; ++i, ++j) {
+        for (int sidx = 2; sidx <= 7; ++sidx)
+          if ((rc = adj_enqueue_eval(c, B, g, ADJ_STAGE, sidx, j, sidx > 2, ADJ_STAGE, sidx - 1))) return rc;
+        if ((rc = adj_enqueue_pgrad(c, B, g, ADJ_STAGE, 7, j))) return rc;
+        hipLaunchKernelGGL(k_adj_err_dev, dim3(512), dim3(256), 0, c->stream, e, g, j);
+        HIPCHK(c, hipGetLastError());
+      }
+      const int slot = (nchunk++) & 1;
+      HIPCHK(c, hipMemcpyAsync(c->adj_ctl_host + slot, c->adj_ctl + (j & 1), sizeof(AdjCtrl), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipEventRecord(c->adj_ev[slot], c->stream));
+      if (pending >= 0) {
+        for (;;) {  // poll (a blocking wait would put the thread to sleep for the scheduler's quantum)
+          const hipError_t q = hipEventQuery(c->adj_ev[pending]);
+          if (q == hipSuccess) break;
+          if (q != hipErrorNotReady) return fail(c, LRNDE_HIP_ERROR, "adjoint status poll: %s", hipGetErrorString(q));
+        }
+        const AdjCtrl& k = c->adj_ctl_host[pending];
+        if (k.status != ST_RUNNING) done = true;
+        else if (k.dt > 0.f) {
+          double est = ceil((double)(g.s1 - k.t) / (double)k.dt);
+          if (est > 1e6) est = 1e6;
+          const int tg = j + (int)(est / 2);
+          if (tg > target) target = tg;
+        }
+      }
+      pending = slot;
+      if (target <= j) target = j + 1;
+      if (j > maxiters + 16) break;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->adj_ctl_host, c->adj_ctl + (j & 1), sizeof(AdjCtrl), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fin = c->adj_ctl_host[0];
+    if (fin.status != ST_DONE) break;  // error status (or still running after the launch cap: MaxIters)
+    if (last_seg) break;
+    // cotangent impulse at the saved time just reached, then go on
+    const float* gi[1] = {impulses[iseg].du}; const float one = 1.0f;
+    float* zc = c->adj + (size_t)fin.cur * N;
+    if ((rc = vec_axpy(c, zc, zc, 1.0f, 1, gi, &one, n))) return rc;
+    ++iseg;
+    hipLaunchKernelGGL(k_adj_ctrl_continue, dim3(1), dim3(1), 0, c->stream, c->adj_ctl, j & 1);
+  }
+  st->retcode = (fin.status == ST_DONE) ? LRNDE_OK : (fin.status == ST_RUNNING ? LRNDE_MAXITERS : fin.status);
+  st->nf = fin.nf + extra_nf; st->naccept = fin.naccept; st->nreject = fin.nreject; st->iters = fin.iter;
+  st->t_final = fin.t; st->dt_final = fin.dt; st->eest_last = fin.eest_last; st->dt_init = fin.dt_init;
+  // the end state is zb[cur]; cotangents at the end time itself (a saved start value) are added to it
+  float* zend = c->adj + (size_t)fin.cur * N;
+  if (st->retcode == LRNDE_OK)
+    for (; iseg < impulses.size(); ++iseg) {
+      const float* gi[1] = {impulses[iseg].du}; const float one = 1.0f;
+      if ((rc = vec_axpy(c, zend, zend, 1.0f, 1, gi, &one, n))) return rc;
+    }
+  if (fin.cur != 0) HIPCHK(c, hipMemcpyAsync(v.z, zend, sizeof(float) * N, hipMemcpyDeviceToDevice, c->stream));
+  return st->retcode;
 }
 
 }  // namespace
@@ -2998,9 +3304,10 @@ int lrnde_step_reg_grad(lrnde_ctx* c, const float* uprev, const float* k1, int32
 
 // node_forward that also keeps what the backward pass needs: the dense record of every accepted
 // step (retry with a larger record if it overflows) and the solve's arguments.
-int lrnde_node_forward_record(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
-                              int32_t mode, int32_t reg_type, float t1_or_rand, float* u_end, float* reg_val_host,
-                              int32_t* nfe_host, lrnde_stats* st, float* t1_used_host) {
+}  // extern "C"
+static int node_forward_record_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
+                                    int32_t mode, int32_t reg_type, float t1_or_rand, const float* user_sv, int nuser,
+                                    float* u_end, float* reg_val_host, int32_t* nfe_host, lrnde_stats* st, float* t1_used_host) {
   int rc = check_ready(c, B);
   if (rc) return rc;
   if (!x || !o || !u_end || !reg_val_host || !nfe_host || !st) return fail(c, LRNDE_BADARG, "null pointer");
@@ -3018,7 +3325,7 @@ int lrnde_node_forward_record(lrnde_ctx* c, const float* x, int32_t B, float t0,
       c->dense_n = n;
     }
     c->dense_on = true;
-    rc = lrnde_node_forward(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, u_end, reg_val_host, nfe_host, st, &t1);
+    rc = node_forward_impl(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, user_sv, nuser, u_end, reg_val_host, nfe_host, st, &t1);
     c->dense_on = false;
     if (rc == LRNDE_CAPACITY && attempt < 8) { c->dense_cap *= 2; c->dense_n = 0; continue; }
     break;
@@ -3039,15 +3346,57 @@ int lrnde_node_forward_record(lrnde_ctx* c, const float* x, int32_t B, float t0,
   c->rec_reg_type = reg_type; c->rec_t1 = t1; c->rec_naccept = st->naccept;
   return LRNDE_OK;
 }
+extern "C" {
+
+int lrnde_node_forward_record(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
+                              int32_t mode, int32_t reg_type, float t1_or_rand, float* u_end, float* reg_val_host,
+                              int32_t* nfe_host, lrnde_stats* st, float* t1_used_host) {
+  return node_forward_record_impl(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, nullptr, 0, u_end, reg_val_host, nfe_host, st,
+                                  t1_used_host);
+}
+
+// the recorded forward with the layer's `saveat` kwarg: the solution the caller sees (sol.u / sol.t after
+// _CorrectedDESolution) goes to u_series (device, cap_series x B x D) / t_series_host
+int lrnde_node_forward_record_ts(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
+                                 int32_t mode, int32_t reg_type, float t1_or_rand, const float* saveat_host, int32_t nsave,
+                                 float* u_series, float* t_series_host, int32_t cap_series, int32_t* nseries_host,
+                                 float* reg_val_host, int32_t* nfe_host, lrnde_stats* st, float* t1_used_host) {
+  if (!c) return LRNDE_BADARG;
+  if (nsave < 0 || !u_series || !t_series_host || !nseries_host) return fail(c, LRNDE_BADARG, "null pointer / negative count");
+  const size_t n = (size_t)B * c->desc.state_dim;
+  float* u_end = nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMalloc(&u_end, sizeof(float) * n));
+  float regv = 0.f; int nfe = 0;
+  int rc = node_forward_record_impl(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, saveat_host, nsave, u_end, &regv, &nfe, st,
+                                    t1_used_host);
+  hipFree(u_end);
+  if (rc) return rc;
+  if (reg_val_host) *reg_val_host = regv;
+  if (nfe_host) *nfe_host = nfe;
+  const int ns = (int)c->series_idx.size();
+  *nseries_host = ns;
+  if (ns > cap_series) return fail(c, LRNDE_CAPACITY, "series buffer too small (%d > %d)", ns, cap_series);
+  for (int i = 0; i < ns; ++i) {
+    HIPCHK(c, hipMemcpyAsync(u_series + (size_t)i * n, c->usave + (size_t)c->series_idx[i] * n, sizeof(float) * n,
+                             hipMemcpyDeviceToDevice, c->stream));
+    t_series_host[i] = c->series_t[i];
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRNDE_OK;
+}
 
 // backward of  loss = <du_end, sol.u[end]> + w_reg * reg_val  from the record of the last
 // lrnde_node_forward_record: continuous adjoint (InterpolatingAdjoint restatement) + the regulariser's
 // reverse sweep.  dx (B,D), dp (P): device.
-int lrnde_node_backward_recorded(lrnde_ctx* c, int32_t B, const float* du_end, float w_reg, float* dx, float* dp,
-                                 lrnde_stats* st_bwd) {
+}  // extern "C"
+// du_end: the cotangent of sol.u[end] (nser == 0), or du_series: one cotangent per state of the caller's series
+// (c->series_t, ascending): each enters the reversed solve as an impulse on lambda at its time
+static int node_backward_recorded_impl(lrnde_ctx* c, int32_t B, const float* du_end, const float* du_series, int nser,
+                                       float w_reg, float* dx, float* dp, lrnde_stats* st_bwd) {
   int rc = check_ready(c, B);
   if (rc) return rc;
-  if (!du_end || !dx || !dp || !st_bwd) return fail(c, LRNDE_BADARG, "null pointer");
+  if ((!du_end && !du_series) || !dx || !dp || !st_bwd) return fail(c, LRNDE_BADARG, "null pointer");
   if (!c->rec_valid || c->rec_B != B) return fail(c, LRNDE_BADARG, "no forward record for this batch (call lrnde_node_forward_record first)");
   const lrnde_solve_opts* o = &c->rec_opts;
   const float t0 = c->rec_t0, t2 = c->rec_t2, t1 = c->rec_t1;
@@ -3055,26 +3404,46 @@ int lrnde_node_backward_recorded(lrnde_ctx* c, int32_t B, const float* du_end, f
   const size_t n = (size_t)B * c->desc.state_dim;
   const size_t P = lrnde_param_count(&c->desc);
   const int nsteps = c->rec_naccept;
-  std::vector<float> dts(nsteps), dds(nsteps);
-  HIPCHK(c, hipMemcpy(dts.data(), c->dense_t, sizeof(float) * nsteps, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(dds.data(), c->dense_dt, sizeof(float) * nsteps, hipMemcpyDeviceToHost));
   // adjoint solve on z = [lambda; mu] in s = -t from -t2 to -t0, tstops at the saved times
   const size_t N = n + P;
   AdjVec v;
   if ((rc = adj_alloc(c, N, v))) return rc;
   v.n_lam = n; v.P = P;
   HIPCHK(c, hipMemsetAsync(v.z, 0, sizeof(float) * N, c->stream));
-  HIPCHK(c, hipMemcpyAsync(v.z, du_end, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  std::vector<AdjImpulse> impulses;  // ascending in s = -t
+  if (du_series) {
+    if (nser != (int)c->series_t.size()) return fail(c, LRNDE_BADARG, "%d cotangents for a series of %zu states", nser, c->series_t.size());
+    for (int i = nser - 1; i >= 0; --i) {
+      const float tv = c->series_t[i];
+      const float* du = du_series + (size_t)i * n;
+      if (tv >= t2) {  // cotangents at the end time: lambda(s0)
+        const float* gi[1] = {du}; const float one = 1.0f;
+        if ((rc = vec_axpy(c, v.z, v.z, 1.0f, 1, gi, &one, n))) return rc;
+      } else {
+        impulses.push_back(AdjImpulse{-tv, du});
+      }
+    }
+  } else {
+    HIPCHK(c, hipMemcpyAsync(v.z, du_end, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  }
   std::vector<float> stops;
-  if (mode != LRNDE_MODE_NONE)
+  if (mode != LRNDE_MODE_NONE || du_series)
     for (int i = (int)c->last_ts.size() - 1; i >= 0; --i) {
       const float tv = c->last_ts[i];
       if (tv > t0 && tv < t2) stops.push_back(-tv);
     }
-  auto rhs = [&](const float* zs, float sg, float* K) { return adj_rhs(c, dts, dds, B, n, zs, sg, K); };
-  auto rhs_fused = [&](const StageIn& sin, float sg, float* K) { return adj_rhs(c, dts, dds, B, n, nullptr, sg, K, &sin); };
-  rc = vec_tsit5_solve(c, v, rhs, rhs_fused, vjp_uses_qtile(c, B), -t2, -t0, o->abstol, o->reltol, o->maxiters, o->exact_pow,
-                       stops, st_bwd);
+  static const bool adj_host = getenv("LRNDE_ADJ_HOST") != nullptr;  // diagnostic: the round-1 host-controlled loop
+  if (vjp_uses_qtile(c, B) && !sharded(c) && !adj_host) {
+    rc = adj_solve_device(c, v, B, -t2, -t0, o->abstol, o->reltol, o->maxiters, o->exact_pow, stops, impulses, nsteps, st_bwd);
+  } else {
+    std::vector<float> dts(nsteps), dds(nsteps);
+    HIPCHK(c, hipMemcpy(dts.data(), c->dense_t, sizeof(float) * nsteps, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(dds.data(), c->dense_dt, sizeof(float) * nsteps, hipMemcpyDeviceToHost));
+    auto rhs = [&](const float* zs, float sg, float* K) { return adj_rhs(c, dts, dds, B, n, zs, sg, K); };
+    auto rhs_fused = [&](const StageIn& sin, float sg, float* K) { return adj_rhs(c, dts, dds, B, n, nullptr, sg, K, &sin); };
+    rc = vec_tsit5_solve(c, v, rhs, rhs_fused, vjp_uses_qtile(c, B), -t2, -t0, o->abstol, o->reltol, o->maxiters, o->exact_pow,
+                         stops, impulses, st_bwd);
+  }
   if (rc) return fail(c, rc, "adjoint solve stopped with retcode %d", rc);
   HIPCHK(c, hipMemcpyAsync(dx, v.z, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dp, v.z + n, sizeof(float) * P, hipMemcpyDeviceToDevice, c->stream));
@@ -3091,6 +3460,19 @@ int lrnde_node_backward_recorded(lrnde_ctx* c, int32_t B, const float* du_end, f
   }
   c->rec_valid = false;  // the regulariser sweep reused the state workspace
   return LRNDE_OK;
+}
+extern "C" {
+
+int lrnde_node_backward_recorded(lrnde_ctx* c, int32_t B, const float* du_end, float w_reg, float* dx, float* dp,
+                                 lrnde_stats* st_bwd) {
+  return node_backward_recorded_impl(c, B, du_end, nullptr, 0, w_reg, dx, dp, st_bwd);
+}
+
+int lrnde_node_backward_recorded_ts(lrnde_ctx* c, int32_t B, const float* du_series, int32_t nseries, float w_reg, float* dx,
+                                    float* dp, lrnde_stats* st_bwd) {
+  if (!c) return LRNDE_BADARG;
+  if (!du_series || nseries <= 0) return fail(c, LRNDE_BADARG, "null pointer / empty series");
+  return node_backward_recorded_impl(c, B, nullptr, du_series, nseries, w_reg, dx, dp, st_bwd);
 }
 
 // forward (with record) + backward in one call

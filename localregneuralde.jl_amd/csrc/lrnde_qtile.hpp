@@ -74,15 +74,20 @@ static size_t smem_bytes_q(int KQ1p, int KQ2p, int RG1, int RG2) {
   return ((size_t)KQ1p * 4 + (size_t)KQ2p * 4 + nseg1 * RG1 * 64) * 16 + 128 * (size_t)(RG1 + RG2) * 4 +
          QNW * 3 * sizeof(double) + sizeof(Bcast) + 16;
 }
+// SKIP0 = true: wave 0 takes no part (it runs the device prologue meanwhile, k_step_q); the other waves cover everything
+template <bool SKIP0 = false>
 __device__ __forceinline__ void smem_init_q(const ModelDev& m, const SmemQ& s) {
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < (m.KQ1p + m.KQ2p) * 4; i += QNT) s.xl[i] = z;  // xl and hl are adjacent
+  constexpr int NTH = SKIP0 ? QNT - 64 : QNT;
+  const int tid = SKIP0 ? (int)threadIdx.x - 64 : (int)threadIdx.x;
+  if (SKIP0 && tid < 0) return;
+  for (int i = tid; i < (m.KQ1p + m.KQ2p) * 4; i += NTH) s.xl[i] = z;  // xl and hl are adjacent
   const int h64 = m.RG1 * 64, d64 = m.RG2 * 64;
-  for (int i = threadIdx.x; i < h64; i += QNT) {
+  for (int i = tid; i < h64; i += NTH) {
     s.bias[i] = (i < m.Hp) ? m.w1t[i] : 0.f;
     s.bias[h64 + i] = (i < m.Hp) ? m.b1[i] : 0.f;
   }
-  for (int i = threadIdx.x; i < d64; i += QNT) {
+  for (int i = tid; i < d64; i += NTH) {
     s.bias[2 * h64 + i] = (i < m.Dp) ? m.w2t[i] : 0.f;
     s.bias[2 * h64 + d64 + i] = (i < m.Dp) ? m.b2[i] : 0.f;
   }
@@ -140,6 +145,7 @@ template <int S> struct EpiStageQ {
   float dt;
   f32x4* xl; int KQ1;
   f32x4* kl; int KL;
+  int store_k;  // Bcast::store_k: 0 = k_S stays in LDS (its global store gets an out-of-range offset and is dropped)
   __device__ __forceinline__ void pre(int rg, f32x4 (&pb)[NPRE]) const {
     const int li = rg * 64 + (threadIdx.x & 63);
 #pragma unroll
@@ -149,7 +155,7 @@ template <int S> struct EpiStageQ {
     const int lane = threadIdx.x & 63, sidx = lane & 3, q = lane >> 2;
     constexpr int off = (S - 1) * S / 2;
     const int vo = q_voff(io, rg);
-    qstore(io, vo, off_out, kv);
+    qstore(io, store_k ? vo : 0x7ffffff0, off_out, kv);
     kl[(size_t)S * KL + rg * 64 + lane] = kv;
     f32x4 x;
 #pragma unroll
@@ -489,8 +495,8 @@ __device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cas
 __device__ __forceinline__ void block_sum3_q(double* red, double& a, double& b, double& c, bool three = true) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  a = wave_sum(a);
-  if (three) { b = wave_sum(b); c = wave_sum(c); }
+  a = wave_sum_dpp(a);
+  if (three) { b = wave_sum_dpp(b); c = wave_sum_dpp(c); }
   if (lane == 0) { red[wave * 3 + 0] = a; red[wave * 3 + 1] = b; red[wave * 3 + 2] = c; }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -498,7 +504,7 @@ __device__ __forceinline__ void block_sum3_q(double* red, double& a, double& b, 
     for (int w = 0; w < QNW; ++w) { sa += red[w * 3]; sb += red[w * 3 + 1]; sc += red[w * 3 + 2]; }
     a = sa; b = sb; c = sc;
   }
-  __syncthreads();
+  // (no second barrier: `red` is not written again in this launch, and the callers only use thread 0's totals)
 }
 
 __device__ __forceinline__ void q_feval_store(const ModelDev& m, const SmemQ& sm, StreamQ& fc, float ts,
@@ -608,13 +614,15 @@ __global__ __launch_bounds__(QNT) void k_init2_q(StepArgs a) {
 template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a, int j) {
   STAMP(9);
   const SmemQ s = carve_q(a.m);
-  smem_init_q(a.m, s);
   StreamQ fc;
-  stream_init_q(a.m, fc);
+  stream_init_q(a.m, fc);   // the first two weight blocks are requested before anything waits
   const int b0 = blockIdx.x * QNB, nvalid = min(QNB, a.B - b0);
   const int KQ1 = a.m.D / 4;
   STAMP(10);
+  // wave 0 runs the device prologue (a chain of dependent global loads: control block, partial sums) while the other
+  // six waves clear the LDS tiles and stage the bias vectors: the two used to run one after the other
   if (threadIdx.x < 64) step_prologue(a, j, s.bc);
+  smem_init_q<true>(a.m, s);
   __syncthreads();
   STAMP(11);
   const Bcast bc = *s.bc;
@@ -713,7 +721,7 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
     _Pragma("unroll") for (int qq = 0; qq < 5; ++qq) e.off_k[1 + qq] = arr_off(a, 4 + qq); \
     e.off_out = arr_off(a, 4 + (S - 2));                                                \
     e.off_x = (S == 6) ? o_un : ((S == 5 && a.want_stiff) ? o_g6 : -1);                 \
-    e.dt = dt; e.xl = s.xl; e.KQ1 = KQ1; e.kl = kl; e.KL = KL;                          \
+    e.dt = dt; e.xl = s.xl; e.KQ1 = KQ1; e.kl = kl; e.KL = KL; e.store_k = bc.store_k;  \
     feval_qs<EpiStageQ<S>, (QSB * (S - 2)) % QRING, KT>(a.m, s, fc, (TS), e);                 \
     STAMP(11 + S);                                                                      \
   } while (0)

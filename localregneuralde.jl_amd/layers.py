@@ -255,6 +255,37 @@ class Handle:
                                                      _dev_ptr(dx, "dx"), C.c_void_p(dp.data_ptr()), C.byref(sb)))
         return dict(dx=dx, dp=dp, stats_bwd=sb.asdict())
 
+    def node_forward_record_ts(self, x, t0, t2, abstol, reltol, saveat, mode="unbiased", reg_type="error_estimate",
+                               t1_or_rand=0.5, maxiters=1000, save_start=False, exact_pow=False):
+        """the recorded layer forward with the layer's `saveat` kwarg: dict(u (nseries,B,D), t, u_end, reg_val, nfe, ...) —
+        sol.u / sol.t as the caller of the layer sees them (after _CorrectedDESolution)"""
+        B = x.numel() // self.D
+        sv = np.ascontiguousarray(saveat, dtype=np.float32)
+        o = L.SolveOpts(float(abstol), float(reltol), int(maxiters), int(save_start), 0, int(exact_pow))
+        cap = int(sv.size) + 3 + (0 if sv.size or mode != "biased" else min(int(maxiters), 510))
+        us = torch.empty((cap,) + tuple(x.shape), dtype=torch.float32, device=x.device)
+        ts = np.empty(cap, dtype=np.float32)
+        ns, reg, nfe, st, t1u = C.c_int32(), C.c_float(), C.c_int32(), L.Stats(), C.c_float()
+        self._chk(L.lib.lrnde_node_forward_record_ts(
+            self._ctx, _dev_ptr(x, "x", self.D), B, float(t0), float(t2), C.byref(o), L.MODE[mode], L.REG_TYPE[reg_type],
+            float(t1_or_rand), sv.ctypes.data_as(C.POINTER(C.c_float)) if sv.size else None, int(sv.size), C.c_void_p(us.data_ptr()),
+            ts.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(ns), C.byref(reg), C.byref(nfe), C.byref(st), C.byref(t1u)))
+        n = int(ns.value)
+        return dict(u=us[:n], t=ts[:n].copy(), u_end=us[n - 1], reg_val=np.float32(reg.value), nfe=int(nfe.value),
+                    stats=st.asdict(), t1=np.float32(t1u.value))
+
+    def node_backward_recorded_ts(self, du_series, w_reg=0.0):
+        """pullback from the record of node_forward_record_ts for one cotangent per state of the series (nseries,B,D)"""
+        du_series = du_series.contiguous()
+        nser = int(du_series.shape[0])
+        B = du_series[0].numel() // self.D
+        dx = torch.empty_like(du_series[0])
+        dp = torch.empty(int(L.lib.lrnde_param_count(C.byref(self.desc))), dtype=torch.float32, device=du_series.device)
+        sb = L.Stats()
+        self._chk(L.lib.lrnde_node_backward_recorded_ts(self._ctx, B, _dev_ptr(du_series, "du_series", self.D), nser, float(w_reg),
+                                                        _dev_ptr(dx, "dx"), C.c_void_p(dp.data_ptr()), C.byref(sb)))
+        return dict(dx=dx, dp=dp, stats_bwd=sb.asdict())
+
     def classifier_ce(self, u, pc, K, labels, want_grads=True):
         """Dense(D => K) + logitcrossentropy on device: dict(loss, logits, du, dpc)."""
         B = u.numel() // self.D
@@ -435,23 +466,40 @@ class NeuralODE:
             h.set_bn_state(model_state["bn_state"])
         return sol, dict(model=model_state, nfe=nfe, reg_val=reg_val, rng=rng, training=st["training"])
 
-    def pullback(self, x, ps, st, du_end, w_reg=0.0):
-        """What `Zygote.pullback` returns for this layer in the reference's training step
-        (experiments/src/utils.jl:104-115) for  loss = <du_end, sol.u[end]> + w_reg * reg_val:
-        (dx, dps, info).  One forward with the dense record, then the backward from it; t1 comes from the same single
-        draw of st['rng'] as in `__call__` (biased_index), so info['reg_val'] / info['t1'] are `__call__`'s."""
+    def pullback(self, x, ps, st, du, w_reg=0.0):
+        """What `Zygote.pullback` returns for this layer in the reference's training steps
+        (experiments/src/utils.jl:104-115) for  loss = <du, sol> + w_reg * reg_val: (dx, dps, info).
+        du: the cotangent of sol.u[end] (what `diffeqsol_to_array` consumers send back), or — with a user `saveat` — one
+        cotangent per state of the returned solution, stacked (nseries, B, D) (`diffeqsol_to_timeseries` consumers,
+        src/utils.jl:42-46, experiments/src/construct.jl:244-249).  One forward with the dense record, then the backward
+        from it; t1 comes from the same single draw of st['rng'] as in `__call__` (biased_index), so info['reg_val'] /
+        info['t1'] are `__call__`'s."""
         h = self._bind(ps, x)
         t0, t2 = self.tspan
         kw = self.kwargs
-        if kw.get("saveat", None) is not None:
-            raise NotImplementedError("pullback with user saveat is not built")
         abstol, reltol = kw.get("abstol", 1e-6), kw.get("reltol", 1e-3)
         mode = self.regularize if st["training"] else "none"
         rng = copy.deepcopy(st["rng"])
         r01 = np.float32(rng.random(dtype=np.float32))
         t1_or_rand = np.float32(r01 * (t2 - t0) + t0) if mode == "unbiased" else r01
-        fw = h.node_forward_record(x, t0, t2, abstol, reltol, mode=mode, reg_type=self.regularize_type,
-                                   t1_or_rand=t1_or_rand, maxiters=self.maxiters, save_start=kw.get("save_start", True))
-        bw = h.node_backward_recorded(du_end, w_reg=w_reg) if not self._conv else h.node_backward_recorded(x.shape[0], du_end, w_reg=w_reg)
-        info = dict(bw, reg_val=fw["reg_val"], t1=fw["t1"], nfe=fw["nfe"], u_end=fw["u_end"], stats_fwd=fw["stats"])
+        common = dict(mode=mode, reg_type=self.regularize_type, t1_or_rand=t1_or_rand, maxiters=self.maxiters,
+                      save_start=kw.get("save_start", True))
+        saveat = kw.get("saveat", None)
+        if saveat is not None:
+            if self._conv:
+                raise NotImplementedError("time-series cotangents are built for the MLP field")
+            fw = h.node_forward_record_ts(x, t0, t2, abstol, reltol, saveat, **common)
+            nser = int(fw["u"].shape[0])
+            if du.dim() == x.dim():  # a cotangent for sol.u[end] only
+                full = torch.zeros_like(fw["u"])
+                full[nser - 1] = du
+                du = full
+            if int(du.shape[0]) != nser:
+                raise ValueError(f"{int(du.shape[0])} cotangents for a solution of {nser} saved states")
+            bw = h.node_backward_recorded_ts(du, w_reg=w_reg)
+        else:
+            fw = h.node_forward_record(x, t0, t2, abstol, reltol, **common)
+            bw = h.node_backward_recorded(du, w_reg=w_reg) if not self._conv else h.node_backward_recorded(x.shape[0], du, w_reg=w_reg)
+        info = dict(bw, reg_val=fw["reg_val"], t1=fw["t1"], nfe=fw["nfe"], u_end=fw["u_end"], stats_fwd=fw["stats"],
+                    sol_t=fw.get("t"), sol_u=fw.get("u"))
         return bw["dx"], bw["dp"], info

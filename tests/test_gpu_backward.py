@@ -61,6 +61,7 @@ def test_reg_gradient_matches_oracle(oracle, gpu_pkg, reg_type, D, H, B, act, td
     gp_ref, rv_ref = oracle.step_reg_grad(fld, x, k1, 0.2, 0.1, 1e-3, 1e-3, reg_type)
     gp, rv = h.step_reg_grad(torch.from_numpy(x).cuda(), torch.from_numpy(k1).cuda(), 0.2, 0.1, 1e-3, 1e-3, reg_type)
     assert rv == rv_ref
+    print(f"reg-grad {reg_type} D={D} B={B}: rel err vs oracle {_rel(gp.cpu().numpy(), gp_ref):.2e}")
     assert _rel(gp.cpu().numpy(), gp_ref) < 1e-3, _rel(gp.cpu().numpy(), gp_ref)
     assert np.isfinite(gp.cpu().numpy()).all() and (gp.cpu().numpy() != 0).any()     # runtests.jl:130-131
 
@@ -78,6 +79,7 @@ def test_node_backward_matches_oracle(oracle, gpu_pkg, mode, w_reg):
     assert ref["retcode"] == 0
     assert got["stats_fwd"]["naccept"] == ref["stats_fwd"]["naccept"]       # forward is bit-exact
     dx, dp = got["dx"].cpu().numpy(), got["dp"].cpu().numpy()
+    print(f"node_backward {mode} w_reg={w_reg}: rel err dx {_rel(dx, ref['dx']):.2e} dp {_rel(dp, ref['dp']):.2e}")
     assert _rel(dx, ref["dx"]) < 2e-4, _rel(dx, ref["dx"])
     assert _rel(dp, ref["dp"]) < 2e-4, _rel(dp, ref["dp"])
     # test/runtests.jl:24-29: gradients finite and non-zero
