@@ -45,6 +45,10 @@ struct AdjArgs {
   const double* ipart;  // [3][512 + 64]: the same for initdt's d0, d1, d2
   int nranks;           // > 1 (or a forced communicator): the lambda part's sum is the rank slots', added in rank order
   int use_slots;
+  // pinned host memory (device-mapped), written by block 0 of every attempt's first launch: {seq, status, t, dt} — the
+  // host driver reads the integrator's progress from it without putting copy packets between the kernels
+  int* hstat;
+  int seq0;             // seq written by attempt j is seq0 + j + 1
 };
 
 // how a backward kernel gets its per-launch arguments: from the host (round-1 path, single calls), or from AdjCtrl:
@@ -105,6 +109,28 @@ __device__ __forceinline__ AdjStage adj_lookup(const AdjArgs& g, float tt) {
   return s;
 }
 
+// The same for several times at once without a memory round trip per time: lane i holds (dense_t[i], dense_dt[i]) of
+// the record (nrec <= 64: one load each, issued with the prologue's other loads), a lookup is a ballot and two readlanes.
+struct AdjRecLanes { float t, dt; };
+__device__ __forceinline__ AdjRecLanes adj_rec_load(const AdjArgs& g) {
+  const int lane = threadIdx.x & 63;
+  AdjRecLanes r;
+  r.t = (lane < g.nrec) ? g.dense_t[lane] : 3.0e38f;
+  r.dt = (lane < g.nrec) ? g.dense_dt[lane] : 1.0f;
+  return r;
+}
+__device__ __forceinline__ AdjStage adj_lookup_lanes(const AdjArgs& g, const AdjRecLanes& r, float tt) {
+  if (g.nrec > 64) return adj_lookup(g, tt);
+  const int cnt = __popcll(__ballot(r.t <= tt));
+  AdjStage s;
+  s.lo = cnt > 0 ? cnt - 1 : 0;
+  const float t_lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.t), s.lo));
+  s.ddt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.dt), s.lo));
+  s.theta = (tt - t_lo) / s.ddt;
+  s.t = tt;
+  return s;
+}
+
 __device__ __forceinline__ float adj_dt0(float d0, float d1, float dtmax) {
   float dt0 = ((double)d0 < 1e-5 || (double)d1 < 1e-5) ? 1e-6f : (d0 / d1) / 100.0f;
   return fminf_(dt0, dtmax);
@@ -115,10 +141,17 @@ __device__ __forceinline__ float adj_dt0(float d0, float d1, float dtmax) {
 __device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
   const int lane = threadIdx.x & 63;
   AdjCtrl c = g.ctl[j & 1];
+  const AdjRecLanes rec = adj_rec_load(g);  // (independent of the control block: in flight with it)
   AdjCtrl* cout = g.ctl + ((j + 1) & 1);
   c.do_step = 0;
   if (c.status != ST_RUNNING) {
-    if (blockIdx.x == 0 && lane == 0) *cout = c;
+    if (blockIdx.x == 0 && lane == 0) {
+      *cout = c;
+      if (g.hstat) {
+        g.hstat[1] = c.status; g.hstat[2] = __builtin_bit_cast(int, c.t); g.hstat[3] = __builtin_bit_cast(int, c.dt);
+        __hip_atomic_store(g.hstat, g.seq0 + j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     return c;
   }
   const float gamma = 0.9f, qmin = 0.2f, qmax = 10.0f, qoldinit = 1e-4f;
@@ -191,12 +224,18 @@ __device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
         c.do_step = 1; c.nf += 6; c.tstop = tstop;
         const float cs[6] = {(float)Tsit5::C[0], (float)Tsit5::C[1], (float)Tsit5::C[2], (float)Tsit5::C[3], 1.0f, 1.0f};
 #pragma unroll
-        for (int q = 0; q < 6; ++q) c.st[q] = adj_lookup(g, -(t + cs[q] * dt));
+        for (int q = 0; q < 6; ++q) c.st[q] = adj_lookup_lanes(g, rec, -(t + cs[q] * dt));
       }
     }
   }
   c.t = t; c.dt = dt; c.first = 0;
-  if (blockIdx.x == 0 && lane == 0) *cout = c;
+  if (blockIdx.x == 0 && lane == 0) {
+    *cout = c;
+    if (g.hstat) {
+      g.hstat[1] = c.status; g.hstat[2] = __builtin_bit_cast(int, c.t); g.hstat[3] = __builtin_bit_cast(int, c.dt);
+      __hip_atomic_store(g.hstat, g.seq0 + j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   return c;
 }
 

@@ -641,15 +641,15 @@ static size_t smem_bytes_vq(int KQ1p, int KQ2p, int RG1, int RG2) {
 }
 
 // fills the decision-dependent fields of `a` for a launch of the adjoint loop; false: nothing to do (solve finished)
-__device__ __forceinline__ bool vjp_q_resolve(VjpQArgs& a) {
+// For stages 3..7 the control block is requested at the head of the kernel (`early`, thread 0) and consumed here, after
+// the LDS initialisation and the first weight-stream requests: its round trip hides behind them.
+__device__ __forceinline__ bool vjp_q_resolve(VjpQArgs& a, const AdjCtrl& early) {
   if (a.adj_mode == ADJ_HOST) return true;
   __shared__ AdjCtrl sh_c;
   const AdjArgs& g = a.adj;
   if (a.adj_mode == ADJ_STAGE && a.adj_stage > 2) {
-    // control block of this attempt, published by the stage-2 launch (uniform address: scalar loads)
-    const AdjCtrl* cp = g.ctl + ((a.adj_j + 1) & 1);
-    if (!cp->do_step) return false;
-    if (threadIdx.x == 0) sh_c = *cp;
+    // control block of this attempt, published by the stage-2 launch
+    if (threadIdx.x == 0) sh_c = early;
   } else if (threadIdx.x < 64) {
     AdjCtrl c;
     if (a.adj_mode == ADJ_STAGE) {
@@ -682,9 +682,7 @@ __device__ __forceinline__ bool vjp_q_resolve(VjpQArgs& a) {
   if (a.adj_mode == ADJ_STAGE) {
     a.lbase = adj_zb(g, cur); a.ldt = sh_c.dt; a.lnk = sidx - 1;
     // row sidx of the tableau; terms beyond the row: the base vector with coefficient 0 (adds +-0, as the host path does)
-    const float* arow = nullptr;
     float cf[6];
-    (void)arow;
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       float v = 0.0f;
@@ -713,7 +711,8 @@ __device__ __forceinline__ bool vjp_q_resolve(VjpQArgs& a) {
 }
 
 template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
-  if (!vjp_q_resolve(a)) return;
+  AdjCtrl early;
+  if (a.adj_mode == ADJ_STAGE && a.adj_stage > 2 && threadIdx.x == 0) early = a.adj.ctl[(a.adj_j + 1) & 1];
   const ModelDev& m = a.m;
   const SmemQ s = carve_q(m);
   // extra LDS behind the forward layout: the lambda tile and act'(pre)
@@ -746,6 +745,9 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
     vq_stream_load<1, 1>(st);
   }
   for (int i = threadIdx.x; i < (m.KQ1p - KQ1) * 4; i += QNT) ll[KQ1 * 4 + i] = zero4;
+  // adjoint loop: decision-dependent arguments from the control block (a barrier inside; nothing to do -> leave, the
+  // outstanding weight requests are simply dropped with the wave)
+  if (!vjp_q_resolve(a, early)) return;
   // ---- phase 0: y tile (given or interpolated) and lambda tile -> LDS; y -> scratch ----
   float bw[7];
   if (!a.y) tsit5_bweights(a.theta, bw);

@@ -1610,11 +1610,14 @@ struct lrnde_ctx {
   // device-side adjoint controller (lrnde_adjoint.hpp): control blocks, initdt partial sums, tstops, pinned read-back slots
   AdjCtrl* adj_ctl = nullptr; AdjCtrl* adj_ctl_host = nullptr; double* adj_ipart = nullptr; float* adj_stops = nullptr; int adj_stops_cap = 0;
   hipEvent_t adj_ev[2] = {nullptr, nullptr};
+  int* adj_hstat = nullptr; int* adj_hstat_dev = nullptr; int adj_seq = 0;  // pinned progress word of the adjoint loop (host / device view)
   std::vector<float> last_ts;  // sol.t of the last node_forward (cotangent times of the adjoint)
   std::vector<int> series_idx; std::vector<float> series_t;  // the caller's view of that solution: save slots and times
   float last_t1 = 0.f; int last_i1 = 0;
   // backward workspace kept across calls: u(t1) of the recorded forward, k1 and the regulariser's gradient
   float *rec_u1 = nullptr, *rec_k1 = nullptr, *rec_gr = nullptr; size_t rec_n = 0;
+  float rec_dt1 = 0.f, rec_eest = 0.f, rec_snum = 0.f, rec_sden = 0.f;  // the local step's dt and scalars (forward's)
+  float loc_dt = 0.f, loc_eest = 0.f, loc_snum = 0.f, loc_sden = 0.f;    // the same of the LAST layer forward
   // arguments of the last lrnde_node_forward_record (what lrnde_node_backward_recorded differentiates)
   bool rec_valid = false; int rec_B = 0, rec_mode = 0, rec_reg_type = 0, rec_naccept = 0;
   float rec_t0 = 0.f, rec_t2 = 0.f, rec_t1 = 0.f; lrnde_solve_opts rec_opts{};
@@ -1965,6 +1968,7 @@ int lrnde_destroy(lrnde_ctx* c) {
   if (c->ctrl_host) hipHostFree(c->ctrl_host);
   if (c->adj_ctl) hipFree(c->adj_ctl);
   if (c->adj_ctl_host) hipHostFree(c->adj_ctl_host);
+  if (c->adj_hstat) hipHostFree(c->adj_hstat);
   if (c->adj_ipart) hipFree(c->adj_ipart);
   if (c->adj_stops) hipFree(c->adj_stops);
   if (c->adj_ev[0]) hipEventDestroy(c->adj_ev[0]);
@@ -2329,6 +2333,7 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
   HIPCHK(c, hipMemcpyAsync(c->ctrl_host, c->ctrl + 1, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const Ctrl k = c->ctrl_host[0];
+  c->loc_dt = k.dt; c->loc_eest = k.eest_last; c->loc_snum = k.stiff_num; c->loc_sden = k.stiff_den;
   if (reg_val_host) *reg_val_host = a.want_stiff ? k.reg_stiff : k.reg_error;
   if (nfe_host) *nfe_host = st->nf + k.nf;  // sol.destats.nf + (6 + 3), perform_step.jl:31
   return LRNDE_OK;
@@ -2719,6 +2724,7 @@ static int ensure_bw(lrnde_ctx* c, int B) {
 // (df/dp)^T lam from the scratch left by the last VJP launch (y, h, dpre); gp may be NULL
 static PgradArgs pgrad_args(const lrnde_ctx* c, int B, float t, const float* lam, float* gp, int set) {
   PgradArgs g;
+  memset(&g, 0, sizeof(g));  // adj_mode = ADJ_HOST: t / lam / gp as given here
   g.D = c->m.D; g.H = c->m.H; g.Hp = c->m.Hp; g.td = c->m.td; g.B = B; g.t = t;
   g.lam = lam; g.gp = gp;
   g.y = c->bw_y + (size_t)set * B * c->desc.state_dim; g.h = c->bw_h + (size_t)set * B * c->m.Hp; g.dpre = c->bw_dp + (size_t)set * B * c->m.Hp;
@@ -3131,6 +3137,9 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
     HIPCHK(c, hipMalloc(&c->adj_ipart, sizeof(double) * 3 * 576));
     HIPCHK(c, hipEventCreateWithFlags(&c->adj_ev[0], hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->adj_ev[1], hipEventDisableTiming));
+    HIPCHK(c, hipHostMalloc(&c->adj_hstat, sizeof(int) * 16, hipHostMallocMapped));
+    memset(c->adj_hstat, 0, sizeof(int) * 16);
+    HIPCHK(c, hipHostGetDevicePointer((void**)&c->adj_hstat_dev, c->adj_hstat, 0));
   }
   if ((int)tstops.size() > c->adj_stops_cap) {
     if (c->adj_stops) HIPCHK(c, hipFree(c->adj_stops));
@@ -3180,42 +3189,35 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
       ++extra_nf;
     }
     first_seg = false;
-    // attempts, enqueued in chunks, status polled one chunk behind
-    int j = 0, pending = -1, target = 2, nchunk = 0;
-    bool done = false;
-    while (!done) {
-      int ch = target - j;
-      if (ch < 1) ch = 1;
-      if (ch > 8) ch = 8;
-      for (int i = 0; i < ch; ++i, ++j) {
-        for (int sidx = 2; sidx <= 7; ++sidx)
-          if ((rc = adj_enqueue_eval(c, B, g, ADJ_STAGE, sidx, j, sidx > 2, ADJ_STAGE, sidx - 1))) return rc;
-        if ((rc = adj_enqueue_pgrad(c, B, g, ADJ_STAGE, 7, j))) return rc;
-        hipLaunchKernelGGL(k_adj_err_dev, dim3(512), dim3(256), 0, c->stream, e, g, j);
-        HIPCHK(c, hipGetLastError());
-      }
-      const int slot = (nchunk++) & 1;
-      HIPCHK(c, hipMemcpyAsync(c->adj_ctl_host + slot, c->adj_ctl + (j & 1), sizeof(AdjCtrl), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipEventRecord(c->adj_ev[slot], c->stream));
-      if (pending >= 0) {
-        for (;;) {  // poll (a blocking wait would put the thread to sleep for the scheduler's quantum)
-          const hipError_t q = hipEventQuery(c->adj_ev[pending]);
-          if (q == hipSuccess) break;
-          if (q != hipErrorNotReady) return fail(c, LRNDE_HIP_ERROR, "adjoint status poll: %s", hipGetErrorString(q));
-        }
-        const AdjCtrl& k = c->adj_ctl_host[pending];
-        if (k.status != ST_RUNNING) done = true;
-        else if (k.dt > 0.f) {
-          double est = ceil((double)(g.s1 - k.t) / (double)k.dt);
-          if (est > 1e6) est = 1e6;
-          const int tg = j + (int)(est / 2);
-          if (tg > target) target = tg;
+    // Attempts are enqueued ONE ahead of what the device has decided: the first launch of attempt j publishes the
+    // integrator's status in pinned host memory (AdjArgs::hstat), and attempt j+1 is enqueued when attempt j is known
+    // to be running (its remaining seven launches, ~130 us, cover the host's enqueue).  So the solve ends with exactly
+    // one attempt whose launches find nothing to do, and no copy packet sits between the kernels.
+    g.hstat = c->adj_hstat_dev; g.seq0 = c->adj_seq;
+    volatile int* hs = c->adj_hstat;
+    int j = 0;
+    for (bool done = false; !done;) {
+      for (int sidx = 2; sidx <= 7; ++sidx)
+        if ((rc = adj_enqueue_eval(c, B, g, ADJ_STAGE, sidx, j, sidx > 2, ADJ_STAGE, sidx - 1))) return rc;
+      if ((rc = adj_enqueue_pgrad(c, B, g, ADJ_STAGE, 7, j))) return rc;
+      hipLaunchKernelGGL(k_adj_err_dev, dim3(512), dim3(256), 0, c->stream, e, g, j);
+      HIPCHK(c, hipGetLastError());
+      ++j;
+      // wait for the prologue of the attempt just enqueued (bounded: a faulted queue must not hang the caller)
+      const int want = g.seq0 + j;
+      long spins = 0;
+      while ((int)(__atomic_load_n(hs, __ATOMIC_ACQUIRE) - want) < 0) {
+        if (((++spins) & 0xFFFFF) == 0) {
+          const hipError_t q = hipStreamQuery(c->stream);
+          if (q != hipSuccess && q != hipErrorNotReady) return fail(c, LRNDE_HIP_ERROR, "adjoint loop: %s", hipGetErrorString(q));
+          if (q == hipSuccess && (int)(__atomic_load_n(hs, __ATOMIC_ACQUIRE) - want) < 0)
+            return fail(c, LRNDE_HIP_ERROR, "adjoint loop: the stream drained without the status of attempt %d", j - 1);
         }
       }
-      pending = slot;
-      if (target <= j) target = j + 1;
+      if (hs[1] != ST_RUNNING) done = true;
       if (j > maxiters + 16) break;
     }
+    c->adj_seq += j;
     HIPCHK(c, hipMemcpyAsync(c->adj_ctl_host, c->adj_ctl + (j & 1), sizeof(AdjCtrl), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fin = c->adj_ctl_host[0];
@@ -3247,18 +3249,32 @@ extern "C" {
 
 // gradient of the local regularisation value w.r.t. p (reverse sweep through one Tsit5 step with
 // k1, dt, uprev constant: src/layers/neural_ode.jl:40, src/perform_step.jl:3-47).  gp: device (P).
+}  // extern "C"
+// the reverse sweep proper, enqueued without a host synchronisation: the forward step's state (uprev, u, k1..k7, g6) is
+// in the state workspace (by stream order), its scalars (EEst, the two stiffness rms values) are given
+static int step_reg_sweep(lrnde_ctx* c, const float* uprev, int32_t B, float t, float dt, float abstol, float reltol,
+                          int32_t reg_type, float eest, float stiff_num, float stiff_den, float* gp);
+extern "C" {
 int lrnde_step_reg_grad(lrnde_ctx* c, const float* uprev, const float* k1, int32_t B, float t, float dt,
                         float abstol, float reltol, int32_t reg_type, float* gp, float* reg_val_host) {
   int rc = check_ready(c, B);
   if (rc) return rc;
   if (!uprev || !k1 || !gp) return fail(c, LRNDE_BADARG, "null pointer");
-  const size_t n = (size_t)B * c->desc.state_dim;
-  const size_t P = lrnde_param_count(&c->desc);
   // forward step (keeps k2..k6, g6, u, k7 in the state workspace) and its scalars
   float ee, re, rs;
   if ((rc = lrnde_perform_step(c, uprev, k1, B, t, dt, abstol, reltol, nullptr, nullptr, &ee, &re, &rs))) return rc;
   const Ctrl fin = c->ctrl_host[0];
   if (reg_val_host) *reg_val_host = (reg_type == LRNDE_REG_STIFFNESS_ESTIMATE) ? rs : re;
+  if ((rc = step_reg_sweep(c, uprev, B, t, dt, abstol, reltol, reg_type, fin.eest_last, fin.stiff_num, fin.stiff_den, gp))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRNDE_OK;
+}
+}  // extern "C"
+static int step_reg_sweep(lrnde_ctx* c, const float* uprev, int32_t B, float t, float dt, float abstol, float reltol,
+                          int32_t reg_type, float eest, float stiff_num, float stiff_den, float* gp) {
+  int rc;
+  const size_t n = (size_t)B * c->desc.state_dim;
+  const size_t P = lrnde_param_count(&c->desc);
   float* S = c->state;  // ubuf0 (uprev) ubuf1 (u) kfsal0 (k1) kfsal1 (k7) ks0..4 (k2..k6) g6
   const float* kk[7] = {S + 2 * n, S + 4 * n, S + 5 * n, S + 6 * n, S + 7 * n, S + 8 * n, S + 3 * n};
   const float* u = S + n; const float* g6 = S + 9 * n;
@@ -3276,7 +3292,7 @@ int lrnde_step_reg_grad(lrnde_ctx* c, const float* uprev, const float* k1, int32
   for (int j = 0; j < 7; ++j) sa.k[j] = kk[j];
   for (int j = 1; j < 7; ++j) sa.kb[j] = kb[j];
   sa.ub = ub; sa.g6b = g6b; sa.dt = dt; sa.abstol = abstol; sa.reltol = reltol; sa.reg_type = reg_type;
-  sa.eest = fin.eest_last; sa.num = fin.stiff_num; sa.den = fin.stiff_den;
+  sa.eest = eest; sa.num = stiff_num; sa.den = stiff_den;
   { int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(k_reg_seed, dim3(nb), dim3(256), 0, c->stream, sa); HIPCHK(c, hipGetLastError()); }
   float A[21];
@@ -3298,9 +3314,9 @@ int lrnde_step_reg_grad(lrnde_ctx* c, const float* uprev, const float* k1, int32
       if ((rc = vec_axpy(c, kb[j], kb[j], dt, 1, g1, cc, n))) return rc;
     }
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRNDE_OK;
 }
+extern "C" {
 
 // node_forward that also keeps what the backward pass needs: the dense record of every accepted
 // step (retry with a larger record if it overflows) and the solve's arguments.
@@ -3340,8 +3356,14 @@ static int node_forward_record_impl(lrnde_ctx* c, const float* x, int32_t B, flo
     HIPCHK(c, hipMalloc(&c->rec_gr, sizeof(float) * lrnde_param_count(&c->desc)));
     c->rec_n = n;
   }
-  if (mode != LRNDE_MODE_NONE)  // u(t1): the local step's uprev, kept out of the save slots a later solve may reuse
+  if (mode != LRNDE_MODE_NONE) {
+    // u(t1) = the local step's uprev (kept out of the save slots a later solve may reuse), k1 = its fsalfirst (still in
+    // the state workspace: kfsal[0] of the single-step run), and the step's scalars: the backward pass re-runs the step
+    // (to have k2..k6 in memory) and starts the regulariser's reverse sweep from these without asking the device again
     HIPCHK(c, hipMemcpyAsync(c->rec_u1, c->usave + (size_t)c->last_i1 * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rec_k1, c->state + 2 * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+    c->rec_dt1 = c->loc_dt; c->rec_eest = c->loc_eest; c->rec_snum = c->loc_snum; c->rec_sden = c->loc_sden;
+  }
   c->rec_valid = true; c->rec_B = B; c->rec_t0 = t0; c->rec_t2 = t2; c->rec_opts = *o; c->rec_mode = mode;
   c->rec_reg_type = reg_type; c->rec_t1 = t1; c->rec_naccept = st->naccept;
   return LRNDE_OK;
@@ -3447,16 +3469,26 @@ static int node_backward_recorded_impl(lrnde_ctx* c, int32_t B, const float* du_
   if (rc) return fail(c, rc, "adjoint solve stopped with retcode %d", rc);
   HIPCHK(c, hipMemcpyAsync(dx, v.z, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dp, v.z + n, sizeof(float) * P, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!(mode != LRNDE_MODE_NONE && w_reg != 0.0f)) HIPCHK(c, hipStreamSynchronize(c->stream));
   // regulariser: dp += w_reg * d reg_val / d p   (no gradient w.r.t. x: test/runtests.jl:129)
   if (mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
     float *k1 = c->rec_k1, *gr = c->rec_gr, *u1 = c->rec_u1;
-    float dtl = 0.f, rv = 0.f;
-    rc = lrnde_init_dt(c, u1, B, t1, t2, o->abstol, o->reltol, k1, &dtl);
-    if (!rc) rc = lrnde_step_reg_grad(c, u1, k1, B, t1, dtl, o->abstol, o->reltol, reg_type, gr, &rv);
+    // the local step again, from the record (uprev = u(t1), k1, dt: what the forward's fresh init produced), enqueued
+    // without a read-back, then the reverse sweep from the forward's own scalars
+    if ((rc = ensure_workspace(c, B))) return rc;
+    StepArgs a;
+    fill_args(c, a, B);
+    a.t0 = t1; a.t1 = t1 + 1.0f; a.abstol = o->abstol; a.reltol = o->reltol; a.mode = MODE_SINGLE_GIVEN_DT;
+    a.want_stiff = 1; a.maxiters = 1;
+    HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u1, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(a.kfsal[0], k1, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t1, c->rec_dt1, 0, 0);
+    if ((rc = launch_step(c, B, a, 0))) return rc;
+    { const size_t cnt = (size_t)a.nwg_global * PSTRIDE; if ((rc = exchange(c, c->part + cnt, c->part_rx + cnt, cnt))) return rc; }
+    rc = step_reg_sweep(c, u1, B, t1, c->rec_dt1, o->abstol, o->reltol, reg_type, c->rec_eest, c->rec_snum, c->rec_sden, gr);
     if (!rc) { const float* g1[2] = {dp, gr}; const float cc[2] = {1.0f, w_reg}; rc = vec_axpy(c, dp, nullptr, 1.0f, 2, g1, cc, P); }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   c->rec_valid = false;  // the regulariser sweep reused the state workspace
   return LRNDE_OK;

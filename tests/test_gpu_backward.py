@@ -53,8 +53,12 @@ def test_vjp_around_the_phase3_tail(oracle, gpu_pkg, H):
 @pytest.mark.parametrize("reg_type", ["error_estimate", "stiffness_estimate"])
 @pytest.mark.parametrize("D,H,B,act,td", [(784, 100, 32, "tanh", True), (32, 64, 20, "gelu", True)])
 def test_reg_gradient_matches_oracle(oracle, gpu_pkg, reg_type, D, H, B, act, td):
-    """d reg_val/d ps through one local step; rtol 1e-3 on the gradient norm (fp32 reverse sweep
-    through six stages), reg_val itself is bit-exact."""
+    """d reg_val/d ps through one local step: reg_val itself is bit-exact; the gradient within 3e-4 of the oracle's norm.
+    Where that bound comes from: both sides start the reverse sweep from the SAME forward values (bit-exact step), so the
+    cotangent seeds agree; what differs is the summation order of six chained VJPs (2e-5 each, test_vjp_matches_oracle)
+    whose cotangents carry the seeds' 1/(abstol + |u| reltol) ~ 1e3 dynamic range — measured 1.1e-4 (:error_estimate,
+    MNIST shape), 8e-6 (32/64), 1e-6 (:stiffness_estimate).  Against the EXACT gradient no fp32 implementation is closer
+    than ~1e-2 (tests/test_np_restatement.py::test_reg_gradient_conditioning_in_fp32): utilde cancels to 1e-4 of its terms."""
     import torch
     fld, h, p, x = _mk(oracle, gpu_pkg, D, H, B, act, td, scale=3.0)
     k1 = fld.rhs(x, 0.2)
@@ -62,14 +66,15 @@ def test_reg_gradient_matches_oracle(oracle, gpu_pkg, reg_type, D, H, B, act, td
     gp, rv = h.step_reg_grad(torch.from_numpy(x).cuda(), torch.from_numpy(k1).cuda(), 0.2, 0.1, 1e-3, 1e-3, reg_type)
     assert rv == rv_ref
     print(f"reg-grad {reg_type} D={D} B={B}: rel err vs oracle {_rel(gp.cpu().numpy(), gp_ref):.2e}")
-    assert _rel(gp.cpu().numpy(), gp_ref) < 1e-3, _rel(gp.cpu().numpy(), gp_ref)
+    assert _rel(gp.cpu().numpy(), gp_ref) < 3e-4, _rel(gp.cpu().numpy(), gp_ref)
     assert np.isfinite(gp.cpu().numpy()).all() and (gp.cpu().numpy() != 0).any()     # runtests.jl:130-131
 
 
 @pytest.mark.parametrize("mode,w_reg", [("none", 0.0), ("unbiased", 0.0), ("unbiased", 2.5), ("biased", 1.0)])
 def test_node_backward_matches_oracle(oracle, gpu_pkg, mode, w_reg):
-    """Continuous adjoint + regulariser sweep vs the oracle: rtol 2e-4 on ||dx||, ||dp|| (both sides
-    solve the adjoint ODE adaptively at abstol=reltol=1e-5; step sequences may differ)."""
+    """Continuous adjoint + regulariser sweep vs the oracle: 2e-5 of ||dx||, ||dp|| — the north star's fp32 bar with a
+    factor for two adaptive solves of the adjoint ODE at abstol=reltol=1e-5 whose step sequences may differ (measured
+    5e-7 .. 8e-7: the solves are far more accurate than their tolerance on this smooth field)."""
     import torch
     fld, h, p, x = _mk(oracle, gpu_pkg, 784, 100, 32, "tanh", True, scale=1.5)
     g = np.random.default_rng(4).standard_normal(x.shape).astype(np.float32)
@@ -80,8 +85,8 @@ def test_node_backward_matches_oracle(oracle, gpu_pkg, mode, w_reg):
     assert got["stats_fwd"]["naccept"] == ref["stats_fwd"]["naccept"]       # forward is bit-exact
     dx, dp = got["dx"].cpu().numpy(), got["dp"].cpu().numpy()
     print(f"node_backward {mode} w_reg={w_reg}: rel err dx {_rel(dx, ref['dx']):.2e} dp {_rel(dp, ref['dp']):.2e}")
-    assert _rel(dx, ref["dx"]) < 2e-4, _rel(dx, ref["dx"])
-    assert _rel(dp, ref["dp"]) < 2e-4, _rel(dp, ref["dp"])
+    assert _rel(dx, ref["dx"]) < 2e-5, _rel(dx, ref["dx"])
+    assert _rel(dp, ref["dp"]) < 2e-5, _rel(dp, ref["dp"])
     # test/runtests.jl:24-29: gradients finite and non-zero
     assert np.isfinite(dx).all() and np.isfinite(dp).all() and np.all(dx != 0) and np.mean(dp != 0) > 0.99
     print(mode, w_reg, "bwd steps gpu/oracle:", got["stats_bwd"]["naccept"], ref["stats_bwd"]["naccept"])
@@ -119,7 +124,9 @@ def test_full_size_mnist_b512_backward(oracle, gpu_pkg):
     assert ref["retcode"] == 0 and got["stats_fwd"]["naccept"] == ref["stats_fwd"]["naccept"]   # the forward is bit-exact
     # the two adjoint solves are adaptive on summation-order-dependent norms: their step sequences may differ by a few steps
     assert abs(got["stats_bwd"]["naccept"] - ref["stats_bwd"]["naccept"]) <= 4
-    assert _rel(got["dx"].cpu().numpy(), ref["dx"]) < 2e-4 and _rel(got["dp"].cpu().numpy(), ref["dp"]) < 2e-4
+    print("B=512 backward: dx rel", _rel(got["dx"].cpu().numpy(), ref["dx"]), "dp rel", _rel(got["dp"].cpu().numpy(), ref["dp"]),
+          "adjoint steps gpu/oracle", got["stats_bwd"]["naccept"], ref["stats_bwd"]["naccept"])
+    assert _rel(got["dx"].cpu().numpy(), ref["dx"]) < 2e-5 and _rel(got["dp"].cpu().numpy(), ref["dp"]) < 2e-5
 
 
 def test_training_step_matches_oracle_and_one_call_backward(oracle, gpu_pkg):
