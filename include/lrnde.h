@@ -311,6 +311,19 @@ int lrnde_sde_solve_fixed(lrnde_sde* sde, int32_t which, const float* u0, const 
                           int32_t nsteps, float abstol, float reltol, float delta, float* u_traj, float* eest_host,
                           float* reg_val_host);
 
+/* Gradient path of the NeuralDSDE layer.  The reference differentiates the SDE solve with TrackerAdjoint — a tape of the
+ * solver's own arithmetic (src/layers/neural_sde.jl:12; test/runtests.jl:361-365,386-397) — and reg_val w.r.t. the
+ * parameters only (the local step's integrator is built under CRC.@non_differentiable, neural_sde.jl:42).
+ * lrnde_sde_solve_fixed_backward: pullback of lrnde_sde_solve_fixed (which = 0, Euler-Heun) for
+ * loss = <du_end, u_traj[nsteps-1]>: the reverse sweep through the nsteps steps with the same increments dW
+ * (discretise-then-differentiate); dx (B x D), dp_drift (flat drift parameters), dp_diff ([vec(Wg); bg]): device.
+ * lrnde_sde_euler_heun_reg_grad: d (EEst*dt) / d (p_drift, p_diffusion) of one local Euler-Heun step
+ * (src/perform_step.jl:172-206) with uprev, dW, dt constant; reg_val_host receives EEst*dt. */
+int lrnde_sde_solve_fixed_backward(lrnde_sde* sde, const float* u0, const float* u_traj, const float* dW, int32_t B, float t0,
+                                   float dt, int32_t nsteps, const float* du_end, float* dx, float* dp_drift, float* dp_diff);
+int lrnde_sde_euler_heun_reg_grad(lrnde_sde* sde, const float* uprev, const float* dW, int32_t B, float t, float dt, float abstol,
+                                  float reltol, float delta, float* dp_drift, float* dp_diff, float* reg_val_host);
+
 /* `_perform_step(integrator, cache::FourStageSRIConstantCache, p)`, src/perform_step.jl:49-106 — the step the
  * reference's default SDE solver SOSRI runs — diagonal noise: four drift and four diffusion evaluations, the
  * increments dW and dZ of the caller's noise process (device, B x D each), u, EEst from the 7-argument

@@ -2451,6 +2451,7 @@ struct lrnde_sde {
   int diff_bias = 1;
   Ctrl *traj_host = nullptr, *traj_dev = nullptr; int traj_cap = 0;  // per-step records of lrnde_sde_solve_fixed (pinned / device)
   float* sri_ws = nullptr; size_t sri_n = 0; double *sri_part = nullptr, *sri_part_host = nullptr;  // lrnde_sde_sri_step scratch
+  float* bwd_ws = nullptr; size_t bwd_n = 0;  // lrnde_sde_*_backward / _reg_grad scratch
 };
 
 int lrnde_sde_create(lrnde_sde** out, const lrnde_model_desc* drift, int32_t diffusion_bias, int device, void* stream) {
@@ -2477,6 +2478,7 @@ int lrnde_sde_destroy(lrnde_sde* s) {
   if (s->traj_host) hipHostFree(s->traj_host);
   if (s->traj_dev) hipFree(s->traj_dev);
   if (s->sri_ws) hipFree(s->sri_ws);
+  if (s->bwd_ws) hipFree(s->bwd_ws);
   if (s->sri_part) hipFree(s->sri_part);
   if (s->sri_part_host) hipHostFree(s->sri_part_host);
   delete s;
@@ -2829,6 +2831,9 @@ int lrnde_vjp(lrnde_ctx* c, const float* y, float t, const float* lam, int32_t B
   return launch_vjp(c, y, nullptr, 0.f, 0.f, t, lam, B, dy, gp);
 }
 
+}  // extern "C"
+#include "lrnde_sde_bwd.hpp"
+extern "C" {
 // ---- backward drivers -----------------------------------------------------------------------
 }  // extern "C"
 namespace {

@@ -315,7 +315,11 @@ __device__ __forceinline__ void stream_init_q(const ModelDev& m, StreamQ& st) {
   const bool has1 = wave < q_nseg1(m);
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
+#ifdef LRNDE_X_FULLROWS  // experiment: rows H..64*RG1-1 of W1q are real (zero) memory instead of out-of-range lanes
+    st.v1[c] = (has1 && c < m.RG1) ? voff : 0x7ffffff0;
+#else
     st.v1[c] = (has1 && c < m.RG1 && c * 64 + lane < m.H) ? voff : 0x7ffffff0;
+#endif
     st.s1[c] = (c * m.KQ1p + (has1 ? wave * QSEG : 0)) * 1024;
     const int g = wave + c * QNW;
     st.v2[c] = (g < m.RG2 && g * 64 + lane < m.D) ? voff : 0x7ffffff0;

@@ -102,6 +102,36 @@ class SdeHandle:
         return dict(u=u, eest=np.frombuffer(ee, dtype=np.float32).copy(), reg_val=np.frombuffer(rv, dtype=np.float32).copy())
 
 
+    def _pcounts(self):
+        return self._keep[0].numel(), self._keep[1].numel()
+
+    def solve_fixed_backward(self, u0, u_traj, dW, t0, dt, du_end):
+        """pullback of solve_fixed (Euler-Heun) for <du_end, u_traj[-1]>: dict(dx, dp_drift, dp_diff)"""
+        nsteps = int(dW.shape[0])
+        B = u0.numel() // self.D
+        nf, ng = self._pcounts()
+        dx = torch.empty_like(u0)
+        dpf = torch.empty(nf, dtype=torch.float32, device=u0.device)
+        dpg = torch.empty(ng, dtype=torch.float32, device=u0.device)
+        self._chk(L.lib.lrnde_sde_solve_fixed_backward(self._h, _dev_ptr(u0, "u0", self.D), _dev_ptr(u_traj.contiguous(), "u_traj"),
+                                                       _dev_ptr(dW.contiguous(), "dW"), B, float(t0), float(dt), nsteps,
+                                                       _dev_ptr(du_end, "du_end", self.D), _dev_ptr(dx, "dx"),
+                                                       C.c_void_p(dpf.data_ptr()), C.c_void_p(dpg.data_ptr())))
+        return dict(dx=dx, dp_drift=dpf, dp_diff=dpg)
+
+    def euler_heun_reg_grad(self, uprev, dW, t, dt, abstol, reltol, delta):
+        """d (EEst*dt) / d (p_drift, p_diffusion) of one local Euler-Heun step, uprev / dW / dt constant"""
+        B = uprev.numel() // self.D
+        nf, ng = self._pcounts()
+        dpf = torch.empty(nf, dtype=torch.float32, device=uprev.device)
+        dpg = torch.empty(ng, dtype=torch.float32, device=uprev.device)
+        rv = C.c_float()
+        self._chk(L.lib.lrnde_sde_euler_heun_reg_grad(self._h, _dev_ptr(uprev, "uprev", self.D), _dev_ptr(dW, "dW", self.D), B,
+                                                      float(t), float(dt), float(abstol), float(reltol), float(delta),
+                                                      C.c_void_p(dpf.data_ptr()), C.c_void_p(dpg.data_ptr()), C.byref(rv)))
+        return dict(dp_drift=dpf, dp_diff=dpg, reg_val=np.float32(rv.value))
+
+
 class NeuralDSDE:
     """`(sol, st) = nsde(x, ps, st)`; ps = dict(drift=flat, diffusion=[vec(Wg); bg]).
     src/layers/neural_sde.jl:1-123 with a fixed-grid Euler-Heun integrator (see module docstring)."""
@@ -167,6 +197,7 @@ class NeuralDSDE:
                 step = lambda uu, i, tt: h.euler_heun_step(uu, noise[i].contiguous(), tt, dt, abstol, reltol, self.delta)
             traj = h.solve_fixed(x, noise[:n], t0, dt, abstol, reltol, self.delta, self.solver)  # the n steps, one host sync
             us = [traj["u"][i] for i in range(n)]
+            self._last_solve = dict(u_traj=traj["u"], dW=noise[:n], t0=t0, dt=dt)
         ts = [np.float32(t0 + np.float32(i + 1) * dt) if i + 1 < n else t2 for i in range(n)]
         per_step = {"RKMil": (1, 2), "SRI": (4, 4)}.get(self.solver, (3, 3))  # (drift, diffusion) evaluations of one step
         nfe, nfe_g = per_step[0] * n, per_step[1] * n
@@ -195,7 +226,28 @@ class NeuralDSDE:
                 r = h.euler_heun_step(u1, noise[n].contiguous(), t1, dt_loc, abstol, reltol, self.delta)
             reg_val = r["reg_val"]
             nfe += per_step[0]; nfe_g += per_step[1]
-            self._last_local = dict(t1=t1, dt=dt_loc, u1=u1, dW=noise[n])
+            self._last_local = dict(t1=t1, dt=dt_loc, u1=u1, dW=noise[n].contiguous(), abstol=abstol, reltol=reltol)
         sol = ODESolution([us[-1]], [t2], nfe)
         return sol, dict(drift=st["drift"], diffusion=st["diffusion"], nfe_drift=nfe, nfe_diffusion=nfe_g,
                          reg_val=reg_val, rng=rng, training=st["training"])
+
+    def pullback(self, x, ps, st, du_end, w_reg=0.0, noise=None):
+        """What the reference's Tracker-based pullback gives for  loss = <du_end, sol.u[end]> + w_reg * reg_val
+        (test/runtests.jl:361-365, 386-397): (dx, dict(drift=, diffusion=), info).  The forward is re-run with the same
+        draws as `__call__` (st['rng']; `noise` if given); the solve is differentiated through its own steps, reg_val
+        w.r.t. the parameters only (info['dx_reg'] is None: `gs_x === nothing` in the reference)."""
+        if self.solver != "EulerHeun":
+            raise NotImplementedError("the gradient path is built for the Euler-Heun step (src/perform_step.jl:172-206)")
+        sol, st2 = self(x, ps, st, noise=noise)
+        h = self.handle()
+        fs = self._last_solve
+        bw = h.solve_fixed_backward(x, fs["u_traj"], fs["dW"].contiguous(), fs["t0"], fs["dt"], du_end)
+        dpf, dpg = bw["dp_drift"], bw["dp_diff"]
+        mode = self.regularize if st["training"] else "none"
+        if mode != "none" and w_reg != 0.0:
+            lo = self._last_local
+            rg = h.euler_heun_reg_grad(lo["u1"], lo["dW"], lo["t1"], lo["dt"], lo["abstol"], lo["reltol"], self.delta)
+            assert rg["reg_val"] == st2["reg_val"]
+            dpf = dpf + np.float32(w_reg) * rg["dp_drift"]
+            dpg = dpg + np.float32(w_reg) * rg["dp_diff"]
+        return bw["dx"], dict(drift=dpf, diffusion=dpg), dict(sol=sol, st=st2, dx_reg=None)

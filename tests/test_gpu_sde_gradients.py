@@ -1,0 +1,132 @@
+"""the gradient path of NeuralDSDE.  The reference differentiates the SDE solve with TrackerAdjoint (a
+tape of the solver's arithmetic) and asserts (test/runtests.jl:361-365, 386-397): d sum(sol)/d(x, ps) finite and non-zero,
+d reg_val/d ps finite and non-zero, d reg_val/d x === nothing.  Here the same assertions, plus parity of every gradient
+with float64 torch autograd through a restatement of the same steps (src/perform_step.jl:172-206) written in this file —
+no code shared with the library.  Tolerance 2e-5 of each gradient's norm (fp32 kernels vs float64; the solve's and the
+step's sensitivities are well conditioned at the experiment's tolerance 0.14)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _params(D, H, seed):
+    rng = np.random.default_rng(seed)
+    l1, l2, l3 = np.sqrt(6.0 / (D + H)), np.sqrt(6.0 / (H + D)), np.sqrt(6.0 / (2 * D))
+    pd = np.concatenate([(rng.random(H * D) * 2 - 1) * l1, rng.standard_normal(H) * 0.05,
+                         (rng.random(D * H) * 2 - 1) * l2, rng.standard_normal(D) * 0.05]).astype(np.float32)
+    pg = np.concatenate([(rng.random(D * D) * 2 - 1) * l3, rng.standard_normal(D) * 0.05]).astype(np.float32)
+    return pd, pg
+
+
+def _fields64(pd, pg, D, H):
+    """drift Chain(Dense(D=>H,tanh), Dense(H=>D)) and diffusion Dense(D=>D) on (B, D) float64 tensors, flat Lux layouts"""
+    def f(u):
+        W1 = pd[:H * D].reshape(D, H).T; b1 = pd[H * D:H * D + H]; o = H * D + H
+        W2 = pd[o:o + D * H].reshape(H, D).T; b2 = pd[o + D * H:]
+        return torch.tanh(u @ W1.T + b1) @ W2.T + b2
+
+    def g(u):
+        Wg = pg[:D * D].reshape(D, D).T; bg = pg[D * D:]
+        return u @ Wg.T + bg
+    return f, g
+
+
+def _eh_step64(f, g, u, dW, dt):
+    du1 = f(u); L = g(u)
+    K = u + dt * du1
+    tmp = K + L * dW
+    un = u + (dt / 2) * (du1 + f(tmp)) + 0.5 * (L + g(tmp)) * dW
+    return un, du1, L, K
+
+
+def _eh_reg64(f, g, u, dW, dt, abstol, reltol, delta):
+    un, du1, L, K = _eh_step64(f, g, u, dW, dt)
+    du2 = f(K)
+    Ed = dt * (du2 - du1) / 2
+    sq = np.sqrt(dt)
+    ggp = (g(u + L * sq) - L) / sq
+    En = ggp * dW * dW / 2
+    r = (delta * Ed + En) / (abstol + torch.maximum(u.abs(), un.abs()) * reltol)
+    return torch.sqrt((r * r).mean()) * dt
+
+
+def test_sde_solve_and_regulariser_gradients_match_float64_autograd(gpu_pkg):
+    P = gpu_pkg
+    from localregneuralde_jl_amd.layers import _mlp_desc
+    D, H, B, n = 32, 64, 512, 20          # BASELINE config 5's shape (experiments/src/construct.jl:204-205, mnist_sde/mlp.yml)
+    pd, pg = _params(D, H, 3)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((B, D)).astype(np.float32)
+    dt = np.float32(1.0 / n)
+    dW = (rng.standard_normal((n, B, D)) * np.sqrt(dt)).astype(np.float32)
+    gend = rng.standard_normal((B, D)).astype(np.float32)
+    h = P.SdeHandle(_mlp_desc(P.Chain(P.Dense(D, H, "tanh"), P.Dense(H, D))))
+    h.set_params(pd, pg)
+    xd, dWd = torch.from_numpy(x).cuda(), torch.from_numpy(dW).cuda()
+    tr = h.solve_fixed(xd, dWd, 0.0, dt, 0.14, 0.14, 1.0 / 6.0)
+    bw = h.solve_fixed_backward(xd, tr["u"], dWd, 0.0, dt, torch.from_numpy(gend).cuda())
+    # float64 autograd through the same n steps
+    pdt = torch.tensor(pd, dtype=torch.float64, requires_grad=True)
+    pgt = torch.tensor(pg, dtype=torch.float64, requires_grad=True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    f, g = _fields64(pdt, pgt, D, H)
+    u = xt
+    for i in range(n):
+        u = _eh_step64(f, g, u, torch.tensor(dW[i], dtype=torch.float64), float(dt))[0]
+    assert _rel(tr["u"][-1].cpu().numpy(), u.detach().numpy()) < 1e-5
+    (u * torch.tensor(gend, dtype=torch.float64)).sum().backward()
+    for name, got, ref in (("dx", bw["dx"], xt.grad), ("dp_drift", bw["dp_drift"], pdt.grad), ("dp_diff", bw["dp_diff"], pgt.grad)):
+        e = _rel(got.cpu().numpy(), ref.numpy())
+        print(f"sde solve backward {name}: rel err {e:.2e}")
+        assert e < 2e-5, (name, e)
+        assert np.isfinite(got.cpu().numpy()).all() and (got.cpu().numpy() != 0).all()     # runtests.jl:363-365
+    # regulariser of a local step: d (EEst*dt) / d ps, nothing w.r.t. the state
+    u1 = tr["u"][7].contiguous()
+    w1 = (rng.standard_normal((B, D)) * np.sqrt(dt)).astype(np.float32)
+    rg = h.euler_heun_reg_grad(u1, torch.from_numpy(w1).cuda(), 0.4, dt, 0.14, 0.14, 1.0 / 6.0)
+    st = h.euler_heun_step(u1, torch.from_numpy(w1).cuda(), 0.4, dt, 0.14, 0.14, 1.0 / 6.0)
+    assert rg["reg_val"] == st["reg_val"]
+    pdt.grad = None; pgt.grad = None
+    val = _eh_reg64(f, g, torch.tensor(u1.cpu().numpy(), dtype=torch.float64), torch.tensor(w1, dtype=torch.float64), float(dt),
+                    0.14, 0.14, 1.0 / 6.0)
+    assert abs(float(val) - float(rg["reg_val"])) < 1e-5 * abs(float(val))
+    val.backward()
+    for name, got, ref in (("dp_drift", rg["dp_drift"], pdt.grad), ("dp_diff", rg["dp_diff"], pgt.grad)):
+        e = _rel(got.cpu().numpy(), ref.numpy())
+        print(f"sde reg gradient {name}: rel err {e:.2e}")
+        assert e < 2e-5, (name, e)
+        assert np.isfinite(got.cpu().numpy()).all() and (got.cpu().numpy() != 0).any()      # runtests.jl:394-396
+
+
+@pytest.mark.parametrize("regularize", ["none", "unbiased", "biased"])
+def test_neural_dsde_pullback_behaviour(gpu_pkg, regularize):
+    """the layer-level pullback: loss = sum(sol.u[end]) + w_reg*reg_val — the reference's two gradient checks in one"""
+    P = gpu_pkg
+    D, H, B, n = 32, 64, 16, 8
+    pd, pg = _params(D, H, 5)
+    x = np.random.default_rng(2).standard_normal((B, D)).astype(np.float32)
+    node = P.NeuralDSDE(P.Chain(P.Dense(D, H, "tanh"), P.Dense(H, D)), P.Dense(D, D), regularize=regularize, nsteps=n,
+                        abstol=0.14, reltol=0.14)
+    st = node.initialstates(np.random.default_rng(0))
+    ps = dict(drift=pd, diffusion=pg)
+    xd = torch.from_numpy(x).cuda()
+    ones = torch.ones_like(xd)
+    dx0, dps0, info0 = node.pullback(xd, ps, st, ones, w_reg=0.0)
+    dx1, dps1, info1 = node.pullback(xd, ps, st, ones, w_reg=2.0)
+    assert torch.isfinite(dx0).all() and (dx0 != 0).all()
+    for k in ("drift", "diffusion"):
+        assert torch.isfinite(dps0[k]).all() and (dps0[k] != 0).any()
+    assert torch.equal(dx0, dx1) and info1["dx_reg"] is None          # reg_val has no gradient w.r.t. x
+    changed = not torch.equal(dps0["drift"], dps1["drift"])
+    assert changed == (regularize != "none")
+    assert (info1["st"]["reg_val"] == 0) == (regularize == "none")
+    # same rng => same forward as __call__
+    sol, st2 = node(xd, ps, st)
+    assert torch.equal(sol.u[-1], info1["sol"].u[-1]) and st2["reg_val"] == info1["st"]["reg_val"]
