@@ -361,6 +361,17 @@ int lrnde_node_backward(lrnde_ctx* ctx, const float* x, int32_t B, float t0, flo
                         const float* du_end, float w_reg, float* dx, float* dp, lrnde_stats* stats_fwd_host,
                         lrnde_stats* stats_bwd_host);
 
+/* ---- optimiser update rules of the experiments: experiments/src/construct.jl:104-126 builds
+ * Adam / AdamW / AdaMax / Descent / Momentum / Nesterov (Optimisers.jl, un-vendored: rules restated from its documented
+ * update formulas) and chains WeightDecay when cfg.weight_decay != 0.  One fused pass over a flat parameter vector:
+ * x -= rule(grad) + weight_decay * x.  state1 / state2: the rule's moment vectors (device, n floats, zero-initialised by
+ * the caller; unused ones may be NULL); step: 1-based update count (bias correction beta^step); eta: the learning rate
+ * the scheduler returned for this step (experiments/src/utils.jl:1-68; host mirror: localregneuralde.jl_amd/optim.py).
+ * AdamW(eta) = LRNDE_OPT_ADAM with weight_decay = its decay. */
+enum { LRNDE_OPT_DESCENT = 0, LRNDE_OPT_MOMENTUM = 1, LRNDE_OPT_NESTEROV = 2, LRNDE_OPT_ADAM = 3, LRNDE_OPT_ADAMAX = 4 };
+int lrnde_opt_update(int32_t kind, float* x, const float* grad, float* state1, float* state2, size_t n, float eta,
+                     float rho_or_beta1, float beta2, float eps, int32_t step, float weight_decay, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

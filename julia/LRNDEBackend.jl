@@ -185,6 +185,23 @@ function sri_step(h, tab::SriTableau, uprev, dW, dZ, t, dt, abstol, reltol, delt
     return u, rv[], 0, dt               # src/perform_step.jl:105
 end
 
+# gradient path of NeuralDSDE (TrackerAdjoint in the reference, src/layers/neural_sde.jl:12): reverse sweep of the
+# fixed-grid Euler-Heun solve, and d(EEst*dt)/d(p_drift, p_diffusion) of the local step (uprev, dW, dt constant)
+function sde_solve_fixed_backward(h, u0, u_traj, dW, t0, dt, nsteps, du_end, dp_drift, dp_diff)
+    dx = similar(u0)
+    sde_check(h, ccall((:lrnde_sde_solve_fixed_backward, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int32, Float32, Float32, Int32, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+        h, pointer(u0), pointer(u_traj), pointer(dW), nbatch(u0), t0, dt, nsteps, pointer(du_end), pointer(dx), pointer(dp_drift), pointer(dp_diff)))
+    return dx, dp_drift, dp_diff
+end
+function sde_euler_heun_reg_grad(h, uprev, dW, t, dt, abstol, reltol, delta, dp_drift, dp_diff)
+    rv = Ref{Float32}()
+    sde_check(h, ccall((:lrnde_sde_euler_heun_reg_grad, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int32, Float32, Float32, Float32, Float32, Float32, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+        h, pointer(uprev), pointer(dW), nbatch(uprev), t, dt, abstol, reltol, delta, pointer(dp_drift), pointer(dp_diff), rv))
+    return dp_drift, dp_diff, rv[]
+end
+
 # ---- multi-GPU: one process per GPU, batch sharded (not in the reference) ----
 comm_unique_id() = (id = zeros(UInt8, 128); ccall((:lrnde_comm_unique_id, lib), Cint, (Ptr{UInt8},), id) == 0 || error("unique id"); id)
 comm_init!(ctx, id::Vector{UInt8}, rank, nranks) = check(ctx, ccall((:lrnde_comm_init, lib), Cint,

@@ -12,4 +12,6 @@ from .layers import (Chain, Dense, Handle, NeuralODE, ODESolution, TDChain,  # n
 from .sde import NeuralDSDE, SdeHandle  # noqa: F401
 from .conv import BatchNorm, Conv, ConvHandle, glorot_conv_params  # noqa: F401
 from .training import run_cifar_training_step, run_training_step  # noqa: F401
+from .optim import (Constant, CosineAnneal, ExponentialDecay, InverseDecay, Optimiser, Step,  # noqa: F401
+                    construct_scheduler)
 from .sharding import LocalComm, init_comm, run_ranks, shard_columns  # noqa: F401

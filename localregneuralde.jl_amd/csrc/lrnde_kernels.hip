@@ -3586,6 +3586,57 @@ int lrnde_classifier_ce(lrnde_ctx* c, const float* u, int32_t B, const float* pc
   return LRNDE_OK;
 }
 
+// ---- optimiser update rules of the experiments (experiments/src/construct.jl:104-126) ----
+}  // extern "C"
+namespace {
+// one fused elementwise pass: gradient -> update direction (Optimisers.jl rules, UPSTREAM-RECALL) -> optional
+// WeightDecay (OptimiserChain(rule, WeightDecay(gamma)): gamma * x added to the direction) -> x -= direction
+__global__ void k_opt_update(size_t n, int kind, float* x, const float* g, float* s1, float* s2, float eta, float rho_b1, float b2,
+                             float eps, float b1t, float b2t, float wd) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float dx = g[i];
+    float d;
+    if (kind == LRNDE_OPT_DESCENT) {
+      d = eta * dx;
+    } else if (kind == LRNDE_OPT_MOMENTUM) {          // v = rho v - eta dx ; dx' = -v
+      const float v = rho_b1 * s1[i] - eta * dx;
+      s1[i] = v; d = -v;
+    } else if (kind == LRNDE_OPT_NESTEROV) {          // dx' = -rho^2 v + (1 + rho) eta dx ; v = rho v - eta dx
+      const float v0 = s1[i];
+      d = -(rho_b1 * rho_b1) * v0 + (1.0f + rho_b1) * eta * dx;
+      s1[i] = rho_b1 * v0 - eta * dx;
+    } else if (kind == LRNDE_OPT_ADAM) {              // mt, vt moments; dx' = mt/(1-b1^t) / (sqrt(vt/(1-b2^t)) + eps) * eta
+      const float mt = rho_b1 * s1[i] + (1.0f - rho_b1) * dx;
+      const float vt = b2 * s2[i] + (1.0f - b2) * (dx * dx);
+      s1[i] = mt; s2[i] = vt;
+      d = mt / (1.0f - b1t) / (sqrtf(vt / (1.0f - b2t)) + eps) * eta;
+    } else {                                           // AdaMax: ut = max(b2 ut, |dx|); dx' = eta/(1-b1^t) * mt / (ut + eps)
+      const float mt = rho_b1 * s1[i] + (1.0f - rho_b1) * dx;
+      const float ut = fmaxf(b2 * s2[i], fabsf(dx));
+      s1[i] = mt; s2[i] = ut;
+      d = (eta / (1.0f - b1t)) * mt / (ut + eps);
+    }
+    if (wd != 0.0f) d = d + wd * x[i];
+    x[i] = x[i] - d;
+  }
+}
+}  // namespace
+extern "C" {
+
+int lrnde_opt_update(int32_t kind, float* x, const float* grad, float* state1, float* state2, size_t n, float eta, float rho_or_beta1,
+                     float beta2, float eps, int32_t step, float weight_decay, int device, void* stream) {
+  if (!x || !grad || kind < LRNDE_OPT_DESCENT || kind > LRNDE_OPT_ADAMAX || step < 1) return LRNDE_BADARG;
+  if (kind != LRNDE_OPT_DESCENT && !state1) return LRNDE_BADARG;
+  if (kind >= LRNDE_OPT_ADAM && !state2) return LRNDE_BADARG;
+  if (hipSetDevice(device) != hipSuccess) return LRNDE_HIP_ERROR;
+  if (n == 0) return LRNDE_OK;
+  const float b1t = powf(rho_or_beta1, (float)step), b2t = powf(beta2, (float)step);
+  int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_opt_update, dim3(nb), dim3(256), 0, (hipStream_t)stream, n, (int)kind, x, grad, state1, state2, eta,
+                     rho_or_beta1, beta2, eps, b1t, b2t, weight_decay);
+  return hipGetLastError() == hipSuccess ? LRNDE_OK : LRNDE_HIP_ERROR;
+}
+
 int lrnde_last_solve_kernel_ms(lrnde_ctx* c, float* ms, int32_t* launches) {
   if (!c) return LRNDE_BADARG;
   if (ms) *ms = c->last_ms;

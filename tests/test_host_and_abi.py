@@ -47,8 +47,12 @@ def test_julia_binding_matches_the_header():
     the same number of arguments, and its structs have the field counts of the C ones."""
     from localregneuralde_jl_amd import _lib
     src = open(os.path.join(ROOT, "julia", "LRNDEBackend.jl")).read()
+    layer = open(os.path.join(ROOT, "julia", "LRNDELayer.jl")).read()   # the drop-in layer: (n::NeuralODE)(x, ps, st) + its rrule
+    assert "function (n::NeuralODE)(x::AbstractArray{Float32}, ps, st::NamedTuple)" in layer and "CRC_.rrule(n::NeuralODE" in layer
+    for fld in ("u::Vector", "t::Vector{Float32}", "destats::LRNDEDestats"):
+        assert fld in layer, fld
     arity = {n: len(a) for n, _, a in _lib.SYMBOLS}
-    calls = re.findall(r"ccall\(\(:?(\w+), lib\), \w+,\s*\((.*?)\),\s*\n?", src, flags=re.S)
+    calls = re.findall(r"ccall\(\(:?(\w+), (?:LRNDEBackend\.)?lib\), \w+,\s*\((.*?)\),\s*\n?", src + layer, flags=re.S)
     seen = set()
     for name, types in calls:
         if name in ("last_error", "f"):   # dispatched through a variable: checked below
@@ -60,7 +64,8 @@ def test_julia_binding_matches_the_header():
     for name in re.findall(r":(lrnde_\w+)", src):
         assert name in arity, name
     assert {"lrnde_create", "lrnde_node_forward", "lrnde_node_forward_record", "lrnde_node_backward_recorded", "lrnde_conv_create",
-            "lrnde_sde_sri_step", "lrnde_comm_init"} <= seen
+            "lrnde_sde_sri_step", "lrnde_comm_init", "lrnde_node_forward_record_ts", "lrnde_node_backward_recorded_ts",
+            "lrnde_sde_solve_fixed_backward", "lrnde_sde_euler_heun_reg_grad"} <= seen
     fields = lambda name: len(re.findall(r"::(?:Int32|Float32)", re.search(r"struct %s\b(.*?)\bend\b" % name, src, re.S).group(1)))
     assert fields("ModelDesc") == 4 and fields("SolveOpts") == 6 and fields("Stats") == 10 and fields("ConvDesc") == 8
     assert fields("SriTableau") == len(_lib.SRI_FIELDS) == 51
