@@ -218,6 +218,7 @@ struct PgradArgs {
   int ntile1, ntile2, nt1c, nt2c;  // tiles of gW1: ceil(H/16) x ceil(D/16); gW2: ceil(D/16) x ceil(H/16)
   // device-resolved form (lrnde_adjoint.hpp): t, lam and gp of the evaluation come from the control block
   int adj_mode, adj_stage, adj_j;
+  int accumulate;  // 1: gp += result (the regulariser's reverse sweep sums six evaluations' cotangents), 0: overwrite
 };
 
 // t / lam / gp of a parameter-gradient GEMM that belongs to the adjoint loop's evaluation (mode, stage) of attempt j
@@ -309,9 +310,11 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile) {
   for (int r = 0; r < 4; ++r) {
     const int rr = ti * 16 + lk * 4 + r;
     if (rr >= M) continue;
-    if (c < N) gW[(size_t)rr + (size_t)M * c] = acc[r];
-    else if (c == N) { if (a.td) gW[(size_t)rr + (size_t)M * N] = acc[r]; }
-    else if (c == N + 1) gb[rr] = acc[r];
+    float* dst = nullptr;
+    if (c < N) dst = gW + (size_t)rr + (size_t)M * c;
+    else if (c == N) { if (a.td) dst = gW + (size_t)rr + (size_t)M * N; }
+    else if (c == N + 1) dst = gb + rr;
+    if (dst) *dst = a.accumulate ? *dst + acc[r] : acc[r];
   }
 }
 
@@ -391,6 +394,18 @@ __global__ __launch_bounds__(256) void k_norm2(NormArgs a, NormArgs b) {
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) g.part[bx] = red[0] + red[1] + red[2] + red[3];
+}
+
+// regulariser sweep, end of a stage: xbar (+= ubar / g6bar), then kbar_j += dt * a_sj * xbar for the earlier stages j
+struct SweepJoinArgs { size_t n; float* xb; const float* extra; float dt; int nk; float* kb[5]; float c[5]; };
+__global__ void k_sweep_join(SweepJoinArgs a) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
+    float x = a.xb[i];
+    if (a.extra) { x = x + a.extra[i]; a.xb[i] = x; }
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (j < a.nk) a.kb[j][i] = a.kb[j][i] + a.dt * (a.c[j] * x);
+  }
 }
 
 // End of an adjoint Tsit5 step in one launch: utilde = dt * sum btilde_j K_j is formed on the fly (the arithmetic of

@@ -124,6 +124,7 @@ struct StepArgs {
   // sharded handles, per-rank pre-reduction: every tile writes its partial to tile_part / tile_pinit (rank local), the
   // LAST workgroup of the launch to arrive (arrive[] counters) reduces them in the fixed order of reduce_partials and
   // publishes ONE triple in this rank's slot of part_send / pinit_send: the all-reduce carries nranks triples
+  int force_store_k;   // 1: keep k2..k6 of a single step in global memory (the recorded forward's local step: its reverse sweep reads them)
   int prered;
   int* arrive;         // [4]: step parity 0/1, init phase 1/2
   double* tile_part;   // [2][nwg_local*PSTRIDE]
@@ -1002,7 +1003,7 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
   c.t = t; c.dt = dt; c.first = 0;
   b.do_step = do_step; b.cur = c.cur; b.t = t; b.dt = dt;
   // (the margin covers the snap of t + dt onto t1 within 100 eps; a pending saveat equal to the new time is a copy of u)
-  b.store_k = (a.mode == MODE_SINGLE_GIVEN_DT) || a.dense != nullptr ||
+  b.store_k = (a.mode == MODE_SINGLE_GIVEN_DT) || a.dense != nullptr || a.force_store_k ||
               (a.mode == MODE_SOLVE && c.isave < a.nsave && a.saveat[c.isave] < t + dt * 1.001f);
   if (lane == 0) {
     *bc = b;
@@ -1601,6 +1602,7 @@ struct lrnde_ctx {
   // deferred parameter-gradient GEMM (adjoint Tsit5 loop): the GEMM of RHS evaluation e rides in the launch of the VJP
   // of evaluation e+1 (k_vjp_q_pg); scratch set bw_cur is the one the next VJP writes
   bool pg_defer = false, pg_pending = false; int bw_cur = 0; PgradArgs pg_args;
+  bool pg_accumulate = false;  // the next parameter-gradient GEMM adds to gp instead of overwriting it (regulariser sweep)
   int bwB = 0;
   // dense forward record + adjoint work vectors
   float *dense = nullptr, *dense_t = nullptr, *dense_dt = nullptr;
@@ -2030,6 +2032,7 @@ int lrnde_init_dt(lrnde_ctx* c, const float* u0, int32_t B, float t0, float tend
   if (!u0 || !dt_host) return fail(c, LRNDE_BADARG, "null pointer");
   if (!(tend > t0)) return fail(c, LRNDE_BADARG, "tspan must be increasing");
   if ((rc = ensure_workspace(c, B))) return rc;
+  c->rec_valid = false;
   StepArgs a;
   fill_args(c, a, B);
   a.t0 = t0; a.t1 = tend; a.abstol = abstol; a.reltol = reltol; a.mode = MODE_SINGLE_INIT_DT;
@@ -2087,6 +2090,7 @@ int lrnde_perform_step(lrnde_ctx* c, const float* uprev, const float* k1, int32_
   if (rc) return rc;
   if (!uprev || !k1) return fail(c, LRNDE_BADARG, "null state pointer");
   if ((rc = ensure_workspace(c, B))) return rc;
+  c->rec_valid = false;  // the state workspace a recorded forward left for its backward is overwritten
   StepArgs a;
   fill_args(c, a, B);
   a.t0 = t; a.t1 = t + 1.0f; a.abstol = abstol; a.reltol = reltol; a.mode = MODE_SINGLE_GIVEN_DT;
@@ -2124,6 +2128,7 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
     if (!(saveat_host[i] >= saveat_host[i - 1])) return fail(c, LRNDE_BADARG, "saveat must be ascending");
   if (cap_saved > 0 && !u_saved) return fail(c, LRNDE_BADARG, "null save buffer");
   if ((rc = ensure_workspace(c, B))) return rc;
+  if (!c->dense_on) c->rec_valid = false;
   const size_t n = (size_t)B * c->desc.state_dim;
   if (nsave > c->saveat_cap) {
     if (c->saveat_dev) HIPCHK(c, hipFree(c->saveat_dev));
@@ -2322,6 +2327,7 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
   fill_args(c, a, B);
   a.t0 = t1; a.t1 = t2; a.abstol = oo.abstol; a.reltol = oo.reltol; a.mode = MODE_SINGLE_INIT_DT;
   a.want_stiff = (reg_type == LRNDE_REG_STIFFNESS_ESTIMATE); a.maxiters = 1;
+  a.force_store_k = c->dense_on ? 1 : 0;  // recorded forward: the backward's regulariser sweep starts from this step's k2..k6
   HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u1, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t1, 0.f, 0, 0);
   if ((rc = run_init(c, B, a))) return rc;
@@ -2727,6 +2733,7 @@ static int ensure_bw(lrnde_ctx* c, int B) {
 static PgradArgs pgrad_args(const lrnde_ctx* c, int B, float t, const float* lam, float* gp, int set) {
   PgradArgs g;
   memset(&g, 0, sizeof(g));  // adj_mode = ADJ_HOST: t / lam / gp as given here
+  g.accumulate = c->pg_accumulate ? 1 : 0;
   g.D = c->m.D; g.H = c->m.H; g.Hp = c->m.Hp; g.td = c->m.td; g.B = B; g.t = t;
   g.lam = lam; g.gp = gp;
   g.y = c->bw_y + (size_t)set * B * c->desc.state_dim; g.h = c->bw_h + (size_t)set * B * c->m.Hp; g.dpre = c->bw_dp + (size_t)set * B * c->m.Hp;
@@ -3303,20 +3310,31 @@ static int step_reg_sweep(lrnde_ctx* c, const float* uprev, int32_t B, float t, 
   float A[21];
   for (int i = 0; i < 21; ++i) A[i] = (float)Tsit5::A[i];
   const float cs[6] = {(float)Tsit5::C[0], (float)Tsit5::C[1], (float)Tsit5::C[2], (float)Tsit5::C[3], 1.0f, 1.0f};
-  const float one = 1.0f;
+  // per stage, newest first: stage input (one launch), vector-Jacobian product, parameter-gradient GEMM ACCUMULATING
+  // into gp, and one fused join (xbar += ubar / g6bar; kbar_j += dt a_sj xbar for every earlier stage): 4 launches
+  // (the sweep is launch-bound: it was 7..9 small launches per stage)
   for (int sidx = 7; sidx >= 2; --sidx) {
     const int off = (sidx - 2) * (sidx - 1) / 2;
     const float* x;
     if (sidx == 7) x = u;
     else { if ((rc = vec_axpy(c, xs, uprev, dt, sidx - 1, kk, A + off, n))) return rc; x = xs; }
-    if ((rc = launch_vjp(c, x, nullptr, 0.f, 0.f, t + cs[sidx - 2] * dt, kb[sidx - 1], B, xb, gtmp))) return rc;
-    { const float* g1[2] = {gp, gtmp}; const float cc[2] = {1.0f, 1.0f};
-      if ((rc = vec_axpy(c, gp, nullptr, one, 2, g1, cc, P))) return rc; }
-    if (sidx == 7) { const float* g1[2] = {xb, ub}; const float cc[2] = {1.0f, 1.0f}; if ((rc = vec_axpy(c, xb, nullptr, one, 2, g1, cc, n))) return rc; }
-    if (sidx == 6) { const float* g1[2] = {xb, g6b}; const float cc[2] = {1.0f, 1.0f}; if ((rc = vec_axpy(c, xb, nullptr, one, 2, g1, cc, n))) return rc; }
-    for (int j = 1; j < sidx - 1; ++j) {  // kbar_{j+1} += dt * a_{s,j+1} * xbar
-      const float* g1[1] = {xb}; const float cc[1] = {A[off + j]};
-      if ((rc = vec_axpy(c, kb[j], kb[j], dt, 1, g1, cc, n))) return rc;
+    if (sharded(c)) {  // every evaluation's cotangent is all-reduced over the ranks by itself, then added
+      if ((rc = launch_vjp(c, x, nullptr, 0.f, 0.f, t + cs[sidx - 2] * dt, kb[sidx - 1], B, xb, gtmp))) return rc;
+      const float* g1[2] = {gp, gtmp}; const float cc[2] = {1.0f, 1.0f};
+      if ((rc = vec_axpy(c, gp, nullptr, 1.0f, 2, g1, cc, P))) return rc;
+    } else {
+      c->pg_accumulate = true;
+      rc = launch_vjp(c, x, nullptr, 0.f, 0.f, t + cs[sidx - 2] * dt, kb[sidx - 1], B, xb, gp);
+      c->pg_accumulate = false;
+      if (rc) return rc;
+    }
+    SweepJoinArgs ja;
+    ja.n = n; ja.xb = xb; ja.extra = (sidx == 7) ? ub : ((sidx == 6) ? g6b : nullptr); ja.dt = dt; ja.nk = sidx - 2;
+    for (int j = 1; j < 6; ++j) { ja.kb[j - 1] = (j < sidx - 1) ? kb[j] : nullptr; ja.c[j - 1] = (j < sidx - 1) ? A[off + j] : 0.f; }
+    if (ja.nk > 0 || ja.extra) {
+      int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048;
+      hipLaunchKernelGGL(k_sweep_join, dim3(nb), dim3(256), 0, c->stream, ja);
+      HIPCHK(c, hipGetLastError());
     }
   }
   return LRNDE_OK;
@@ -3478,19 +3496,11 @@ static int node_backward_recorded_impl(lrnde_ctx* c, int32_t B, const float* du_
   // regulariser: dp += w_reg * d reg_val / d p   (no gradient w.r.t. x: test/runtests.jl:129)
   if (mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
     float *k1 = c->rec_k1, *gr = c->rec_gr, *u1 = c->rec_u1;
-    // the local step again, from the record (uprev = u(t1), k1, dt: what the forward's fresh init produced), enqueued
-    // without a read-back, then the reverse sweep from the forward's own scalars
-    if ((rc = ensure_workspace(c, B))) return rc;
-    StepArgs a;
-    fill_args(c, a, B);
-    a.t0 = t1; a.t1 = t1 + 1.0f; a.abstol = o->abstol; a.reltol = o->reltol; a.mode = MODE_SINGLE_GIVEN_DT;
-    a.want_stiff = 1; a.maxiters = 1;
-    HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u1, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(a.kfsal[0], k1, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
-    hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t1, c->rec_dt1, 0, 0);
-    if ((rc = launch_step(c, B, a, 0))) return rc;
-    { const size_t cnt = (size_t)a.nwg_global * PSTRIDE; if ((rc = exchange(c, c->part + cnt, c->part_rx + cnt, cnt))) return rc; }
-    rc = step_reg_sweep(c, u1, B, t1, c->rec_dt1, o->abstol, o->reltol, reg_type, c->rec_eest, c->rec_snum, c->rec_sden, gr);
+    // The forward's own local step is still in the state workspace (uprev = u(t1), u, k1..k7, g6: the recorded forward
+    // keeps k2..k6 in memory, StepArgs::force_store_k), and its scalars are in the record: the reverse sweep starts from
+    // them, nothing is re-run and nothing is read back.
+    (void)k1; (void)u1;
+    rc = step_reg_sweep(c, c->state, B, t1, c->rec_dt1, o->abstol, o->reltol, reg_type, c->rec_eest, c->rec_snum, c->rec_sden, gr);
     if (!rc) { const float* g1[2] = {dp, gr}; const float cc[2] = {1.0f, w_reg}; rc = vec_axpy(c, dp, nullptr, 1.0f, 2, g1, cc, P); }
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
