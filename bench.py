@@ -411,7 +411,7 @@ def sde_main(args):
                    "last_eest": float(r["eest"]), "last_reg_val": float(r["reg_val"])},
         "roofline": {"bound": "mfma", "achieved": flop / (el / nst) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": flop / (el / nst) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                     "kernel": "k_ctrl_init + k_sde_step + k_finalize + 1 record copy per step (15.7 MFLOP: latency bound by construction)",
+                     "kernel": "k_sde_eh_fast: ONE launch per step (weights resident in registers, the step's footer by the last workgroup to arrive); 15.7 MFLOP: latency bound by construction",
                      "us_per_launch": el / nst * 1e6, "flop_per_launch": flop},
     }
     if not args.no_cpu_baseline:

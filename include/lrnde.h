@@ -311,6 +311,25 @@ int lrnde_sde_solve_fixed(lrnde_sde* sde, int32_t which, const float* u0, const 
                           int32_t nsteps, float abstol, float reltol, float delta, float* u_traj, float* eest_host,
                           float* reg_val_host);
 
+/* Adaptive Euler-Heun solve: the loop that consumes the step's error estimate (src/perform_step.jl:200-205), which the
+ * reference reaches through `solve(prob, solver; ...)` in src/layers/neural_sde.jl:60-72 (StochasticDiffEq, un-vendored).
+ * The Brownian path is the CALLER's: W (device, (nfine+1) x B x D) holds it on a uniform grid of nfine intervals over
+ * (t0, t1), W[0] = 0.  Steps are whole numbers of grid intervals, so every increment dW = W[j] - W[i] is the path's own
+ * and a rejected step is retried over a shorter piece of the SAME path — what StochasticDiffEq's rejection sampling with
+ * memory guarantees in distribution, made exact by fixing the path up front.  Step-size control: the PI form of the ODE
+ * controller on EEst; StochasticDiffEq's own constants could not be read in this image, so they are
+ * options (suggested: gamma 0.9, qmin 0.2, qmax 1.125, beta1 0.14, beta2 0.08).  u_end: the state at t1; the trace
+ * (may be NULL) gets one row per attempted step.  Host-controlled: one stream sync per attempted step (a step is 10 us). */
+typedef struct {
+  float abstol, reltol, delta;   /* integrator.opts.abstol / reltol / delta */
+  float dt0;                     /* first step (rounded down to whole grid intervals, at least one) */
+  float gamma, qmin, qmax, beta1, beta2;
+  int32_t maxiters;
+} lrnde_sde_adapt_opts;
+int lrnde_sde_solve_adaptive(lrnde_sde* sde, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
+                             const lrnde_sde_adapt_opts* opts, float* u_end, lrnde_stats* stats_host,
+                             lrnde_trace_row* trace_host, int32_t cap_trace);
+
 /* Gradient path of the NeuralDSDE layer.  The reference differentiates the SDE solve with TrackerAdjoint — a tape of the
  * solver's own arithmetic (src/layers/neural_sde.jl:12; test/runtests.jl:361-365,386-397) — and reg_val w.r.t. the
  * parameters only (the local step's integrator is built under CRC.@non_differentiable, neural_sde.jl:42).

@@ -35,6 +35,11 @@ class ConvDesc(C.Structure):
                 ("act", C.c_int32), ("bn_train", C.c_int32), ("compute_dtype", C.c_int32), ("bn_eps", C.c_float)]
 
 
+class SdeAdaptOpts(C.Structure):
+    _fields_ = [("abstol", C.c_float), ("reltol", C.c_float), ("delta", C.c_float), ("dt0", C.c_float), ("gamma", C.c_float),
+                ("qmin", C.c_float), ("qmax", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("maxiters", C.c_int32)]
+
+
 class SolveOpts(C.Structure):
     _fields_ = [("abstol", C.c_float), ("reltol", C.c_float), ("maxiters", C.c_int32),
                 ("save_start", C.c_int32), ("save_everystep", C.c_int32), ("exact_pow", C.c_int32)]
@@ -83,6 +88,8 @@ SYMBOLS = [
     ("lrnde_sde_euler_heun_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _vp, _fp, _fp]),
     ("lrnde_sde_rkmil_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _vp, _fp, _fp]),
     ("lrnde_sde_solve_fixed", C.c_int, [_vp, _i32, _vp, _vp, _i32, _f, _f, _i32, _f, _f, _f, _vp, _fp, _fp]),
+    ("lrnde_sde_solve_adaptive", C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _f, C.POINTER(SdeAdaptOpts), _vp, C.POINTER(Stats),
+                                           C.POINTER(TraceRow), _i32]),
     ("lrnde_sde_solve_fixed_backward", C.c_int, [_vp, _vp, _vp, _vp, _i32, _f, _f, _i32, _vp, _vp, _vp, _vp]),
     ("lrnde_sde_euler_heun_reg_grad", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _vp, _vp, _fp]),
     ("lrnde_sde_sri_step", C.c_int, [_vp, C.POINTER(SriTableau), _vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _vp, _fp, _fp]),

@@ -1480,6 +1480,7 @@ template <int W> __global__ __launch_bounds__(NT) void k_sde_rkmil(StepArgs a) {
   }
 }
 
+#include "lrnde_sde_fast.hpp"
 #include "lrnde_qtile.hpp"
 #include "lrnde_adjoint.hpp"
 #include "lrnde_backward.hpp"
@@ -2458,6 +2459,8 @@ struct lrnde_sde {
   Ctrl *traj_host = nullptr, *traj_dev = nullptr; int traj_cap = 0;  // per-step records of lrnde_sde_solve_fixed (pinned / device)
   float* sri_ws = nullptr; size_t sri_n = 0; double *sri_part = nullptr, *sri_part_host = nullptr;  // lrnde_sde_sri_step scratch
   float* bwd_ws = nullptr; size_t bwd_n = 0;  // lrnde_sde_*_backward / _reg_grad scratch
+  int* arrive = nullptr;                      // arrival counter of the one-launch step's footer (lrnde_sde_fast.hpp)
+  float* ad_ws = nullptr; size_t ad_n = 0;    // lrnde_sde_solve_adaptive: two states + the current increment
 };
 
 int lrnde_sde_create(lrnde_sde** out, const lrnde_model_desc* drift, int32_t diffusion_bias, int device, void* stream) {
@@ -2485,6 +2488,8 @@ int lrnde_sde_destroy(lrnde_sde* s) {
   if (s->traj_dev) hipFree(s->traj_dev);
   if (s->sri_ws) hipFree(s->sri_ws);
   if (s->bwd_ws) hipFree(s->bwd_ws);
+  if (s->arrive) hipFree(s->arrive);
+  if (s->ad_ws) hipFree(s->ad_ws);
   if (s->sri_part) hipFree(s->sri_part);
   if (s->sri_part_host) hipHostFree(s->sri_part_host);
   delete s;
@@ -2528,6 +2533,32 @@ static int sde_step_enqueue(lrnde_sde* s, int which, const float* uprev, const f
   a.t0 = t; a.bench_dt = dt; a.abstol = abstol; a.reltol = reltol; a.delta = delta;
   a.dW = dW; a.sde_scratch = c->state; a.sde_uprev = uprev; a.sde_u = u;
   const int nwg = (B + NB - 1) / NB;
+  // the MNIST-SDE shape (state 32, hidden 64, no time input) has a one-launch small-latency kernel (lrnde_sde_fast.hpp)
+  static const bool no_fast = getenv("LRNDE_NO_SDE_FAST") != nullptr;
+  if (which == 0 && !no_fast && !sharded(c) && c->desc.state_dim == 32 && c->desc.hidden_dim == 64 && !c->desc.time_dep) {
+    SdeFastArgs f;
+    memset(&f, 0, sizeof(f));
+    f.W1p = c->m.W1p; f.KG1 = c->m.KG1;
+    f.W2p = c->m.W2p; f.KG2p = ((c->m.KG2 + SEGK - 1) / SEGK) * SEGK;
+    f.Wgp = s->diff->m.W2p; f.KGgp = ((s->diff->m.KG2 + SEGK - 1) / SEGK) * SEGK;
+    f.b1 = c->m.b1; f.b2 = c->m.b2; f.bg = s->diff->m.b2; f.act = c->m.act;
+    f.u = uprev; f.dW = dW; f.un = u; f.B = B; f.dt = dt; f.abstol = abstol; f.reltol = reltol; f.delta = delta;
+    f.part = c->part + (size_t)a.nwg_global * PSTRIDE;  // the parity-1 block k_finalize reads
+    f.n_norm = a.n_global;
+    if (rec_dev) {  // fixed-grid solve: the step writes its own record (no footer launch)
+      if (!s->arrive) { HIPCHK(c, hipMalloc(&s->arrive, sizeof(int))); HIPCHK(c, hipMemsetAsync(s->arrive, 0, sizeof(int), c->stream)); }
+      f.arrive = s->arrive; f.rec = rec_dev;
+      hipLaunchKernelGGL(k_sde_eh_fast, dim3(nwg), dim3(SF_NT), 0, c->stream, f);
+      HIPCHK(c, hipGetLastError());
+      return LRNDE_OK;
+    }
+    hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t, dt, 0, 0);
+    hipLaunchKernelGGL(k_sde_eh_fast, dim3(nwg), dim3(SF_NT), 0, c->stream, f);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, a, 1);
+    HIPCHK(c, hipGetLastError());
+    if (rec) HIPCHK(c, hipMemcpyAsync(rec, c->ctrl + 1, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+    return LRNDE_OK;
+  }
   size_t sm = smem_bytes(c->m.Dp, c->m.Hp);
   const size_t sm2 = smem_bytes(s->diff->m.Dp, s->diff->m.Hp);
   if (sm2 > sm) sm = sm2;
@@ -2599,6 +2630,76 @@ int lrnde_sde_solve_fixed(lrnde_sde* s, int32_t which, const float* u0, const fl
     if (eest_host) eest_host[i] = s->traj_host[i].eest_last;
     if (reg_val_host) reg_val_host[i] = s->traj_host[i].reg_error;
   }
+  return LRNDE_OK;
+}
+
+// ---- adaptive Euler-Heun solve on a caller-supplied Brownian path ----
+__global__ void k_sde_dw(size_t n, const float* Wlo, const float* Whi, float* dW) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dW[i] = Whi[i] - Wlo[i];
+}
+
+int lrnde_sde_solve_adaptive(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
+                             const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
+                             int32_t cap_trace) {
+  int rc = sde_check(s, u0, W, u_end, B, 1.0f);
+  if (rc) return rc;
+  lrnde_ctx* c = s->drift;
+  if (!o || !st || nfine < 1 || !(t1 > t0)) return fail(c, LRNDE_BADARG, "bad arguments (nfine >= 1, t1 > t0)");
+  memset(st, 0, sizeof(*st));
+  const size_t n = (size_t)B * c->desc.state_dim;
+  if (s->ad_n != n) {
+    if (s->ad_ws) HIPCHK(c, hipFree(s->ad_ws));
+    s->ad_ws = nullptr; s->ad_n = 0;
+    HIPCHK(c, hipMalloc(&s->ad_ws, sizeof(float) * 3 * n));
+    s->ad_n = n;
+  }
+  float *ua = s->ad_ws, *ub = s->ad_ws + n, *dW = s->ad_ws + 2 * n;
+  HIPCHK(c, hipMemcpyAsync(ua, u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  const float h = (t1 - t0) / (float)nfine;
+  const float gamma = o->gamma, qmin = o->qmin, qmax = o->qmax, qoldinit = 1e-4f;
+  int i = 0;                                                  // position on the path's grid
+  int m = (int)(o->dt0 / h); if (m < 1) m = 1;                // step length in grid intervals
+  float qold = qoldinit;
+  int nb = (int)((n + 255) / 256); if (nb > 1024) nb = 1024;
+  while (i < nfine) {
+    if (m > nfine - i) m = nfine - i;
+    if (++st->iters > o->maxiters) { st->retcode = LRNDE_MAXITERS; break; }
+    const float t = t0 + (float)i * h, dt = (float)m * h;
+    hipLaunchKernelGGL(k_sde_dw, dim3(nb), dim3(256), 0, c->stream, n, W + (size_t)i * n, W + (size_t)(i + m) * n, dW);
+    if ((rc = sde_step_enqueue(s, 0, ua, dW, B, t, dt, o->abstol, o->reltol, o->delta, ub, c->ctrl_host))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const float eest = c->ctrl_host[0].eest_last;
+    st->nf += 3; st->eest_last = eest;
+    if (eest != eest) { st->retcode = LRNDE_DT_NAN; break; }
+    // PI controller on EEst (the form of SURVEY.md 3.5; StochasticDiffEq's constants are the caller's options)
+    float q;
+    if (eest == 0.0f) q = 1.0f / qmax;
+    else {
+      const float q11 = fastpow(eest, o->beta1);
+      q = q11 / fastpow(qold, o->beta2);
+      q = fmaxf(1.0f / qmax, fminf(1.0f / qmin, q / gamma));
+    }
+    const int accepted = eest <= 1.0f;
+    const int ntr = st->naccept + st->nreject;
+    if (trace_host && ntr < cap_trace) { trace_host[ntr].t = t; trace_host[ntr].dt = dt; trace_host[ntr].eest = eest; trace_host[ntr].accepted = accepted; }
+    int mnew = (int)((dt / q) / h);
+    if (mnew < 1) mnew = 1;
+    if (accepted) {
+      st->naccept++;
+      qold = fmaxf(eest, qoldinit);
+      i += m;
+      std::swap(ua, ub);
+      m = mnew;
+    } else {
+      st->nreject++;
+      if (m == 1) { st->retcode = LRNDE_DT_LESS_THAN_MIN; break; }  // the path's grid cannot be refined further
+      m = mnew < m ? mnew : m - 1;
+    }
+  }
+  st->t_final = t0 + (float)i * h; st->dt_final = (float)m * h;
+  HIPCHK(c, hipMemcpyAsync(u_end, ua, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (st->retcode != LRNDE_OK) return fail(c, st->retcode, "adaptive SDE solve stopped with retcode %d at t=%g", st->retcode, (double)st->t_final);
   return LRNDE_OK;
 }
 

@@ -102,6 +102,25 @@ class SdeHandle:
         return dict(u=u, eest=np.frombuffer(ee, dtype=np.float32).copy(), reg_val=np.frombuffer(rv, dtype=np.float32).copy())
 
 
+    def solve_adaptive(self, u0, W, t0, t1, abstol, reltol, delta=1.0 / 6.0, dt0=None, gamma=0.9, qmin=0.2, qmax=1.125,
+                       beta1=7.0 / 50.0, beta2=2.0 / 25.0, maxiters=10000):
+        """adaptive Euler-Heun on the caller's Brownian path W ((nfine+1, B, D), W[0] = 0, uniform grid over (t0, t1)):
+        dict(u_end, stats, trace) — steps are whole grid intervals, EEst drives a PI controller (lrnde.h)"""
+        nfine = int(W.shape[0]) - 1
+        B = u0.numel() // self.D
+        o = L.SdeAdaptOpts(float(abstol), float(reltol), float(delta), float((t1 - t0) / nfine if dt0 is None else dt0),
+                           float(gamma), float(qmin), float(qmax), float(beta1), float(beta2), int(maxiters))
+        u_end = torch.empty_like(u0)
+        st = L.Stats()
+        ntr = int(maxiters) + 4
+        tr = (L.TraceRow * ntr)()
+        self._chk(L.lib.lrnde_sde_solve_adaptive(self._h, _dev_ptr(u0, "u0", self.D), _dev_ptr(W.contiguous(), "W"), nfine, B,
+                                                 float(t0), float(t1), C.byref(o), _dev_ptr(u_end, "u_end"), C.byref(st), tr, ntr))
+        nt = st.naccept + st.nreject
+        trace = np.array([(tr[i].t, tr[i].dt, tr[i].eest, tr[i].accepted) for i in range(nt)],
+                         dtype=[("t", "f4"), ("dt", "f4"), ("eest", "f4"), ("accepted", "i4")])
+        return dict(u_end=u_end, stats=st.asdict(), trace=trace)
+
     def _pcounts(self):
         return self._keep[0].numel(), self._keep[1].numel()
 

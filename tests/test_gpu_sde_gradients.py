@@ -130,3 +130,54 @@ def test_neural_dsde_pullback_behaviour(gpu_pkg, regularize):
     # same rng => same forward as __call__
     sol, st2 = node(xd, ps, st)
     assert torch.equal(sol.u[-1], info1["sol"].u[-1]) and st2["reg_val"] == info1["st"]["reg_val"]
+
+
+@pytest.mark.parametrize("D,H,B,tol", [(32, 64, 64, 0.14), (32, 64, 512, 0.05), (16, 16, 9, 0.02)])
+def test_adaptive_euler_heun_solve_equals_the_oracle_step_loop(oracle, gpu_pkg, D, H, B, tol):
+    """The adaptive loop that consumes EEst (src/perform_step.jl:200-205): the library's controller over its own step on a
+    supplied Brownian path against the SAME controller written here over the oracle's step (bit-exact steps => identical
+    accept / reject decisions, step lengths and end state).  Shapes cover the one-launch kernel (32/64) and the generic one."""
+    from test_gpu_parity import _sde_fields
+    from localregneuralde_jl_amd.layers import _mlp_desc
+    import np_restatement as R
+    P, O = gpu_pkg, oracle
+    f32 = np.float32
+    pd, pg, drift, diff = _sde_fields(O, D, H, seed=11)
+    pd = (pd * f32(2.5)).astype(f32)                       # a rougher drift: the controller has something to do
+    drift = O.MlpField(D, H, pd, time_dep=False, act="tanh", nthreads=4)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((B, D)).astype(f32)
+    nfine = 64
+    h = f32(1.0) / f32(nfine)
+    W = np.concatenate([np.zeros((1, B, D), f32), np.cumsum((rng.standard_normal((nfine, B, D)) * np.sqrt(h)).astype(f32), axis=0,
+                                                            dtype=f32)], axis=0)
+    hd = P.SdeHandle(_mlp_desc(P.Chain(P.Dense(D, H, "tanh"), P.Dense(H, D))))
+    hd.set_params(pd, pg)
+    got = hd.solve_adaptive(torch.from_numpy(x).cuda(), torch.from_numpy(W).cuda(), 0.0, 1.0, tol, tol, dt0=8 * float(h))
+    # the same loop on the host over the oracle's step
+    gamma, qmin, qmax, b1, b2 = f32(0.9), f32(0.2), f32(1.125), f32(7.0 / 50.0), f32(2.0 / 25.0)
+    i, m, qold, u = 0, 8, f32(1e-4), x
+    rows = []
+    while i < nfine:
+        m = min(m, nfine - i)
+        t, dt = f32(f32(i) * h), f32(f32(m) * h)
+        dW = (W[i + m] - W[i]).astype(f32)
+        r = O.euler_heun_step(drift, diff, u, dW, t, dt, tol, tol, 1.0 / 6.0)
+        ee = f32(r["eest"])
+        q = f32(1) / qmax if ee == 0 else max(f32(1) / qmax, min(f32(1) / qmin, f32(f32(R.fastpow(ee, b1) / R.fastpow(qold, b2)) / gamma)))
+        acc = bool(ee <= 1)
+        rows.append((t, dt, ee, acc))
+        mnew = max(int(f32(f32(dt / q) / h)), 1)
+        if acc:
+            qold, i, u, m = max(ee, f32(1e-4)), i + m, r["u"], mnew
+        else:
+            assert m > 1
+            m = mnew if mnew < m else m - 1
+    tr = got["trace"]
+    assert len(tr) == len(rows) and got["stats"]["naccept"] == sum(1 for r in rows if r[3])
+    assert got["stats"]["nreject"] == sum(1 for r in rows if not r[3])
+    for a, b in zip(tr, rows):
+        assert (a["t"], a["dt"], a["eest"], bool(a["accepted"])) == (b[0], b[1], b[2], b[3])
+    assert np.array_equal(got["u_end"].cpu().numpy(), u)
+    print(f"adaptive SDE D={D} B={B} tol={tol}: accepted {got['stats']['naccept']}, rejected {got['stats']['nreject']}")
+    assert got["stats"]["naccept"] >= 3
