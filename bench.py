@@ -187,12 +187,21 @@ def main():
                      "what": "run_training_step: node forward with dense record + Dense(784=>10) + logitcrossentropy, "
                              "then continuous adjoint + regulariser sweep + classifier cotangents"}
 
-    # roofline leg: the dominant kernel (one full Tsit5 step per launch), HIP events on its stream
+    # roofline leg: the dominant kernel (one full Tsit5 step per launch).  Two HIP-event clocks on the handle's stream:
+    #  (a) us_per_launch: 100 back-to-back launches of the step kernel on fixed inputs (lrnde_bench_step) — the number
+    #      the roofline fraction is computed from;
+    #  (b) in_solve: events around the kernels of one real solve (2 init launches + full steps + the terminal /
+    #      speculative launches that find the solve finished), divided by its full steps — what a per-dispatch profile of
+    #      the same command averages to for FULL steps, minus the profiler's own per-dispatch overhead
+    #      (profiles/r2/README.md compares the three).
     k1 = h.rhs(x, 0.0)
     dt_typ = float(r["stats"]["dt_final"]) if r["stats"]["dt_final"] > 0 else 0.02
     us = h.bench_step(x, k1, 0.0, dt_typ, args.tol, args.tol, reps=100)
     flop_per_launch = 6 * FLOP_PER_FEVAL_PER_COL * args.batch
     achieved = flop_per_launch / (us * 1e-6) / 1e12
+    rs = one_pass(args.warmup + args.steps - 1)
+    solve_ms, solve_launches = h.last_solve_kernel_ms()
+    full_steps = rs["stats"]["naccept"] + rs["stats"]["nreject"]
 
     out = {
         "metric": "NFE/s (vector-field evals/s inside the adaptive Tsit5 NeuralODE forward, MNIST-ODE B=512/GPU)",
@@ -221,7 +230,11 @@ def main():
                      "traffic": measured_traffic(f"k_step_q_b{args.batch}") if world == 1 else None,
                      "kernel": "k_step_q<false, 1> (one attempted Tsit5 step: 6 f-evals, fused stage combination, error norm)"
                                if args.batch <= 2048 else "k_step<4,false>",
-                     "us_per_launch": us, "flop_per_launch": flop_per_launch},
+                     "us_per_launch": us, "flop_per_launch": flop_per_launch,
+                     "in_solve": {"solve_kernel_ms": solve_ms, "step_launches": solve_launches, "full_steps": full_steps,
+                                  "us_per_full_step": solve_ms * 1e3 / max(full_steps, 1),
+                                  "what": "HIP events around all kernels of one adaptive solve (2 init + steps + terminal/"
+                                          "speculative launches) / full steps: an upper bound of the step kernel's in-solve duration"}},
     }
     if rank == 0 and world == 1 and not args.no_conv:
         # BASELINE.json configs[1] read literally ("28x28 conv vector field, batch=512 fp32"): the CIFAR block topology on a
