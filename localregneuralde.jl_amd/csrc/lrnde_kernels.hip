@@ -154,6 +154,9 @@ struct StepArgs {
   float* dense_t;   // device [dense_cap]
   float* dense_dt;  // device [dense_cap]
   int dense_cap;
+  int dense_direct;  // 1 (4-column kernel): every attempted step writes its own record slot [uprev,k1..k7] straight from LDS /
+                     // registers at its end (slot = accepted steps so far; a rejected attempt's slot is rewritten by the
+                     // retry) instead of the next launch's prologue copying eight state arrays through global memory
 };
 
 // ---------------------------------------------------------------------------
@@ -849,6 +852,7 @@ struct Bcast {
   // a saveat point inside the step to interpolate) or the caller does (single-step entry points).  Otherwise they live in
   // LDS for the launch only: five state-sized stores per attempted step (8 MB of 21 at B=512) that nothing would read
   int store_k;
+  int dense_slot;  // dense_direct: the record slot this attempt writes (-1: none)
 };
 
 __device__ __forceinline__ float init_dt0(const double s[3], double n, float dtmax) {
@@ -1003,7 +1007,12 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
   c.t = t; c.dt = dt; c.first = 0;
   b.do_step = do_step; b.cur = c.cur; b.t = t; b.dt = dt;
   // (the margin covers the snap of t + dt onto t1 within 100 eps; a pending saveat equal to the new time is a copy of u)
-  b.store_k = (a.mode == MODE_SINGLE_GIVEN_DT) || a.dense != nullptr || a.force_store_k ||
+  b.dense_slot = -1;
+  if (a.dense && a.dense_direct && do_step) {
+    if (c.naccept >= a.dense_cap) { c.status = LRNDE_CAPACITY; b.do_step = 0; }  // the host retries with a larger record
+    else b.dense_slot = c.naccept;
+  }
+  b.store_k = (a.mode == MODE_SINGLE_GIVEN_DT) || (a.dense != nullptr && !a.dense_direct) || a.force_store_k ||
               (a.mode == MODE_SOLVE && c.isave < a.nsave && a.saveat[c.isave] < t + dt * 1.001f);
   if (lane == 0) {
     *bc = b;
@@ -2151,7 +2160,11 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   a.t0 = t0; a.t1 = t1; a.abstol = o->abstol; a.reltol = o->reltol;
   a.maxiters = o->maxiters; a.save_everystep = o->save_everystep; a.exact_pow = o->exact_pow;
   a.want_stiff = 0; a.mode = MODE_SOLVE;
-  if (c->dense_on) { a.dense = c->dense; a.dense_t = c->dense_t; a.dense_dt = c->dense_dt; a.dense_cap = c->dense_cap; }
+  if (c->dense_on) {
+    a.dense = c->dense; a.dense_t = c->dense_t; a.dense_dt = c->dense_dt; a.dense_cap = c->dense_cap;
+    static const bool no_direct = getenv("LRNDE_DENSE_COPY") != nullptr;  // diagnostic: round 1's prologue copy
+    a.dense_direct = (use_qtile(c, B) && !no_direct) ? 1 : 0;
+  }
   a.cap_saved = cap_saved; a.u_saved = u_saved; a.t_saved = c->tsaved_dev;
   a.trace = trace_host ? c->trace_dev : nullptr; a.cap_trace = trace_host ? cap_trace : 0;
   // saveat points at/before t0 are the start value (save_start), as in the oracle

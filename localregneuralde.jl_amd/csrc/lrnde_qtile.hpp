@@ -183,6 +183,9 @@ struct EpiFinalQ {
   int want_stiff, nvalid, D;
   double *aerr, *anum, *aden;
   const f32x4* xl; const f32x4* kl; int KL;  // u is the x tile of this (last) f-eval; uprev, k1..k6 as in EpiStageQ
+  // dense record written by the step itself (StepArgs::dense_direct): descriptor over the slot [uprev,k1..k7] of this
+  // attempt, voff out of range when there is none
+  __amdgpu_buffer_rsrc_t rsD; int nstB; bool rec;
   __device__ __forceinline__ void pre(int rg, f32x4 (&pb)[NPRE]) const {
     const int li = rg * 64 + (threadIdx.x & 63);
     pb[0] = kl[li];
@@ -195,6 +198,15 @@ struct EpiFinalQ {
     const int lane = threadIdx.x & 63, sidx = lane & 3, q = lane >> 2;
     const int vo = q_voff(io, rg);
     qstore(io, vo, off_out, kv);
+    if (rec) {
+      // the attempt's record slot, straight from the operands this lane already holds: uprev (pb[0]), k1..k6 (pb[2..7]),
+      // k7 (kv) — eight 16-byte stores per row group instead of a 25-MB copy through global memory in the next prologue
+      const int vd = vo;  // the slot's arrays have the state arrays' (column, row) layout
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pb[0]), rsD, vd, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pb[2 + j]), rsD, vd + (1 + j) * nstB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, kv), rsD, vd + 7 * nstB, 0, 0);
+    }
     if (sidx >= nvalid || rg * 64 + q * 4 >= D) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -679,6 +691,7 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
       const size_t nst = (size_t)a.n_local;
       float* dd = a.dense + (size_t)bc.dense_idx * 8 * nst;
       const float* src[8] = {up, k1, a.ks[0], a.ks[1], a.ks[2], a.ks[3], a.ks[4], k7};
+      if (!a.dense_direct)  // (direct mode: the step wrote this slot itself at its end, EpiFinalQ)
       q_tile_foreach(a.m, b0, nvalid, KQ1, [&](int, int, bool valid, size_t g) {
         if (!valid) return;
 #pragma unroll
@@ -744,6 +757,9 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
   ef.D = a.m.D;
   ef.aerr = &aerr; ef.anum = &anum; ef.aden = &aden;
   ef.xl = s.xl; ef.kl = kl; ef.KL = KL;
+  ef.rec = bc.dense_slot >= 0; ef.nstB = (int)(a.n_local * 4);
+  ef.rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dense + (size_t)(ef.rec ? bc.dense_slot : 0) * 8 * (size_t)a.n_local), 0,
+                                             (int)(a.n_local * 32), 0x00020000);
   feval_qs<EpiFinalQ, (QSB * 5) % QRING, KT>(a.m, s, fc, t + dt, ef);
   STAMP(18);
   block_sum3_q(s.red, aerr, anum, aden, a.want_stiff != 0);
