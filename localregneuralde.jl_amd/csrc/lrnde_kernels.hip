@@ -903,7 +903,7 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
   // wave 0 only
   const int lane = threadIdx.x & 63;
   if (a.mode == MODE_BENCH) {  // timing hook: every launch is a full step on fixed inputs
-    if (lane == 0) { bc->do_step = 1; bc->cur = 0; bc->t = a.t0; bc->dt = a.bench_dt; bc->accepted_prev = 0; bc->store_k = 0; }
+    if (lane == 0) { bc->do_step = 1; bc->cur = 0; bc->t = a.t0; bc->dt = a.bench_dt; bc->accepted_prev = 0; bc->store_k = 0; bc->dense_idx = -1; bc->dense_slot = -1; }
     return;
   }
   const Ctrl* cin = a.ctrl + (j & 1);

@@ -757,7 +757,7 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
   ef.D = a.m.D;
   ef.aerr = &aerr; ef.anum = &anum; ef.aden = &aden;
   ef.xl = s.xl; ef.kl = kl; ef.KL = KL;
-  ef.rec = bc.dense_slot >= 0; ef.nstB = (int)(a.n_local * 4);
+  ef.rec = a.dense != nullptr && a.dense_direct && bc.dense_slot >= 0; ef.nstB = (int)(a.n_local * 4);
   ef.rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dense + (size_t)(ef.rec ? bc.dense_slot : 0) * 8 * (size_t)a.n_local), 0,
                                              (int)(a.n_local * 32), 0x00020000);
   feval_qs<EpiFinalQ, (QSB * 5) % QRING, KT>(a.m, s, fc, t + dt, ef);

@@ -238,3 +238,31 @@ def test_training_step_is_run_to_run_deterministic(oracle, gpu_pkg):
     assert l1 == l2
     for k in g1:
         assert torch.equal(g1[k], g2[k]), k
+
+
+@pytest.mark.gpu
+def test_timing_hook_after_a_recorded_forward_leaves_the_record_alone(oracle, gpu_pkg):
+    """lrnde_bench_step (MODE_BENCH launches of the step kernel) on a handle that has just recorded a forward: the hook's
+    launches carry no dense record and must not write one (bench.py runs exactly this order); the backward of the recorded
+    pass afterwards returns the same bits as without the hook in between."""
+    import torch
+    P = gpu_pkg
+    D, H, B, K = 784, 100, 64, 10
+    model = P.TDChain(P.Chain(P.Dense(D + 1, H, "tanh"), P.Dense(H + 1, D)))
+    node = P.NeuralODE(model, regularize="unbiased", abstol=1e-4, reltol=1e-4, save_start=False, maxiters=2000)
+    rng = np.random.default_rng(9)
+    ps = torch.from_numpy(P.glorot_params(model, seed=3)).cuda()
+    pc = torch.from_numpy((rng.standard_normal(K * (D + 1)) * 0.05).astype(np.float32)).cuda()
+    x = torch.from_numpy(rng.random((B, D), dtype=np.float32)).cuda()
+    lab = torch.from_numpy(rng.integers(0, K, B).astype(np.int32)).cuda()
+    st = node.initialstates(np.random.default_rng(0))
+    l1, _, _, g1, _ = P.run_training_step(node, ps, pc, st, x, lab, 2.5)
+    h = node._handle
+    us = h.bench_step(x, h.rhs(x, 0.0), 0.0, 0.03, 1e-4, 1e-4, reps=5)
+    assert us > 0
+    plain = h.node_forward(x, 0.0, 1.0, 1e-4, 1e-4, mode="unbiased", reg_type="error_estimate", t1_or_rand=0.4, maxiters=2000)
+    assert plain["stats"]["naccept"] > 0
+    l2, _, _, g2, _ = P.run_training_step(node, ps, pc, st, x, lab, 2.5)
+    assert l1 == l2
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
