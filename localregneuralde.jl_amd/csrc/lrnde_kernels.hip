@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "lrnde.h"
@@ -135,7 +136,11 @@ struct StepArgs {
   int nsave, cap_saved, cap_trace;
   const float* saveat;  // device copy
   float* u_saved;
-  float* t_saved;  // device
+  float* t_saved;  // device view of a pinned host array: the few saved times are written straight to the host
+  // unsharded solves: progress word in pinned host memory (one 64-bit posted store per launch, see solve_progress) and
+  // the final control block, both written by workgroup 0's prologue; NULL elsewhere
+  unsigned long long* prog;
+  Ctrl* fin_host;
   Ctrl* ctrl;      // [2]
   double* part_send;        // [2][nwg_global*PSTRIDE] (this rank writes its own segment)
   const double* part_recv;  // [2][...]  == part_send when nranks == 1
@@ -264,13 +269,29 @@ __device__ __forceinline__ void reduce_partials(const double* p, int nwg, double
   const Sum3 r = reduce_partials3(p, nwg);
   out[0] = r.a; out[1] = r.b; out[2] = r.c;
 }
-__device__ __forceinline__ Sum3 reduce_partials3(const double* p, int nwg) {
+// (the loads and the sum are separate calls so that a caller can put other loads in flight between them)
+struct PartLoads { double va[4], vb[4], vc[4]; };
+__device__ __forceinline__ void part_issue(PartLoads& L, const double* p, int nwg) {
   const int lane = threadIdx.x & 63;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   // agent-scope loads (the vector was written by the previous launch / by RCCL), four workgroups' triples per lane in
   // flight at once: this reduction opens every step launch, one round trip per loop trip was on its critical path.
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = lane + 64 * u;
+    const size_t o = (size_t)(i < nwg ? i : 0) * PSTRIDE;
+    L.va[u] = __hip_atomic_load(p + o + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    L.vb[u] = __hip_atomic_load(p + o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    L.vc[u] = __hip_atomic_load(p + o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ Sum3 part_finish(const PartLoads& L, const double* p, int nwg) {
+  const int lane = threadIdx.x & 63;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   // The adds run in the same order as a plain loop over i = lane, lane + 64, ...
-  for (int i0 = lane; i0 < nwg; i0 += 256) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (lane + 64 * u < nwg) { s0 += L.va[u]; s1 += L.vb[u]; s2 += L.vc[u]; }
+  for (int i0 = lane + 256; i0 < nwg; i0 += 256) {
     double va[4], vb[4], vc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -284,10 +305,16 @@ __device__ __forceinline__ Sum3 reduce_partials3(const double* p, int nwg) {
     for (int u = 0; u < 4; ++u)
       if (i0 + 64 * u < nwg) { s0 += va[u]; s1 += vb[u]; s2 += vc[u]; }
   }
-  s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+  // lane totals -> wave total with DPP row operations (wave-uniform result; fp64 sums of fp32 squares: the rounded fp32
+  // norm does not depend on the order of these adds)
   Sum3 r;
-  r.a = __shfl(s0, 0, 64); r.b = __shfl(s1, 0, 64); r.c = __shfl(s2, 0, 64);
+  r.a = wave_sum_dpp(s0); r.b = wave_sum_dpp(s1); r.c = wave_sum_dpp(s2);
   return r;
+}
+__device__ __forceinline__ Sum3 reduce_partials3(const double* p, int nwg) {
+  PartLoads L;
+  part_issue(L, p, nwg);
+  return part_finish(L, p, nwg);
 }
 
 // A workgroup hands in its three fp64 partial sums (valid on thread 0).  which = 0/1: the step's parity block of
@@ -899,6 +926,22 @@ __device__ __forceinline__ float init_dt_final3(const Sum3& r1, const Sum3& r2, 
   return fminf_(fminf_(100.0f * dt0, dt1), dtmax);
 }
 
+// Progress of a solve, for the host loop that keeps the stream fed (lrnde_solve): ONE 64-bit store per launch into
+// pinned host memory — [launches run : 24][status : 8][saves completed : 16][steps still to go at this dt : 16].  A
+// posted write: the wave does not wait for it, and the host only steers by it (how many launches to enqueue next, when
+// to start the companion's local step); everything it reports is read after the stream has been synchronised.  A
+// finished solve also leaves its control block in host memory, so the host needs no copy packet on the stream.
+__device__ __forceinline__ void solve_progress(const StepArgs& a, int j, const Ctrl& c, int nsaved_done, float steps_left) {
+  if (!a.prog) return;
+  if (c.status != ST_RUNNING) *a.fin_host = c;
+  const unsigned long long cnt = (unsigned long long)(j + 1) & 0xffffffull;
+  const unsigned long long stt = (unsigned long long)(c.status & 0xff);
+  const unsigned long long nsv = (unsigned long long)(nsaved_done > 65535 ? 65535 : nsaved_done);
+  const float sl = __builtin_ceilf(steps_left);
+  const unsigned long long rem = (unsigned long long)(sl > 65535.f ? 65535 : (sl > 0.f ? (int)sl : 0));
+  __hip_atomic_store(a.prog, cnt | (stt << 24) | (nsv << 32) | (rem << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* bc) {
   // wave 0 only
   const int lane = threadIdx.x & 63;
@@ -909,8 +952,24 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
   const Ctrl* cin = a.ctrl + (j & 1);
   Ctrl c = *cin;
   Ctrl* cout = a.ctrl + ((j + 1) & 1);
+  // Everything the decision needs from memory is put in flight at once: the control block, the previous attempt's
+  // partial sums (unused on the first launch), and — as soon as the block is here — the next two saveat times.  One after
+  // the other these round trips (each to memory: the writers were other launches) were the start of every step.
+  const double* ppart = a.part_recv + (size_t)(j & 1) * a.nwg_global * PSTRIDE;
+  PartLoads pl;
+  part_issue(pl, ppart, a.nwg_global);
+  const float sv_inf = __builtin_inff();
+  float svp0 = sv_inf, svp1 = sv_inf;
+  const int isave_in = c.isave;
+  if (a.mode == MODE_SOLVE) {
+    if (isave_in < a.nsave) svp0 = a.saveat[isave_in];
+    if (isave_in + 1 < a.nsave) svp1 = a.saveat[isave_in + 1];
+  }
+  auto saveat_at = [&](int is) -> float {  // a.saveat[is] for is < a.nsave
+    return is == isave_in ? svp0 : (is == isave_in + 1 ? svp1 : a.saveat[is]);
+  };
   if (c.status != ST_RUNNING) {
-    if (blockIdx.x == 0 && lane == 0) *cout = c;
+    if (blockIdx.x == 0 && lane == 0) { *cout = c; solve_progress(a, j, c, c.nsaved, 0.f); }
     if (lane == 0) bc->do_step = 0, bc->accepted_prev = 0;
     return;
   }
@@ -934,7 +993,7 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
     c.dt_init = dt;
     c.dtpropose = dt;
   } else {
-    const Sum3 sr = reduce_partials3(a.part_recv + (size_t)(j & 1) * a.nwg_global * PSTRIDE, a.nwg_global);
+    const Sum3 sr = part_finish(pl, ppart, a.nwg_global);
     const float eest = rms_from(sr.a, a.n_global);
     c.eest_last = eest;
     float q;
@@ -973,7 +1032,7 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
       }
       // savevalues!: count what this step saves (performed by all threads afterwards)
       int is = c.isave, ns = c.nsaved;
-      while (is < a.nsave && a.saveat[is] <= t) { ++is; ++ns; }
+      while (is < a.nsave && saveat_at(is) <= t) { ++is; ++ns; }
       if (a.save_everystep) ++ns;
       if (ns > a.cap_saved) c.status = LRNDE_CAPACITY, b.accepted_prev = 0;
       else { c.isave = is; c.nsaved = ns; }
@@ -1013,10 +1072,14 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
     else b.dense_slot = c.naccept;
   }
   b.store_k = (a.mode == MODE_SINGLE_GIVEN_DT) || (a.dense != nullptr && !a.dense_direct) || a.force_store_k ||
-              (a.mode == MODE_SOLVE && c.isave < a.nsave && a.saveat[c.isave] < t + dt * 1.001f);
+              (a.mode == MODE_SOLVE && c.isave < a.nsave && saveat_at(c.isave) < t + dt * 1.001f);
   if (lane == 0) {
     *bc = b;
-    if (blockIdx.x == 0) *cout = c;
+    if (blockIdx.x == 0) {
+      *cout = c;
+      // (nsaved0: the saves of COMPLETED launches — what this launch saves is written by its body, after this word)
+      solve_progress(a, j, c, b.nsaved0, (do_step && dt > 0.f) ? (a.t1 - t) / dt : 0.f);
+    }
   }
 }
 
@@ -1541,6 +1604,20 @@ __global__ void k_ctrl_init(Ctrl* ctrl, float t0, float dt, int cur, int nsaved)
   ctrl[1] = c;
 }
 
+// start of a solve in one launch: control blocks, the (few) saveat times and the save_start time — no copy packets
+struct SaveInit { float* saveat; int n; float v[8]; float* tsaved; int save_start; };
+__global__ void k_solve_init(Ctrl* ctrl, float t0, int nsaved, SaveInit si) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Ctrl c;
+  memset(&c, 0, sizeof(c));
+  c.status = ST_RUNNING; c.first = 1; c.cur = 0; c.nsaved = nsaved;
+  c.t = t0; c.dt = 0.f; c.qold = 1e-4f; c.q11 = 1.0f; c.dtpropose = 0.f;
+  ctrl[0] = c;
+  ctrl[1] = c;
+  for (int i = 0; i < si.n; ++i) si.saveat[i] = si.v[i];
+  if (si.save_start) si.tsaved[0] = t0;
+}
+
 // Dense(D=>D) parameters [vec(Wg); bg] -> the 2-layer form [vec(I); 0; vec(Wg); bg] (identity first layer)
 __global__ void k_diff_expand(const float* pd, int D, int has_bias, float* p2) {
   const size_t nI = (size_t)D * D;
@@ -1627,7 +1704,7 @@ struct lrnde_ctx {
   std::vector<int> series_idx; std::vector<float> series_t;  // the caller's view of that solution: save slots and times
   float last_t1 = 0.f; int last_i1 = 0;
   // backward workspace kept across calls: u(t1) of the recorded forward, k1 and the regulariser's gradient
-  float *rec_u1 = nullptr, *rec_k1 = nullptr, *rec_gr = nullptr; size_t rec_n = 0;
+  float* rec_gr = nullptr; size_t rec_n = 0;
   float rec_dt1 = 0.f, rec_eest = 0.f, rec_snum = 0.f, rec_sden = 0.f;  // the local step's dt and scalars (forward's)
   float loc_dt = 0.f, loc_eest = 0.f, loc_snum = 0.f, loc_sden = 0.f;    // the same of the LAST layer forward
   // arguments of the last lrnde_node_forward_record (what lrnde_node_backward_recorded differentiates)
@@ -1644,8 +1721,11 @@ struct lrnde_ctx {
   double* pinit_rx = nullptr;
   float* saveat_dev = nullptr;
   int saveat_cap = 0;
-  float* tsaved_dev = nullptr;
+  float* tsaved_dev = nullptr;   // saved times: pinned host array (tsaved_host) as the device sees it
+  float* tsaved_host = nullptr;
   int tsaved_cap = 0;
+  // pinned host block the step prologue reports to (solve_progress): [0] the progress word, +64 B the final control block
+  unsigned long long* prog_host = nullptr; unsigned long long* prog_dev = nullptr;
   lrnde_trace_row* trace_dev = nullptr;
   int trace_cap = 0;
   float* usave = nullptr;  // internal save slots for node_forward
@@ -1665,6 +1745,14 @@ struct lrnde_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evp[2] = {nullptr, nullptr};
   float last_ms = 0.f;
   int last_launches = 0;
+  // companion context on its own (non-blocking) stream: shares the packed weights, owns a second state workspace.  The
+  // layer forward runs its local step there (and, recording, the regulariser's reverse sweep) WHILE the main solve
+  // finishes [t1, t2] on the handle's stream: at B <= 512 a step kernel is 128 workgroups, half of the chip.
+  lrnde_ctx* side = nullptr;
+  bool is_side = false, side_busy = false, rec_gr_ready = false;
+  hipEvent_t ev_side_local = nullptr, ev_side_sweep = nullptr;
+  float* tail_copy_dst = nullptr; const float* tail_copy_src = nullptr;  // lrnde_solve: one D2D copy enqueued before its final sync
+  std::function<int(int, hipEvent_t)> poll_hook;  // lrnde_solve calls it after every status poll (event: that poll's)
   std::string err;
 };
 
@@ -1904,6 +1992,39 @@ void stats_from_ctrl(const Ctrl& k, lrnde_stats* st) {
   st->dt_init = k.dt_init;
 }
 
+// ---- companion context (lrnde_ctx::side) ----
+// A shallow clone: same descriptor and packed-weight pointers, own stream, state workspace, partial sums, control blocks
+// and backward scratch.  Unsharded handles only (a communicator's collectives must stay in one stream order).
+int side_get(lrnde_ctx* c, int B, lrnde_ctx** out) {
+  if (!c->side) {
+    lrnde_ctx* s = new lrnde_ctx();
+    s->is_side = true; s->device = c->device;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_side_local, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_side_sweep, hipEventDisableTiming) != hipSuccess) {
+      delete s;
+      return fail(c, LRNDE_HIP_ERROR, "companion stream / events could not be created");
+    }
+    c->side = s;
+  }
+  lrnde_ctx* s = c->side;
+  s->desc = c->desc; s->m = c->m; s->have_params = c->have_params;
+  s->W1p = c->W1p; s->W2p = c->W2p; s->w1t = c->w1t; s->b1 = c->b1; s->w2t = c->w2t; s->b2 = c->b2;
+  s->W1q = c->W1q; s->W2q = c->W2q; s->V1p = c->V1p; s->U2p = c->U2p; s->V1q = c->V1q; s->U2q = c->U2q;
+  const int rc = ensure_workspace(s, B);
+  if (rc) { c->err = s->err; return rc; }
+  *out = s;
+  return LRNDE_OK;
+}
+// nothing of the companion's is in flight after this (before the weights are repacked, a new forward, destroy)
+int side_quiesce(lrnde_ctx* c) {
+  if (c->side && c->side_busy) {
+    HIPCHK(c, hipStreamSynchronize(c->side->stream));
+    c->side_busy = false;
+  }
+  return LRNDE_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1971,13 +2092,26 @@ int lrnde_destroy(lrnde_ctx* c) {
   if (!c) return LRNDE_OK;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
+  if (c->side) {  // the companion borrows the packed weights: drop the borrowed pointers, free what it owns
+    lrnde_ctx* s = c->side;
+    hipStream_t ss = s->stream;
+    hipStreamSynchronize(ss);
+    s->W1p = s->W2p = s->w1t = s->b1 = s->w2t = s->b2 = s->W1q = s->W2q = s->V1p = s->U2p = s->V1q = s->U2q = nullptr;
+    lrnde_destroy(s);
+    hipStreamDestroy(ss);
+    if (c->ev_side_local) hipEventDestroy(c->ev_side_local);
+    if (c->ev_side_sweep) hipEventDestroy(c->ev_side_sweep);
+    c->side = nullptr;
+  }
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->adj_part_host) hipHostFree(c->adj_part_host);
   void* ptrs[] = {c->dense, c->dense_t, c->dense_dt, c->adj, c->adj_part, c->V1p, c->U2p, c->V1q, c->U2q, c->bw_y, c->bw_h, c->bw_dp, c->W1q, c->W2q, c->W1p, c->W2p, c->w1t, c->b1, c->w2t, c->b2, c->state, c->ctrl, c->part,
-                  c->part_rx, c->pinit, c->pinit_rx, c->arrive, c->tile_part, c->tile_pinit, c->rec_u1, c->rec_k1, c->rec_gr, c->saveat_dev, c->tsaved_dev, c->trace_dev,
+                  c->part_rx, c->pinit, c->pinit_rx, c->arrive, c->tile_part, c->tile_pinit, c->rec_gr, c->saveat_dev, c->trace_dev,
                   c->usave};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ctrl_host) hipHostFree(c->ctrl_host);
+  if (c->tsaved_host) hipHostFree(c->tsaved_host);
+  if (c->prog_host) hipHostFree(c->prog_host);
   if (c->adj_ctl) hipFree(c->adj_ctl);
   if (c->adj_ctl_host) hipHostFree(c->adj_ctl_host);
   if (c->adj_hstat) hipHostFree(c->adj_hstat);
@@ -2001,6 +2135,8 @@ int lrnde_set_params(lrnde_ctx* c, const float* p, size_t n) {
   if (n != lrnde_param_count(&c->desc))
     return fail(c, LRNDE_BADARG, "parameter count %zu != expected %zu", n, lrnde_param_count(&c->desc));
   HIPCHK(c, hipSetDevice(c->device));
+  { const int rq = side_quiesce(c); if (rq) return rq; }
+  c->rec_gr_ready = false;
   const ModelDev& m = c->m;
   hipLaunchKernelGGL(k_pack, dim3(256), dim3(256), 0, c->stream, p, m.D, m.H, m.td, m.Dp, m.Hp, c->W1p,
                      c->w1t, c->b1, c->W2p, c->w2t, c->b2);
@@ -2145,10 +2281,18 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
     HIPCHK(c, hipMalloc(&c->saveat_dev, sizeof(float) * nsave));
     c->saveat_cap = nsave;
   }
-  if (cap_saved > c->tsaved_cap) {
-    if (c->tsaved_dev) HIPCHK(c, hipFree(c->tsaved_dev));
-    HIPCHK(c, hipMalloc(&c->tsaved_dev, sizeof(float) * cap_saved));
-    c->tsaved_cap = cap_saved;
+  if (cap_saved > c->tsaved_cap || !c->tsaved_host) {
+    if (c->tsaved_host) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipHostFree(c->tsaved_host)); }
+    c->tsaved_host = nullptr; c->tsaved_cap = 0;
+    const int cap = cap_saved > 16 ? cap_saved : 16;
+    HIPCHK(c, hipHostMalloc(&c->tsaved_host, sizeof(float) * cap, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&c->tsaved_dev, c->tsaved_host, 0));
+    c->tsaved_cap = cap;
+  }
+  if (!c->prog_host) {
+    HIPCHK(c, hipHostMalloc(&c->prog_host, 64 + sizeof(Ctrl), hipHostMallocMapped));
+    memset(c->prog_host, 0, 64 + sizeof(Ctrl));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&c->prog_dev, c->prog_host, 0));
   }
   if (trace_host && cap_trace > c->trace_cap) {
     if (c->trace_dev) HIPCHK(c, hipFree(c->trace_dev));
@@ -2172,19 +2316,35 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   while (skip < nsave && saveat_host[skip] <= t0) ++skip;
   a.nsave = nsave - skip;
   a.saveat = c->saveat_dev;
-  if (a.nsave > 0)
+  SaveInit si;
+  memset(&si, 0, sizeof(si));
+  si.saveat = c->saveat_dev; si.tsaved = c->tsaved_dev;
+  if (a.nsave > 8)
     HIPCHK(c, hipMemcpyAsync(c->saveat_dev, saveat_host + skip, sizeof(float) * a.nsave,
                              hipMemcpyHostToDevice, c->stream));
+  else
+    for (si.n = 0; si.n < a.nsave; ++si.n) si.v[si.n] = saveat_host[skip + si.n];   // written by k_solve_init
   int nsaved0 = 0;
   if (o->save_start) {
     if (cap_saved < 1) return fail(c, LRNDE_CAPACITY, "save buffer too small for save_start");
     HIPCHK(c, hipMemcpyAsync(u_saved, u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->tsaved_dev, &t0, sizeof(float), hipMemcpyHostToDevice, c->stream));
+    si.save_start = 1;
     nsaved0 = 1;
+  }
+  // unsharded: the prologue reports to pinned host memory and the loop below steers by that word; sharded handles keep
+  // the status copy one chunk behind (every rank must take its decisions from the SAME launch's state, or the ranks'
+  // launch — and collective — counts would drift apart)
+  const bool by_word = !sharded(c);
+  volatile unsigned long long* pw = c->prog_host;
+  Ctrl* fin_host = reinterpret_cast<Ctrl*>(reinterpret_cast<char*>(c->prog_host) + 64);
+  if (by_word) {
+    *pw = 0ull;
+    a.prog = c->prog_dev;
+    a.fin_host = reinterpret_cast<Ctrl*>(reinterpret_cast<char*>(c->prog_dev) + 64);
   }
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t0, 0.f, 0, nsaved0);
+  hipLaunchKernelGGL(k_solve_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t0, nsaved0, si);
   if ((rc = run_init(c, B, a))) return rc;
 
   // Enqueue attempted steps in chunks and poll the device status word one chunk behind, so the
@@ -2192,9 +2352,42 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   // needed, estimated from the polled (t, dt); launches beyond it are speculative (k_step<.,true>).
   const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
   int j = 0, pending = -1, pending_j = 0, launches = 0, target = 4, nchunk = 0;
-  bool done = false;
+  bool done = false, word_ok = by_word;
   const long hard_cap = (long)o->maxiters + 8;
-  while (!done) {
+  if (word_ok) {
+    // Report-driven feed: after every report keep enqueued what it says is still to come at the current dt (an
+    // over-estimate while dt grows, exact for the last step, whose dt is clipped to t1 - t), the launch that will find the
+    // solve finished, and never fewer than two launches beyond the reporting one — so the stream neither runs dry nor
+    // ends with a tail of launches that have nothing to do.
+    int seen = 0, rem = 3;
+    while (!done) {
+      int ahead = rem + 1;
+      if (ahead < 2) ahead = 2;
+      if (ahead > 16) ahead = 16;
+      const int certain = seen + (rem > 1 ? rem / 2 : 1);  // launches beyond it carry the speculative kernel name
+      for (const int want = seen + ahead; j < want; ++j) {
+        if ((rc = launch_step(c, B, a, j, j >= certain))) return rc;
+        ++launches;
+      }
+      if (j > hard_cap + 64) break;
+      unsigned long long w = *pw;
+      for (long spin = 1; (int)(w & 0xffffffull) <= seen; ++spin) {
+        if ((spin & 0x3fff) == 0 && hipStreamQuery(c->stream) == hipSuccess) {
+          w = *pw;
+          if ((int)(w & 0xffffffull) <= seen) word_ok = false;  // the stream drained and the word did not move: poll by copies
+          break;
+        }
+        w = *pw;
+      }
+      if (!word_ok) break;
+      seen = (int)(w & 0xffffffull);
+      rem = (int)((w >> 48) & 0xffff);
+      if (c->poll_hook && (rc = c->poll_hook((int)((w >> 32) & 0xffff), nullptr))) return rc;
+      if ((int)((w >> 24) & 0xff) != (ST_RUNNING & 0xff)) done = true;
+    }
+    target = j;
+  }
+  while (!done && !word_ok) {
     int ch = target - j;
     if (ch < 2) ch = 2;
     if (ch > 16) ch = 16;
@@ -2210,6 +2403,7 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
     if (pending >= 0) {
       HIPCHK(c, hipEventSynchronize(c->evp[pending]));
       const Ctrl& k = c->ctrl_host[pending];
+      if (c->poll_hook && (rc = c->poll_hook(k.nsaved, c->evp[pending]))) return rc;
       if (k.status != ST_RUNNING) done = true;
       else if (k.dt > 0.f) {
         double est = ceil((double)(t1 - k.t) / (double)k.dt);
@@ -2224,14 +2418,23 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
     if (target < j) target = j;  // never re-label launches already issued
     if (j > hard_cap + 64) break;
   }
+  if (c->tail_copy_dst) {  // the caller's copy of the last save slot, ahead of the synchronisation below
+    HIPCHK(c, hipMemcpyAsync(c->tail_copy_dst, c->tail_copy_src, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+    c->tail_copy_dst = nullptr;
+  }
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->ctrl_host, c->ctrl + (j & 1), sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  const Ctrl fin = c->ctrl_host[0];
+  Ctrl fin;
+  if (word_ok && done) {  // the finished solve left its control block in host memory (solve_progress)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fin = *fin_host;
+  } else {
+    HIPCHK(c, hipMemcpyAsync(c->ctrl_host, c->ctrl + (j & 1), sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fin = c->ctrl_host[0];
+  }
   stats_from_ctrl(fin, st);
   if (fin.status == ST_RUNNING) st->retcode = LRNDE_MAXITERS;
-  if (t_saved_host && fin.nsaved > 0)
-    HIPCHK(c, hipMemcpy(t_saved_host, c->tsaved_dev, sizeof(float) * fin.nsaved, hipMemcpyDeviceToHost));
+  if (t_saved_host && fin.nsaved > 0) memcpy(t_saved_host, c->tsaved_host, sizeof(float) * fin.nsaved);
   if (trace_host) {
     int nt = fin.naccept + fin.nreject;
     if (nt > cap_trace) nt = cap_trace;
@@ -2251,6 +2454,8 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
 // time equal to t1 out again (_CorrectedDESolution, src/utils.jl:31-33: `sol.u[t1 .!= sol.t]`); :biased draws t1 from
 // the saved times but the last.  The series (the times the caller sees as sol.t) is kept in c->series_* for the caller
 // and for lrnde_node_backward_recorded_ts.
+static int step_reg_sweep(lrnde_ctx* c, const float* uprev, int32_t B, float t, float dt, float abstol, float reltol,
+                          int32_t reg_type, float eest, float stiff_num, float stiff_den, float* gp);
 static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2,
                              const lrnde_solve_opts* o, int32_t mode, int32_t reg_type, float t1_or_rand,
                              const float* user_sv, int nuser, float* u_end, float* reg_val_host, int32_t* nfe_host,
@@ -2267,6 +2472,8 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
   // a plain forward overwrites what a recorded one left for lrnde_node_backward_recorded (usave, last_ts, the state
   // workspace): the record is gone
   if (!c->dense_on) c->rec_valid = false;
+  if ((rc = side_quiesce(c))) return rc;
+  c->rec_gr_ready = false;
   lrnde_solve_opts oo = *o;
   size_t need = 3;
   if (mode == LRNDE_MODE_BIASED) need = (size_t)(oo.maxiters < 510 ? oo.maxiters + 2 : 512);
@@ -2287,22 +2494,60 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
   std::vector<float> ts(c->usave_slots);
   float t1 = t2;
   const float* u1 = nullptr;
+  bool u_end_done = false;  // u_end already copied by the solve (early_slot)
   auto series_all = [&](int nsaved, float drop) {  // the caller's sol: every saved entry (drop: t1 of the corrected solution)
     for (int i = 0; i < nsaved; ++i)
       if (!(ts[i] == drop)) { c->series_idx.push_back(i); c->series_t.push_back(ts[i]); }
   };
   const float no_drop = nanf("");
+  // sol.u[end] is the last save slot; when every saveat time lies in (t0, t2] that slot is known before the solve and
+  // the solve itself copies it to u_end ahead of its final synchronisation (-1: not known, copy afterwards)
+  auto early_slot = [&](const float* sv_, int nsv_) -> int {
+    if (oo.save_start || nsv_ < 1) return -1;
+    for (int i = 0; i < nsv_; ++i) if (!(sv_[i] > t0 && sv_[i] <= t2)) return -1;
+    return nsv_ - 1;
+  };
+  // _get_ode_integrator (neural_ode.jl:33-38): fresh init on (t1, t2); then _perform_step (:77).  `L` is the context the
+  // step runs on: the handle itself, or its companion (own stream) while the main solve is still going.
+  StepArgs a;
+  auto enqueue_local = [&](lrnde_ctx* L, const float* u_at_t1, float t1v) -> int {
+    int r;
+    fill_args(L, a, B);
+    a.t0 = t1v; a.t1 = t2; a.abstol = oo.abstol; a.reltol = oo.reltol; a.mode = MODE_SINGLE_INIT_DT;
+    a.want_stiff = (reg_type == LRNDE_REG_STIFFNESS_ESTIMATE); a.maxiters = 1;
+    a.force_store_k = c->dense_on ? 1 : 0;  // recorded forward: the regulariser's reverse sweep starts from this step's k2..k6
+    HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u_at_t1, sizeof(float) * n, hipMemcpyDeviceToDevice, L->stream));
+    hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, L->stream, L->ctrl, t1v, 0.f, 0, 0);
+    if ((r = run_init(L, B, a))) return r;
+    if ((r = launch_step(L, B, a, 0))) return r;
+    const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
+    if ((r = exchange(L, L->part + cnt, L->part_rx + cnt, cnt))) return r;
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, L->stream, a, 1);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(L->ctrl_host, L->ctrl + 1, sizeof(Ctrl), hipMemcpyDeviceToHost, L->stream));
+    return LRNDE_OK;
+  };
+  auto local_results = [&](const Ctrl& k) {
+    c->loc_dt = k.dt; c->loc_eest = k.eest_last; c->loc_snum = k.stiff_num; c->loc_sden = k.stiff_den;
+    if (reg_val_host) *reg_val_host = a.want_stiff ? k.reg_stiff : k.reg_error;
+    if (nfe_host) *nfe_host = st->nf + k.nf;  // sol.destats.nf + (6 + 3), perform_step.jl:31
+  };
   if (mode == LRNDE_MODE_NONE) {  // _vanilla_node_fallback, neural_ode.jl:56-60
     const float sv1[1] = {t2};
     oo.save_everystep = 0;
+    const int early = early_slot(nuser ? user_sv : sv1, nuser ? nuser : 1);
+    if (early >= 0) { c->tail_copy_dst = u_end; c->tail_copy_src = c->usave + (size_t)early * n; }
     rc = lrnde_solve(c, x, B, t0, t2, &oo, nuser ? user_sv : sv1, nuser ? nuser : 1, c->usave, ts.data(), (int)c->usave_slots, st, nullptr, 0);
+    c->tail_copy_dst = nullptr;
     if (rc) return rc;
     if (st->nsaved < 1) return fail(c, LRNDE_BADARG, "the solve saved nothing (saveat outside the time span)");
     series_all(st->nsaved, no_drop);
     c->last_ts.assign(ts.begin(), ts.begin() + st->nsaved);
-    HIPCHK(c, hipMemcpyAsync(u_end, c->usave + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
     if (nfe_host) *nfe_host = st->nf;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (st->nsaved - 1 != early) {
+      HIPCHK(c, hipMemcpyAsync(u_end, c->usave + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return LRNDE_OK;
   } else if (mode == LRNDE_MODE_UNBIASED) {  // neural_ode.jl:68-84, saveat = [t1, t2] or vcat(user saveat, t1)
     t1 = t1_or_rand;
@@ -2310,14 +2555,68 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
     if (nuser) { sv.assign(user_sv, user_sv + nuser); sv.insert(std::upper_bound(sv.begin(), sv.end(), t1), t1); }
     else { sv.push_back(t1); sv.push_back(t2); }
     oo.save_everystep = 0;
+    // Overlap (unsharded handles): t1 is known before the solve, so as soon as a status poll shows sol(t1) in its save slot
+    // the local step is enqueued on the companion's stream — and, recording, the regulariser's reverse sweep once the
+    // step's scalars have come back — while this stream goes on with [t1, t2].  LRNDE_NO_OVERLAP=1: everything in order
+    // on the handle's stream (the results are the same bits either way: same kernels, same inputs).
+    static const bool no_overlap = getenv("LRNDE_NO_OVERLAP") != nullptr;
+    lrnde_ctx* sd = nullptr;
+    int side_state = 0;  // 0: nothing enqueued, 1: local step enqueued, 2: + sweep
+    const int pos = (int)(std::upper_bound(sv.begin(), sv.end(), t1) - sv.begin()) - 1;  // slot of the LAST entry equal to t1
+    auto enqueue_sweep = [&]() -> int {
+      const Ctrl k = sd->ctrl_host[0];
+      const int r = step_reg_sweep(sd, sd->state, B, t1, k.dt, oo.abstol, oo.reltol, reg_type, k.eest_last, k.stiff_num, k.stiff_den,
+                                   c->rec_gr);
+      if (r) { c->err = sd->err; return r; }
+      HIPCHK(c, hipEventRecord(c->ev_side_sweep, sd->stream));
+      c->rec_gr_ready = true;
+      side_state = 2;
+      return LRNDE_OK;
+    };
+    auto side_advance = [&](int nsaved_now, hipEvent_t ev) -> int {
+      if (side_state == 0 && nsaved_now > pos) {
+        if (ev) HIPCHK(c, hipStreamWaitEvent(sd->stream, ev, 0));
+        c->side_busy = true;
+        const int r = enqueue_local(sd, c->usave + (size_t)pos * n, t1);
+        if (r) { if (!sd->err.empty()) c->err = sd->err; return r; }
+        HIPCHK(c, hipEventRecord(c->ev_side_local, sd->stream));
+        side_state = 1;
+      } else if (side_state == 1 && c->dense_on && hipEventQuery(c->ev_side_local) == hipSuccess) {
+        return enqueue_sweep();
+      }
+      return LRNDE_OK;
+    };
+    if (!sharded(c) && !no_overlap && pos >= 0 && sv[pos] == t1) {
+      if ((rc = side_get(c, B, &sd))) return rc;
+      c->poll_hook = [&](int nsaved_done, hipEvent_t ev) { return side_advance(nsaved_done, ev); };
+    }
+    const int early = early_slot(sv.data(), (int)sv.size());
+    if (early >= 0) { c->tail_copy_dst = u_end; c->tail_copy_src = c->usave + (size_t)early * n; }
     rc = lrnde_solve(c, x, B, t0, t2, &oo, sv.data(), (int)sv.size(), c->usave, ts.data(), (int)c->usave_slots, st, nullptr, 0);
+    c->poll_hook = nullptr; c->tail_copy_dst = nullptr;
     if (rc) return rc;
+    u_end_done = (st->nsaved - 1 == early);
     int i1 = -1;
     for (int i = 0; i < st->nsaved; ++i) if (ts[i] == t1) i1 = i;   // the last entry saved at t1 is sol(t1)
     if (i1 < 0) return fail(c, LRNDE_BADARG, "t1 = %g is not inside the time span", (double)t1);
     u1 = c->usave + (size_t)i1 * n;
     c->last_i1 = i1;
     series_all(st->nsaved, nuser ? t1 : no_drop);
+    if (sd && i1 == pos) {
+      c->last_ts.assign(ts.begin(), ts.begin() + st->nsaved);
+      c->last_t1 = t1;
+      if (!u_end_done)
+        HIPCHK(c, hipMemcpyAsync(u_end, c->usave + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+      if (t1_used_host) *t1_used_host = t1;
+      if ((rc = side_advance(st->nsaved, nullptr))) return rc;   // (a t1 reported last: the handle's stream is idle by now)
+      HIPCHK(c, hipEventSynchronize(c->ev_side_local));
+      local_results(sd->ctrl_host[0]);
+      if (c->dense_on && side_state == 1 && (rc = enqueue_sweep())) return rc;
+      if (!c->dense_on) c->side_busy = false;  // nothing of the companion's is left in flight
+      if (!u_end_done) HIPCHK(c, hipStreamSynchronize(c->stream));
+      return LRNDE_OK;
+    }
+    if ((rc = side_quiesce(c))) return rc;  // (not reached with a companion step in flight; kept for safety)
   } else {  // neural_ode.jl:88-100, saveat = [] => every accepted step (or the user's saveat)
     oo.save_everystep = nuser ? 0 : 1;
     rc = lrnde_solve(c, x, B, t0, t2, &oo, nuser ? user_sv : nullptr, nuser, c->usave, ts.data(), (int)c->usave_slots, st, nullptr, 0);
@@ -2334,28 +2633,13 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
   }
   c->last_ts.assign(ts.begin(), ts.begin() + st->nsaved);
   c->last_t1 = t1;
-  HIPCHK(c, hipMemcpyAsync(u_end, c->usave + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  if (!u_end_done)
+    HIPCHK(c, hipMemcpyAsync(u_end, c->usave + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   if (t1_used_host) *t1_used_host = t1;
-  // _get_ode_integrator (neural_ode.jl:33-38): fresh init on (t1, t2); then _perform_step (:77)
-  StepArgs a;
-  fill_args(c, a, B);
-  a.t0 = t1; a.t1 = t2; a.abstol = oo.abstol; a.reltol = oo.reltol; a.mode = MODE_SINGLE_INIT_DT;
-  a.want_stiff = (reg_type == LRNDE_REG_STIFFNESS_ESTIMATE); a.maxiters = 1;
-  a.force_store_k = c->dense_on ? 1 : 0;  // recorded forward: the backward's regulariser sweep starts from this step's k2..k6
-  HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u1, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t1, 0.f, 0, 0);
-  if ((rc = run_init(c, B, a))) return rc;
-  if ((rc = launch_step(c, B, a, 0))) return rc;
-  const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
-  if ((rc = exchange(c, c->part + cnt, c->part_rx + cnt, cnt))) return rc;
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, a, 1);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->ctrl_host, c->ctrl + 1, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+  // the local step in order on the handle's stream (biased t1, sharded handles, LRNDE_NO_OVERLAP)
+  if ((rc = enqueue_local(c, u1, t1))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  const Ctrl k = c->ctrl_host[0];
-  c->loc_dt = k.dt; c->loc_eest = k.eest_last; c->loc_snum = k.stiff_num; c->loc_sden = k.stiff_den;
-  if (reg_val_host) *reg_val_host = a.want_stiff ? k.reg_stiff : k.reg_error;
-  if (nfe_host) *nfe_host = st->nf + k.nf;  // sol.destats.nf + (6 + 3), perform_step.jl:31
+  local_results(c->ctrl_host[0]);
   return LRNDE_OK;
 }
 extern "C" {
@@ -3467,6 +3751,13 @@ static int node_forward_record_impl(lrnde_ctx* c, const float* x, int32_t B, flo
   const size_t n = (size_t)B * c->desc.state_dim;
   c->rec_valid = false;
   float t1 = t2;
+  if (c->rec_n != n) {  // the regulariser's parameter gradient (written by the forward's overlapped sweep, or by the backward)
+    if ((rc = side_quiesce(c))) return rc;
+    if (c->rec_gr) HIPCHK(c, hipFree(c->rec_gr));
+    c->rec_gr = nullptr; c->rec_n = 0;
+    HIPCHK(c, hipMalloc(&c->rec_gr, sizeof(float) * lrnde_param_count(&c->desc)));
+    c->rec_n = n;
+  }
   for (int attempt = 0;; ++attempt) {
     if (c->dense_cap == 0 || c->dense_n != n) {
       if (c->dense) { hipFree(c->dense); hipFree(c->dense_t); hipFree(c->dense_dt); c->dense = nullptr; }
@@ -3485,20 +3776,9 @@ static int node_forward_record_impl(lrnde_ctx* c, const float* x, int32_t B, flo
   }
   if (rc) return rc;
   if (t1_used_host) *t1_used_host = t1;
-  if (c->rec_n != n) {
-    if (c->rec_u1) { hipFree(c->rec_u1); hipFree(c->rec_k1); hipFree(c->rec_gr); }
-    c->rec_u1 = c->rec_k1 = c->rec_gr = nullptr; c->rec_n = 0;
-    HIPCHK(c, hipMalloc(&c->rec_u1, sizeof(float) * n));
-    HIPCHK(c, hipMalloc(&c->rec_k1, sizeof(float) * n));
-    HIPCHK(c, hipMalloc(&c->rec_gr, sizeof(float) * lrnde_param_count(&c->desc)));
-    c->rec_n = n;
-  }
   if (mode != LRNDE_MODE_NONE) {
-    // u(t1) = the local step's uprev (kept out of the save slots a later solve may reuse), k1 = its fsalfirst (still in
-    // the state workspace: kfsal[0] of the single-step run), and the step's scalars: the backward pass re-runs the step
-    // (to have k2..k6 in memory) and starts the regulariser's reverse sweep from these without asking the device again
-    HIPCHK(c, hipMemcpyAsync(c->rec_u1, c->usave + (size_t)c->last_i1 * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->rec_k1, c->state + 2 * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+    // the local step's operands (uprev = u(t1), u, k1..k7, g6) stay in the state workspace it ran in and its scalars are
+    // kept here: the regulariser's reverse sweep starts from them without re-running the step or asking the device again
     c->rec_dt1 = c->loc_dt; c->rec_eest = c->loc_eest; c->rec_snum = c->loc_snum; c->rec_sden = c->loc_sden;
   }
   c->rec_valid = true; c->rec_B = B; c->rec_t0 = t0; c->rec_t2 = t2; c->rec_opts = *o; c->rec_mode = mode;
@@ -3609,16 +3889,23 @@ static int node_backward_recorded_impl(lrnde_ctx* c, int32_t B, const float* du_
   if (!(mode != LRNDE_MODE_NONE && w_reg != 0.0f)) HIPCHK(c, hipStreamSynchronize(c->stream));
   // regulariser: dp += w_reg * d reg_val / d p   (no gradient w.r.t. x: test/runtests.jl:129)
   if (mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
-    float *k1 = c->rec_k1, *gr = c->rec_gr, *u1 = c->rec_u1;
-    // The forward's own local step is still in the state workspace (uprev = u(t1), u, k1..k7, g6: the recorded forward
-    // keeps k2..k6 in memory, StepArgs::force_store_k), and its scalars are in the record: the reverse sweep starts from
-    // them, nothing is re-run and nothing is read back.
-    (void)k1; (void)u1;
-    rc = step_reg_sweep(c, c->state, B, t1, c->rec_dt1, o->abstol, o->reltol, reg_type, c->rec_eest, c->rec_snum, c->rec_sden, gr);
+    float* gr = c->rec_gr;
+    if (c->rec_gr_ready) {
+      // the forward already ran the sweep on the companion's stream (it depends on the forward alone): wait for it there
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_side_sweep, 0));
+      rc = LRNDE_OK;
+    } else {
+      // The forward's own local step is still in the state workspace (uprev = u(t1), u, k1..k7, g6: the recorded forward
+      // keeps k2..k6 in memory, StepArgs::force_store_k), and its scalars are in the record: the reverse sweep starts from
+      // them, nothing is re-run and nothing is read back.
+      rc = step_reg_sweep(c, c->state, B, t1, c->rec_dt1, o->abstol, o->reltol, reg_type, c->rec_eest, c->rec_snum, c->rec_sden, gr);
+    }
     if (!rc) { const float* g1[2] = {dp, gr}; const float cc[2] = {1.0f, w_reg}; rc = vec_axpy(c, dp, nullptr, 1.0f, 2, g1, cc, P); }
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  if (c->rec_gr_ready && mode != LRNDE_MODE_NONE && w_reg != 0.0f) c->side_busy = false;  // waited for above, then synchronised
+  c->rec_gr_ready = false;
   c->rec_valid = false;  // the regulariser sweep reused the state workspace
   return LRNDE_OK;
 }
