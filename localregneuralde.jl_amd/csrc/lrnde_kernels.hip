@@ -31,6 +31,7 @@
 
 #include <math.h>
 #include <stdarg.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -77,13 +78,19 @@ struct ModelDev {
 // Diagnostic build only (tools/probe.hip): per-phase s_memtime/s_memrealtime stamps of
 // workgroup 0 into a buffer of their own.  The shipped library is built without this macro.
 __device__ unsigned long long g_stamps[64];
+__device__ unsigned long long g_pre[8];  // stamps 9..11 (launch entry .. prologue) are kept only by launches that go on to a
+                                         // full step (stamp 12): the trailing launches of a solve do not overwrite them
 #define STAMP(i)                                                              \
   do {                                                                        \
     if (blockIdx.x == 0 && threadIdx.x == 0) {                                \
-      g_stamps[2 * (i)] = __builtin_amdgcn_s_memtime();                       \
-      g_stamps[2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();               \
+      const unsigned long long m_ = __builtin_amdgcn_s_memtime(), r_ = __builtin_amdgcn_s_memrealtime(); \
+      if ((i) >= 9 && (i) <= 11) { g_pre[2 * ((i) - 9)] = m_; g_pre[2 * ((i) - 9) + 1] = r_; }           \
+      else { g_stamps[2 * (i)] = m_; g_stamps[2 * (i) + 1] = r_; }            \
+      if ((i) == 12) for (int k_ = 0; k_ < 6; ++k_) g_stamps[18 + k_] = g_pre[k_];                      \
     }                                                                         \
   } while (0)
+__device__ unsigned long long g_pstamps[8];  // inside step_prologue (workgroup 0, wave 0), kept by full steps only
+#define PSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_pstamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 __device__ unsigned long long g_wstamps[8 * 8];
 #define STAMPW(i)                                                             \
   do {                                                                        \
@@ -96,6 +103,7 @@ __device__ unsigned long long g_wstamps[8 * 8];
 // whose stamps split basic blocks at exactly these points, was that much faster).
 #define STAMP(i) __builtin_amdgcn_sched_barrier(0)
 #define STAMPW(i) __builtin_amdgcn_sched_barrier(0)
+#define PSTAMP(i) do { } while (0)
 #endif
 
 struct Ctrl {  // device-resident integrator state, double-buffered by attempt parity
@@ -109,6 +117,21 @@ struct Ctrl {  // device-resident integrator state, double-buffered by attempt p
   float reg_error, reg_stiff;  // single-step modes: filled by k_finalize
   float stiff_num, stiff_den;  // ||k7-k6||_rms, ||u-g6||_rms (for the regulariser's reverse sweep)
 };
+
+// The controller's part of Ctrl: exactly 16 dwords, one s_load_dwordx16.  The step prologue reads and writes only this
+// (as a whole Ctrl the last four floats came through a vector load that was waited for — and spilled — before the
+// partial-sum loads were even issued: one more memory round trip at the head of every step).
+struct CtrlHead {
+  int status, first;
+  int iter, naccept, nreject, nf;
+  int cur;
+  int isave, nsaved;
+  float t, dt;
+  float qold, q11, dtpropose;
+  float eest_last, dt_init;
+};
+static_assert(sizeof(CtrlHead) == 64 && offsetof(Ctrl, reg_error) == 64 && offsetof(Ctrl, dt_init) == offsetof(CtrlHead, dt_init),
+              "CtrlHead must be the first 64 bytes of Ctrl");
 
 struct StepArgs {
   ModelDev m;
@@ -269,9 +292,11 @@ __device__ __forceinline__ void reduce_partials(const double* p, int nwg, double
   const Sum3 r = reduce_partials3(p, nwg);
   out[0] = r.a; out[1] = r.b; out[2] = r.c;
 }
-// (the loads and the sum are separate calls so that a caller can put other loads in flight between them)
+// (the loads and the sum are separate calls so that a caller can put other loads in flight between them; ALL = false
+// reads the first sum of each triple only — the step prologue's error norm.  A loaded-but-unused value is not free here:
+// its destination register is reused at once and the reuse waits for the load.)
 struct PartLoads { double va[4], vb[4], vc[4]; };
-__device__ __forceinline__ void part_issue(PartLoads& L, const double* p, int nwg) {
+template <bool ALL> __device__ __forceinline__ void part_issue(PartLoads& L, const double* p, int nwg) {
   const int lane = threadIdx.x & 63;
   // agent-scope loads (the vector was written by the previous launch / by RCCL), four workgroups' triples per lane in
   // flight at once: this reduction opens every step launch, one round trip per loop trip was on its critical path.
@@ -280,41 +305,47 @@ __device__ __forceinline__ void part_issue(PartLoads& L, const double* p, int nw
     const int i = lane + 64 * u;
     const size_t o = (size_t)(i < nwg ? i : 0) * PSTRIDE;
     L.va[u] = __hip_atomic_load(p + o + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    L.vb[u] = __hip_atomic_load(p + o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    L.vc[u] = __hip_atomic_load(p + o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ALL) {
+      L.vb[u] = __hip_atomic_load(p + o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      L.vc[u] = __hip_atomic_load(p + o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
-__device__ __forceinline__ Sum3 part_finish(const PartLoads& L, const double* p, int nwg) {
+template <bool ALL> __device__ __forceinline__ Sum3 part_finish(const PartLoads& L, const double* p, int nwg) {
   const int lane = threadIdx.x & 63;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   // The adds run in the same order as a plain loop over i = lane, lane + 64, ...
 #pragma unroll
   for (int u = 0; u < 4; ++u)
-    if (lane + 64 * u < nwg) { s0 += L.va[u]; s1 += L.vb[u]; s2 += L.vc[u]; }
+    if (lane + 64 * u < nwg) { s0 += L.va[u]; if (ALL) { s1 += L.vb[u]; s2 += L.vc[u]; } }
   for (int i0 = lane + 256; i0 < nwg; i0 += 256) {
-    double va[4], vb[4], vc[4];
+    double va[4], vb[4] = {0.0, 0.0, 0.0, 0.0}, vc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + 64 * u;
       const size_t o = (size_t)(i < nwg ? i : i0) * PSTRIDE;
       va[u] = __hip_atomic_load(p + o + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      vb[u] = __hip_atomic_load(p + o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      vc[u] = __hip_atomic_load(p + o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ALL) {
+        vb[u] = __hip_atomic_load(p + o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        vc[u] = __hip_atomic_load(p + o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (i0 + 64 * u < nwg) { s0 += va[u]; s1 += vb[u]; s2 += vc[u]; }
+      if (i0 + 64 * u < nwg) { s0 += va[u]; if (ALL) { s1 += vb[u]; s2 += vc[u]; } }
   }
   // lane totals -> wave total with DPP row operations (wave-uniform result; fp64 sums of fp32 squares: the rounded fp32
   // norm does not depend on the order of these adds)
   Sum3 r;
-  r.a = wave_sum_dpp(s0); r.b = wave_sum_dpp(s1); r.c = wave_sum_dpp(s2);
+  r.a = wave_sum_dpp(s0);
+  r.b = ALL ? wave_sum_dpp(s1) : 0.0;
+  r.c = ALL ? wave_sum_dpp(s2) : 0.0;
   return r;
 }
 __device__ __forceinline__ Sum3 reduce_partials3(const double* p, int nwg) {
   PartLoads L;
-  part_issue(L, p, nwg);
-  return part_finish(L, p, nwg);
+  part_issue<true>(L, p, nwg);
+  return part_finish<true>(L, p, nwg);
 }
 
 // A workgroup hands in its three fp64 partial sums (valid on thread 0).  which = 0/1: the step's parity block of
@@ -931,9 +962,9 @@ __device__ __forceinline__ float init_dt_final3(const Sum3& r1, const Sum3& r2, 
 // posted write: the wave does not wait for it, and the host only steers by it (how many launches to enqueue next, when
 // to start the companion's local step); everything it reports is read after the stream has been synchronised.  A
 // finished solve also leaves its control block in host memory, so the host needs no copy packet on the stream.
-__device__ __forceinline__ void solve_progress(const StepArgs& a, int j, const Ctrl& c, int nsaved_done, float steps_left) {
+template <class A> __device__ __forceinline__ void solve_progress(const A& a, int j, const CtrlHead& c, int nsaved_done, float steps_left) {
   if (!a.prog) return;
-  if (c.status != ST_RUNNING) *a.fin_host = c;
+  if (c.status != ST_RUNNING) *reinterpret_cast<CtrlHead*>(a.fin_host) = c;
   const unsigned long long cnt = (unsigned long long)(j + 1) & 0xffffffull;
   const unsigned long long stt = (unsigned long long)(c.status & 0xff);
   const unsigned long long nsv = (unsigned long long)(nsaved_done > 65535 ? 65535 : nsaved_done);
@@ -942,31 +973,52 @@ __device__ __forceinline__ void solve_progress(const StepArgs& a, int j, const C
   __hip_atomic_store(a.prog, cnt | (stt << 24) | (nsv << 32) | (rem << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* bc) {
+// the launch arguments step_prologue works with (see there), each forced into a vector register
+template <class T> __device__ __forceinline__ T pin_v(T x) { asm volatile("" : "+v"(x)); return x; }
+struct PrologueArgs {
+  int mode, maxiters, nsave, cap_saved, save_everystep, exact_pow, nwg_global, dense_cap, dense_direct, force_store_k, cap_trace;
+  float t0, t1;
+  double n_global;
+  Ctrl* ctrl; const double* part_recv; const double* pinit_recv; const float* saveat; float* dense; lrnde_trace_row* trace;
+  unsigned long long* prog; Ctrl* fin_host;
+};
+__device__ __forceinline__ PrologueArgs pin_args(const StepArgs& a) {
+  PrologueArgs p;
+  p.mode = pin_v(a.mode); p.maxiters = pin_v(a.maxiters); p.nsave = pin_v(a.nsave); p.cap_saved = pin_v(a.cap_saved);
+  p.save_everystep = pin_v(a.save_everystep); p.exact_pow = pin_v(a.exact_pow); p.nwg_global = pin_v(a.nwg_global);
+  p.dense_cap = pin_v(a.dense_cap); p.dense_direct = pin_v(a.dense_direct); p.force_store_k = pin_v(a.force_store_k);
+  p.cap_trace = pin_v(a.cap_trace); p.t0 = pin_v(a.t0); p.t1 = pin_v(a.t1); p.n_global = pin_v(a.n_global);
+  p.ctrl = pin_v(a.ctrl); p.part_recv = pin_v(a.part_recv); p.pinit_recv = pin_v(a.pinit_recv); p.saveat = pin_v(a.saveat);
+  p.dense = pin_v(a.dense); p.trace = pin_v(a.trace); p.prog = pin_v(a.prog); p.fin_host = pin_v(a.fin_host);
+  return p;
+}
+
+__device__ __forceinline__ void step_prologue(const StepArgs& a_, int j, Bcast* bc) {
   // wave 0 only
   const int lane = threadIdx.x & 63;
-  if (a.mode == MODE_BENCH) {  // timing hook: every launch is a full step on fixed inputs
-    if (lane == 0) { bc->do_step = 1; bc->cur = 0; bc->t = a.t0; bc->dt = a.bench_dt; bc->accepted_prev = 0; bc->store_k = 0; bc->dense_idx = -1; bc->dense_slot = -1; }
+  if (a_.mode == MODE_BENCH) {  // timing hook: every launch is a full step on fixed inputs
+    if (lane == 0) { bc->do_step = 1; bc->cur = 0; bc->t = a_.t0; bc->dt = a_.bench_dt; bc->accepted_prev = 0; bc->store_k = 0; bc->dense_idx = -1; bc->dense_slot = -1; }
     return;
   }
-  const Ctrl* cin = a.ctrl + (j & 1);
-  Ctrl c = *cin;
-  Ctrl* cout = a.ctrl + ((j + 1) & 1);
+  // The launch arguments the decision uses, pinned in vector registers once.  Left to itself the compiler re-reads each of
+  // them from the kernel-argument segment at every use (the step kernel has no scalar registers to spare): some two dozen
+  // scalar loads, each waited for on the spot, in the one stretch of the launch that every wave is waiting on.
+  const PrologueArgs a = pin_args(a_);
+  PSTAMP(0);
+  const CtrlHead* cin = reinterpret_cast<const CtrlHead*>(a.ctrl + (j & 1));
+  CtrlHead c = *cin;
+  CtrlHead* cout = reinterpret_cast<CtrlHead*>(a.ctrl + ((j + 1) & 1));
   // Everything the decision needs from memory is put in flight at once: the control block, the previous attempt's
-  // partial sums (unused on the first launch), and — as soon as the block is here — the next two saveat times.  One after
-  // the other these round trips (each to memory: the writers were other launches) were the start of every step.
+  // partial sums (unused on the first launch) and the saveat times.  One after the other these round trips (each to
+  // memory: the writers were other launches) were the start of every step.
   const double* ppart = a.part_recv + (size_t)(j & 1) * a.nwg_global * PSTRIDE;
   PartLoads pl;
-  part_issue(pl, ppart, a.nwg_global);
-  const float sv_inf = __builtin_inff();
-  float svp0 = sv_inf, svp1 = sv_inf;
-  const int isave_in = c.isave;
-  if (a.mode == MODE_SOLVE) {
-    if (isave_in < a.nsave) svp0 = a.saveat[isave_in];
-    if (isave_in + 1 < a.nsave) svp1 = a.saveat[isave_in + 1];
-  }
-  auto saveat_at = [&](int is) -> float {  // a.saveat[is] for is < a.nsave
-    return is == isave_in ? svp0 : (is == isave_in + 1 ? svp1 : a.saveat[is]);
+  part_issue<false>(pl, ppart, a.nwg_global);
+  // (the first 64 saveat times ride in the lanes: no second, dependent round trip once the save index is known)
+  float svl = 0.f;
+  if (lane < a.nsave) svl = a.saveat[lane];
+  auto saveat_at = [&](int is) -> float {  // a.saveat[is] for is < a.nsave (is: wave-uniform)
+    return is < 64 ? __shfl(svl, is, 64) : a.saveat[is];
   };
   if (c.status != ST_RUNNING) {
     if (blockIdx.x == 0 && lane == 0) { *cout = c; solve_progress(a, j, c, c.nsaved, 0.f); }
@@ -993,8 +1045,11 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
     c.dt_init = dt;
     c.dtpropose = dt;
   } else {
-    const Sum3 sr = part_finish(pl, ppart, a.nwg_global);
+    PSTAMP(1);
+    const Sum3 sr = part_finish<false>(pl, ppart, a.nwg_global);
+    PSTAMP(2);
     const float eest = rms_from(sr.a, a.n_global);
+    PSTAMP(3);
     c.eest_last = eest;
     float q;
     if (eest == 0.0f) {
@@ -1063,6 +1118,7 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
     if (c.first) { do_step = 1; c.iter = 1; c.nf += 6; }
     else c.status = ST_DONE;
   }
+  PSTAMP(4);
   c.t = t; c.dt = dt; c.first = 0;
   b.do_step = do_step; b.cur = c.cur; b.t = t; b.dt = dt;
   // (the margin covers the snap of t + dt onto t1 within 100 eps; a pending saveat equal to the new time is a copy of u)
@@ -1081,6 +1137,7 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a, int j, Bcast* b
       solve_progress(a, j, c, b.nsaved0, (do_step && dt > 0.f) ? (a.t1 - t) / dt : 0.f);
     }
   }
+  PSTAMP(5);
 }
 
 // ---------------------------------------------------------------------------

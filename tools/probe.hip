@@ -38,6 +38,24 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 9; ++i) printf("  %-14s %8llu cycles\n", sn[i], st[2 * (11 + i)] - st[2 * (10 + i)]);
     printf("  total          %8llu cycles = %.1f us\n", st[2 * 19] - st[2 * 10], (st[2 * 19 + 1] - st[2 * 10 + 1]) / 100.0);
   }
+  {  // the same phases of the last FULL step of a real adaptive solve (controller prologue instead of the bench hook's)
+    lrnde_solve_opts o{1.4e-8f, 1.4e-8f, 24, 0, 0, 0};
+    lrnde_stats stt;
+    float* us; hipMalloc(&us, (size_t)B * 784 * 4 * 2);
+    float ts[4]; const float sv[1] = {5.0f};
+    lrnde_solve(c, u, B, 0.f, 5.0f, &o, sv, 1, us, ts, 2, &stt, nullptr, 0);  // stops at maxiters: every launch but the trailing ones is a full step
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st));
+    const char* sn[] = {"prologue", "x2 combine", "stage k2", "stage k3", "stage k4", "stage k5", "stage k6", "stage k7+err", "block reduce"};
+    printf("step kernel inside a solve (naccept %d nreject %d): wave-0 phase cycles:\n", stt.naccept, stt.nreject);
+    printf("  %-14s %8llu cycles\n", "launch init", st[2 * 10] - st[2 * 9]);
+    for (int i = 0; i < 9; ++i) printf("  %-14s %8llu cycles\n", sn[i], st[2 * (11 + i)] - st[2 * (10 + i)]);
+    printf("  total          %8llu cycles = %.1f us\n", st[2 * 19] - st[2 * 10], (st[2 * 19 + 1] - st[2 * 10 + 1]) / 100.0);
+    unsigned long long ps[8];
+    hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_pstamps), sizeof(ps));
+    printf("  inside the prologue (last launch that ran it; cycles): entry->control block here %llu, ->partials summed %llu, ->eest %llu, ->decision %llu, ->broadcast written %llu;  launch entry -> prologue entry %lld\n",
+           ps[1] - ps[0], ps[2] - ps[1], ps[3] - ps[2], ps[4] - ps[3], ps[5] - ps[4], (long long)(ps[0] - st[2 * 9]));
+  }
   unsigned long long ws[64];
   hipMemcpyFromSymbol(ws, HIP_SYMBOL(g_wstamps), sizeof(ws));
   printf("  per-wave cycles: dense1 | epilogue1 | dense2   (start offsets vs wave0)\n");
