@@ -903,6 +903,8 @@ struct Bcast {
   float t, dt;
   // footer of the previous attempt (save actions)
   int accepted_prev, cur_prev, isave0, nsaved0;
+  int isave1;  // the accepted step saves the saveat points [isave0, isave1) (counted by the prologue: no thread of the
+               // launch has to read the saveat list to find out that, as for most steps, there is nothing to save)
   float t_new, tprev, dt_prev;
   float dt0;  // init phase 2
   int dense_idx;  // index of the accepted step in the dense record (-1: none)
@@ -997,7 +999,7 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a_, int j, Bcast* 
   // wave 0 only
   const int lane = threadIdx.x & 63;
   if (a_.mode == MODE_BENCH) {  // timing hook: every launch is a full step on fixed inputs
-    if (lane == 0) { bc->do_step = 1; bc->cur = 0; bc->t = a_.t0; bc->dt = a_.bench_dt; bc->accepted_prev = 0; bc->store_k = 0; bc->dense_idx = -1; bc->dense_slot = -1; }
+    if (lane == 0) { bc->do_step = 1; bc->cur = 0; bc->t = a_.t0; bc->dt = a_.bench_dt; bc->accepted_prev = 0; bc->store_k = 0; bc->dense_idx = -1; bc->dense_slot = -1; bc->isave0 = 0; bc->isave1 = 0; }
     return;
   }
   // The launch arguments the decision uses, pinned in vector registers once.  Left to itself the compiler re-reads each of
@@ -1032,7 +1034,7 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a_, int j, Bcast* 
   int accepted = 0, do_step = 0;
   float t = c.t, dt = c.dt;
   Bcast b;
-  b.accepted_prev = 0; b.cur_prev = c.cur; b.isave0 = c.isave; b.nsaved0 = c.nsaved;
+  b.accepted_prev = 0; b.cur_prev = c.cur; b.isave0 = c.isave; b.isave1 = c.isave; b.nsaved0 = c.nsaved;
   b.t_new = c.t; b.tprev = c.t; b.dt_prev = c.dt; b.dt0 = 0.f; b.dense_idx = -1;
 
   if (c.first) {
@@ -1090,7 +1092,7 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a_, int j, Bcast* 
       while (is < a.nsave && saveat_at(is) <= t) { ++is; ++ns; }
       if (a.save_everystep) ++ns;
       if (ns > a.cap_saved) c.status = LRNDE_CAPACITY, b.accepted_prev = 0;
-      else { c.isave = is; c.nsaved = ns; }
+      else { c.isave = is; c.nsaved = ns; b.isave1 = is; }
     } else {
       c.nreject++;
     }
@@ -1296,7 +1298,7 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
     const float* k1 = kfsal_at(a, bc.cur_prev);
     const float* k7 = kfsal_at(a, bc.cur_prev ^ 1);
     int slot = bc.nsaved0;
-    for (int is = bc.isave0; is < a.nsave && a.saveat[is] <= bc.t_new; ++is, ++slot) {
+    for (int is = bc.isave0; is < bc.isave1; ++is, ++slot) {
       const float ts = a.saveat[is];
       float* dst = a.u_saved + (size_t)slot * a.B * a.m.D;
       if (ts != bc.t_new) {
@@ -1953,7 +1955,7 @@ template <class K> int launch_tile_kernel(lrnde_ctx* c, K kern, int B, const Ste
 int launch_step(lrnde_ctx* c, int B, const StepArgs& a, int j, bool spec = false) {
   if (use_qtile(c, B)) {
     const int nq = (B + QNB - 1) / QNB;
-    const size_t smq = smem_q(c) + (size_t)7 * c->m.KQ1p * 4 * 16 + 16;  // + the LDS-resident stage operands (uprev, k1..k6)
+    const size_t smq = smem_q(c) + (size_t)9 * c->m.KQ1p * 4 * 16 + 64 * 16 + 16;  // + the LDS-resident stage operands (both candidate (uprev, k1) pairs, k2..k6; one padded row group of slack)
     // KT: real k-quads in the last Dense-2 stream block (lrnde_qtile.hpp); 1 for H = 97..100, else the generic form
     const bool kt1 = (c->desc.hidden_dim + 3) / 4 == (QSB2 - 1) * QSQ + 1;
     if (kt1) {

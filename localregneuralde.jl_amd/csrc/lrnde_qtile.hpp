@@ -145,18 +145,22 @@ template <int S> struct EpiStageQ {
   float dt;
   f32x4* xl; int KQ1;
   f32x4* kl; int KL;
+  const f32x4* klu; const f32x4* klk;  // uprev / k1 of THIS step (one of the two preloaded candidate pairs, k_step_q)
   int store_k;  // Bcast::store_k: 0 = k_S stays in LDS (its global store gets an out-of-range offset and is dropped)
   __device__ __forceinline__ void pre(int rg, f32x4 (&pb)[NPRE]) const {
     const int li = rg * 64 + (threadIdx.x & 63);
+    pb[0] = klu[li];
+    if (S > 1) pb[S > 1 ? 1 : 0] = klk[li];
 #pragma unroll
-    for (int j = 0; j < S; ++j) pb[j] = kl[(size_t)j * KL + li];
+    for (int j = 2; j < S; ++j) pb[j] = kl[(size_t)(j + 2) * KL + li];
   }
   __device__ __forceinline__ void post(int rg, const f32x4& kv, f32x4 (&pb)[NPRE]) const {
     const int lane = threadIdx.x & 63, sidx = lane & 3, q = lane >> 2;
     constexpr int off = (S - 1) * S / 2;
     const int vo = q_voff(io, rg);
     qstore(io, store_k ? vo : 0x7ffffff0, off_out, kv);
-    kl[(size_t)S * KL + rg * 64 + lane] = kv;
+    kl[(size_t)(S + 2) * KL + rg * 64 + lane] = kv;  // (row groups are padded to 64 quads: the last one spills into the next slot's head, which
+                                                     //  is written later — the slot order is the stage order, the two preloaded pairs come first)
     f32x4 x;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -183,15 +187,17 @@ struct EpiFinalQ {
   int want_stiff, nvalid, D;
   double *aerr, *anum, *aden;
   const f32x4* xl; const f32x4* kl; int KL;  // u is the x tile of this (last) f-eval; uprev, k1..k6 as in EpiStageQ
+  const f32x4* klu; const f32x4* klk;
   // dense record written by the step itself (StepArgs::dense_direct): descriptor over the slot [uprev,k1..k7] of this
   // attempt, voff out of range when there is none
   __amdgpu_buffer_rsrc_t rsD; int nstB; bool rec;
   __device__ __forceinline__ void pre(int rg, f32x4 (&pb)[NPRE]) const {
     const int li = rg * 64 + (threadIdx.x & 63);
-    pb[0] = kl[li];
+    pb[0] = klu[li];
     pb[1] = xl[li];
+    pb[2] = klk[li];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) pb[2 + j] = kl[(size_t)(1 + j) * KL + li];
+    for (int j = 1; j < 6; ++j) pb[2 + j] = kl[(size_t)(3 + j) * KL + li];
     if (want_stiff) pb[8] = qload(io, q_voff(io, rg), off_g6);
   }
   __device__ __forceinline__ void post(int rg, const f32x4& kv, f32x4 (&pb)[NPRE]) const {
@@ -627,6 +633,9 @@ __global__ __launch_bounds__(QNT) void k_init2_q(StepArgs a) {
 }
 
 // one attempted Tsit5 step, 4 columns per workgroup (same flow as k_step's fused path)
+#ifdef LRNDE_DBG_RELOAD
+__device__ int g_dbg_bad[8] = {0, 0, 1 << 30, 0, 0, 0, 0, 0};
+#endif
 template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(StepArgs a, int j) {
   STAMP(9);
   const SmemQ s = carve_q(a.m);
@@ -637,8 +646,39 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
   STAMP(10);
   // wave 0 runs the device prologue (a chain of dependent global loads: control block, partial sums) while the other
   // six waves clear the LDS tiles and stage the bias vectors: the two used to run one after the other
-  if (threadIdx.x < 64) step_prologue(a, j, s.bc);
-  smem_init_q<true>(a.m, s);
+  // ... and load BOTH candidate pairs (ubuf[p], kfsal[p]), p = 0, 1, of this tile into LDS: which pair is (uprev, k1)
+  // is what the prologue is deciding, and its round trip to memory plus the controller arithmetic is time in which the
+  // tile would otherwise sit unread (then one more round trip, after the decision, at the head of the step).
+  f32x4* kl = q_extra_smem(s);  // [9][KL]: 0,1 = pair 0; 2,3 = pair 1; 4..8 = k2..k6
+  const int KL = a.m.KQ1p * 4;
+  if (threadIdx.x < 64) {
+    step_prologue(a, j, s.bc);
+  } else {
+    // (LDS init first: the prologue's own loads are already on their way when these 72 wave-loads reach the CU's
+    //  address path, which takes them one every ~16 cycles)
+    smem_init_q<true>(a.m, s);
+#ifndef LRNDE_NO_PRELOAD  // (diagnostic builds: the pair is read after the decision, in the x2 pass below)
+    constexpr int NTH = QNT - 64;
+    const int tid = (int)threadIdx.x - 64;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {  // KQ1 * 4 <= 784 quads (shape limit of this kernel) = at most three per thread
+      const int i = tid + r * NTH;
+      const int sidx = i & 3, kq = i >> 2;
+      const bool ok = i < KQ1 * 4 && sidx < nvalid;
+      const size_t g = ok ? (size_t)(b0 + sidx) * a.m.D + kq * 4 : 0;
+      v[r][0] = ld4(a.ubuf[0] + g); v[r][1] = ld4(a.kfsal[0] + g);
+      v[r][2] = ld4(a.ubuf[1] + g); v[r][3] = ld4(a.kfsal[1] + g);
+      if (!ok) { v[r][0] = z; v[r][1] = z; v[r][2] = z; v[r][3] = z; }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int i = tid + r * NTH;
+      if (i < KQ1 * 4) { kl[i] = v[r][0]; kl[KL + i] = v[r][1]; kl[2 * KL + i] = v[r][2]; kl[3 * KL + i] = v[r][3]; }
+    }
+#endif
+  }
   __syncthreads();
   STAMP(11);
   const Bcast bc = *s.bc;
@@ -649,7 +689,7 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
     const float* k1 = kfsal_at(a, bc.cur_prev);
     const float* k7 = kfsal_at(a, bc.cur_prev ^ 1);
     int slot = bc.nsaved0;
-    for (int is = bc.isave0; is < a.nsave && a.saveat[is] <= bc.t_new; ++is, ++slot) {
+    for (int is = bc.isave0; is < bc.isave1; ++is, ++slot) {
       const float ts = a.saveat[is];
       float* dst = a.u_saved + (size_t)slot * a.B * a.m.D;
       if (ts != bc.t_new) {
@@ -703,14 +743,12 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
   if (!bc.do_step) return;
 
   const float t = bc.t, dt = bc.dt;
-  const float* uprev = ubuf_at(a, bc.cur);
-  const float* k1 = kfsal_at(a, bc.cur);
   const float c1 = (float)Tsit5::C[0], c2 = (float)Tsit5::C[1], c3 = (float)Tsit5::C[2],
               c4 = (float)Tsit5::C[3];
   double aerr = 0.0, anum = 0.0, aden = 0.0;
   const TileIOQ io = make_tile_io_q(a, b0, nvalid);
-  f32x4* kl = q_extra_smem(s);  // [7][KL] stage operands
-  const int KL = a.m.KQ1p * 4;
+  const f32x4* klu = kl + (bc.cur ? 2 : 0) * KL;  // the pair the prologue chose
+  const f32x4* klk = kl + (bc.cur ? 3 : 1) * KL;
   const int o_up = arr_off(a, bc.cur), o_un = arr_off(a, bc.cur ^ 1);
   const int o_k1 = arr_off(a, 2 + bc.cur), o_k7 = arr_off(a, 2 + (bc.cur ^ 1));
   const int o_g6 = arr_off(a, 9);
@@ -718,15 +756,28 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
   {  // x2 = uprev + (dt*a21)*k1   (src/perform_step.jl:11-12)
     const float a21dt = dt * (float)Tsit5::A[0];
     q_tile_foreach(a.m, b0, nvalid, KQ1, [&](int kq, int sidx, bool valid, size_t g) {
-      f32x4 x = {0.f, 0.f, 0.f, 0.f}, u = x, f = x;
-      if (valid) {
-        u = ld4(uprev + g); f = ld4(k1 + g);
-#pragma unroll
-        for (int h = 0; h < 4; ++h) x[h] = u[h] + a21dt * f[h];
+#ifdef LRNDE_DBG_RELOAD
+      {  // diagnostic: compare the preloaded pair with what global memory holds now; count the quads that differ
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 ug = valid ? ld4(ubuf_at(a, bc.cur) + g) : z, fg = valid ? ld4(kfsal_at(a, bc.cur) + g) : z;
+        const f32x4 ul = klu[kq * 4 + sidx], fl = klk[kq * 4 + sidx];
+        bool bad = false;
+        for (int h = 0; h < 4; ++h) bad = bad || __builtin_bit_cast(unsigned, ug[h]) != __builtin_bit_cast(unsigned, ul[h]) || __builtin_bit_cast(unsigned, fg[h]) != __builtin_bit_cast(unsigned, fl[h]);
+        if (bad) { atomicAdd(&g_dbg_bad[0], 1); atomicMax(&g_dbg_bad[1], kq * 4 + sidx); atomicMin(&g_dbg_bad[2], kq * 4 + sidx); atomicAdd(&g_dbg_bad[3 + (bc.cur & 1)], 1); }
       }
+#endif
+#ifdef LRNDE_NO_PRELOAD
+      {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const_cast<f32x4*>(klu)[kq * 4 + sidx] = valid ? ld4(ubuf_at(a, bc.cur) + g) : z;
+        const_cast<f32x4*>(klk)[kq * 4 + sidx] = valid ? ld4(kfsal_at(a, bc.cur) + g) : z;
+      }
+#endif
+      const f32x4 u = klu[kq * 4 + sidx], f = klk[kq * 4 + sidx];  // (zeros in the columns past the batch)
+      f32x4 x;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) x[h] = u[h] + a21dt * f[h];
       s.xl[kq * 4 + sidx] = x;
-      kl[kq * 4 + sidx] = u;
-      kl[KL + kq * 4 + sidx] = f;
     });
   }
   __syncthreads();
@@ -738,7 +789,7 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
     _Pragma("unroll") for (int qq = 0; qq < 5; ++qq) e.off_k[1 + qq] = arr_off(a, 4 + qq); \
     e.off_out = arr_off(a, 4 + (S - 2));                                                \
     e.off_x = (S == 6) ? o_un : ((S == 5 && a.want_stiff) ? o_g6 : -1);                 \
-    e.dt = dt; e.xl = s.xl; e.KQ1 = KQ1; e.kl = kl; e.KL = KL; e.store_k = bc.store_k;  \
+    e.dt = dt; e.xl = s.xl; e.KQ1 = KQ1; e.kl = kl; e.KL = KL; e.klu = klu; e.klk = klk; e.store_k = bc.store_k;  \
     feval_qs<EpiStageQ<S>, (QSB * (S - 2)) % QRING, KT>(a.m, s, fc, (TS), e);                 \
     STAMP(11 + S);                                                                      \
   } while (0)
@@ -756,7 +807,7 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
   ef.dt = dt; ef.abstol = a.abstol; ef.reltol = a.reltol; ef.want_stiff = a.want_stiff; ef.nvalid = nvalid;
   ef.D = a.m.D;
   ef.aerr = &aerr; ef.anum = &anum; ef.aden = &aden;
-  ef.xl = s.xl; ef.kl = kl; ef.KL = KL;
+  ef.xl = s.xl; ef.kl = kl; ef.KL = KL; ef.klu = klu; ef.klk = klk;
   ef.rec = a.dense != nullptr && a.dense_direct && bc.dense_slot >= 0; ef.nstB = (int)(a.n_local * 4);
   ef.rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dense + (size_t)(ef.rec ? bc.dense_slot : 0) * 8 * (size_t)a.n_local), 0,
                                              (int)(a.n_local * 32), 0x00020000);
