@@ -1048,6 +1048,17 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a_, int j, Bcast* 
     c.dtpropose = dt;
   } else {
     PSTAMP(1);
+    // What does not depend on the error norm is computed while the partial sums are still on their way: the controller's
+    // qold^beta2, and everything the ACCEPTED branch needs about the new time (the snap onto t1, its eps floor, the saveat
+    // points it passes).  Same expressions as before, earlier.
+    const float pq = a.exact_pow ? (float)pow((double)c.qold, (double)beta2) : fastpow(c.qold, beta2);
+    const float ttmp = c.t + c.dt;
+    const float t_acc = (__builtin_fabsf(ttmp - a.t1) < 100.0f * eps_f(fmaxf_(c.t, a.t1))) ? a.t1 : ttmp;
+    const float floor_acc = fmaxf_(eps_f(t_acc), dtmin);
+    int is_acc = c.isave, ns_acc = c.nsaved;
+    while (is_acc < a.nsave && saveat_at(is_acc) <= t_acc) { ++is_acc; ++ns_acc; }
+    if (a.save_everystep) ++ns_acc;
+    __builtin_amdgcn_sched_barrier(0);
     const Sum3 sr = part_finish<false>(pl, ppart, a.nwg_global);
     PSTAMP(2);
     const float eest = rms_from(sr.a, a.n_global);
@@ -1057,13 +1068,8 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a_, int j, Bcast* 
     if (eest == 0.0f) {
       q = 1.0f / qmax;
     } else {
-      if (a.exact_pow) {
-        c.q11 = (float)pow((double)eest, (double)beta1);
-        q = c.q11 / (float)pow((double)c.qold, (double)beta2);
-      } else {
-        c.q11 = fastpow(eest, beta1);
-        q = c.q11 / fastpow(c.qold, beta2);
-      }
+      c.q11 = a.exact_pow ? (float)pow((double)eest, (double)beta1) : fastpow(eest, beta1);
+      q = c.q11 / pq;
       q = fmaxf_(1.0f / qmax, fminf_(1.0f / qmin, q / gamma));
     }
     accepted = (eest <= 1.0f);
@@ -1078,19 +1084,16 @@ __device__ __forceinline__ void step_prologue(const StepArgs& a_, int j, Bcast* 
       c.naccept++;
       const float dtnew = c.dt / q;
       c.qold = fmaxf_(eest, qoldinit);
-      const float ttmp = c.t + c.dt;
       b.tprev = c.t; b.dt_prev = c.dt;
-      t = (__builtin_fabsf(ttmp - a.t1) < 100.0f * eps_f(fmaxf_(c.t, a.t1))) ? a.t1 : ttmp;
-      c.dtpropose = fmaxf_(fminf_(dtmax, dtnew), fmaxf_(eps_f(t), dtmin));
+      t = t_acc;
+      c.dtpropose = fmaxf_(fminf_(dtmax, dtnew), floor_acc);
       b.accepted_prev = 1; b.t_new = t;
       if (a.dense) {
         b.dense_idx = c.naccept - 1;
         if (b.dense_idx >= a.dense_cap) { c.status = LRNDE_CAPACITY; b.accepted_prev = 0; b.dense_idx = -1; }
       }
       // savevalues!: count what this step saves (performed by all threads afterwards)
-      int is = c.isave, ns = c.nsaved;
-      while (is < a.nsave && saveat_at(is) <= t) { ++is; ++ns; }
-      if (a.save_everystep) ++ns;
+      const int is = is_acc, ns = ns_acc;
       if (ns > a.cap_saved) c.status = LRNDE_CAPACITY, b.accepted_prev = 0;
       else { c.isave = is; c.nsaved = ns; b.isave1 = is; }
     } else {

@@ -113,13 +113,14 @@ LRNDE_HD float fastpow(float x, float y) {
 }
 
 // Julia eps(::Float32) by bit manipulation
-LRNDE_HD float eps_f(float x) {
+LRNDE_HD float eps_f(float x) {  // (selects, no branches: it sits in the step kernel's decision chain)
   const uint32_t b = f2u(x) & 0x7fffffffu;
   const uint32_t e = b >> 23;
-  if (e == 0xffu) return u2f(0x7fc00000u);
-  if (e == 0u) return u2f(1u);
-  if (e <= 23u) return u2f(1u << (e - 1u));
-  return u2f((e - 23u) << 23);
+  uint32_t r = (e - 23u) << 23;
+  r = (e <= 23u) ? (1u << ((e - 1u) & 31u)) : r;
+  r = (e == 0u) ? 1u : r;
+  r = (e == 0xffu) ? 0x7fc00000u : r;
+  return u2f(r);
 }
 
 LRNDE_HD float fminf_(float a, float b) { return __builtin_fminf(a, b); }
