@@ -92,14 +92,14 @@ def measured_traffic(key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=512, help="columns per GPU (weak scaling)")
     ap.add_argument("--tol", type=float, default=1.4e-8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=512)
     ap.add_argument("--no-conv", action="store_true", help="skip the 28x28 conv-field side measurement of the default run")
-    ap.add_argument("--adjoint-steps", type=int, default=5, help="timed forward+adjoint passes (single GPU)")
+    ap.add_argument("--adjoint-steps", type=int, default=10, help="timed forward+adjoint passes (single GPU)")
     ap.add_argument("--workload", default="mlp", choices=["mlp", "cifar_conv_bf16", "cifar_conv_f32", "cifar_conv_f32_split", "mnist_conv_f32", "mnist_conv_f32_split", "mnist_sde"],  # *_split: opt-in fast mode, never part of the default line
                     help="mlp: the headline MNIST-ODE MLP field (default).  The conv workloads time the CIFAR10 node_core "
                          "(BASELINE.json configs 4 and 2-ii); single GPU.")
@@ -182,10 +182,13 @@ def main():
             fw_t.append(times["fwd_time"]); bw_t.append(times["bwd_time"])
         fwd_adj_ms = (sum(fw_t) + sum(bw_t)) / args.adjoint_steps * 1e3
         bwd_stats = {"train_fwd_ms": sum(fw_t) / len(fw_t) * 1e3, "train_bwd_ms": sum(bw_t) / len(bw_t) * 1e3,
+                     "train_fwd_ms_median": float(np.median(fw_t)) * 1e3, "train_bwd_ms_median": float(np.median(bw_t)) * 1e3,
                      "adjoint_naccept": times["adjoint"]["naccept"], "adjoint_nreject": times["adjoint"]["nreject"],
                      "adjoint_nf": times["adjoint"]["nf"], "loss": float(loss), "w_reg": 2.5,
-                     "what": "run_training_step: node forward with dense record + Dense(784=>10) + logitcrossentropy, "
-                             "then continuous adjoint + regulariser sweep + classifier cotangents"}
+                     "what": "run_training_step: node forward with dense record + Dense(784=>10) + logitcrossentropy "
+                             "(the regulariser's reverse sweep depends on the forward alone and runs on the handle's companion "
+                             "stream from the moment sol(t1) exists, beside the rest of the solve), then continuous adjoint + "
+                             "classifier cotangents + the sweep's gradient added"}
 
     # roofline leg: the dominant kernel (one full Tsit5 step per launch).  Two HIP-event clocks on the handle's stream:
     #  (a) us_per_launch: 100 back-to-back launches of the step kernel on fixed inputs (lrnde_bench_step) — the number
@@ -196,7 +199,8 @@ def main():
     #      (profiles/r2/README.md compares the three).
     k1 = h.rhs(x, 0.0)
     dt_typ = float(r["stats"]["dt_final"]) if r["stats"]["dt_final"] > 0 else 0.02
-    us = h.bench_step(x, k1, 0.0, dt_typ, args.tol, args.tol, reps=100)
+    us_batches = sorted(h.bench_step(x, k1, 0.0, dt_typ, args.tol, args.tol, reps=100) for _ in range(5))
+    us = us_batches[2]  # median of five batches of 100 launches (each batch: one HIP-event pair, mean over its launches)
     flop_per_launch = 6 * FLOP_PER_FEVAL_PER_COL * args.batch
     achieved = flop_per_launch / (us * 1e-6) / 1e12
     rs = one_pass(args.warmup + args.steps - 1)
@@ -230,7 +234,7 @@ def main():
                      "traffic": measured_traffic(f"k_step_q_b{args.batch}") if world == 1 else None,
                      "kernel": "k_step_q<false, 1> (one attempted Tsit5 step: 6 f-evals, fused stage combination, error norm)"
                                if args.batch <= 2048 else "k_step<4,false>",
-                     "us_per_launch": us, "flop_per_launch": flop_per_launch,
+                     "us_per_launch": us, "us_per_launch_batches": us_batches, "flop_per_launch": flop_per_launch,
                      "in_solve": {"solve_kernel_ms": solve_ms, "step_launches": solve_launches, "full_steps": full_steps,
                                   "us_per_full_step": solve_ms * 1e3 / max(full_steps, 1),
                                   "what": "HIP events around all kernels of one adaptive solve (2 init + steps + terminal/"

@@ -108,7 +108,10 @@ int lrnde_init_dt(lrnde_ctx* ctx, const float* u0, int32_t B, float t0, float te
 /* `_perform_step(integrator, cache::Tsit5ConstantCache, p, Val(reg_type))`,
  * src/perform_step.jl:3-47.  Reads uprev, k1 (= integrator.fsalfirst), t, dt;
  * writes u and k7 (= integrator.fsallast); returns EEst and both regularisation
- * values on the host (reg_error = EEst*dt, :34-38; reg_stiff, :40-47). */
+ * values on the host (reg_error = EEst*dt, :34-38; reg_stiff, :40-47).  The
+ * reference's tuple (u, reg_val, 6 + sol.destats.nf, dt), :31, is these plus two
+ * constants of the call: the step costs 6 f-evals and does not change dt
+ * (julia/LRNDEBackend.jl `_perform_step`; lrnde_node_forward adds the 6 + 3 itself). */
 int lrnde_perform_step(lrnde_ctx* ctx, const float* uprev, const float* k1, int32_t B, float t,
                        float dt, float abstol, float reltol, float* u, float* k7,
                        float* eest_host, float* reg_error_host, float* reg_stiff_host);

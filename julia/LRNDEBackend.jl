@@ -90,6 +90,13 @@ function perform_step(ctx, uprev, k1, t, dt, abstol, reltol)
     return u, k7, ee[], re[], rs[]
 end
 
+# the reference's own return tuple, src/perform_step.jl:31: (u, reg_val, 6 + integrator.sol.destats.nf, dt) — the step
+# costs six f-evals (k2..k7; k1 is fsalfirst) and leaves integrator.dt as it was
+function _perform_step(ctx, uprev, k1, t, dt, abstol, reltol, ::Val{RT}, nf_sol::Integer) where {RT}
+    u, _, _, re, rs = perform_step(ctx, uprev, k1, t, dt, abstol, reltol)
+    return u, (RT === :stiffness_estimate ? rs : re), 6 + nf_sol, dt
+end
+
 # (n::NeuralODE{R,RT})(x, ps, st) — src/layers/neural_ode.jl:56-100; t1_or_rand: t1 for :unbiased, rand for :biased
 function node_forward(ctx, x, t0, t2, opts::SolveOpts, mode::Symbol, reg_type::Symbol, t1_or_rand)
     u_end = similar(x); reg = Ref{Float32}(); nfe = Ref{Int32}(); st = Stats(); t1 = Ref{Float32}()
