@@ -34,6 +34,10 @@ int lrnde_bench_step(lrnde_ctx* ctx, const float* uprev, const float* k1, int32_
                      float abstol, float reltol, int32_t reps, float* avg_us_host);
 /* HIP events on the handle's stream around the kernels of the last solve (ms), and its step-kernel launches */
 int lrnde_last_solve_kernel_ms(lrnde_ctx* ctx, float* total_ms_host, int32_t* step_launches_host);
+/* Diagnostic: 0 = the layer forward keeps its local step (and the recorded forward's regulariser sweep) in order on the
+ * handle's stream instead of its companion stream; 1 = overlap (the default for unsharded handles).
+ * Results are the same bits either way — tests/test_gpu_overlap.py holds the library to that. */
+int lrnde_set_overlap(lrnde_ctx* ctx, int32_t on);
 /* average microseconds of one f-eval (3 conv + 2 batch-norm statistics launches), HIP events */
 int lrnde_conv_bench_rhs(lrnde_conv* c, const float* u, float t, int32_t B, int32_t reps, float* us_host);
 

@@ -1811,7 +1811,7 @@ struct lrnde_ctx {
   // layer forward runs its local step there (and, recording, the regulariser's reverse sweep) WHILE the main solve
   // finishes [t1, t2] on the handle's stream: at B <= 512 a step kernel is 128 workgroups, half of the chip.
   lrnde_ctx* side = nullptr;
-  bool is_side = false, side_busy = false, rec_gr_ready = false;
+  bool is_side = false, side_busy = false, rec_gr_ready = false, overlap_off = false;
   hipEvent_t ev_side_local = nullptr, ev_side_sweep = nullptr;
   float* tail_copy_dst = nullptr; const float* tail_copy_src = nullptr;  // lrnde_solve: one D2D copy enqueued before its final sync
   std::function<int(int, hipEvent_t)> poll_hook;  // lrnde_solve calls it after every status poll (event: that poll's)
@@ -2648,7 +2648,7 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
       }
       return LRNDE_OK;
     };
-    if (!sharded(c) && !no_overlap && pos >= 0 && sv[pos] == t1) {
+    if (!sharded(c) && !no_overlap && !c->overlap_off && pos >= 0 && sv[pos] == t1) {
       if ((rc = side_get(c, B, &sd))) return rc;
       c->poll_hook = [&](int nsaved_done, hipEvent_t ev) { return side_advance(nsaved_done, ev); };
     }
@@ -2783,6 +2783,14 @@ int lrnde_comm_init_local(lrnde_ctx* c, lrnde_local_comm* lc, int32_t rank) {
   c->lcomm = lc; c->rank = rank; c->nranks = lc->n;
   c->prered = getenv("LRNDE_GATHER_TILES") == nullptr;
   c->wsB = 0;  // partial vectors are sized by nranks
+  return LRNDE_OK;
+}
+
+int lrnde_set_overlap(lrnde_ctx* c, int32_t on) {
+  if (!c) return LRNDE_BADARG;
+  const int rc = side_quiesce(c);
+  if (rc) return rc;
+  c->overlap_off = !on;
   return LRNDE_OK;
 }
 

@@ -311,6 +311,10 @@ class Handle:
                                          float(t), float(dt), float(abstol), float(reltol), int(reps), C.byref(us)))
         return float(us.value)
 
+    def set_overlap(self, on):
+        """diagnostic (lrnde_hooks.h): False keeps the layer forward's local step / regulariser sweep on the handle's own stream"""
+        self._chk(L.lib.lrnde_set_overlap(self._ctx, 1 if on else 0))
+
     def last_solve_kernel_ms(self):
         ms, n = C.c_float(), C.c_int32()
         L.lib.lrnde_last_solve_kernel_ms(self._ctx, C.byref(ms), C.byref(n))

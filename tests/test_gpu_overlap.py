@@ -1,0 +1,59 @@
+"""The layer forward runs its local step — and, recording, the regulariser's reverse sweep — on the handle's companion
+stream while the main solve is still integrating [t1, t2].  Same kernels on the same inputs: every
+output must be the SAME BITS as with everything in order on one stream (lrnde_set_overlap(0), include/lrnde_hooks.h)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(P, B, seed):
+    import torch
+    D, H, K = 784, 100, 10
+    model = P.TDChain(P.Chain(P.Dense(D + 1, H, "tanh"), P.Dense(H + 1, D)))
+    rng = np.random.default_rng(seed)
+    ps = torch.from_numpy(P.glorot_params(model, seed=seed)).cuda()
+    pc = torch.from_numpy((rng.standard_normal(K * (D + 1)) * 0.05).astype(np.float32)).cuda()
+    x = torch.from_numpy(rng.random((B, D), dtype=np.float32)).cuda()
+    lab = torch.from_numpy(rng.integers(0, K, B).astype(np.int32)).cuda()
+    return model, ps, pc, x, lab
+
+
+@pytest.mark.parametrize("t1", [0.03, 0.5, 0.97, 1.0])   # early, middle, inside the last steps, t1 == t2
+@pytest.mark.parametrize("reg_type", ["error_estimate", "stiffness_estimate"])
+def test_forward_same_bits_with_and_without_the_companion_stream(gpu_pkg, t1, reg_type):
+    import torch
+    P = gpu_pkg
+    model, ps, _, x, _ = _setup(P, 96, 3)
+    from localregneuralde_jl_amd.layers import Handle, _mlp_desc
+    h = Handle(_mlp_desc(model)); h.set_params(ps)
+    out = []
+    for on in (True, False, True):
+        h.set_overlap(on)
+        out.append(h.node_forward(x, 0.0, 1.0, 1e-5, 1e-5, mode="unbiased", reg_type=reg_type, t1_or_rand=t1, maxiters=2000))
+    for o in out[1:]:
+        assert torch.equal(o["u_end"], out[0]["u_end"])
+        assert o["reg_val"] == out[0]["reg_val"] and o["nfe"] == out[0]["nfe"] and o["stats"] == out[0]["stats"]
+
+
+@pytest.mark.parametrize("saveat", [None, [0.25, 0.5, 1.0]])
+def test_training_step_same_bits_with_and_without_the_companion_stream(gpu_pkg, saveat):
+    import torch
+    P = gpu_pkg
+    model, ps, pc, x, lab = _setup(P, 64, 5)
+    res = []
+    for on in (True, False):
+        kw = {} if saveat is None else {"saveat": saveat}
+        node = P.NeuralODE(model, regularize="unbiased", abstol=1e-5, reltol=1e-5, save_start=False, maxiters=2000, **kw)
+        st = node.initialstates(np.random.default_rng(0))
+        node._bind(ps, x).set_overlap(on)
+        if saveat is None:
+            loss, _, _, grads, _ = P.run_training_step(node, ps, pc, st, x, lab, 2.5)
+            res.append((loss, grads))
+        else:   # the layer's saveat kwarg: one cotangent per state of the series (src/utils.jl:25-46)
+            du = torch.stack([torch.full_like(x, 0.01 * (i + 1)) for i in range(len(saveat))])
+            dx, dp, info = node.pullback(x, ps, st, du, w_reg=2.5)
+            res.append((float(info["reg_val"]), {"dx": dx, "dp": dp}))
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
