@@ -960,10 +960,14 @@ __device__ __forceinline__ float init_dt_final3(const Sum3& r1, const Sum3& r2, 
 }
 
 // Progress of a solve, for the host loop that keeps the stream fed (lrnde_solve): ONE 64-bit store per launch into
-// pinned host memory — [launches run : 24][status : 8][saves completed : 16][steps still to go at this dt : 16].  A
-// posted write: the wave does not wait for it, and the host only steers by it (how many launches to enqueue next, when
-// to start the companion's local step); everything it reports is read after the stream has been synchronised.  A
-// finished solve also leaves its control block in host memory, so the host needs no copy packet on the stream.
+// pinned host memory — [launches run : 24][status : 8][saves completed : 16][steps still to go at this dt : 16] — into
+// slot (launch index mod PROG_RING) of a small ring, so the host can read the report of EVERY launch, in order: a
+// batch-sharded run needs that (all ranks must steer by the same launch's report or their collective counts drift
+// apart), and each entry validates itself by the launch count it carries.  A posted write: the wave does not wait for
+// it, and the host only steers by it (how many launches to enqueue next, when to start the companion's local step);
+// everything it reports is read after the stream has been synchronised.  A finished solve also leaves its control block
+// in host memory, so the host needs no copy packet on the stream.
+constexpr int PROG_RING = 32;  // > the deepest queue the host keeps (16 launches ahead of the last report it has read)
 template <class A> __device__ __forceinline__ void solve_progress(const A& a, int j, const CtrlHead& c, int nsaved_done, float steps_left) {
   if (!a.prog) return;
   if (c.status != ST_RUNNING) *reinterpret_cast<CtrlHead*>(a.fin_host) = c;
@@ -972,7 +976,7 @@ template <class A> __device__ __forceinline__ void solve_progress(const A& a, in
   const unsigned long long nsv = (unsigned long long)(nsaved_done > 65535 ? 65535 : nsaved_done);
   const float sl = __builtin_ceilf(steps_left);
   const unsigned long long rem = (unsigned long long)(sl > 65535.f ? 65535 : (sl > 0.f ? (int)sl : 0));
-  __hip_atomic_store(a.prog, cnt | (stt << 24) | (nsv << 32) | (rem << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(a.prog + (j & (PROG_RING - 1)), cnt | (stt << 24) | (nsv << 32) | (rem << 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // the launch arguments step_prologue works with (see there), each forced into a vector register
@@ -2352,8 +2356,8 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
     c->tsaved_cap = cap;
   }
   if (!c->prog_host) {
-    HIPCHK(c, hipHostMalloc(&c->prog_host, 64 + sizeof(Ctrl), hipHostMallocMapped));
-    memset(c->prog_host, 0, 64 + sizeof(Ctrl));
+    HIPCHK(c, hipHostMalloc(&c->prog_host, PROG_RING * 8 + sizeof(Ctrl), hipHostMallocMapped));
+    memset(c->prog_host, 0, PROG_RING * 8 + sizeof(Ctrl));
     HIPCHK(c, hipHostGetDevicePointer((void**)&c->prog_dev, c->prog_host, 0));
   }
   if (trace_host && cap_trace > c->trace_cap) {
@@ -2393,17 +2397,13 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
     si.save_start = 1;
     nsaved0 = 1;
   }
-  // unsharded: the prologue reports to pinned host memory and the loop below steers by that word; sharded handles keep
-  // the status copy one chunk behind (every rank must take its decisions from the SAME launch's state, or the ranks'
-  // launch — and collective — counts would drift apart)
-  const bool by_word = !sharded(c);
+  // the prologue reports to pinned host memory (solve_progress) and the loop below steers by those reports, one per
+  // launch, read in launch order — the same sequence of decisions on every rank of a sharded run
   volatile unsigned long long* pw = c->prog_host;
-  Ctrl* fin_host = reinterpret_cast<Ctrl*>(reinterpret_cast<char*>(c->prog_host) + 64);
-  if (by_word) {
-    *pw = 0ull;
-    a.prog = c->prog_dev;
-    a.fin_host = reinterpret_cast<Ctrl*>(reinterpret_cast<char*>(c->prog_dev) + 64);
-  }
+  Ctrl* fin_host = reinterpret_cast<Ctrl*>(reinterpret_cast<char*>(c->prog_host) + PROG_RING * 8);
+  for (int i = 0; i < PROG_RING; ++i) pw[i] = 0ull;
+  a.prog = c->prog_dev;
+  a.fin_host = reinterpret_cast<Ctrl*>(reinterpret_cast<char*>(c->prog_dev) + PROG_RING * 8);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   hipLaunchKernelGGL(k_solve_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t0, nsaved0, si);
@@ -2414,12 +2414,12 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   // needed, estimated from the polled (t, dt); launches beyond it are speculative (k_step<.,true>).
   const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
   int j = 0, pending = -1, pending_j = 0, launches = 0, target = 4, nchunk = 0;
-  bool done = false, word_ok = by_word;
+  bool done = false, word_ok = true;
   const long hard_cap = (long)o->maxiters + 8;
-  if (word_ok) {
-    // Report-driven feed: after every report keep enqueued what it says is still to come at the current dt (an
-    // over-estimate while dt grows, exact for the last step, whose dt is clipped to t1 - t), the launch that will find the
-    // solve finished, and never fewer than two launches beyond the reporting one — so the stream neither runs dry nor
+  {
+    // Report-driven feed: after the report of launch `seen - 1` keep enqueued what it says is still to come at the current
+    // dt (an over-estimate while dt grows, exact for the last step, whose dt is clipped to t1 - t), the launch that will find
+    // the solve finished, and never fewer than two launches beyond the reporting one — so the stream neither runs dry nor
     // ends with a tail of launches that have nothing to do.
     int seen = 0, rem = 3;
     while (!done) {
@@ -2430,19 +2430,23 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
       for (const int want = seen + ahead; j < want; ++j) {
         if ((rc = launch_step(c, B, a, j, j >= certain))) return rc;
         ++launches;
+        const size_t par = (size_t)((j + 1) & 1);
+        if ((rc = exchange(c, c->part + par * cnt, c->part_rx + par * cnt, cnt))) return rc;
       }
       if (j > hard_cap + 64) break;
-      unsigned long long w = *pw;
-      for (long spin = 1; (int)(w & 0xffffffull) <= seen; ++spin) {
+      // the report of launch `seen` (it carries seen + 1 as its launch count)
+      volatile unsigned long long* slot = pw + (seen & (PROG_RING - 1));
+      unsigned long long w = *slot;
+      for (long spin = 1; (int)(w & 0xffffffull) != seen + 1; ++spin) {
         if ((spin & 0x3fff) == 0 && hipStreamQuery(c->stream) == hipSuccess) {
-          w = *pw;
-          if ((int)(w & 0xffffffull) <= seen) word_ok = false;  // the stream drained and the word did not move: poll by copies
+          w = *slot;
+          if ((int)(w & 0xffffffull) != seen + 1) word_ok = false;  // the stream drained and no report came: poll by copies
           break;
         }
-        w = *pw;
+        w = *slot;
       }
       if (!word_ok) break;
-      seen = (int)(w & 0xffffffull);
+      ++seen;
       rem = (int)((w >> 48) & 0xffff);
       if (c->poll_hook && (rc = c->poll_hook((int)((w >> 32) & 0xffff), nullptr))) return rc;
       if ((int)((w >> 24) & 0xff) != (ST_RUNNING & 0xff)) done = true;
