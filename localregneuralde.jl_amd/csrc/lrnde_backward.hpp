@@ -658,14 +658,49 @@ static size_t smem_bytes_vq(int KQ1p, int KQ2p, int RG1, int RG2) {
 // fills the decision-dependent fields of `a` for a launch of the adjoint loop; false: nothing to do (solve finished)
 // For stages 3..7 the control block is requested at the head of the kernel (`early`, thread 0) and consumed here, after
 // the LDS initialisation and the first weight-stream requests: its round trip hides behind them.
-__device__ __forceinline__ bool vjp_q_resolve(VjpQArgs& a, const AdjCtrl& early) {
+// what a stage-3..7 launch needs of the attempt's control block (published by the stage-2 launch): read by every thread
+// through the uniform pointer at the head of the kernel — scalar loads, no private copy of the 172-byte block (it lived
+// in scratch), no hop through LDS, no barrier
+struct AdjEarly { int do_step, cur; float dt; int lo; float theta, ddt, t; };
+__device__ __forceinline__ AdjEarly adj_early_load(const VjpQArgs& a) {
+  AdjEarly e;
+  e.do_step = 1; e.cur = 0; e.dt = 0.f; e.lo = 0; e.theta = 0.f; e.ddt = 0.f; e.t = 0.f;
+  if (a.adj_mode == ADJ_STAGE && a.adj_stage > 2) {
+    const AdjCtrl* cp = a.adj.ctl + ((a.adj_j + 1) & 1);
+    const AdjStage* sp = &cp->st[a.adj_stage - 2];
+    e.do_step = cp->do_step; e.cur = cp->cur; e.dt = cp->dt;
+    e.lo = sp->lo; e.theta = sp->theta; e.ddt = sp->ddt; e.t = sp->t;
+  }
+  return e;
+}
+__device__ __forceinline__ bool vjp_q_resolve(VjpQArgs& a, const AdjEarly& early) {
   if (a.adj_mode == ADJ_HOST) return true;
   __shared__ AdjCtrl sh_c;
   const AdjArgs& g = a.adj;
   if (a.adj_mode == ADJ_STAGE && a.adj_stage > 2) {
-    // control block of this attempt, published by the stage-2 launch
-    if (threadIdx.x == 0) sh_c = early;
-  } else if (threadIdx.x < 64) {
+    if (!early.do_step) return false;
+    const int cur = early.cur;
+    const size_t nst = g.n_lam;
+    const int sidx = a.adj_stage;
+    a.y = nullptr;
+    a.dense = g.dense + (size_t)early.lo * 8 * nst; a.theta = early.theta; a.dense_dt = early.ddt; a.t = early.t;
+    a.lbase = adj_zb(g, cur); a.ldt = early.dt; a.lnk = sidx - 1;
+    // row sidx of the tableau; terms beyond the row: the base vector with coefficient 0 (adds +-0, as the host path does)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      float v = 0.0f;
+#pragma unroll
+      for (int ss = 3; ss <= 7; ++ss) if (ss == sidx && q < ss - 1) v = (float)Tsit5::A[(ss - 2) * (ss - 1) / 2 + q];
+      const bool on = q < sidx - 1;
+      a.lk[q] = on ? adj_K(g, q, cur) : a.lbase;
+      a.lc[q] = v;
+    }
+    a.lam_out = adj_stage_lam(g, sidx, cur);
+    a.lam = a.lam_out;
+    a.dy = adj_K(g, sidx - 1, cur);
+    return true;
+  }
+  if (threadIdx.x < 64) {
     AdjCtrl c;
     if (a.adj_mode == ADJ_STAGE) {
       c = adj_prologue(g, a.adj_j);
@@ -725,15 +760,24 @@ __device__ __forceinline__ bool vjp_q_resolve(VjpQArgs& a, const AdjCtrl& early)
   return true;
 }
 
+#ifdef LRNDE_STAMPS
+__device__ unsigned long long g_vstamps[16];  // tools/vjp_probe: phases of a stage-5 launch of the adjoint loop (workgroup 0)
+#define VSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && vst_on) g_vstamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VSTAMP(i) do { } while (0)
+#endif
 template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
-  AdjCtrl early;
-  if (a.adj_mode == ADJ_STAGE && a.adj_stage > 2 && threadIdx.x == 0) early = a.adj.ctl[(a.adj_j + 1) & 1];
+#ifdef LRNDE_STAMPS
+  const bool vst_on = a.adj_mode == ADJ_STAGE && a.adj_stage == 5;
+#endif
+  VSTAMP(0);
+  const AdjEarly early = adj_early_load(a);
   const ModelDev& m = a.m;
+  const BiasPreQ bpre = bias_issue_q(m);  // in flight while the weight stream is set up; written to LDS below
   const SmemQ s = carve_q(m);
   // extra LDS behind the forward layout: the lambda tile and act'(pre)
   f32x4* ll = q_extra_smem(s);
   float* dact = reinterpret_cast<float*>(ll + (size_t)m.KQ1p * 4);
-  smem_init_q(m, s);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sidx = lane & 3, q = lane >> 2;
@@ -759,61 +803,90 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
     vq_stream_load<0, 0>(st);
     vq_stream_load<1, 1>(st);
   }
+  smem_zero_q(m, s);
   for (int i = threadIdx.x; i < (m.KQ1p - KQ1) * 4; i += QNT) ll[KQ1 * 4 + i] = zero4;
   // adjoint loop: decision-dependent arguments from the control block (a barrier inside; nothing to do -> leave, the
   // outstanding weight requests are simply dropped with the wave)
+  VSTAMP(1);
   if (!vjp_q_resolve(a, early)) return;
+  VSTAMP(2);
   // ---- phase 0: y tile (given or interpolated) and lambda tile -> LDS; y -> scratch ----
+  // Both passes of the tile walk (KQ1 * 4 <= 784 quads over 448 threads) put ALL their loads in flight — up to 15 arrays
+  // each: the record's (y0, k1..k7), the stage base and six K vectors — before the first store.  As a loop with the
+  // stores in program order it was four memory round trips in series (per pass: record, store y, then the lambda terms,
+  // whose loads could not move above a store that might alias them): 13.5 k of the launch's 44 k cycles.
   float bw[7];
   if (!a.y) tsit5_bweights(a.theta, bw);
   __syncthreads();
-  q_tile_foreach(m, b0, nvalid, KQ1, [&](int kq, int sx, bool valid, size_t g) {
-    f32x4 x = zero4, lv = zero4;
-    if (valid) {
+  {
+    const size_t nst = (size_t)a.B * m.D;
+    bool in[2], ok[2]; size_t gg[2]; int li[2];
+    f32x4 dv[2][8], bs[2], kv[2][6];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int i = (int)threadIdx.x + r * QNT;
+      const int sx = i & 3, kq = i >> 2;
+      in[r] = i < KQ1 * 4; ok[r] = in[r] && sx < nvalid; li[r] = i;
+      gg[r] = ok[r] ? (size_t)(b0 + sx) * m.D + kq * 4 : 0;   // (masked lanes read element 0 and are zeroed below)
+      const size_t g = gg[r];
       if (a.y) {
-        x = ld4(a.y + g);
+        dv[r][0] = ld4(a.y + g);
       } else {
-        const size_t nst = (size_t)a.B * m.D;
-        const f32x4 y0 = ld4(a.dense + g), v1 = ld4(a.dense + nst + g), v2 = ld4(a.dense + 2 * nst + g),
-                    v3 = ld4(a.dense + 3 * nst + g), v4 = ld4(a.dense + 4 * nst + g), v5 = ld4(a.dense + 5 * nst + g),
-                    v6 = ld4(a.dense + 6 * nst + g), v7 = ld4(a.dense + 7 * nst + g);
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          float sum = v1[h] * bw[0] + v2[h] * bw[1];
-          sum = sum + v3[h] * bw[2];
-          sum = sum + v4[h] * bw[3];
-          sum = sum + v5[h] * bw[4];
-          sum = sum + v6[h] * bw[5];
-          sum = sum + v7[h] * bw[6];
-          x[h] = y0[h] + a.dense_dt * sum;
-        }
+        for (int qq = 0; qq < 8; ++qq) dv[r][qq] = ld4(a.dense + (size_t)qq * nst + g);
       }
-      st4(a.ysc + g, x);
       if (a.lnk > 0) {
-        // six loads in flight at once (terms beyond lnk point at lbase with coefficient 0 and add +-0): a loop with a
-        // runtime trip count serialised one memory round trip per term
-        const f32x4 bs = ld4(a.lbase + g);
-        f32x4 kv[6];
+        // six terms always (those beyond lnk point at lbase with coefficient 0 and add +-0)
+        bs[r] = ld4(a.lbase + g);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) kv[j] = ld4(a.lk[j] + g);
-        f32x4 sacc;
-#pragma unroll
-        for (int h = 0; h < 4; ++h) sacc[h] = a.lc[0] * kv[0][h];
-#pragma unroll
-        for (int j = 1; j < 6; ++j)
-#pragma unroll
-          for (int h = 0; h < 4; ++h) sacc[h] = sacc[h] + a.lc[j] * kv[j][h];
-#pragma unroll
-        for (int h = 0; h < 4; ++h) lv[h] = bs[h] + a.ldt * sacc[h];
-        st4(a.lam_out + g, lv);
+        for (int j = 0; j < 6; ++j) kv[r][j] = ld4(a.lk[j] + g);
       } else {
-        lv = ld4(a.lam + g);
+        bs[r] = ld4(a.lam + g);
       }
     }
-    s.xl[kq * 4 + sx] = x;
-    ll[kq * 4 + sx] = lv;
-  });
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (!in[r]) continue;
+      f32x4 x = zero4, lv = zero4;
+      if (ok[r]) {
+        const size_t g = gg[r];
+        if (a.y) {
+          x = dv[r][0];
+        } else {
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            float sum = dv[r][1][h] * bw[0] + dv[r][2][h] * bw[1];
+            sum = sum + dv[r][3][h] * bw[2];
+            sum = sum + dv[r][4][h] * bw[3];
+            sum = sum + dv[r][5][h] * bw[4];
+            sum = sum + dv[r][6][h] * bw[5];
+            sum = sum + dv[r][7][h] * bw[6];
+            x[h] = dv[r][0][h] + a.dense_dt * sum;
+          }
+        }
+        st4(a.ysc + g, x);
+        if (a.lnk > 0) {
+          f32x4 sacc;
+#pragma unroll
+          for (int h = 0; h < 4; ++h) sacc[h] = a.lc[0] * kv[r][0][h];
+#pragma unroll
+          for (int j = 1; j < 6; ++j)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) sacc[h] = sacc[h] + a.lc[j] * kv[r][j][h];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) lv[h] = bs[r][h] + a.ldt * sacc[h];
+          st4(a.lam_out + g, lv);
+        } else {
+          lv = bs[r];
+        }
+      }
+      s.xl[li[r]] = x;
+      ll[li[r]] = lv;
+    }
+  }
+  bias_write_q(m, s, bpre);  // (first read in epilogue 1)
   __syncthreads();
+  VSTAMP(3);
   const int h64 = m.RG1 * 64;
   const float* w1t = s.bias; const float* b1 = w1t + h64;
   const float* plf = reinterpret_cast<const float*>(s.pl);
@@ -823,6 +896,7 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
   // ---- phase 1: pre = W1 [y;t] + b1 ; h, act' ----
   vq_phase_ksplit<0, KT>(m, s, st, s.xl);
   q_barrier();
+  VSTAMP(4);
   for (int e = threadIdx.x; e < ne; e += QNT) {
     const int r = e & 3, l = (e >> 2) & 63, rg = e >> 8;
     const int o = rg * 64 + (l >> 2) * 4 + r, sx = l & 3;
@@ -835,9 +909,11 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
     if (sx < nvalid && o < m.Hp) a.hsc[(size_t)(b0 + sx) * m.Hp + o] = h;
   }
   q_barrier();
+  VSTAMP(5);
   // ---- phase 2: dh = W2^T lam ; dpre = dh .* act' -> h tile image + scratch ----
   vq_phase_ksplit<QSB1, KT>(m, s, st, ll);
   q_barrier();
+  VSTAMP(6);
   for (int e = threadIdx.x; e < ne; e += QNT) {
     const int r = e & 3, l = (e >> 2) & 63, rg = e >> 8;
     const int o = rg * 64 + (l >> 2) * 4 + r, sx = l & 3;
@@ -848,6 +924,7 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
     if (sx < nvalid && o < m.Hp) a.dpsc[(size_t)(b0 + sx) * m.Hp + o] = dpre;
   }
   q_barrier();
+  VSTAMP(7);
   // ---- phase 3: dy = W1^T dpre (row groups wave and wave + QNW, one chain over K = H) ----
   {
     const f32x4* hp = s.hl + sidx;
@@ -867,6 +944,7 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
       if (g1 < m.RG2 && g1 * 64 + q * 4 < m.D) st4(dst + g1 * 64, acc1);
     }
   }
+  VSTAMP(8);
 }
 
 template <int KT> __global__ __launch_bounds__(QNT) void k_vjp_q(VjpQArgs a) { vjp_q_body<KT>(a); }

@@ -818,6 +818,38 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
   publish_partial(a, (j + 1) & 1, aerr, anum, aden);
 }
 
+// smem_init_q in parts for kernels that have other work to put between them: the bias / time-column loads are issued at
+// the head of the kernel (a round trip to memory), the tiles are cleared at once, and the values are written to LDS only
+// where the kernel first has to wait anyway (they are not read before the first epilogue).  Shape limits of the 4-column family: RG1*64 <= QNT, RG2*64 <= 2*QNT.
+struct BiasPreQ { float w1, b1, w2[2], b2[2]; };
+__device__ __forceinline__ BiasPreQ bias_issue_q(const ModelDev& m) {
+  BiasPreQ p;
+  const int t = (int)threadIdx.x;
+  p.w1 = (t < m.Hp) ? m.w1t[t] : 0.f;
+  p.b1 = (t < m.Hp) ? m.b1[t] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int i = t + r * QNT;
+    p.w2[r] = (i < m.Dp) ? m.w2t[i] : 0.f;
+    p.b2[r] = (i < m.Dp) ? m.b2[i] : 0.f;
+  }
+  return p;
+}
+__device__ __forceinline__ void smem_zero_q(const ModelDev& m, const SmemQ& s) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int i = (int)threadIdx.x; i < (m.KQ1p + m.KQ2p) * 4; i += QNT) s.xl[i] = z;  // xl and hl are adjacent
+}
+__device__ __forceinline__ void bias_write_q(const ModelDev& m, const SmemQ& s, const BiasPreQ& p) {
+  const int t = (int)threadIdx.x;
+  const int h64 = m.RG1 * 64, d64 = m.RG2 * 64;
+  if (t < h64) { s.bias[t] = p.w1; s.bias[h64 + t] = p.b1; }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int i = t + r * QNT;
+    if (i < d64) { s.bias[2 * h64 + i] = p.w2[r]; s.bias[2 * h64 + d64 + i] = p.b2[r]; }
+  }
+}
+
 // flat Lux parameter vector -> quad-tile A layouts (zero padded in k; row groups NOT padded)
 __global__ void k_pack_q(const float* p, int D, int H, int td, int KQ1p, int KQ2p, int RG1, int RG2,
                          float* W1q, float* W2q) {
