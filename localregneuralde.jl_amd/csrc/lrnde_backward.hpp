@@ -836,10 +836,11 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
         for (int qq = 0; qq < 8; ++qq) dv[r][qq] = ld4(a.dense + (size_t)qq * nst + g);
       }
       if (a.lnk > 0) {
-        // six terms always (those beyond lnk point at lbase with coefficient 0 and add +-0)
+        // the lnk real terms only (lnk is launch-uniform: plain branches, no waits between the loads); the others enter
+        // the sum as coefficient 0 times +0
         bs[r] = ld4(a.lbase + g);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) kv[r][j] = ld4(a.lk[j] + g);
+        for (int j = 0; j < 6; ++j) kv[r][j] = (j < a.lnk) ? ld4(a.lk[j] + g) : zero4;
       } else {
         bs[r] = ld4(a.lam + g);
       }
