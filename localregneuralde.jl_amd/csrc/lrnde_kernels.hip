@@ -2438,10 +2438,14 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
       volatile unsigned long long* slot = pw + (seen & (PROG_RING - 1));
       unsigned long long w = *slot;
       for (long spin = 1; (int)(w & 0xffffffull) != seen + 1; ++spin) {
-        if ((spin & 0x3fff) == 0 && hipStreamQuery(c->stream) == hipSuccess) {
-          w = *slot;
-          if ((int)(w & 0xffffffull) != seen + 1) word_ok = false;  // the stream drained and no report came: poll by copies
-          break;
+        if ((spin & 0x3fff) == 0) {  // bounded: a faulted queue must not hang the caller
+          const hipError_t qe = hipStreamQuery(c->stream);
+          if (qe != hipSuccess && qe != hipErrorNotReady) return fail(c, LRNDE_HIP_ERROR, "solve loop: %s", hipGetErrorString(qe));
+          if (qe == hipSuccess) {
+            w = *slot;
+            if ((int)(w & 0xffffffull) != seen + 1) word_ok = false;  // the stream drained and no report came: poll by copies
+            break;
+          }
         }
         w = *slot;
       }
