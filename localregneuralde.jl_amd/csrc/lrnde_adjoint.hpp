@@ -136,6 +136,15 @@ __device__ __forceinline__ float adj_dt0(float d0, float d1, float dtmax) {
   return fminf_(dt0, dtmax);
 }
 
+// the pinned progress block (host view: volatile int hs[16]): [0] seq (written last, release), [1] status, [2] t, [3] dt,
+// [4] cur, [5] nf, [6] naccept, [7] nreject, [8] iter, [9] eest_last, [10] dt_init — everything the host driver needs of
+// the integrator's state, so that a finished solve costs no read-back copy and no synchronisation of its own
+__device__ __forceinline__ void adj_hstat_fill(int* hs, const AdjCtrl& c) {
+  hs[1] = c.status; hs[2] = __builtin_bit_cast(int, c.t); hs[3] = __builtin_bit_cast(int, c.dt);
+  hs[4] = c.cur; hs[5] = c.nf; hs[6] = c.naccept; hs[7] = c.nreject; hs[8] = c.iter;
+  hs[9] = __builtin_bit_cast(int, c.eest_last); hs[10] = __builtin_bit_cast(int, c.dt_init);
+}
+
 // footer of attempt j-1 + header of attempt j (wave 0 of every workgroup; identical inputs => identical results).
 // Returns the control block of attempt j; block 0 also publishes it to ctl[(j+1)&1].
 __device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
@@ -148,7 +157,7 @@ __device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
     if (blockIdx.x == 0 && lane == 0) {
       *cout = c;
       if (g.hstat) {
-        g.hstat[1] = c.status; g.hstat[2] = __builtin_bit_cast(int, c.t); g.hstat[3] = __builtin_bit_cast(int, c.dt);
+        adj_hstat_fill(g.hstat, c);
         __hip_atomic_store(g.hstat, g.seq0 + j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
@@ -232,7 +241,7 @@ __device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
   if (blockIdx.x == 0 && lane == 0) {
     *cout = c;
     if (g.hstat) {
-      g.hstat[1] = c.status; g.hstat[2] = __builtin_bit_cast(int, c.t); g.hstat[3] = __builtin_bit_cast(int, c.dt);
+      adj_hstat_fill(g.hstat, c);
       __hip_atomic_store(g.hstat, g.seq0 + j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }

@@ -3684,7 +3684,8 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
     g.hstat = c->adj_hstat_dev; g.seq0 = c->adj_seq;
     volatile int* hs = c->adj_hstat;
     int j = 0;
-    for (bool done = false; !done;) {
+    bool done = false;
+    while (!done) {
       for (int sidx = 2; sidx <= 7; ++sidx)
         if ((rc = adj_enqueue_eval(c, B, g, ADJ_STAGE, sidx, j, sidx > 2, ADJ_STAGE, sidx - 1))) return rc;
       if ((rc = adj_enqueue_pgrad(c, B, g, ADJ_STAGE, 7, j))) return rc;
@@ -3706,9 +3707,17 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
       if (j > maxiters + 16) break;
     }
     c->adj_seq += j;
-    HIPCHK(c, hipMemcpyAsync(c->adj_ctl_host, c->adj_ctl + (j & 1), sizeof(AdjCtrl), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    fin = c->adj_ctl_host[0];
+    if (done) {
+      // the report of the last attempt's prologue carries the integrator's final state (adj_hstat_fill): no read-back
+      // copy on the stream, no synchronisation here — the caller's own, after its output copies, is the only one
+      fin.status = hs[1]; fin.t = __builtin_bit_cast(float, (int)hs[2]); fin.dt = __builtin_bit_cast(float, (int)hs[3]);
+      fin.cur = hs[4]; fin.nf = hs[5]; fin.naccept = hs[6]; fin.nreject = hs[7]; fin.iter = hs[8];
+      fin.eest_last = __builtin_bit_cast(float, (int)hs[9]); fin.dt_init = __builtin_bit_cast(float, (int)hs[10]);
+    } else {  // launch cap reached with the solve still running
+      HIPCHK(c, hipMemcpyAsync(c->adj_ctl_host, c->adj_ctl + (j & 1), sizeof(AdjCtrl), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      fin = c->adj_ctl_host[0];
+    }
     if (fin.status != ST_DONE) break;  // error status (or still running after the launch cap: MaxIters)
     if (last_seg) break;
     // cotangent impulse at the saved time just reached, then go on
@@ -3728,7 +3737,8 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
       const float* gi[1] = {impulses[iseg].du}; const float one = 1.0f;
       if ((rc = vec_axpy(c, zend, zend, 1.0f, 1, gi, &one, n))) return rc;
     }
-  if (fin.cur != 0) HIPCHK(c, hipMemcpyAsync(v.z, zend, sizeof(float) * N, hipMemcpyDeviceToDevice, c->stream));
+  v.z = zend;  // (the caller copies dx / dp out of it; no move to the first buffer)
+  if (st->retcode != LRNDE_OK) hipStreamSynchronize(c->stream);  // nothing of a failed solve is left in flight
   return st->retcode;
 }
 
