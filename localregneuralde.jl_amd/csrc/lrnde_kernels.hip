@@ -3685,12 +3685,26 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
     volatile int* hs = c->adj_hstat;
     int j = 0;
     bool done = false;
-    while (!done) {
-      for (int sidx = 2; sidx <= 7; ++sidx)
-        if ((rc = adj_enqueue_eval(c, B, g, ADJ_STAGE, sidx, j, sidx > 2, ADJ_STAGE, sidx - 1))) return rc;
-      if ((rc = adj_enqueue_pgrad(c, B, g, ADJ_STAGE, 7, j))) return rc;
-      hipLaunchKernelGGL(k_adj_err_dev, dim3(512), dim3(256), 0, c->stream, e, g, j);
+    // maybe_last: the attempt whose prologue reported last reaches the end of the segment if it is accepted.  The next
+    // attempt is then enqueued as its FIRST launch only (whose prologue takes that decision); its other seven follow
+    // once the report says the solve goes on (a rejection: the stream idles for one host round trip) — otherwise the
+    // solve would always end with eight launches that find nothing to do.
+    bool maybe_last = false;
+    auto enqueue_rest = [&](int jj) -> int {
+      for (int sidx = 3; sidx <= 7; ++sidx) {
+        const int r = adj_enqueue_eval(c, B, g, ADJ_STAGE, sidx, jj, true, ADJ_STAGE, sidx - 1);
+        if (r) return r;
+      }
+      const int r = adj_enqueue_pgrad(c, B, g, ADJ_STAGE, 7, jj);
+      if (r) return r;
+      hipLaunchKernelGGL(k_adj_err_dev, dim3(512), dim3(256), 0, c->stream, e, g, jj);
       HIPCHK(c, hipGetLastError());
+      return LRNDE_OK;
+    };
+    while (!done) {
+      if ((rc = adj_enqueue_eval(c, B, g, ADJ_STAGE, 2, j, false, ADJ_STAGE, 1))) return rc;
+      const bool rest_ahead = !maybe_last;
+      if (rest_ahead && (rc = enqueue_rest(j))) return rc;
       ++j;
       // wait for the prologue of the attempt just enqueued (bounded: a faulted queue must not hang the caller)
       const int want = g.seq0 + j;
@@ -3704,6 +3718,11 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
         }
       }
       if (hs[1] != ST_RUNNING) done = true;
+      else {
+        if (!rest_ahead && (rc = enqueue_rest(j - 1))) return rc;
+        const float te = __builtin_bit_cast(float, (int)hs[2]) + __builtin_bit_cast(float, (int)hs[3]);
+        maybe_last = fabsf(te - g.s1) <= 100.0f * eps_f(fmaxf(fabsf(te), fabsf(g.s1)));
+      }
       if (j > maxiters + 16) break;
     }
     c->adj_seq += j;
