@@ -1816,6 +1816,11 @@ struct lrnde_ctx {
   // finishes [t1, t2] on the handle's stream: at B <= 512 a step kernel is 128 workgroups, half of the chip.
   lrnde_ctx* side = nullptr;
   bool is_side = false, side_busy = false, rec_gr_ready = false, overlap_off = false;
+  // a recorded forward whose t1 came too late to enqueue the sweep beside the solve leaves it to the backward pass, which
+  // enqueues it on the companion's stream once its first adjoint attempt is on the handle's (the host would otherwise
+  // spend the sweep's ~30 launch calls inside the forward, with the device idle)
+  bool sweep_pending = false; int sw_B = 0, sw_reg_type = 0; float sw_t1 = 0.f, sw_abstol = 0.f, sw_reltol = 0.f;
+  std::function<int()> after_first_attempt;  // adj_solve_device calls it once, after enqueuing its first attempt
   hipEvent_t ev_side_local = nullptr, ev_side_sweep = nullptr;
   float* tail_copy_dst = nullptr; const float* tail_copy_src = nullptr;  // lrnde_solve: one D2D copy enqueued before its final sync
   std::function<int(int, hipEvent_t)> poll_hook;  // lrnde_solve calls it after every status poll (event: that poll's)
@@ -2202,7 +2207,7 @@ int lrnde_set_params(lrnde_ctx* c, const float* p, size_t n) {
     return fail(c, LRNDE_BADARG, "parameter count %zu != expected %zu", n, lrnde_param_count(&c->desc));
   HIPCHK(c, hipSetDevice(c->device));
   { const int rq = side_quiesce(c); if (rq) return rq; }
-  c->rec_gr_ready = false;
+  c->rec_gr_ready = false; c->sweep_pending = false;
   const ModelDev& m = c->m;
   hipLaunchKernelGGL(k_pack, dim3(256), dim3(256), 0, c->stream, p, m.D, m.H, m.td, m.Dp, m.Hp, c->W1p,
                      c->w1t, c->b1, c->W2p, c->w2t, c->b2);
@@ -2543,7 +2548,7 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
   // workspace): the record is gone
   if (!c->dense_on) c->rec_valid = false;
   if ((rc = side_quiesce(c))) return rc;
-  c->rec_gr_ready = false;
+  c->rec_gr_ready = false; c->sweep_pending = false;
   lrnde_solve_opts oo = *o;
   size_t need = 3;
   if (mode == LRNDE_MODE_BIASED) need = (size_t)(oo.maxiters < 510 ? oo.maxiters + 2 : 512);
@@ -2681,8 +2686,10 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
       if ((rc = side_advance(st->nsaved, nullptr))) return rc;   // (a t1 reported last: the handle's stream is idle by now)
       HIPCHK(c, hipEventSynchronize(c->ev_side_local));
       local_results(sd->ctrl_host[0]);
-      if (c->dense_on && side_state == 1 && (rc = enqueue_sweep())) return rc;
-      if (!c->dense_on) c->side_busy = false;  // nothing of the companion's is left in flight
+      if (c->dense_on && side_state == 1) {  // too late to run beside the solve: the backward pass enqueues it (sweep_pending)
+        c->sweep_pending = true; c->sw_B = B; c->sw_reg_type = reg_type; c->sw_t1 = t1; c->sw_abstol = oo.abstol; c->sw_reltol = oo.reltol;
+      }
+      if (!c->dense_on || side_state == 1) c->side_busy = false;  // nothing of the companion's is left in flight
       if (!u_end_done) HIPCHK(c, hipStreamSynchronize(c->stream));
       return LRNDE_OK;
     }
@@ -3705,6 +3712,11 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
       if ((rc = adj_enqueue_eval(c, B, g, ADJ_STAGE, 2, j, false, ADJ_STAGE, 1))) return rc;
       const bool rest_ahead = !maybe_last;
       if (rest_ahead && (rc = enqueue_rest(j))) return rc;
+      if (c->after_first_attempt) {  // (the handle's stream now holds ~150 us of work: time for the caller's side enqueues)
+        auto fn = std::move(c->after_first_attempt);
+        c->after_first_attempt = nullptr;
+        if ((rc = fn())) return rc;
+      }
       ++j;
       // wait for the prologue of the attempt just enqueued (bounded: a faulted queue must not hang the caller)
       const int want = g.seq0 + j;
@@ -3979,6 +3991,22 @@ static int node_backward_recorded_impl(lrnde_ctx* c, int32_t B, const float* du_
       if (tv > t0 && tv < t2) stops.push_back(-tv);
     }
   static const bool adj_host = getenv("LRNDE_ADJ_HOST") != nullptr;  // diagnostic: the round-1 host-controlled loop
+  auto pending_sweep = [c, t1]() -> int {  // the forward left the regulariser's sweep to us (lrnde_ctx::sweep_pending)
+    lrnde_ctx* sd = c->side;
+    c->sweep_pending = false;
+    c->side_busy = true;
+    const int r = step_reg_sweep(sd, sd->state, c->sw_B, t1, c->rec_dt1, c->sw_abstol, c->sw_reltol, c->sw_reg_type, c->rec_eest,
+                                 c->rec_snum, c->rec_sden, c->rec_gr);
+    if (r) { c->err = sd->err; return r; }
+    HIPCHK(c, hipEventRecord(c->ev_side_sweep, sd->stream));
+    c->rec_gr_ready = true;
+    return LRNDE_OK;
+  };
+  const bool want_sweep = mode != LRNDE_MODE_NONE && w_reg != 0.0f && c->sweep_pending && c->side != nullptr;
+  if (want_sweep) {
+    if (vjp_uses_qtile(c, B) && !sharded(c) && !adj_host) c->after_first_attempt = pending_sweep;
+    else if ((rc = pending_sweep())) return rc;
+  }
   if (vjp_uses_qtile(c, B) && !sharded(c) && !adj_host) {
     rc = adj_solve_device(c, v, B, -t2, -t0, o->abstol, o->reltol, o->maxiters, o->exact_pow, stops, impulses, nsteps, st_bwd);
   } else {
@@ -3990,6 +4018,7 @@ static int node_backward_recorded_impl(lrnde_ctx* c, int32_t B, const float* du_
     rc = vec_tsit5_solve(c, v, rhs, rhs_fused, vjp_uses_qtile(c, B), -t2, -t0, o->abstol, o->reltol, o->maxiters, o->exact_pow,
                          stops, impulses, st_bwd);
   }
+  c->after_first_attempt = nullptr;
   if (rc) return fail(c, rc, "adjoint solve stopped with retcode %d", rc);
   HIPCHK(c, hipMemcpyAsync(dx, v.z, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dp, v.z + n, sizeof(float) * P, hipMemcpyDeviceToDevice, c->stream));

@@ -57,3 +57,28 @@ def test_training_step_same_bits_with_and_without_the_companion_stream(gpu_pkg, 
     assert res[0][0] == res[1][0]
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+@pytest.mark.parametrize("where", ["early", "late"])
+def test_training_step_with_an_early_and_a_late_t1(gpu_pkg, where):
+    """early t1: the sweep is enqueued beside the forward solve; late t1 (sol(t1) appears in the last reports): the forward
+    leaves it to the backward pass, which enqueues it on the companion's stream after its first adjoint attempt.  Either
+    way the gradients are the bits of the one-stream order."""
+    import torch
+    P = gpu_pkg
+    model, ps, pc, x, lab = _setup(P, 64, 7)
+    def r01_of(sd):  # the draw run_training_step makes from initialstates(default_rng(sd))
+        g = np.random.default_rng(sd); g.standard_normal()
+        return float(g.random(dtype=np.float32))
+    seed = next(sd for sd in range(2000) if (r01_of(sd) > 0.95 if where == "late" else r01_of(sd) < 0.08))
+    res = []
+    for on in (True, False, True):
+        node = P.NeuralODE(model, regularize="unbiased", abstol=1e-5, reltol=1e-5, save_start=False, maxiters=2000)
+        st = node.initialstates(np.random.default_rng(seed))
+        node._bind(ps, x).set_overlap(on)
+        loss, st2, _, grads, _ = P.run_training_step(node, ps, pc, st, x, lab, 2.5)
+        res.append((loss, grads))
+    for r in res[1:]:
+        assert r[0] == res[0][0]
+        for k in res[0][1]:
+            assert torch.equal(r[1][k], res[0][1][k]), k
