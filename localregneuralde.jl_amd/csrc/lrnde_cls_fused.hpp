@@ -6,8 +6,19 @@ struct ClsOut { double loss_sum; int bad_label; int pad; };
 
 // one wave per sample: logits[c] = sum_k W[c][k] u[k] + b[c] (the arithmetic and order of k_cls_fwd), softmax, the
 // logit cotangent dl = (softmax - onehot) / Bnorm, and du[k] = sum_c dl[c] W[c][k] (the arithmetic of k_cls_bwd_x)
-__global__ __launch_bounds__(256) void k_cls_fwd_bwdx(const float* u, const float* pc, const int32_t* labels, int B, int D, int K,
+// WLDS: the K x (D+1) parameter block is staged in LDS once per workgroup (coalesced) and both passes read it from
+// there — read straight from memory a lane's ten weights per k are ten 4-byte loads 40 bytes apart from its neighbour's
+// (36 us for 16 MFLOP).  Same values, same order of operations.
+template <bool WLDS>
+__global__ __launch_bounds__(256) void k_cls_fwd_bwdx(const float* u, const float* pcg, const int32_t* labels, int B, int D, int K,
                                                       float Bnorm, float* logits, float* dl, float* loss_b, float* du, ClsOut* out) {
+  extern __shared__ __attribute__((aligned(16))) float cls_w[];
+  if (WLDS) {
+    const int nw = K * (D + 1);
+    for (int i = threadIdx.x; i < nw; i += 256) cls_w[i] = pcg[i];
+    __syncthreads();
+  }
+  const float* pc = WLDS ? cls_w : pcg;  // (a compile-time choice: the LDS pointer keeps its address space)
   const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const float* ub = u + (size_t)b * D;
