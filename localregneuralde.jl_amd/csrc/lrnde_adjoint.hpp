@@ -10,7 +10,8 @@
 // PI controller, accept/reject, FSAL swap, tstop handling) and the header of attempt j (dt, the six stage times and the
 // dense-record step / interpolation parameter each of them falls into); block 0 publishes the result, the other
 // launches of the attempt (stages 3..7, the parameter-gradient GEMMs, the end-of-step norm kernel) just read it.  The
-// host enqueues attempts in chunks and polls the status word one chunk behind; nothing waits for the host.
+// host enqueues one attempt ahead and reads the integrator's progress (and, at the end, its final state) from a block in
+// pinned host memory that the prologue writes; nothing waits for the host.
 //
 // z = [lambda (n_lam local columns); mu (P, replicated)], N = n_lam + P, reversed time s = -t.
 // Buffers (one allocation, c->adj): zb[2] (z / z_new ping-pong), zs, ut (stage lambdas), K[0..6] with K[0], K[6] the

@@ -2414,9 +2414,9 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   hipLaunchKernelGGL(k_solve_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t0, nsaved0, si);
   if ((rc = run_init(c, B, a))) return rc;
 
-  // Enqueue attempted steps in chunks and poll the device status word one chunk behind, so the
-  // GPU never waits for the host.  `target` = launch index up to which steps are expected to be
-  // needed, estimated from the polled (t, dt); launches beyond it are speculative (k_step<.,true>).
+  // Attempted steps are enqueued ahead of the device's decisions, steered by the per-launch reports (below); the copy-polled
+  // chunk loop further down is the fall-back if no report ever arrives.  Launches beyond what a report makes certain are
+  // speculative (k_step<.,true>): they find the solve finished and do nothing.
   const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
   int j = 0, pending = -1, pending_j = 0, launches = 0, target = 4, nchunk = 0;
   bool done = false, word_ok = true;
@@ -3686,8 +3686,8 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
     first_seg = false;
     // Attempts are enqueued ONE ahead of what the device has decided: the first launch of attempt j publishes the
     // integrator's status in pinned host memory (AdjArgs::hstat), and attempt j+1 is enqueued when attempt j is known
-    // to be running (its remaining seven launches, ~130 us, cover the host's enqueue).  So the solve ends with exactly
-    // one attempt whose launches find nothing to do, and no copy packet sits between the kernels.
+    // to be running (its remaining seven launches, ~130 us, cover the host's enqueue); no copy packet sits between the
+    // kernels, and an attempt that would end the segment is followed by the next one's first launch only (maybe_last).
     g.hstat = c->adj_hstat_dev; g.seq0 = c->adj_seq;
     volatile int* hs = c->adj_hstat;
     int j = 0;
