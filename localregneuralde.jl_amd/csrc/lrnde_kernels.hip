@@ -2843,6 +2843,9 @@ struct lrnde_sde {
   float* bwd_ws = nullptr; size_t bwd_n = 0;  // lrnde_sde_*_backward / _reg_grad scratch
   int* arrive = nullptr;                      // arrival counter of the one-launch step's footer (lrnde_sde_fast.hpp)
   float* ad_ws = nullptr; size_t ad_n = 0;    // lrnde_sde_solve_adaptive: two states + the current increment
+  SdeCtl* ad_ctl = nullptr; SdeCtl* ad_ctl_host = nullptr;             // device-controlled adaptive loop: control block (device / pinned)
+  unsigned long long* ad_prog = nullptr; unsigned long long* ad_prog_dev = nullptr;  // its pinned progress word
+  lrnde_trace_row* ad_trace = nullptr; int ad_trace_cap = 0;
 };
 
 int lrnde_sde_create(lrnde_sde** out, const lrnde_model_desc* drift, int32_t diffusion_bias, int device, void* stream) {
@@ -2870,6 +2873,10 @@ int lrnde_sde_destroy(lrnde_sde* s) {
   if (s->traj_dev) hipFree(s->traj_dev);
   if (s->sri_ws) hipFree(s->sri_ws);
   if (s->bwd_ws) hipFree(s->bwd_ws);
+  if (s->ad_ctl) hipFree(s->ad_ctl);
+  if (s->ad_ctl_host) hipHostFree(s->ad_ctl_host);
+  if (s->ad_prog) hipHostFree(s->ad_prog);
+  if (s->ad_trace) hipFree(s->ad_trace);
   if (s->arrive) hipFree(s->arrive);
   if (s->ad_ws) hipFree(s->ad_ws);
   if (s->sri_part) hipFree(s->sri_part);
@@ -2930,12 +2937,12 @@ static int sde_step_enqueue(lrnde_sde* s, int which, const float* uprev, const f
     if (rec_dev) {  // fixed-grid solve: the step writes its own record (no footer launch)
       if (!s->arrive) { HIPCHK(c, hipMalloc(&s->arrive, sizeof(int))); HIPCHK(c, hipMemsetAsync(s->arrive, 0, sizeof(int), c->stream)); }
       f.arrive = s->arrive; f.rec = rec_dev;
-      hipLaunchKernelGGL(k_sde_eh_fast, dim3(nwg), dim3(SF_NT), 0, c->stream, f);
+      hipLaunchKernelGGL(k_sde_eh_fast<false>, dim3(nwg), dim3(SF_NT), 0, c->stream, f);
       HIPCHK(c, hipGetLastError());
       return LRNDE_OK;
     }
     hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t, dt, 0, 0);
-    hipLaunchKernelGGL(k_sde_eh_fast, dim3(nwg), dim3(SF_NT), 0, c->stream, f);
+    hipLaunchKernelGGL(k_sde_eh_fast<false>, dim3(nwg), dim3(SF_NT), 0, c->stream, f);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, a, 1);
     HIPCHK(c, hipGetLastError());
     if (rec) HIPCHK(c, hipMemcpyAsync(rec, c->ctrl + 1, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
@@ -3020,6 +3027,100 @@ __global__ void k_sde_dw(size_t n, const float* Wlo, const float* Whi, float* dW
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dW[i] = Whi[i] - Wlo[i];
 }
 
+__global__ void k_sde_ctl_init(SdeCtl* ctl, int m0) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  SdeCtl c;
+  c.status = ST_RUNNING; c.i = 0; c.m = m0; c.cur = 0; c.naccept = 0; c.nreject = 0; c.iters = 1; c.nf = 0;
+  c.qold = 1e-4f; c.eest_last = 0.f;
+  *ctl = c;
+}
+
+// lrnde_sde_solve_adaptive on the one-launch kernel's shape: the controller runs in the step kernel's footer (SdeCtl,
+// lrnde_sde_fast.hpp), the host only keeps launches enqueued and watches a pinned progress word — one launch per attempted
+// step, no synchronisation inside the solve (the host-controlled loop below paid one per step: ~45 us for a 10-us step).
+static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
+                               const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
+                               int32_t cap_trace, float* ua, float* ub) {
+  lrnde_ctx* c = s->drift;
+  const size_t n = (size_t)B * c->desc.state_dim;
+  if (!s->ad_ctl) {
+    HIPCHK(c, hipMalloc(&s->ad_ctl, sizeof(SdeCtl)));
+    HIPCHK(c, hipHostMalloc(&s->ad_ctl_host, sizeof(SdeCtl)));
+    HIPCHK(c, hipHostMalloc(&s->ad_prog, 64, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&s->ad_prog_dev, s->ad_prog, 0));
+  }
+  if (trace_host && cap_trace > s->ad_trace_cap) {
+    if (s->ad_trace) HIPCHK(c, hipFree(s->ad_trace));
+    s->ad_trace = nullptr; s->ad_trace_cap = 0;
+    HIPCHK(c, hipMalloc(&s->ad_trace, sizeof(lrnde_trace_row) * cap_trace));
+    s->ad_trace_cap = cap_trace;
+  }
+  if (!s->arrive) { HIPCHK(c, hipMalloc(&s->arrive, sizeof(int))); HIPCHK(c, hipMemsetAsync(s->arrive, 0, sizeof(int), c->stream)); }
+  const float h = (t1 - t0) / (float)nfine;
+  int m0 = (int)(o->dt0 / h); if (m0 < 1) m0 = 1;
+  if (m0 > nfine) m0 = nfine;
+  if (1 > o->maxiters) { st->iters = 1; st->retcode = LRNDE_MAXITERS; return fail(c, LRNDE_MAXITERS, "adaptive SDE solve stopped with retcode %d at t=%g", LRNDE_MAXITERS, (double)t0); }
+  HIPCHK(c, hipMemcpyAsync(ua, u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_sde_ctl_init, dim3(1), dim3(1), 0, c->stream, s->ad_ctl, m0);
+  volatile unsigned long long* pw = s->ad_prog;
+  *pw = 0ull;
+  StepArgs a;
+  fill_args(c, a, B, NB);
+  SdeFastArgs f;
+  memset(&f, 0, sizeof(f));
+  f.W1p = c->m.W1p; f.KG1 = c->m.KG1;
+  f.W2p = c->m.W2p; f.KG2p = ((c->m.KG2 + SEGK - 1) / SEGK) * SEGK;
+  f.Wgp = s->diff->m.W2p; f.KGgp = ((s->diff->m.KG2 + SEGK - 1) / SEGK) * SEGK;
+  f.b1 = c->m.b1; f.b2 = c->m.b2; f.bg = s->diff->m.b2; f.act = c->m.act;
+  f.B = B; f.abstol = o->abstol; f.reltol = o->reltol; f.delta = o->delta;
+  f.part = c->part + (size_t)a.nwg_global * PSTRIDE;
+  f.n_norm = a.n_global;
+  f.arrive = s->arrive;
+  f.ctl = s->ad_ctl; f.Wpath = W; f.ua = ua; f.ub = ub; f.nfine = nfine; f.t0 = t0; f.h = h;
+  f.gamma = o->gamma; f.qmin = o->qmin; f.qmax = o->qmax; f.beta1 = o->beta1; f.beta2 = o->beta2; f.maxiters = o->maxiters;
+  f.trace = trace_host ? s->ad_trace : nullptr; f.cap_trace = trace_host ? cap_trace : 0;
+  f.prog = s->ad_prog_dev;
+  const int nwg = (B + NB - 1) / NB;
+  // launches are enqueued eight at a time, the next eight when four of them have reported; launches that find the solve
+  // finished return at once (at most eight of them)
+  int j = 0;
+  bool done = false;
+  const long cap = (long)o->maxiters + 16;
+  while (!done && j <= cap) {
+    for (int k = 0; k < 8; ++k, ++j) {
+      f.jlaunch = j;
+      hipLaunchKernelGGL(k_sde_eh_fast<true>, dim3(nwg), dim3(SF_NT), 0, c->stream, f);
+    }
+    HIPCHK(c, hipGetLastError());
+    const unsigned want = (unsigned)(j - 4);
+    for (long spin = 1;; ++spin) {
+      const unsigned long long w = *pw;
+      if ((unsigned)(w >> 32) != (unsigned)ST_RUNNING) { done = true; break; }
+      if ((unsigned)(w & 0xffffffffull) >= want) break;
+      if ((spin & 0x3fff) == 0) {
+        const hipError_t qe = hipStreamQuery(c->stream);
+        if (qe != hipSuccess && qe != hipErrorNotReady) return fail(c, LRNDE_HIP_ERROR, "adaptive SDE loop: %s", hipGetErrorString(qe));
+        if (qe == hipSuccess) break;  // everything enqueued has run: look at the word again, enqueue more
+      }
+    }
+  }
+  HIPCHK(c, hipMemcpyAsync(s->ad_ctl_host, s->ad_ctl, sizeof(SdeCtl), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const SdeCtl fin = *s->ad_ctl_host;
+  st->naccept = fin.naccept; st->nreject = fin.nreject; st->iters = fin.iters; st->nf = fin.nf; st->eest_last = fin.eest_last;
+  st->t_final = t0 + (float)fin.i * h; st->dt_final = (float)fin.m * h;
+  st->retcode = (fin.status == ST_DONE) ? LRNDE_OK : (fin.status == ST_RUNNING ? LRNDE_MAXITERS : fin.status);
+  if (trace_host) {
+    int nt = fin.naccept + fin.nreject;
+    if (nt > cap_trace) nt = cap_trace;
+    if (nt > 0) HIPCHK(c, hipMemcpy(trace_host, s->ad_trace, sizeof(lrnde_trace_row) * nt, hipMemcpyDeviceToHost));
+  }
+  HIPCHK(c, hipMemcpyAsync(u_end, fin.cur ? ub : ua, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (st->retcode != LRNDE_OK) return fail(c, st->retcode, "adaptive SDE solve stopped with retcode %d at t=%g", st->retcode, (double)st->t_final);
+  return LRNDE_OK;
+}
+
 int lrnde_sde_solve_adaptive(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
                              const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
                              int32_t cap_trace) {
@@ -3036,6 +3137,12 @@ int lrnde_sde_solve_adaptive(lrnde_sde* s, const float* u0, const float* W, int3
     s->ad_n = n;
   }
   float *ua = s->ad_ws, *ub = s->ad_ws + n, *dW = s->ad_ws + 2 * n;
+  {
+    static const bool no_fast = getenv("LRNDE_NO_SDE_FAST") != nullptr;
+    static const bool host_loop = getenv("LRNDE_SDE_HOST_LOOP") != nullptr;  // diagnostic: the host-controlled loop below
+    if (!no_fast && !host_loop && !sharded(c) && c->desc.state_dim == 32 && c->desc.hidden_dim == 64 && !c->desc.time_dep)
+      return sde_adaptive_device(s, u0, W, nfine, B, t0, t1, o, u_end, st, trace_host, cap_trace, ua, ub);
+  }
   HIPCHK(c, hipMemcpyAsync(ua, u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   const float h = (t1 - t0) / (float)nfine;
   const float gamma = o->gamma, qmin = o->qmin, qmax = o->qmax, qoldinit = 1e-4f;

@@ -32,7 +32,16 @@ struct SdeFastArgs {
   int* arrive;       // fixed-grid solve: arrival counter of the step's footer, or NULL
   Ctrl* rec;         //   ... and the record slot the last workgroup fills (EEst, EEst*dt)
   double n_norm;     // elements of the norm (B * 32)
+  // ADAPT (lrnde_sde_solve_adaptive on this shape): the controller lives on the device.  The launch reads the control
+  // block (grid position i, step length m in grid intervals, which of the two state buffers is current), forms dW from the
+  // caller's path itself, and its last workgroup runs the PI controller and writes the block for the next launch.
+  struct SdeCtl* ctl; const float* Wpath; float* ua; float* ub; int nfine; float t0, h;
+  float gamma, qmin, qmax, beta1, beta2; int maxiters;
+  lrnde_trace_row* trace; int cap_trace;
+  unsigned long long* prog;  // pinned host word: (launches whose footer ran) | status << 32
+  int jlaunch;
 };
+struct SdeCtl { int status, i, m, cur, naccept, nreject, iters, nf; float qold, eest_last; };
 
 __device__ __forceinline__ f32x4 sf_chain(const f32x4* frag, int nkg, const f32x4* xb, int lane) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -40,7 +49,17 @@ __device__ __forceinline__ f32x4 sf_chain(const f32x4* frag, int nkg, const f32x
   return acc;
 }
 
+template <bool ADAPT>
 __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
+  int ad_i = 0, ad_m = 0, ad_cur = 0;
+  if (ADAPT) {
+    const SdeCtl cc = *a.ctl;   // written by the previous launch's last workgroup (kernel boundary in between)
+    if (cc.status != ST_RUNNING) return;
+    ad_i = cc.i; ad_m = cc.m; ad_cur = cc.cur;
+    a.dt = (float)ad_m * a.h;
+    a.u = ad_cur ? a.ub : a.ua;
+    a.un = ad_cur ? a.ua : a.ub;
+  }
   // LDS: three x tiles in B-operand layout (32 rows x 16 columns each: [kg][64 lanes] float4), the h tile (64 rows), the
   // diffusion results of waves 2,3 in C-fragment order, the reduction scratch
   __shared__ f32x4 xA[SF_DT * 64], xB[SF_DT * 64], xC[SF_DT * 64], hl[SF_HT * 64], gl[2 * 64];
@@ -66,7 +85,18 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 u4 = zero4, w4 = zero4;
   const size_t g = (size_t)(b0 + n) * 32 + t * 16 + rq * 4;
-  if (wave < 2 && colok) { u4 = *reinterpret_cast<const f32x4*>(a.u + g); w4 = *reinterpret_cast<const f32x4*>(a.dW + g); }
+  if (wave < 2 && colok) {
+    u4 = *reinterpret_cast<const f32x4*>(a.u + g);
+    if (ADAPT) {  // dW = W[i + m] - W[i], the path's own increment (the expression of k_sde_dw)
+      const size_t nn = (size_t)a.B * 32;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(a.Wpath + (size_t)ad_i * nn + g);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(a.Wpath + (size_t)(ad_i + ad_m) * nn + g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w4[r] = hi[r] - lo[r];
+    } else {
+      w4 = *reinterpret_cast<const f32x4*>(a.dW + g);
+    }
+  }
   // B-operand image of rows 16 t + 4 rq + r, column n: float4 index t*64 + r*16 + n, component rq
   auto put = [&](f32x4* x, const f32x4& v) {
     float* p = reinterpret_cast<float*>(x) + ((t * 64 + n) << 2) + rq;
@@ -177,9 +207,54 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
     const Sum3 s = reduce_partials3(a.part, (int)gridDim.x);
     if (lane == 0) {
       const float eest = rms_from(s.a, a.n_norm);
-      a.rec->eest_last = eest;
-      a.rec->reg_error = eest * dt;
-      a.rec->status = ST_DONE;
+      if (!ADAPT) {
+        a.rec->eest_last = eest;
+        a.rec->reg_error = eest * dt;
+        a.rec->status = ST_DONE;
+      } else {
+        // the controller of lrnde_sde_solve_adaptive's host loop, expression for expression
+        SdeCtl c = *a.ctl;
+        const float qoldinit = 1e-4f;
+        c.nf += 3; c.eest_last = eest;
+        if (eest != eest) {
+          c.status = LRNDE_DT_NAN;
+        } else {
+          float q;
+          if (eest == 0.0f) q = 1.0f / a.qmax;
+          else {
+            const float q11 = fastpow(eest, a.beta1);
+            q = q11 / fastpow(c.qold, a.beta2);
+            q = fmaxf_(1.0f / a.qmax, fminf_(1.0f / a.qmin, q / a.gamma));
+          }
+          const int accepted = eest <= 1.0f;
+          const int ntr = c.naccept + c.nreject;
+          if (a.trace && ntr < a.cap_trace) {
+            lrnde_trace_row r; r.t = a.t0 + (float)c.i * a.h; r.dt = dt; r.eest = eest; r.accepted = accepted;
+            a.trace[ntr] = r;
+          }
+          int mnew = (int)((dt / q) / a.h);
+          if (mnew < 1) mnew = 1;
+          if (accepted) {
+            c.naccept++;
+            c.qold = fmaxf_(eest, qoldinit);
+            c.i += c.m;
+            c.cur ^= 1;
+            c.m = mnew;
+            if (c.i >= a.nfine) c.status = ST_DONE;
+          } else {
+            c.nreject++;
+            if (c.m == 1) c.status = LRNDE_DT_LESS_THAN_MIN;  // the path's grid cannot be refined further
+            else c.m = mnew < c.m ? mnew : c.m - 1;
+          }
+          if (c.status == ST_RUNNING) {
+            if (c.m > a.nfine - c.i) c.m = a.nfine - c.i;
+            if (++c.iters > a.maxiters) c.status = LRNDE_MAXITERS;
+          }
+        }
+        *a.ctl = c;
+        __hip_atomic_store(a.prog, (unsigned long long)(unsigned)(a.jlaunch + 1) | ((unsigned long long)(unsigned)c.status << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       __hip_atomic_store(a.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
