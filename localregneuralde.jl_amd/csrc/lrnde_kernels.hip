@@ -133,6 +133,8 @@ struct CtrlHead {
 static_assert(sizeof(CtrlHead) == 64 && offsetof(Ctrl, reg_error) == 64 && offsetof(Ctrl, dt_init) == offsetof(CtrlHead, dt_init),
               "CtrlHead must be the first 64 bytes of Ctrl");
 
+struct SaveInit { float* saveat; int n; float v[8]; float* tsaved; int save_start; };
+
 struct StepArgs {
   ModelDev m;
   float* state;     // one allocation: ubuf[2] kfsal[2] ks[5] g6, each n_local floats
@@ -164,6 +166,10 @@ struct StepArgs {
   // the final control block, both written by workgroup 0's prologue; NULL elsewhere
   unsigned long long* prog;
   Ctrl* fin_host;
+  // k_init1_q as the first launch of a solve / local step (4-column family): the start state is read from init_u0 (the
+  // caller's array; also copied to ubuf[0]) and workgroup 0 initialises the control blocks, saveat times and the
+  // save_start time itself — no copy packet and no one-thread kernel ahead of it
+  const float* init_u0; int init_fresh; int init_nsaved; SaveInit init_si;
   Ctrl* ctrl;      // [2]
   double* part_send;        // [2][nwg_global*PSTRIDE] (this rank writes its own segment)
   const double* part_recv;  // [2][...]  == part_send when nranks == 1
@@ -186,6 +192,18 @@ struct StepArgs {
                      // registers at its end (slot = accepted steps so far; a rejected attempt's slot is rewritten by the
                      // retry) instead of the next launch's prologue copying eight state arrays through global memory
 };
+
+// control blocks, the (few) saveat times and the save_start time of a fresh solve (k_solve_init, k_init1_q)
+__device__ __forceinline__ void solve_init_body(Ctrl* ctrl, float t0, int nsaved, const SaveInit& si) {
+  Ctrl c;
+  memset(&c, 0, sizeof(c));
+  c.status = ST_RUNNING; c.first = 1; c.cur = 0; c.nsaved = nsaved;
+  c.t = t0; c.dt = 0.f; c.qold = 1e-4f; c.q11 = 1.0f; c.dtpropose = 0.f;
+  ctrl[0] = c;
+  ctrl[1] = c;
+  for (int i = 0; i < si.n; ++i) si.saveat[i] = si.v[i];
+  if (si.save_start) si.tsaved[0] = t0;
+}
 
 // ---------------------------------------------------------------------------
 // small helpers
@@ -1671,17 +1689,9 @@ __global__ void k_ctrl_init(Ctrl* ctrl, float t0, float dt, int cur, int nsaved)
 }
 
 // start of a solve in one launch: control blocks, the (few) saveat times and the save_start time — no copy packets
-struct SaveInit { float* saveat; int n; float v[8]; float* tsaved; int save_start; };
 __global__ void k_solve_init(Ctrl* ctrl, float t0, int nsaved, SaveInit si) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Ctrl c;
-  memset(&c, 0, sizeof(c));
-  c.status = ST_RUNNING; c.first = 1; c.cur = 0; c.nsaved = nsaved;
-  c.t = t0; c.dt = 0.f; c.qold = 1e-4f; c.q11 = 1.0f; c.dtpropose = 0.f;
-  ctrl[0] = c;
-  ctrl[1] = c;
-  for (int i = 0; i < si.n; ++i) si.saveat[i] = si.v[i];
-  if (si.save_start) si.tsaved[0] = t0;
+  solve_init_body(ctrl, t0, nsaved, si);
 }
 
 // Dense(D=>D) parameters [vec(Wg); bg] -> the 2-layer form [vec(I); 0; vec(Wg); bg] (identity first layer)
@@ -2410,9 +2420,15 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   a.prog = c->prog_dev;
   a.fin_host = reinterpret_cast<Ctrl*>(reinterpret_cast<char*>(c->prog_dev) + PROG_RING * 8);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-  HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(k_solve_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t0, nsaved0, si);
+  if (use_qtile(c, B)) {
+    // (4-column family: the first init launch reads the caller's array, copies it to ubuf[0] and writes the control blocks)
+    a.init_u0 = u0; a.init_fresh = 1; a.init_nsaved = nsaved0; a.init_si = si;
+  } else {
+    HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_solve_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t0, nsaved0, si);
+  }
   if ((rc = run_init(c, B, a))) return rc;
+  a.init_u0 = nullptr; a.init_fresh = 0;
 
   // Attempted steps are enqueued ahead of the device's decisions, steered by the per-launch reports (below); the copy-polled
   // chunk loop further down is the fall-back if no report ever arrives.  Launches beyond what a report makes certain are
@@ -2591,9 +2607,14 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
     a.t0 = t1v; a.t1 = t2; a.abstol = oo.abstol; a.reltol = oo.reltol; a.mode = MODE_SINGLE_INIT_DT;
     a.want_stiff = (reg_type == LRNDE_REG_STIFFNESS_ESTIMATE); a.maxiters = 1;
     a.force_store_k = c->dense_on ? 1 : 0;  // recorded forward: the regulariser's reverse sweep starts from this step's k2..k6
-    HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u_at_t1, sizeof(float) * n, hipMemcpyDeviceToDevice, L->stream));
-    hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, L->stream, L->ctrl, t1v, 0.f, 0, 0);
+    if (use_qtile(L, B)) {
+      a.init_u0 = u_at_t1; a.init_fresh = 1; a.init_nsaved = 0; memset(&a.init_si, 0, sizeof(a.init_si));
+    } else {
+      HIPCHK(c, hipMemcpyAsync(a.ubuf[0], u_at_t1, sizeof(float) * n, hipMemcpyDeviceToDevice, L->stream));
+      hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, L->stream, L->ctrl, t1v, 0.f, 0, 0);
+    }
     if ((r = run_init(L, B, a))) return r;
+    a.init_u0 = nullptr; a.init_fresh = 0;
     if ((r = launch_step(L, B, a, 0))) return r;
     const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
     if ((r = exchange(L, L->part + cnt, L->part_rx + cnt, cnt))) return r;

@@ -561,16 +561,26 @@ __global__ __launch_bounds__(QNT) void k_init1_q(StepArgs a) {
   stream_init_q(a.m, fc);
   const int b0 = blockIdx.x * QNB, nvalid = min(QNB, a.B - b0);
   const int KQ1 = a.m.D / 4;
-  const Ctrl c = a.ctrl[0];
-  const float* u0 = ubuf_at(a, c.cur);
-  float* f0 = kfsal_at(a, c.cur);
+  int cur0; float tinit;
+  if (a.init_fresh) {  // first launch of a solve: the control blocks are written here (StepArgs::init_fresh)
+    cur0 = 0; tinit = a.t0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) solve_init_body(a.ctrl, a.t0, a.init_nsaved, a.init_si);
+  } else {
+    const Ctrl c = a.ctrl[0];
+    cur0 = c.cur; tinit = c.t;
+  }
+  const float* u0 = a.init_u0 ? a.init_u0 : ubuf_at(a, cur0);
+  float* ucopy = a.init_u0 ? ubuf_at(a, cur0) : nullptr;
+  float* f0 = kfsal_at(a, cur0);
   __syncthreads();
   q_tile_foreach(a.m, b0, nvalid, KQ1, [&](int kq, int sidx, bool valid, size_t g) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    s.xl[kq * 4 + sidx] = valid ? ld4(u0 + g) : z;
+    const f32x4 v = valid ? ld4(u0 + g) : z;
+    s.xl[kq * 4 + sidx] = v;
+    if (valid && ucopy) st4(ucopy + g, v);
   });
   __syncthreads();
-  q_feval_store(a.m, s, fc, c.t, f0, b0, nvalid);
+  q_feval_store(a.m, s, fc, tinit, f0, b0, nvalid);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   q_tile_foreach(a.m, b0, nvalid, KQ1, [&](int, int, bool valid, size_t g) {
     if (!valid) return;
