@@ -207,7 +207,8 @@ __device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
         const float dtnew = c.dt / q;
         c.qold = fmaxf_(eest, qoldinit);
         const float ttmp = c.t + c.dt;
-        t = (__builtin_fabsf(ttmp - c.tstop) < 100.0f * eps_f(fmaxf_(c.t, c.tstop))) ? c.tstop : ttmp;
+        // (magnitudes: see vec_tsit5_solve)
+        t = (__builtin_fabsf(ttmp - c.tstop) < 100.0f * eps_f(fmaxf_(__builtin_fabsf(c.t), __builtin_fabsf(c.tstop)))) ? c.tstop : ttmp;
         c.dtpropose = fmaxf_(fminf_(dtmax, dtnew), fmaxf_(eps_f(t), dtmin));
         c.cur ^= 1;  // z <- z_new, K1 <- K7 (FSAL)
         dt = c.dtpropose;

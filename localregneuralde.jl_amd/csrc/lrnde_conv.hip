@@ -2621,7 +2621,7 @@ int adjoint_solve(lrnde_conv* c, size_t N, RHS&& rhs, float* Z, float s0, float 
       st->naccept++;
       const float dtnew = dt / q;
       qold = fmaxf(eest, qoldinit);
-      t = (fabsf(ttmp - tstop) < 100.0f * eps_f(fmaxf(t, tstop))) ? tstop : ttmp;
+      t = (fabsf(ttmp - tstop) < 100.0f * eps_f(fmaxf(fabsf(t), fabsf(tstop)))) ? tstop : ttmp;  // (magnitudes: reversed time)
       dtpropose = fmaxf(fminf(dtmax, dtnew), fmaxf(eps_f(t), dtmin));
     } else st->nreject++;
   }

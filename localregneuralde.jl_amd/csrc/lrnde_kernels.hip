@@ -3667,7 +3667,9 @@ int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, RHSF rhs_fused, bool fuse_
       st->naccept++;
       const float dtnew = dt / q;
       qold = fmaxf(eest, qoldinit);
-      t = (fabsf(ttmp - tstop) < 100.0f * eps_f(fmaxf(t, tstop))) ? tstop : ttmp;
+      // (magnitudes: reversed time s = -t <= 0 — a signed max would take the time nearer zero, and with it an eps far below
+      //  the rounding of t + dt; the reference's adjoint runs t from t2 down to t0 with positive times)
+      t = (fabsf(ttmp - tstop) < 100.0f * eps_f(fmaxf(fabsf(t), fabsf(tstop)))) ? tstop : ttmp;
       dtpropose = fmaxf(fminf(dtmax, dtnew), fmaxf(eps_f(t), dtmin));
     } else {
       st->nreject++;

@@ -761,7 +761,9 @@ int lro_solve_ex(const lro_field* f, const float* u0, int B, float t0, float t1,
       float dtnew = dt / q;
       qold = fmaxf(eest, qoldinit);
       float tprev = t;
-      t = (fabsf(ttmp - tstop) < 100.0f * eps_f(fmaxf(t, tstop))) ? tstop : ttmp;
+      /* (magnitudes: this loop also runs the adjoint in reversed time s = -t <= 0, where a signed max picks the time nearer
+         zero and its eps; the reference's adjoint runs t from t2 down to t0 with positive times) */
+      t = (fabsf(ttmp - tstop) < 100.0f * eps_f(fmaxf(fabsf(t), fabsf(tstop)))) ? tstop : ttmp;
       dtpropose = fmaxf(fminf(dtmax, dtnew), fmaxf(eps_f(t), dtmin));
       if (dense) {
         const float* kk7[7] = {k1, ks, ks + n, ks + 2 * n, ks + 3 * n, ks + 4 * n, k7};

@@ -266,3 +266,25 @@ def test_timing_hook_after_a_recorded_forward_leaves_the_record_alone(oracle, gp
     assert l1 == l2
     for k in g1:
         assert torch.equal(g1[k], g2[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t1", [1.2e-4, 5e-4, 2.1e-3, 0.9995])
+def test_node_backward_with_t1_next_to_an_end_of_the_span(oracle, gpu_pkg, t1):
+    """The adjoint stops at every saved time, t1 included.  With t1 a few 1e-4 from t0 the step that ends on that tstop starts
+    at a time hundreds of times larger in magnitude, and t + dt misses it by more than 100 eps(tstop): the snap onto the
+    tstop has to be judged at the magnitude of the step's start (the reference's adjoint runs t from t2 DOWN to t0, both
+    positive, so its max(t, tstop) is that magnitude; in reversed time s = -t a signed max is not).  Before the fix this
+    ended in DtLessThanMin about once per thousand training steps (tools/bench/soak_forward.py found it).  CPU oracle and
+    both GPU loops (device-controlled and LRNDE_ADJ_HOST) share the expression."""
+    import torch
+    fld, h, p, x = _mk(oracle, gpu_pkg, 784, 100, 32, "tanh", True, scale=1.5)
+    g = (np.random.default_rng(4).standard_normal(x.shape) * 1e-3).astype(np.float32)
+    ref = oracle.node_backward(fld, x, 0.0, 1.0, 1e-3, 1e-3, g, mode="unbiased", t1_or_rand=t1, w_reg=2.5)
+    got = h.node_backward(torch.from_numpy(x).cuda(), 0.0, 1.0, 1e-3, 1e-3, torch.from_numpy(g).cuda(), mode="unbiased",
+                          t1_or_rand=t1, w_reg=2.5, maxiters=10000)
+    assert ref["retcode"] == 0 and got["stats_bwd"]["retcode"] == 0
+    dx, dp = got["dx"].cpu().numpy(), got["dp"].cpu().numpy()
+    print(f"t1={t1}: bwd steps gpu/oracle {got['stats_bwd']['naccept']}/{ref['stats_bwd']['naccept']}, rel err dx {_rel(dx, ref['dx']):.2e} dp {_rel(dp, ref['dp']):.2e}")
+    assert _rel(dx, ref["dx"]) < 2e-4 and _rel(dp, ref["dp"]) < 2e-4   # (tol 1e-3: two adaptive adjoint solves, looser than at 1e-5)
+    assert np.isfinite(dx).all() and np.isfinite(dp).all()
