@@ -491,3 +491,32 @@ def test_layer_forward_soak_bit_exact(oracle, gpu_pkg, seed):
             # implementations in 3 of 4000 random cases, all with 1 - t1 < 1e-3; dx, which the regulariser does not touch, 1e-6)
             bar = 50 * tol + (5e-3 if 1.0 - t1 < 1e-2 else 1e-3)
         assert rel(bg["dx"].cpu().numpy(), bo["dx"]) < bar and rel(bg["dp"].cpu().numpy(), bo["dp"]) < bar, what
+
+
+@pytest.mark.parametrize("seed", list(range(int(_os.environ.get("LRNDE_SOAK_SEEDS", "8")))))
+def test_solve_soak_bit_exact(oracle, gpu_pkg, seed):
+    """`solve` with random saveat lists (0..12 points, sorted, possibly with duplicates, a point at t0 / t1, more than the
+    eight the init launch carries by value), save_start, save_everystep, tolerance, span and shape: statistics, saved times and
+    every saved state GPU == oracle bit for bit.  LRNDE_SOAK_SEEDS=N runs N seeds."""
+    import torch
+    rng = np.random.default_rng(90_000 + seed)
+    D = int(rng.choice([4, 12, 32, 100, 452, 784])); H = int(rng.choice([4, 16, 64, 100, 112, 130]))
+    B = int(rng.choice([1, 4, 5, 33, 64])); act = str(rng.choice(["tanh", "gelu"])); td = bool(rng.integers(0, 2))
+    tol = float(rng.choice([1e-3, 1e-5, 1e-7]))
+    t0 = float(np.float32(rng.choice([0.0, 0.25, -1.0]))); t1 = float(np.float32(t0 + rng.choice([0.5, 1.0, 3.0])))
+    ns = int(rng.integers(0, 13))
+    sv = sorted(float(np.float32(t0 + (t1 - t0) * v)) for v in rng.random(ns))
+    if ns and rng.random() < 0.3: sv = sorted(sv + [sv[int(rng.integers(0, ns))]])       # a duplicate
+    if rng.random() < 0.5: sv = sorted(sv + [t1])
+    if rng.random() < 0.2: sv = sorted(sv + [t0])
+    save_start = bool(rng.integers(0, 2))
+    every = (None if sv else True) if rng.random() < 0.8 else True
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, D, H, B, act, td, scale=1.5, seed=seed)
+    what = f"seed={seed} D={D} H={H} B={B} {act} td={td} tol={tol} span=({t0},{t1}) saveat={sv} save_start={save_start} everystep={every}"
+    ref = oracle.solve(fld, x, t0, t1, tol, tol, saveat=sv, maxiters=20000, save_start=save_start, save_everystep=every, cap=600)
+    got = h.solve(torch.from_numpy(x).cuda(), t0, t1, tol, tol, saveat=sv, maxiters=20000, save_start=save_start, save_everystep=every,
+                  cap=600)
+    for k in ("nf", "naccept", "nreject", "iters", "nsaved", "dt_init", "t_final"):
+        assert got["stats"][k] == ref["stats"][k], (k, what, got["stats"], ref["stats"])
+    _eq(got["t"], ref["t"], "sol.t " + what)
+    _eq(got["u"].cpu().numpy(), ref["u"], "sol.u " + what)
