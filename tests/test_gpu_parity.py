@@ -520,3 +520,31 @@ def test_solve_soak_bit_exact(oracle, gpu_pkg, seed):
         assert got["stats"][k] == ref["stats"][k], (k, what, got["stats"], ref["stats"])
     _eq(got["t"], ref["t"], "sol.t " + what)
     _eq(got["u"].cpu().numpy(), ref["u"], "sol.u " + what)
+
+
+@pytest.mark.parametrize("seed", list(range(int(_os.environ.get("LRNDE_SOAK_SEEDS", "8")))))
+def test_sde_steps_soak_bit_exact(oracle, gpu_pkg, seed):
+    """Euler-Heun and RKMil steps (src/perform_step.jl:172-206, 108-170) with random shape (the one-launch 32/64 kernel and the
+    generic one), batch, time, step and tolerances: u, EEst and reg_val GPU == oracle bit for bit."""
+    import torch
+    from localregneuralde_jl_amd.layers import _mlp_desc
+    rng = np.random.default_rng(70_000 + seed)
+    D, H = [(32, 64), (32, 64), (16, 16), (20, 48), (8, 100), (64, 32)][int(rng.integers(0, 6))]
+    B = int(rng.choice([1, 3, 16, 37, 100, 512]))
+    pd, pg, drift, diff = _sde_fields(oracle, D, H, seed=seed)
+    u = rng.standard_normal((B, D)).astype(np.float32)
+    dt = np.float32(rng.choice([1e-3, 0.02, 0.1])); t = np.float32(rng.random())
+    dW = (rng.standard_normal((B, D)) * np.sqrt(dt)).astype(np.float32)
+    tol = float(rng.choice([0.14, 0.01, 1e-3])); delta = float(rng.choice([1.0 / 6.0, 0.5]))
+    h = gpu_pkg.SdeHandle(_mlp_desc(gpu_pkg.Chain(gpu_pkg.Dense(D, H, "tanh"), gpu_pkg.Dense(H, D))))
+    h.set_params(pd, pg)
+    what = f"seed={seed} D={D} H={H} B={B} t={t} dt={dt} tol={tol} delta={delta}"
+    ud, wd = torch.from_numpy(u).cuda(), torch.from_numpy(dW).cuda()
+    ref = oracle.euler_heun_step(drift, diff, u, dW, t, dt, tol, tol, delta)
+    got = h.euler_heun_step(ud, wd, t, dt, tol, tol, delta)
+    _eq(got["u"].cpu().numpy(), ref["u"], "euler-heun u " + what)
+    assert got["eest"] == ref["eest"] and got["reg_val"] == ref["reg_val"], what
+    ref = oracle.rkmil_step(drift, diff, u, dW, t, dt, tol, tol)
+    got = h.rkmil_step(ud, wd, t, dt, tol, tol)
+    _eq(got["u"].cpu().numpy(), ref["u"], "rkmil u " + what)
+    assert got["eest"] == ref["eest"], what
