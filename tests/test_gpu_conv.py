@@ -590,3 +590,26 @@ def test_conv_wide_images(W, H, B):
     hb = P.ConvHandle(W, H, 8, 64, act="gelu", bn_train=True, compute_dtype="bf16")
     hb.set_params(p)
     _close(hb.rhs(ud, 0.3), fld.rhs(u.reshape(B, -1), 0.3).reshape(u.shape), rtol=3e-2)
+
+
+import os as _os
+
+
+@pytest.mark.parametrize("seed", list(range(int(_os.environ.get("LRNDE_SOAK_SEEDS", "6")))))
+def test_conv_rhs_and_vjp_soak(seed):
+    """the conv field's f-eval and VJP with random image size (W % 4 == 0 up to 32, any height >= 2), batch, activation, BN mode
+    and time, fp32: 1e-5 of scale against the oracle (f-eval), 2e-5 (state cotangent), 1e-4 (parameter cotangent, batch sums)"""
+    P, O = _mods()
+    rng = np.random.default_rng(30_000 + seed)
+    W = int(rng.choice([4, 8, 12, 16, 28, 32])); H = int(rng.choice([2, 3, 8, 9, 16, 28, 32]))
+    B = int(rng.choice([1, 2, 3, 5])); act = str(rng.choice(["gelu", "tanh", "identity"])); train = bool(rng.integers(0, 2))
+    if train and B * W * H < 8: B = 4
+    fld, h, p, u = _case(W, H, B, seed=seed, act=act, train=train)
+    t = float(np.float32(rng.random()))
+    ud = torch.from_numpy(u).cuda()
+    _close(h.rhs(ud, t), fld.rhs(u.reshape(B, -1), t))
+    lam = rng.standard_normal(u.shape).astype(np.float32)
+    dy_o, gp_o = O.conv_vjp(fld, u.reshape(B, -1), t, lam.reshape(B, -1))
+    dy_g, gp_g = h.vjp(ud, t, torch.from_numpy(lam).cuda())
+    _close(dy_g, dy_o, rtol=2e-5)
+    _close(gp_g, gp_o, rtol=1e-4)
