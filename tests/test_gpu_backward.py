@@ -288,3 +288,28 @@ def test_node_backward_with_t1_next_to_an_end_of_the_span(oracle, gpu_pkg, t1):
     print(f"t1={t1}: bwd steps gpu/oracle {got['stats_bwd']['naccept']}/{ref['stats_bwd']['naccept']}, rel err dx {_rel(dx, ref['dx']):.2e} dp {_rel(dp, ref['dp']):.2e}")
     assert _rel(dx, ref["dx"]) < 2e-4 and _rel(dp, ref["dp"]) < 2e-4   # (tol 1e-3: two adaptive adjoint solves, looser than at 1e-5)
     assert np.isfinite(dx).all() and np.isfinite(dp).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,H,B", [(784, 100, 8), (32, 64, 5)])
+def test_recorded_forward_with_more_steps_than_the_record_holds(oracle, gpu_pkg, D, H, B):
+    """The dense record starts with room for 64 accepted steps; a solve that needs more stops with the capacity status, the
+    record is doubled and the forward runs again (twice here: > 128 steps).  The adjoint's record lookup leaves its
+    64-lane fast path.  Forward bit-exact against the oracle, pullback within tolerance."""
+    import torch
+    fld, h, p, x = _mk(oracle, gpu_pkg, D, H, B, "tanh", True, scale=2.5)
+    g = (np.random.default_rng(4).standard_normal(x.shape) * 1e-2).astype(np.float32)
+    tol, t2 = 1e-7, 9.0
+    ref = oracle.node_backward(fld, x, 0.0, t2, tol, tol, g, mode="unbiased", t1_or_rand=3.7, w_reg=2.5)
+    got = h.node_backward(torch.from_numpy(x).cuda(), 0.0, t2, tol, tol, torch.from_numpy(g).cuda(), mode="unbiased",
+                          t1_or_rand=3.7, w_reg=2.5, maxiters=10000)
+    print(f"D={D}: forward steps {got['stats_fwd']['naccept']}, adjoint steps gpu/oracle {got['stats_bwd']['naccept']}/{ref['stats_bwd']['naccept']}")
+    assert got["stats_fwd"]["naccept"] > 128
+    assert got["stats_fwd"]["naccept"] == ref["stats_fwd"]["naccept"] and got["stats_fwd"]["nf"] == ref["stats_fwd"]["nf"]
+    dx, dp = got["dx"].cpu().numpy(), got["dp"].cpu().numpy()
+    assert _rel(dx, ref["dx"]) < 1e-4 and _rel(dp, ref["dp"]) < 1e-4, (_rel(dx, ref["dx"]), _rel(dp, ref["dp"]))
+    # and the recorded forward by itself, against a plain one
+    hx = torch.from_numpy(x).cuda()
+    a = h.node_forward_record(hx, 0.0, t2, tol, tol, mode="unbiased", t1_or_rand=3.7, maxiters=10000)
+    b = h.node_forward(hx, 0.0, t2, tol, tol, mode="unbiased", t1_or_rand=3.7, maxiters=10000)
+    assert torch.equal(a["u_end"], b["u_end"]) and a["reg_val"] == b["reg_val"] and a["nfe"] == b["nfe"]
