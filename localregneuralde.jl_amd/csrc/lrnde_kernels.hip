@@ -2658,7 +2658,12 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
     static const bool no_overlap = getenv("LRNDE_NO_OVERLAP") != nullptr;
     lrnde_ctx* sd = nullptr;
     int side_state = 0;  // 0: nothing enqueued, 1: local step enqueued, 2: + sweep
-    const int pos = (int)(std::upper_bound(sv.begin(), sv.end(), t1) - sv.begin()) - 1;  // slot of the LAST entry equal to t1
+    // save slot of the LAST saveat entry equal to t1: its index among the entries inside the span (those at or before t0 are
+    // the start value and take no slot), behind the save_start slot if there is one
+    const int kpos = (int)(std::upper_bound(sv.begin(), sv.end(), t1) - sv.begin()) - 1;
+    int nskip = 0;
+    while (nskip < (int)sv.size() && sv[nskip] <= t0) ++nskip;
+    const int pos = (kpos >= nskip) ? kpos - nskip + (oo.save_start ? 1 : 0) : -1;
     auto enqueue_sweep = [&]() -> int {
       const Ctrl k = sd->ctrl_host[0];
       const int r = step_reg_sweep(sd, sd->state, B, t1, k.dt, oo.abstol, oo.reltol, reg_type, k.eest_last, k.stiff_num, k.stiff_den,
@@ -2682,7 +2687,7 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
       }
       return LRNDE_OK;
     };
-    if (!sharded(c) && !no_overlap && !c->overlap_off && pos >= 0 && sv[pos] == t1) {
+    if (!sharded(c) && !no_overlap && !c->overlap_off && pos >= 0 && sv[kpos] == t1) {
       if ((rc = side_get(c, B, &sd))) return rc;
       c->poll_hook = [&](int nsaved_done, hipEvent_t ev) { return side_advance(nsaved_done, ev); };
     }
@@ -2714,7 +2719,9 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
       if (!u_end_done) HIPCHK(c, hipStreamSynchronize(c->stream));
       return LRNDE_OK;
     }
-    if ((rc = side_quiesce(c))) return rc;  // (not reached with a companion step in flight; kept for safety)
+    // (not reached with a companion step in flight unless the slot prediction was wrong: then nothing of it may be used)
+    if ((rc = side_quiesce(c))) return rc;
+    c->rec_gr_ready = false; c->sweep_pending = false;
   } else {  // neural_ode.jl:88-100, saveat = [] => every accepted step (or the user's saveat)
     oo.save_everystep = nuser ? 0 : 1;
     rc = lrnde_solve(c, x, B, t0, t2, &oo, nuser ? user_sv : nullptr, nuser, c->usave, ts.data(), (int)c->usave_slots, st, nullptr, 0);

@@ -82,3 +82,26 @@ def test_training_step_with_an_early_and_a_late_t1(gpu_pkg, where):
         assert r[0] == res[0][0]
         for k in res[0][1]:
             assert torch.equal(r[1][k], res[0][1][k]), k
+
+
+@pytest.mark.parametrize("save_start", [True, False])
+@pytest.mark.parametrize("t1", [0.2, 0.8])
+def test_recorded_forward_with_save_start_uses_the_right_slot(oracle, gpu_pkg, save_start, t1):
+    """With save_start the solution's first slot is u(t0) and sol(t1) sits one slot later: the companion stream's local step (and
+    the regulariser sweep it feeds) must start from sol(t1), not from the start value.  (A wrong slot was found by the
+    randomised soak: forward values were right — the serial path recomputed them — but the recorded regulariser gradient came
+    from a local step at u(t0).)  Pullback: both stream orders bit for bit, and the oracle's within tolerance."""
+    import torch
+    from test_gpu_backward import _mk, _rel
+    P = gpu_pkg
+    fld, h, p, x = _mk(oracle, P, 784, 100, 16, "tanh", True, scale=1.5)
+    g = (np.random.default_rng(4).standard_normal(x.shape) * 1e-2).astype(np.float32)
+    xd, gd = torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda()
+    ref = oracle.node_backward(fld, x, 0.0, 1.0, 1e-5, 1e-5, g, mode="unbiased", t1_or_rand=t1, w_reg=2.5, save_start=save_start)
+    out = []
+    for on in (True, False):
+        h.set_overlap(on)
+        out.append(h.node_backward(xd, 0.0, 1.0, 1e-5, 1e-5, gd, mode="unbiased", t1_or_rand=t1, w_reg=2.5, maxiters=10000,
+                                   save_start=save_start))
+    assert torch.equal(out[0]["dx"], out[1]["dx"]) and torch.equal(out[0]["dp"], out[1]["dp"])
+    assert _rel(out[0]["dx"].cpu().numpy(), ref["dx"]) < 2e-5 and _rel(out[0]["dp"].cpu().numpy(), ref["dp"]) < 3e-4

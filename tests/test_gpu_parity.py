@@ -470,18 +470,19 @@ def test_layer_forward_soak_bit_exact(oracle, gpu_pkg, seed):
     mode = str(rng.choice(["unbiased", "unbiased", "biased", "none"]))
     reg_type = str(rng.choice(["error_estimate", "stiffness_estimate"]))
     t1 = float(rng.choice([rng.random(), rng.random(), 1e-5 + rng.random() * 2e-3, 1.0 - rng.random() * 2e-3]))
+    save_start = bool(rng.integers(0, 2))
     fld, h, p, x, _ = _mk(oracle, gpu_pkg, D, H, B, act, td, scale=1.5, seed=seed)
     xd = torch.from_numpy(x).cuda()
-    what = f"seed={seed} D={D} H={H} B={B} {act} td={td} tol={tol} {mode}/{reg_type} t1={t1}"
-    ro = oracle.node_forward(fld, x, 0.0, 1.0, tol, tol, mode=mode, reg_type=reg_type, t1_or_rand=t1, maxiters=20000)
-    rg = h.node_forward(xd, 0.0, 1.0, tol, tol, mode=mode, reg_type=reg_type, t1_or_rand=t1, maxiters=20000)
+    what = f"seed={seed} D={D} H={H} B={B} {act} td={td} tol={tol} {mode}/{reg_type} t1={t1} save_start={save_start}"
+    ro = oracle.node_forward(fld, x, 0.0, 1.0, tol, tol, mode=mode, reg_type=reg_type, t1_or_rand=t1, maxiters=20000, save_start=save_start)
+    rg = h.node_forward(xd, 0.0, 1.0, tol, tol, mode=mode, reg_type=reg_type, t1_or_rand=t1, maxiters=20000, save_start=save_start)
     assert rg["nfe"] == ro["nfe"] and rg["reg_val"] == ro["reg_val"], what
     _eq(rg["u_end"].cpu().numpy(), ro["u_end"], "u_end " + what)
     if D * B <= 784 * 33:   # the pullback of <g, sol.u[end]> + 1.5 reg_val (the oracle's adjoint is a CPU loop)
         g = (np.random.default_rng(seed).standard_normal(x.shape) * 1e-2).astype(np.float32)
-        bo = oracle.node_backward(fld, x, 0.0, 1.0, tol, tol, g, mode=mode, reg_type=reg_type, t1_or_rand=t1, w_reg=1.5)
+        bo = oracle.node_backward(fld, x, 0.0, 1.0, tol, tol, g, mode=mode, reg_type=reg_type, t1_or_rand=t1, w_reg=1.5, save_start=save_start)
         bg = h.node_backward(xd, 0.0, 1.0, tol, tol, torch.from_numpy(g).cuda(), mode=mode, reg_type=reg_type, t1_or_rand=t1,
-                             w_reg=1.5, maxiters=20000)
+                             w_reg=1.5, maxiters=20000, save_start=save_start)
         assert bo["retcode"] == 0, what
         rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
         bar = 50 * tol + 3e-4   # two adaptive adjoint solves at this tolerance; the regulariser's gradient is ill-conditioned in fp32

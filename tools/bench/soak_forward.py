@@ -19,6 +19,7 @@ for it in range(N):
     # (a t1 within dtmin = eps(1) = 1.2e-7 of t0 leaves the adjoint a last interval shorter than dtmin: DtLessThanMin by the
     #  controller's own rule, in both orders — one draw in eight million; not sampled here)
     mode = str(rng.choice(["unbiased", "unbiased", "biased", "none"]))
+    ss = bool(rng.integers(0, 2))
     x = torch.from_numpy(rng.random((B, D), dtype=np.float32)).cuda()
     h = handles.get(B)
     if h is None:
@@ -28,13 +29,13 @@ for it in range(N):
       try:
         h.set_overlap(on)
         if it % 3 == 0 and mode != "none":   # recorded forward + backward
-            fw = h.node_forward_record(x, 0.0, 1.0, tol, tol, mode=mode, reg_type="error_estimate", t1_or_rand=t1, maxiters=10000)
+            fw = h.node_forward_record(x, 0.0, 1.0, tol, tol, mode=mode, reg_type="error_estimate", t1_or_rand=t1, maxiters=10000, save_start=ss)
             du = torch.full_like(x, 1e-3)
             bw = h.node_backward_recorded(du, w_reg=2.5)
             res.append((fw["u_end"], fw["reg_val"], fw["nfe"], bw["dx"], bw["dp"]))
         else:
             fw = h.node_forward(x, 0.0, 1.0, tol, tol, mode=mode, reg_type="stiffness_estimate" if it % 2 else "error_estimate",
-                                t1_or_rand=t1, maxiters=10000)
+                                t1_or_rand=t1, maxiters=10000, save_start=ss)
             res.append((fw["u_end"], fw["reg_val"], fw["nfe"]))
       except Exception as e:   # a solver return code (e.g. DtLessThanMin in the adjoint) is a result too: both orders must agree
         res.append((str(e),))
