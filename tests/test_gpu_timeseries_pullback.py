@@ -91,3 +91,37 @@ def test_timeseries_pullback_rejects_wrong_series_length(gpu_pkg):
     xd, ps = torch.from_numpy(x).cuda(), torch.from_numpy(p).cuda()
     with pytest.raises(ValueError, match="cotangents"):
         node.pullback(xd, ps, st, torch.zeros((3, 4, 32), device="cuda"))
+
+
+import os as _os
+
+
+@pytest.mark.parametrize("seed", list(range(int(_os.environ.get("LRNDE_SOAK_SEEDS", "8")))))
+def test_timeseries_forward_soak_against_the_oracle_solve(oracle, gpu_pkg, seed):
+    """`lrnde_node_forward_record_ts` with random user saveat (duplicates of t1, points at the ends), mode, t1, save_start: the
+    returned series is the oracle's plain solve on the user's saveat bit for bit (saveat points are interpolated, the extra t1
+    changes no step), with the reference's filter `t1 .!= sol.t` applied (src/utils.jl:25-33), and reg_val / nfe are the
+    oracle's layer forward's with that t1.  LRNDE_SOAK_SEEDS=N runs N seeds."""
+    import torch
+    from test_gpu_parity import _mk, _eq
+    rng = np.random.default_rng(40_000 + seed)
+    D, H = [(784, 100), (32, 64), (20, 40), (452, 112)][int(rng.integers(0, 4))]
+    B = int(rng.choice([1, 4, 9, 33])); tol = float(rng.choice([1e-3, 1e-5, 1e-7]))
+    mode = str(rng.choice(["unbiased", "unbiased", "none"]))
+    t1 = float(np.float32(rng.random()))
+    save_start = bool(rng.integers(0, 2))
+    ns = int(rng.integers(1, 7))
+    sv = sorted(set(float(np.float32(v)) for v in rng.random(ns)) | ({1.0} if rng.random() < 0.7 else set()))
+    if rng.random() < 0.25: sv = sorted(set(sv) | {t1})
+    fld, h, p, x, _ = _mk(oracle, gpu_pkg, D, H, B, "tanh", True, scale=1.5, seed=seed)
+    xd = torch.from_numpy(x).cuda()
+    what = f"seed={seed} D={D} B={B} tol={tol} {mode} t1={t1} saveat={sv} save_start={save_start}"
+    fw = h.node_forward_record_ts(xd, 0.0, 1.0, tol, tol, sv, mode=mode, reg_type="error_estimate", t1_or_rand=t1, maxiters=20000,
+                                  save_start=save_start)
+    ref = oracle.solve(fld, x, 0.0, 1.0, tol, tol, saveat=sv, maxiters=20000, save_start=save_start, save_everystep=False)
+    keep = [i for i, tv in enumerate(ref["t"]) if not (mode == "unbiased" and tv == np.float32(t1))]
+    _eq(fw["t"], ref["t"][keep], "sol.t " + what)
+    _eq(fw["u"].cpu().numpy(), ref["u"][keep], "sol.u " + what)
+    lay = oracle.node_forward(fld, x, 0.0, 1.0, tol, tol, mode=mode, reg_type="error_estimate", t1_or_rand=t1, maxiters=20000,
+                              save_start=save_start)
+    assert fw["reg_val"] == lay["reg_val"] and fw["nfe"] == lay["nfe"], what
