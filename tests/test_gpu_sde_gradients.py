@@ -181,3 +181,48 @@ def test_adaptive_euler_heun_solve_equals_the_oracle_step_loop(oracle, gpu_pkg, 
     assert np.array_equal(got["u_end"].cpu().numpy(), u)
     print(f"adaptive SDE D={D} B={B} tol={tol}: accepted {got['stats']['naccept']}, rejected {got['stats']['nreject']}")
     assert got["stats"]["naccept"] >= 3
+
+
+import os as _os
+
+
+@pytest.mark.parametrize("seed", list(range(int(_os.environ.get("LRNDE_SOAK_SEEDS", "6")))))
+def test_sde_gradients_soak_against_float64_autograd(gpu_pkg, seed):
+    """random shape (the one-launch kernel's 32/64 and others), batch, grid length and step: the fixed-grid solve's pullback and
+    the local step's regulariser gradient against float64 autograd (5e-5 of each gradient's norm)"""
+    P = gpu_pkg
+    from localregneuralde_jl_amd.layers import _mlp_desc
+    rng = np.random.default_rng(80_000 + seed)
+    D, H = [(32, 64), (32, 64), (16, 16), (8, 40), (20, 48)][int(rng.integers(0, 5))]
+    B = int(rng.choice([1, 5, 64, 130])); n = int(rng.choice([3, 8, 20])); span = float(rng.choice([0.5, 1.0]))
+    pd, pg = _params(D, H, seed)
+    x = rng.standard_normal((B, D)).astype(np.float32)
+    dt = np.float32(span / n)
+    dW = (rng.standard_normal((n, B, D)) * np.sqrt(dt)).astype(np.float32)
+    gend = rng.standard_normal((B, D)).astype(np.float32)
+    h = P.SdeHandle(_mlp_desc(P.Chain(P.Dense(D, H, "tanh"), P.Dense(H, D))))
+    h.set_params(pd, pg)
+    xd, dWd = torch.from_numpy(x).cuda(), torch.from_numpy(dW).cuda()
+    tr = h.solve_fixed(xd, dWd, 0.0, dt, 0.14, 0.14, 1.0 / 6.0)
+    bw = h.solve_fixed_backward(xd, tr["u"], dWd, 0.0, dt, torch.from_numpy(gend).cuda())
+    pdt = torch.tensor(pd, dtype=torch.float64, requires_grad=True)
+    pgt = torch.tensor(pg, dtype=torch.float64, requires_grad=True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    f, g = _fields64(pdt, pgt, D, H)
+    u = xt
+    for i in range(n):
+        u = _eh_step64(f, g, u, torch.tensor(dW[i], dtype=torch.float64), float(dt))[0]
+    (u * torch.tensor(gend, dtype=torch.float64)).sum().backward()
+    what = f"seed={seed} D={D} H={H} B={B} n={n} dt={dt}"
+    for name, got, ref in (("dx", bw["dx"], xt.grad), ("dp_drift", bw["dp_drift"], pdt.grad), ("dp_diff", bw["dp_diff"], pgt.grad)):
+        assert _rel(got.cpu().numpy(), ref.numpy()) < 5e-5, (what, name, _rel(got.cpu().numpy(), ref.numpy()))
+    k = int(rng.integers(0, n))
+    u1 = tr["u"][k].contiguous()
+    w1 = (rng.standard_normal((B, D)) * np.sqrt(dt)).astype(np.float32)
+    rg = h.euler_heun_reg_grad(u1, torch.from_numpy(w1).cuda(), 0.3, dt, 0.14, 0.14, 1.0 / 6.0)
+    pdt.grad = None; pgt.grad = None
+    val = _eh_reg64(f, g, torch.tensor(u1.cpu().numpy(), dtype=torch.float64), torch.tensor(w1, dtype=torch.float64), float(dt), 0.14, 0.14, 1.0 / 6.0)
+    assert abs(float(val) - float(rg["reg_val"])) < 2e-5 * abs(float(val)), what
+    val.backward()
+    for name, got, ref in (("dp_drift", rg["dp_drift"], pdt.grad), ("dp_diff", rg["dp_diff"], pgt.grad)):
+        assert _rel(got.cpu().numpy(), ref.numpy()) < 5e-5, (what, "reg " + name, _rel(got.cpu().numpy(), ref.numpy()))
