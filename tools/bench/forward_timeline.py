@@ -3,8 +3,13 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_solve_init" in r["Kernel_Name"]]
-if not idx: sys.exit("no k_solve_init in the trace")
+# a forward opens with k_solve_init or, with the folded initialisation, with the first init kernel on the MAIN queue (the
+# local step's own init launches run on the companion queue in the middle of the pass)
+from collections import Counter
+main_q = Counter(r.get("Queue_Id", "0") for r in rows if "k_step" in r["Kernel_Name"]).most_common(1)[0][0]
+idx = [i for i, r in enumerate(rows) if "k_solve_init" in r["Kernel_Name"] or
+       ("k_init1" in r["Kernel_Name"] and r.get("Queue_Id", "0") == main_q)]
+if not idx: sys.exit("no solve start (k_solve_init / k_init1) in the trace")
 seg = rows[idx[-1]:]
 t0 = int(seg[0]["Start_Timestamp"]); prev_end = {}; last_end = t0
 qs = sorted(set(r.get("Queue_Id", "0") for r in seg))
