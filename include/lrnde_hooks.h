@@ -32,8 +32,14 @@ int lrnde_comm_init_local(lrnde_ctx* ctx, lrnde_local_comm* lc, int32_t rank);
  * with HIP events on the handle's stream; avg_us_host = microseconds per launch (roofline leg). */
 int lrnde_bench_step(lrnde_ctx* ctx, const float* uprev, const float* k1, int32_t B, float t, float dt,
                      float abstol, float reltol, int32_t reps, float* avg_us_host);
-/* HIP events on the handle's stream around the kernels of the last solve (ms), and its step-kernel launches */
+/* HIP events on the handle's stream around the kernels of the last solve (ms), and its step-kernel launches.  The first call
+ * ARMS the clock (solves record their two events from then on — each a marker packet in the queue — and this call returns
+ * 0 ms): call it once, run a solve, call it again. */
 int lrnde_last_solve_kernel_ms(lrnde_ctx* ctx, float* total_ms_host, int32_t* step_launches_host);
+/* Diagnostic: mean host-side microseconds per lrnde_node_forward call since the last reset, by phase: [0] entry -> the main
+ * solve's init launches enqueued, [1] -> its last report read (the feed loop: the GPU is busy throughout), [2] -> the final
+ * synchronisation returned, [3] -> the call returned (local-step results, bookkeeping).  tools/bench/host_phases.py */
+int lrnde_host_phases(lrnde_ctx* ctx, double* us4_host, int32_t reset);
 /* Diagnostic: 0 = the layer forward keeps its local step (and the recorded forward's regulariser sweep) in order on the
  * handle's stream instead of its companion stream; 1 = overlap (the default for unsharded handles).
  * Results are the same bits either way — tests/test_gpu_overlap.py holds the library to that. */

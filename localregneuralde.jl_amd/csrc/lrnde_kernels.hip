@@ -37,6 +37,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <functional>
 #include <vector>
@@ -161,6 +162,8 @@ struct StepArgs {
   int nsave, cap_saved, cap_trace;
   const float* saveat;  // device copy
   float* u_saved;
+  float* also_dst;  // save slot `also_slot` is written here as well (the caller's u_end: no copy packet after the solve); or NULL
+  int also_slot;
   float* t_saved;  // device view of a pinned host array: the few saved times are written straight to the host
   // unsharded solves: progress word in pinned host memory (one 64-bit posted store per launch, see solve_progress) and
   // the final control block, both written by workgroup 0's prologue; NULL elsewhere
@@ -1326,6 +1329,7 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
     for (int is = bc.isave0; is < bc.isave1; ++is, ++slot) {
       const float ts = a.saveat[is];
       float* dst = a.u_saved + (size_t)slot * a.B * a.m.D;
+      float* dst2 = slot == a.also_slot ? a.also_dst : nullptr;
       if (ts != bc.t_new) {
         const float theta = (ts - bc.tprev) / bc.dt_prev;
         float bw[7];
@@ -1347,10 +1351,14 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
             o.v[h] = y0.v[h] + bc.dt_prev * sum;
           }
           vstore<W>(dst + g, o);
+          if (dst2) vstore<W>(dst2 + g, o);
         });
       } else {
         tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
-          if (valid) vstore<W>(dst + g, vload<W>(un + g));
+          if (!valid) return;
+          const Vec<W> o = vload<W>(un + g);
+          vstore<W>(dst + g, o);
+          if (dst2) vstore<W>(dst2 + g, o);
         });
       }
       if (blockIdx.x == 0 && threadIdx.x == 0) a.t_saved[slot] = ts;
@@ -1820,6 +1828,7 @@ struct lrnde_ctx {
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evp[2] = {nullptr, nullptr};
   float last_ms = 0.f;
+  bool time_solves = false;  // lrnde_last_solve_kernel_ms has been called once: solves bracket their kernels with events
   int last_launches = 0;
   // companion context on its own (non-blocking) stream: shares the packed weights, owns a second state workspace.  The
   // layer forward runs its local step there (and, recording, the regulariser's reverse sweep) WHILE the main solve
@@ -1832,7 +1841,10 @@ struct lrnde_ctx {
   bool sweep_pending = false; int sw_B = 0, sw_reg_type = 0; float sw_t1 = 0.f, sw_abstol = 0.f, sw_reltol = 0.f;
   std::function<int()> after_first_attempt;  // adj_solve_device calls it once, after enqueuing its first attempt
   hipEvent_t ev_side_local = nullptr, ev_side_sweep = nullptr;
-  float* tail_copy_dst = nullptr; const float* tail_copy_src = nullptr;  // lrnde_solve: one D2D copy enqueued before its final sync
+  // host-side phase clock of the layer forward (lrnde_host_phases, diagnostics): time points of the call in flight, sums over calls
+  std::chrono::steady_clock::time_point hp_t[8];
+  double hp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long hp_n = 0;
+  float* tail_copy_dst = nullptr; int tail_copy_slot = -1;  // lrnde_solve: the step that fills this save slot writes it to tail_copy_dst too
   std::function<int(int, hipEvent_t)> poll_hook;  // lrnde_solve calls it after every status poll (event: that poll's)
   std::string err;
 };
@@ -1863,6 +1875,18 @@ int fail(lrnde_ctx* c, int code, const char* fmt, ...) {
       return fail(c, LRNDE_NCCL_ERROR, "%s failed: %s (%s:%d)", #x, ncclGetErrorString(r_),   \
                   __FILE__, __LINE__);                                                        \
   } while (0)
+
+#define HPT(c, i) ((c)->hp_t[i] = std::chrono::steady_clock::now())
+// for the host loops that spin on a report word in pinned memory: true once a wait has lasted 20 ms (then every 20 ms) — the
+// caller then asks the runtime whether the queue is still alive.  `spin` is the caller's spin count of THIS wait.
+inline bool spin_stalled(long spin) {
+  thread_local std::chrono::steady_clock::time_point t_last;
+  const auto now = std::chrono::steady_clock::now();
+  if (spin <= 0x4000) { t_last = now; return false; }   // first check of this wait (the callers ask every 0x4000 spins): start the clock
+  if (now - t_last < std::chrono::milliseconds(20)) return false;
+  t_last = now;
+  return true;
+}
 
 // a batch-sharded handle: its collectives run (RCCL or the in-process local communicator, lrnde_comm.hpp)
 inline bool sharded(const lrnde_ctx* c) { return c->comm != nullptr || c->lcomm != nullptr; }
@@ -2391,6 +2415,9 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
     a.dense_direct = (use_qtile(c, B) && !no_direct) ? 1 : 0;
   }
   a.cap_saved = cap_saved; a.u_saved = u_saved; a.t_saved = c->tsaved_dev;
+  // (round 2 enqueued a D2D copy of that slot once the last report was in: 30 us of host latency plus a blit kernel
+  //  between the last launch and the caller's synchronisation)
+  a.also_dst = c->tail_copy_dst; a.also_slot = c->tail_copy_dst ? c->tail_copy_slot : -1;
   a.trace = trace_host ? c->trace_dev : nullptr; a.cap_trace = trace_host ? cap_trace : 0;
   // saveat points at/before t0 are the start value (save_start), as in the oracle
   int skip = 0;
@@ -2419,7 +2446,7 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   for (int i = 0; i < PROG_RING; ++i) pw[i] = 0ull;
   a.prog = c->prog_dev;
   a.fin_host = reinterpret_cast<Ctrl*>(reinterpret_cast<char*>(c->prog_dev) + PROG_RING * 8);
-  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  if (c->time_solves) HIPCHK(c, hipEventRecord(c->ev0, c->stream));  // (an event is a marker packet in the queue: only on request)
   if (use_qtile(c, B)) {
     // (4-column family: the first init launch reads the caller's array, copies it to ubuf[0] and writes the control blocks)
     a.init_u0 = u0; a.init_fresh = 1; a.init_nsaved = nsaved0; a.init_si = si;
@@ -2429,6 +2456,7 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   }
   if ((rc = run_init(c, B, a))) return rc;
   a.init_u0 = nullptr; a.init_fresh = 0;
+  HPT(c, 1);
 
   // Attempted steps are enqueued ahead of the device's decisions, steered by the per-launch reports (below); the copy-polled
   // chunk loop further down is the fall-back if no report ever arrives.  Launches beyond what a report makes certain are
@@ -2464,7 +2492,10 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
       volatile unsigned long long* slot = pw + (seen & (PROG_RING - 1));
       unsigned long long w = *slot;
       for (long spin = 1; (int)(w & 0xffffffull) != seen + 1; ++spin) {
-        if ((spin & 0x3fff) == 0) {  // bounded: a faulted queue must not hang the caller
+        // bounded: a faulted queue must not hang the caller.  The query is kept for a report that is LATE (the runtime
+        // answers it by putting a marker packet into the queue: asked every few thousand spins, one landed between two
+        // steps whenever the queue was only a launch or two deep — a 6-us bubble each, five per pass at the end of a solve)
+        if ((spin & 0x3fff) == 0 && spin_stalled(spin)) {
           const hipError_t qe = hipStreamQuery(c->stream);
           if (qe != hipSuccess && qe != hipErrorNotReady) return fail(c, LRNDE_HIP_ERROR, "solve loop: %s", hipGetErrorString(qe));
           if (qe == hipSuccess) {
@@ -2483,6 +2514,7 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
     }
     target = j;
   }
+  HPT(c, 2);
   while (!done && !word_ok) {
     int ch = target - j;
     if (ch < 2) ch = 2;
@@ -2514,14 +2546,12 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
     if (target < j) target = j;  // never re-label launches already issued
     if (j > hard_cap + 64) break;
   }
-  if (c->tail_copy_dst) {  // the caller's copy of the last save slot, ahead of the synchronisation below
-    HIPCHK(c, hipMemcpyAsync(c->tail_copy_dst, c->tail_copy_src, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
-    c->tail_copy_dst = nullptr;
-  }
-  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  c->tail_copy_dst = nullptr;
+  if (c->time_solves) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   Ctrl fin;
   if (word_ok && done) {  // the finished solve left its control block in host memory (solve_progress)
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HPT(c, 3);
     fin = *fin_host;
   } else {
     HIPCHK(c, hipMemcpyAsync(c->ctrl_host, c->ctrl + (j & 1), sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
@@ -2536,7 +2566,7 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
     if (nt > cap_trace) nt = cap_trace;
     if (nt > 0) HIPCHK(c, hipMemcpy(trace_host, c->trace_dev, sizeof(lrnde_trace_row) * nt, hipMemcpyDeviceToHost));
   }
-  hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1);
+  if (c->time_solves) hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1);
   c->last_launches = launches;
   if (st->retcode != LRNDE_OK)
     return fail(c, st->retcode, "solve stopped with retcode %d at t=%g (iter %d)", st->retcode, (double)fin.t, fin.iter);
@@ -2637,7 +2667,7 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
     const float sv1[1] = {t2};
     oo.save_everystep = 0;
     const int early = early_slot(nuser ? user_sv : sv1, nuser ? nuser : 1);
-    if (early >= 0) { c->tail_copy_dst = u_end; c->tail_copy_src = c->usave + (size_t)early * n; }
+    if (early >= 0) { c->tail_copy_dst = u_end; c->tail_copy_slot = early; }
     rc = lrnde_solve(c, x, B, t0, t2, &oo, nuser ? user_sv : sv1, nuser ? nuser : 1, c->usave, ts.data(), (int)c->usave_slots, st, nullptr, 0);
     c->tail_copy_dst = nullptr;
     if (rc) return rc;
@@ -2697,7 +2727,7 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
       c->poll_hook = [&](int nsaved_done, hipEvent_t ev) { return side_advance(nsaved_done, ev); };
     }
     const int early = early_slot(sv.data(), (int)sv.size());
-    if (early >= 0) { c->tail_copy_dst = u_end; c->tail_copy_src = c->usave + (size_t)early * n; }
+    if (early >= 0) { c->tail_copy_dst = u_end; c->tail_copy_slot = early; }
     rc = lrnde_solve(c, x, B, t0, t2, &oo, sv.data(), (int)sv.size(), c->usave, ts.data(), (int)c->usave_slots, st, nullptr, 0);
     c->poll_hook = nullptr; c->tail_copy_dst = nullptr;
     if (rc) return rc;
@@ -2758,7 +2788,15 @@ int lrnde_node_forward(lrnde_ctx* c, const float* x, int32_t B, float t0, float 
                        const lrnde_solve_opts* o, int32_t mode, int32_t reg_type, float t1_or_rand,
                        float* u_end, float* reg_val_host, int32_t* nfe_host, lrnde_stats* st,
                        float* t1_used_host) {
-  return node_forward_impl(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, nullptr, 0, u_end, reg_val_host, nfe_host, st, t1_used_host);
+  if (!c) return LRNDE_BADARG;
+  HPT(c, 0);
+  const int rc = node_forward_impl(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, nullptr, 0, u_end, reg_val_host, nfe_host, st, t1_used_host);
+  HPT(c, 4);
+  if (rc == LRNDE_OK) {
+    for (int i = 1; i <= 4; ++i) c->hp_sum[i] += std::chrono::duration<double, std::micro>(c->hp_t[i] - c->hp_t[i - 1]).count();
+    ++c->hp_n;
+  }
+  return rc;
 }
 
 int lrnde_comm_unique_id(void* out) {
@@ -3130,7 +3168,7 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
       const unsigned long long w = *pw;
       if ((unsigned)(w >> 32) != (unsigned)ST_RUNNING) { done = true; break; }
       if ((unsigned)(w & 0xffffffffull) >= want) break;
-      if ((spin & 0x3fff) == 0) {
+      if ((spin & 0x3fff) == 0 && spin_stalled(spin)) {  // (a stream query is a marker packet in the queue: only when the report is late)
         const hipError_t qe = hipStreamQuery(c->stream);
         if (qe != hipSuccess && qe != hipErrorNotReady) return fail(c, LRNDE_HIP_ERROR, "adaptive SDE loop: %s", hipGetErrorString(qe));
         if (qe == hipSuccess) break;  // everything enqueued has run: look at the word again, enqueue more
@@ -4329,8 +4367,16 @@ int lrnde_opt_update(int32_t kind, float* x, const float* grad, float* state1, f
   return hipGetLastError() == hipSuccess ? LRNDE_OK : LRNDE_HIP_ERROR;
 }
 
+int lrnde_host_phases(lrnde_ctx* c, double* us, int32_t reset) {
+  if (!c || !us) return LRNDE_BADARG;
+  for (int i = 0; i < 4; ++i) us[i] = c->hp_n ? c->hp_sum[i + 1] / (double)c->hp_n : 0.0;
+  if (reset) { for (double& v : c->hp_sum) v = 0; c->hp_n = 0; }
+  return LRNDE_OK;
+}
+
 int lrnde_last_solve_kernel_ms(lrnde_ctx* c, float* ms, int32_t* launches) {
   if (!c) return LRNDE_BADARG;
+  c->time_solves = true;
   if (ms) *ms = c->last_ms;
   if (launches) *launches = c->last_launches;
   return LRNDE_OK;

@@ -702,6 +702,7 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
     for (int is = bc.isave0; is < bc.isave1; ++is, ++slot) {
       const float ts = a.saveat[is];
       float* dst = a.u_saved + (size_t)slot * a.B * a.m.D;
+      float* dst2 = slot == a.also_slot ? a.also_dst : nullptr;
       if (ts != bc.t_new) {
         const float theta = (ts - bc.tprev) / bc.dt_prev;
         float bw[7];
@@ -722,10 +723,14 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
             o[h] = y0[h] + bc.dt_prev * sum;
           }
           st4(dst + g, o);
+          if (dst2) st4(dst2 + g, o);
         });
       } else {
         q_tile_foreach(a.m, b0, nvalid, KQ1, [&](int, int, bool valid, size_t g) {
-          if (valid) st4(dst + g, ld4(un + g));
+          if (!valid) return;
+          const f32x4 o = ld4(un + g);
+          st4(dst + g, o);
+          if (dst2) st4(dst2 + g, o);
         });
       }
       if (blockIdx.x == 0 && threadIdx.x == 0) a.t_saved[slot] = ts;

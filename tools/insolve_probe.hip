@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
   lrnde_set_params(c, p, np);
   lrnde_rhs(c, u, 0.f, B, k1);
   std::vector<float> hook, insolve;
+  lrnde_last_solve_kernel_ms(c, nullptr, nullptr);  // arms the solve's event pair
   for (int rep = 0; rep < 7; ++rep) {
     float usl = 0;
     lrnde_bench_step(c, u, k1, B, 0.f, 0.02f, 1.4e-8f, 1.4e-8f, 100, &usl);
