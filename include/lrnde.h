@@ -204,6 +204,16 @@ int lrnde_node_backward_recorded_ts(lrnde_ctx* ctx, int32_t B, const float* du_s
 int lrnde_classifier_ce(lrnde_ctx* ctx, const float* u, int32_t B, const float* pc, int32_t K, const int32_t* labels,
                         float* loss_host, float* logits, float* du, float* dpc);
 
+/* The forward half of the reference's training step in one call (experiments/src/utils.jl:104-115: model forward + loss inside
+ * one timed pullback): lrnde_node_forward_record followed by lrnde_classifier_ce on its sol.u[end], same arguments and
+ * results as the two calls, same bits.  The head's launches are enqueued when the solve's last report is in, ahead of the
+ * solve's final synchronisation, so the call ends with ONE synchronisation and no host round trip between the layer and
+ * the head (the two calls: two synchronisations and ~60 us of idle GPU between them). */
+int lrnde_node_forward_record_ce(lrnde_ctx* ctx, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* opts,
+                                 int32_t mode, int32_t reg_type, float t1_or_rand, float* u_end, float* reg_val_host,
+                                 int32_t* nfe_host, lrnde_stats* stats_host, float* t1_used_host, const float* pc, int32_t K,
+                                 const int32_t* labels, float* loss_host, float* logits, float* du, float* dpc);
+
 /* ---- conv vector field (experiments/src/construct.jl:213-218) ----
  * node_core = TDChain(Chain(Conv3x3(C+1=>Hc, no bias), BatchNorm(Hc, act)),
  *                     Chain(Conv3x3(Hc+1=>Hc), BatchNorm(Hc, act)), Conv3x3(Hc+1=>C))

@@ -105,6 +105,8 @@ SYMBOLS = [
     ("lrnde_node_backward_recorded_ts", C.c_int, [_vp, _i32, _vp, _i32, _f, _vp, _vp, C.POINTER(Stats)]),
     ("lrnde_opt_update", C.c_int, [_i32, _vp, _vp, _vp, _vp, C.c_size_t, _f, _f, _f, _f, _i32, _f, C.c_int, _vp]),
     ("lrnde_classifier_ce", C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _fp, _vp, _vp, _vp]),
+    ("lrnde_node_forward_record_ce", C.c_int, [_vp, _vp, _i32, _f, _f, C.POINTER(SolveOpts), _i32, _i32, _f, _vp,
+                                               _fp, C.POINTER(_i32), C.POINTER(Stats), _fp, _vp, _i32, _vp, _fp, _vp, _vp, _vp]),
     ("lrnde_conv_param_count", C.c_size_t, [C.POINTER(ConvDesc)]),
     ("lrnde_conv_create", C.c_int, [C.POINTER(_vp), C.POINTER(ConvDesc), C.c_int, _vp]),
     ("lrnde_conv_destroy", C.c_int, [_vp]),

@@ -1846,6 +1846,11 @@ struct lrnde_ctx {
   double hp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long hp_n = 0;
   float* tail_copy_dst = nullptr; int tail_copy_slot = -1;  // lrnde_solve: the step that fills this save slot writes it to tail_copy_dst too
   std::function<int(int, hipEvent_t)> poll_hook;  // lrnde_solve calls it after every status poll (event: that poll's)
+  // lrnde_solve calls it once its last report is in and sol.u[end] is being written to the caller's array by the queued
+  // launches (StepArgs::also_dst), BEFORE its final synchronisation: work enqueued here follows the solve without a host
+  // round trip and is covered by that synchronisation (lrnde_node_forward_record_ce: the classifier head)
+  std::function<int()> final_hook;
+  bool final_hook_fired = false, last_u_end_done = false;
   std::string err;
 };
 
@@ -2549,6 +2554,10 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   c->tail_copy_dst = nullptr;
   if (c->time_solves) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   Ctrl fin;
+  if (word_ok && done && c->final_hook && a.also_dst) {
+    c->final_hook_fired = true;
+    if ((rc = c->final_hook())) return rc;
+  }
   if (word_ok && done) {  // the finished solve left its control block in host memory (solve_progress)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HPT(c, 3);
@@ -2621,6 +2630,7 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
   float t1 = t2;
   const float* u1 = nullptr;
   bool u_end_done = false;  // u_end already copied by the solve (early_slot)
+  c->final_hook_fired = false; c->last_u_end_done = false;
   auto series_all = [&](int nsaved, float drop) {  // the caller's sol: every saved entry (drop: t1 of the corrected solution)
     for (int i = 0; i < nsaved; ++i)
       if (!(ts[i] == drop)) { c->series_idx.push_back(i); c->series_t.push_back(ts[i]); }
@@ -2675,6 +2685,7 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
     series_all(st->nsaved, no_drop);
     c->last_ts.assign(ts.begin(), ts.begin() + st->nsaved);
     if (nfe_host) *nfe_host = st->nf;
+    c->last_u_end_done = (st->nsaved - 1 == early);
     if (st->nsaved - 1 != early) {
       HIPCHK(c, hipMemcpyAsync(u_end, c->usave + (size_t)(st->nsaved - 1) * n, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2732,6 +2743,7 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
     c->poll_hook = nullptr; c->tail_copy_dst = nullptr;
     if (rc) return rc;
     u_end_done = (st->nsaved - 1 == early);
+    c->last_u_end_done = u_end_done;
     int i1 = -1;
     for (int i = 0; i < st->nsaved; ++i) if (ts[i] == t1) i1 = i;   // the last entry saved at t1 is sol(t1)
     if (i1 < 0) return fail(c, LRNDE_BADARG, "t1 = %g is not inside the time span", (double)t1);
@@ -4266,10 +4278,12 @@ namespace {
 }  // namespace
 extern "C" {
 
-int lrnde_classifier_ce(lrnde_ctx* c, const float* u, int32_t B, const float* pc, int32_t K, const int32_t* labels,
-                        float* loss_host, float* logits, float* du, float* dpc) {
-  if (!c) return LRNDE_BADARG;
-  if (!u || !pc || !labels || !loss_host || B <= 0 || K <= 0 || K > 16) return fail(c, LRNDE_BADARG, "bad argument (1 <= K <= 16)");
+}  // extern "C"
+namespace {
+// the classifier head's launches and the read-back of its loss sum, enqueued on the handle's stream (no synchronisation)
+int cls_enqueue(lrnde_ctx* c, const float* u, int32_t B, const float* pc, int32_t K, const int32_t* labels, float* logits, float* du,
+                float* dpc) {
+  if (!u || !pc || !labels || B <= 0 || K <= 0 || K > 16) return fail(c, LRNDE_BADARG, "bad argument (1 <= K <= 16)");
   HIPCHK(c, hipSetDevice(c->device));
   const int D = c->desc.state_dim;
   // cached workspace: dl (B x K), per-sample losses (B), {double loss sum, int bad-label flag}
@@ -4309,11 +4323,46 @@ int lrnde_classifier_ce(lrnde_ctx* c, const float* u, int32_t B, const float* pc
     if ((rc = comm_allreduce(c, &out->loss_sum, &out->loss_sum, 1, true))) return rc;
   }
   HIPCHK(c, hipMemcpyAsync(c->cls_host, out, sizeof(ClsOut), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRNDE_OK;
+}
+// after the stream has been synchronised
+int cls_finish(lrnde_ctx* c, int32_t B, int32_t K, float* loss_host) {
+  const int nr = sharded(c) ? c->nranks : 1;
   const ClsOut* ho = reinterpret_cast<const ClsOut*>(c->cls_host);
   if (ho->bad_label) return fail(c, LRNDE_BADARG, "a label is outside [0, %d)", K);
   *loss_host = (float)(ho->loss_sum / ((double)B * (double)nr));
   return LRNDE_OK;
+}
+}  // namespace
+extern "C" {
+
+int lrnde_classifier_ce(lrnde_ctx* c, const float* u, int32_t B, const float* pc, int32_t K, const int32_t* labels,
+                        float* loss_host, float* logits, float* du, float* dpc) {
+  if (!c) return LRNDE_BADARG;
+  if (!loss_host) return fail(c, LRNDE_BADARG, "null pointer");
+  int rc = cls_enqueue(c, u, B, pc, K, labels, logits, du, dpc);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return cls_finish(c, B, K, loss_host);
+}
+
+int lrnde_node_forward_record_ce(lrnde_ctx* c, const float* x, int32_t B, float t0, float t2, const lrnde_solve_opts* o,
+                                 int32_t mode, int32_t reg_type, float t1_or_rand, float* u_end, float* reg_val_host,
+                                 int32_t* nfe_host, lrnde_stats* st, float* t1_used_host, const float* pc, int32_t K,
+                                 const int32_t* labels, float* loss_host, float* logits, float* du, float* dpc) {
+  if (!c) return LRNDE_BADARG;
+  if (!loss_host || !u_end) return fail(c, LRNDE_BADARG, "null pointer");
+  // the head's launches go into the queue as soon as the solve's last report is in, ahead of its final synchronisation
+  c->final_hook = [&]() { return cls_enqueue(c, u_end, B, pc, K, labels, logits, du, dpc); };
+  int rc = node_forward_record_impl(c, x, B, t0, t2, o, mode, reg_type, t1_or_rand, nullptr, 0, u_end, reg_val_host, nfe_host, st,
+                                    t1_used_host);
+  c->final_hook = nullptr;
+  if (rc) return rc;
+  if (!(c->final_hook_fired && c->last_u_end_done)) {  // (sol.u[end] reached the caller's array by a copy after the solve)
+    if ((rc = cls_enqueue(c, u_end, B, pc, K, labels, logits, du, dpc))) return rc;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // (returns at once when the solve's own synchronisation covered the head)
+  return cls_finish(c, B, K, loss_host);
 }
 
 // ---- optimiser update rules of the experiments (experiments/src/construct.jl:104-126) ----

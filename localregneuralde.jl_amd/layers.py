@@ -303,6 +303,28 @@ class Handle:
                                             C.c_void_p(dpc.data_ptr()) if want_grads else None))
         return dict(loss=np.float32(loss.value), logits=logits, du=du, dpc=dpc)
 
+    def node_forward_record_ce(self, x, t0, t2, abstol, reltol, pc, K, labels, mode="unbiased", reg_type="error_estimate",
+                               t1_or_rand=0.5, maxiters=1000, save_start=False, exact_pow=False):
+        """`node_forward_record` + `classifier_ce` on its sol.u[end] in one call (one synchronisation): (forward dict, head dict)"""
+        B = x.numel() // self.D
+        if pc.numel() != K * (self.D + 1):
+            raise ValueError(f"classifier parameters must have {K * (self.D + 1)} entries")
+        if not (labels.is_cuda and labels.dtype == torch.int32 and labels.numel() == B):
+            raise ValueError("labels must be a CUDA int32 tensor of length B")
+        o = L.SolveOpts(float(abstol), float(reltol), int(maxiters), int(save_start), 0, int(exact_pow))
+        u_end = torch.empty_like(x)
+        logits = torch.empty((B, K), dtype=torch.float32, device=x.device)
+        du = torch.empty_like(x)
+        dpc = torch.empty_like(pc)
+        reg, nfe, st, t1u, loss = C.c_float(), C.c_int32(), L.Stats(), C.c_float(), C.c_float()
+        self._chk(L.lib.lrnde_node_forward_record_ce(
+            self._ctx, _dev_ptr(x, "x", self.D), B, float(t0), float(t2), C.byref(o), L.MODE[mode], L.REG_TYPE[reg_type],
+            float(t1_or_rand), _dev_ptr(u_end, "u_end"), C.byref(reg), C.byref(nfe), C.byref(st), C.byref(t1u),
+            _dev_ptr(pc, "pc"), int(K), C.c_void_p(labels.data_ptr()), C.byref(loss), C.c_void_p(logits.data_ptr()),
+            C.c_void_p(du.data_ptr()), C.c_void_p(dpc.data_ptr())))
+        fw = dict(u_end=u_end, reg_val=np.float32(reg.value), nfe=int(nfe.value), stats=st.asdict(), t1=np.float32(t1u.value))
+        return fw, dict(loss=np.float32(loss.value), logits=logits, du=du, dpc=dpc)
+
     def bench_step(self, uprev, k1, t, dt, abstol, reltol, reps=50):
         """microseconds per launch of the full-step kernel (HIP events on the handle's stream)."""
         B = uprev.numel() // self.D

@@ -25,9 +25,10 @@ def run_training_step(node, ps, pc, st, x, labels, w_reg, num_classes=10):
     torch.cuda.synchronize()
     tic = time.perf_counter()
     h = node._bind(ps)  # the repack of the (updated) parameters is part of the step
-    fw = h.node_forward_record(x, t0, t2, abstol, reltol, mode=mode, reg_type=node.regularize_type,
-                               t1_or_rand=t1_or_rand, maxiters=node.maxiters, save_start=kw.get("save_start", True))
-    head = h.classifier_ce(fw["u_end"], pc, num_classes, labels)
+    # (layer forward and loss head in ONE library call, as they sit inside one pullback in the reference: the head's launches
+    #  follow the solve's last launch in the queue, the call ends with one synchronisation)
+    fw, head = h.node_forward_record_ce(x, t0, t2, abstol, reltol, pc, num_classes, labels, mode=mode, reg_type=node.regularize_type,
+                                        t1_or_rand=t1_or_rand, maxiters=node.maxiters, save_start=kw.get("save_start", True))
     loss = np.float32(head["loss"] + np.float32(w_reg) * fw["reg_val"])
     torch.cuda.synchronize()
     fwd_time = time.perf_counter() - tic
