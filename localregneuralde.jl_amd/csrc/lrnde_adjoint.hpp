@@ -258,6 +258,35 @@ __global__ void k_adj_ctrl_init(AdjCtrl* ctl, float s0) {
   ctl[0] = c; ctl[1] = c;
 }
 
+// The start of a backward pass in ONE launch: z = [du_end; 0], the control blocks, and the (few) tstops — round 2 enqueued a
+// memset, a D2D copy, a H2D copy and k_adj_ctrl_init for these, four packets with the queue's idle gaps between them.
+struct AdjBegin { float* z; const float* src; size_t n, N; AdjCtrl* ctl; float s0; float* stops; int nstops; float sv[8]; };
+__global__ __launch_bounds__(256) void k_adj_begin(AdjBegin a) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.N; i += (size_t)gridDim.x * blockDim.x)
+    a.z[i] = i < a.n ? a.src[i] : 0.f;
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  AdjCtrl c;
+  memset(&c, 0, sizeof(c));
+  c.status = ST_RUNNING; c.first = 1; c.t = a.s0; c.qold = 1e-4f; c.q11 = 1.0f;
+  a.ctl[0] = c; a.ctl[1] = c;
+  for (int k = 0; k < a.nstops; ++k) a.stops[k] = a.sv[k];
+}
+// ... and its end: dx = lambda, dp = mu (+ w_reg * the regulariser's gradient, in k_axpy's operation order) in one launch
+// instead of two copy packets and an axpy
+__global__ __launch_bounds__(256) void k_adj_out(const float* z, size_t n, size_t P, float* dx, float* dp, const float* gr, float w_reg) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n + P; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < n) { dx[i] = z[i]; continue; }
+    const size_t j = i - n;
+    if (gr) {
+      float s = 1.0f * z[i];
+      s = s + w_reg * gr[j];
+      dp[j] = 0.f + 1.0f * s;
+    } else {
+      dp[j] = z[i];
+    }
+  }
+}
+
 // a later segment of the same solve (after a cotangent impulse at a saved time): the integrator goes on with its
 // proposed dt and controller memory, K1 has been re-evaluated by the host driver at the modified state
 __global__ void k_adj_ctrl_continue(AdjCtrl* ctl, int from) {

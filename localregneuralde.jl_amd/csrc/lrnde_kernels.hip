@@ -1849,6 +1849,7 @@ struct lrnde_ctx {
   // lrnde_solve calls it once its last report is in and sol.u[end] is being written to the caller's array by the queued
   // launches (StepArgs::also_dst), BEFORE its final synchronisation: work enqueued here follows the solve without a host
   // round trip and is covered by that synchronisation (lrnde_node_forward_record_ce: the classifier head)
+  const float* adj_init_src = nullptr;  // adj_solve_device: its first launch also sets z = [this; 0] (k_adj_begin)
   std::function<int()> final_hook;
   bool final_hook_fired = false, last_u_end_done = false;
   std::string err;
@@ -3834,7 +3835,8 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
     HIPCHK(c, hipMalloc(&c->adj_stops, sizeof(float) * (tstops.size() + 8)));
     c->adj_stops_cap = (int)tstops.size() + 8;
   }
-  if (!tstops.empty())
+  const bool one_begin = c->adj_init_src != nullptr && tstops.size() <= 8;
+  if (!tstops.empty() && !one_begin)
     HIPCHK(c, hipMemcpyAsync(c->adj_stops, tstops.data(), sizeof(float) * tstops.size(), hipMemcpyHostToDevice, c->stream));
   AdjArgs g;
   memset(&g, 0, sizeof(g));
@@ -3852,7 +3854,22 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
   for (int q = 0; q < 6; ++q) e.A7[q] = (float)Tsit5::A[15 + q];
   e.n_lam = v.n_lam; e.P = v.P; e.abstol = abstol; e.reltol = reltol; e.part = c->adj_part;
 
-  hipLaunchKernelGGL(k_adj_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->adj_ctl, s0);
+  if (one_begin) {
+    AdjBegin b;
+    memset(&b, 0, sizeof(b));
+    b.z = v.z; b.src = c->adj_init_src; b.n = v.n_lam; b.N = v.N; b.ctl = c->adj_ctl; b.s0 = s0;
+    b.stops = c->adj_stops; b.nstops = (int)tstops.size();
+    for (size_t k = 0; k < tstops.size(); ++k) b.sv[k] = tstops[k];
+    int nb = (int)((v.N + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_adj_begin, dim3(nb), dim3(256), 0, c->stream, b);
+  } else {
+    if (c->adj_init_src) {
+      HIPCHK(c, hipMemsetAsync(v.z, 0, sizeof(float) * v.N, c->stream));
+      HIPCHK(c, hipMemcpyAsync(v.z, c->adj_init_src, sizeof(float) * v.n_lam, hipMemcpyDeviceToDevice, c->stream));
+    }
+    hipLaunchKernelGGL(k_adj_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->adj_ctl, s0);
+  }
+  c->adj_init_src = nullptr;
   size_t iseg = 0;
   while (iseg < impulses.size() && impulses[iseg].s <= s0) ++iseg;  // a cotangent at the start time is the caller's lambda(s0)
   bool first_seg = true;
@@ -4159,7 +4176,10 @@ static int node_backward_recorded_impl(lrnde_ctx* c, int32_t B, const float* du_
   AdjVec v;
   if ((rc = adj_alloc(c, N, v))) return rc;
   v.n_lam = n; v.P = P;
-  HIPCHK(c, hipMemsetAsync(v.z, 0, sizeof(float) * N, c->stream));
+  static const bool adj_host = getenv("LRNDE_ADJ_HOST") != nullptr;  // diagnostic: the round-1 host-controlled loop
+  const bool dev_loop = vjp_uses_qtile(c, B) && !sharded(c) && !adj_host;
+  const bool begin_in_solve = dev_loop && !du_series;  // the device loop's first launch sets z = [du_end; 0] itself
+  if (!begin_in_solve) HIPCHK(c, hipMemsetAsync(v.z, 0, sizeof(float) * N, c->stream));
   std::vector<AdjImpulse> impulses;  // ascending in s = -t
   if (du_series) {
     if (nser != (int)c->series_t.size()) return fail(c, LRNDE_BADARG, "%d cotangents for a series of %zu states", nser, c->series_t.size());
@@ -4173,7 +4193,7 @@ static int node_backward_recorded_impl(lrnde_ctx* c, int32_t B, const float* du_
         impulses.push_back(AdjImpulse{-tv, du});
       }
     }
-  } else {
+  } else if (!begin_in_solve) {
     HIPCHK(c, hipMemcpyAsync(v.z, du_end, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   }
   std::vector<float> stops;
@@ -4182,7 +4202,6 @@ static int node_backward_recorded_impl(lrnde_ctx* c, int32_t B, const float* du_
       const float tv = c->last_ts[i];
       if (tv > t0 && tv < t2) stops.push_back(-tv);
     }
-  static const bool adj_host = getenv("LRNDE_ADJ_HOST") != nullptr;  // diagnostic: the round-1 host-controlled loop
   auto pending_sweep = [c, t1]() -> int {  // the forward left the regulariser's sweep to us (lrnde_ctx::sweep_pending)
     lrnde_ctx* sd = c->side;
     c->sweep_pending = false;
@@ -4199,8 +4218,10 @@ static int node_backward_recorded_impl(lrnde_ctx* c, int32_t B, const float* du_
     if (vjp_uses_qtile(c, B) && !sharded(c) && !adj_host) c->after_first_attempt = pending_sweep;
     else if ((rc = pending_sweep())) return rc;
   }
-  if (vjp_uses_qtile(c, B) && !sharded(c) && !adj_host) {
+  if (dev_loop) {
+    c->adj_init_src = begin_in_solve ? du_end : nullptr;
     rc = adj_solve_device(c, v, B, -t2, -t0, o->abstol, o->reltol, o->maxiters, o->exact_pow, stops, impulses, nsteps, st_bwd);
+    c->adj_init_src = nullptr;
   } else {
     std::vector<float> dts(nsteps), dds(nsteps);
     HIPCHK(c, hipMemcpy(dts.data(), c->dense_t, sizeof(float) * nsteps, hipMemcpyDeviceToHost));
@@ -4212,23 +4233,32 @@ static int node_backward_recorded_impl(lrnde_ctx* c, int32_t B, const float* du_
   }
   c->after_first_attempt = nullptr;
   if (rc) return fail(c, rc, "adjoint solve stopped with retcode %d", rc);
-  HIPCHK(c, hipMemcpyAsync(dx, v.z, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(dp, v.z + n, sizeof(float) * P, hipMemcpyDeviceToDevice, c->stream));
-  if (!(mode != LRNDE_MODE_NONE && w_reg != 0.0f)) HIPCHK(c, hipStreamSynchronize(c->stream));
+  auto adj_out = [&](const float* grad_reg) -> int {   // dx = lambda, dp = mu [+ w_reg * grad_reg]: one launch
+    int nb = (int)((N + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_adj_out, dim3(nb), dim3(256), 0, c->stream, (const float*)v.z, n, P, dx, dp, grad_reg, w_reg);
+    HIPCHK(c, hipGetLastError());
+    return LRNDE_OK;
+  };
+  if (!(mode != LRNDE_MODE_NONE && w_reg != 0.0f)) {
+    if ((rc = adj_out(nullptr))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   // regulariser: dp += w_reg * d reg_val / d p   (no gradient w.r.t. x: test/runtests.jl:129)
   if (mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
     float* gr = c->rec_gr;
     if (c->rec_gr_ready) {
       // the forward already ran the sweep on the companion's stream (it depends on the forward alone): wait for it there
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_side_sweep, 0));
-      rc = LRNDE_OK;
+      rc = adj_out(gr);
     } else {
       // The forward's own local step is still in the state workspace (uprev = u(t1), u, k1..k7, g6: the recorded forward
       // keeps k2..k6 in memory, StepArgs::force_store_k), and its scalars are in the record: the reverse sweep starts from
       // them, nothing is re-run and nothing is read back.
+      // (the sweep works in the adjoint vector's buffers: lambda and mu leave them first)
+      if ((rc = adj_out(nullptr))) return rc;
       rc = step_reg_sweep(c, c->state, B, t1, c->rec_dt1, o->abstol, o->reltol, reg_type, c->rec_eest, c->rec_snum, c->rec_sden, gr);
+      if (!rc) { const float* g1[2] = {dp, gr}; const float cc[2] = {1.0f, w_reg}; rc = vec_axpy(c, dp, nullptr, 1.0f, 2, g1, cc, P); }
     }
-    if (!rc) { const float* g1[2] = {dp, gr}; const float cc[2] = {1.0f, w_reg}; rc = vec_axpy(c, dp, nullptr, 1.0f, 2, g1, cc, P); }
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
