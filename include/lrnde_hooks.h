@@ -36,6 +36,10 @@ int lrnde_bench_step(lrnde_ctx* ctx, const float* uprev, const float* k1, int32_
  * ARMS the clock (solves record their two events from then on — each a marker packet in the queue — and this call returns
  * 0 ms): call it once, run a solve, call it again. */
 int lrnde_last_solve_kernel_ms(lrnde_ctx* ctx, float* total_ms_host, int32_t* step_launches_host);
+/* Diagnostic: 0 = the solve loop does not use the per-launch reports in pinned host memory and steers by polled copies of the
+ * control block instead — its fall-back for a platform where no report arrives.  Same results
+ * (tests/test_gpu_overlap.py::test_solve_loop_without_reports_gives_the_same_bits). */
+int lrnde_set_reports(lrnde_ctx* ctx, int32_t on);
 /* Diagnostic: mean host-side microseconds per lrnde_node_forward call since the last reset, by phase: [0] entry -> the main
  * solve's init launches enqueued, [1] -> its last report read (the feed loop: the GPU is busy throughout), [2] -> the final
  * synchronisation returned, [3] -> the call returned (local-step results, bookkeeping).  tools/bench/host_phases.py */

@@ -1852,6 +1852,7 @@ struct lrnde_ctx {
   const float* adj_init_src = nullptr;  // adj_solve_device: its first launch also sets z = [this; 0] (k_adj_begin)
   std::function<int()> final_hook;
   bool final_hook_fired = false, last_u_end_done = false;
+  bool reports_off = false;  // lrnde_set_reports(ctx, 0): the solve loop polls by copies (its fall-back when no report arrives)
   std::string err;
 };
 
@@ -2450,7 +2451,7 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   volatile unsigned long long* pw = c->prog_host;
   Ctrl* fin_host = reinterpret_cast<Ctrl*>(reinterpret_cast<char*>(c->prog_host) + PROG_RING * 8);
   for (int i = 0; i < PROG_RING; ++i) pw[i] = 0ull;
-  a.prog = c->prog_dev;
+  a.prog = c->reports_off ? nullptr : c->prog_dev;
   a.fin_host = reinterpret_cast<Ctrl*>(reinterpret_cast<char*>(c->prog_dev) + PROG_RING * 8);
   if (c->time_solves) HIPCHK(c, hipEventRecord(c->ev0, c->stream));  // (an event is a marker packet in the queue: only on request)
   if (use_qtile(c, B)) {
@@ -2469,9 +2470,9 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   // speculative (k_step<.,true>): they find the solve finished and do nothing.
   const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
   int j = 0, pending = -1, pending_j = 0, launches = 0, target = 4, nchunk = 0;
-  bool done = false, word_ok = true;
+  bool done = false, word_ok = !c->reports_off;
   const long hard_cap = (long)o->maxiters + 8;
-  {
+  if (word_ok) {
     // Report-driven feed: after the report of launch `seen - 1` keep enqueued what it says is still to come at the current
     // dt (an over-estimate while dt grows, exact for the last step, whose dt is clipped to t1 - t), the launch that will find
     // the solve finished, and never fewer than two launches beyond the reporting one — so the stream neither runs dry nor
@@ -4444,6 +4445,12 @@ int lrnde_opt_update(int32_t kind, float* x, const float* grad, float* state1, f
   hipLaunchKernelGGL(k_opt_update, dim3(nb), dim3(256), 0, (hipStream_t)stream, n, (int)kind, x, grad, state1, state2, eta,
                      rho_or_beta1, beta2, eps, b1t, b2t, weight_decay);
   return hipGetLastError() == hipSuccess ? LRNDE_OK : LRNDE_HIP_ERROR;
+}
+
+int lrnde_set_reports(lrnde_ctx* c, int32_t on) {
+  if (!c) return LRNDE_BADARG;
+  c->reports_off = (on == 0);
+  return LRNDE_OK;
 }
 
 int lrnde_host_phases(lrnde_ctx* c, double* us, int32_t reset) {

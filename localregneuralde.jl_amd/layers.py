@@ -333,6 +333,10 @@ class Handle:
                                          float(t), float(dt), float(abstol), float(reltol), int(reps), C.byref(us)))
         return float(us.value)
 
+    def set_reports(self, on):
+        """diagnostic (lrnde_hooks.h): False makes the solve loop poll by copies instead of reading the per-launch reports"""
+        self._chk(L.lib.lrnde_set_reports(self._ctx, 1 if on else 0))
+
     def set_overlap(self, on):
         """diagnostic (lrnde_hooks.h): False keeps the layer forward's local step / regulariser sweep on the handle's own stream"""
         self._chk(L.lib.lrnde_set_overlap(self._ctx, 1 if on else 0))

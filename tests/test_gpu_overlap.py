@@ -105,3 +105,38 @@ def test_recorded_forward_with_save_start_uses_the_right_slot(oracle, gpu_pkg, s
                                    save_start=save_start))
     assert torch.equal(out[0]["dx"], out[1]["dx"]) and torch.equal(out[0]["dp"], out[1]["dp"])
     assert _rel(out[0]["dx"].cpu().numpy(), ref["dx"]) < 2e-5 and _rel(out[0]["dp"].cpu().numpy(), ref["dp"]) < 3e-4
+
+
+@pytest.mark.parametrize("t1", [0.04, 0.5, 0.96])
+def test_solve_loop_without_reports_gives_the_same_bits(gpu_pkg, t1):
+    """`lrnde_set_reports(ctx, 0)`: the solve loop's fall-back (polled copies of the control block instead of the per-launch
+    reports in pinned host memory) against the report-driven loop — plain solve with a trace, layer forward, recorded
+    forward + head + backward"""
+    import numpy as np
+    import torch
+    from localregneuralde_jl_amd.layers import Handle, _mlp_desc
+    P = gpu_pkg
+    D, H, B, K = 784, 100, 40, 10
+    model = P.TDChain(P.Chain(P.Dense(D + 1, H, "tanh"), P.Dense(H + 1, D)))
+    p = torch.from_numpy(P.glorot_params(model, seed=1) * np.float32(1.5))
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy(rng.random((B, D), dtype=np.float32)).cuda()
+    pc = torch.from_numpy((rng.random(K * (D + 1), dtype=np.float32) - np.float32(0.5)) * np.float32(0.1)).cuda()
+    lab = torch.from_numpy(rng.integers(0, K, B).astype(np.int32)).cuda()
+    ha, hb = Handle(_mlp_desc(model)), Handle(_mlp_desc(model))
+    ha.set_params(p); hb.set_params(p)
+    hb.set_reports(False)
+    sa = ha.solve(x, 0.0, 1.0, 1e-6, 1e-6, saveat=[0.3, t1, 1.0] if t1 > 0.3 else [t1, 0.3, 1.0], maxiters=10000, trace=True)
+    sb = hb.solve(x, 0.0, 1.0, 1e-6, 1e-6, saveat=[0.3, t1, 1.0] if t1 > 0.3 else [t1, 0.3, 1.0], maxiters=10000, trace=True)
+    assert sa["stats"] == sb["stats"] and torch.equal(sa["u"], sb["u"]) and np.array_equal(sa["t"], sb["t"])
+    assert np.array_equal(sa["trace"], sb["trace"])
+    kw = dict(mode="unbiased", reg_type="stiffness_estimate", t1_or_rand=t1, maxiters=10000, save_start=True)
+    fa = ha.node_forward(x, 0.0, 1.0, 1e-5, 1e-5, **kw); fb = hb.node_forward(x, 0.0, 1.0, 1e-5, 1e-5, **kw)
+    assert torch.equal(fa["u_end"], fb["u_end"]) and fa["reg_val"] == fb["reg_val"] and fa["nfe"] == fb["nfe"] and fa["stats"] == fb["stats"]
+    ra, qa = ha.node_forward_record_ce(x, 0.0, 1.0, 1e-5, 1e-5, pc, K, lab, **kw)
+    rb, qb = hb.node_forward_record_ce(x, 0.0, 1.0, 1e-5, 1e-5, pc, K, lab, **kw)
+    assert torch.equal(ra["u_end"], rb["u_end"]) and ra["reg_val"] == rb["reg_val"] and qa["loss"] == qb["loss"] and torch.equal(qa["du"], qb["du"])
+    ba = ha.node_backward_recorded(qa["du"], w_reg=2.0); bb = hb.node_backward_recorded(qb["du"], w_reg=2.0)
+    assert torch.equal(ba["dx"], bb["dx"]) and torch.equal(ba["dp"], bb["dp"])
+    with pytest.raises(P.LrndeError):     # failures come back through the fall-back loop as well
+        hb.solve(x, 0.0, 1.0, 1e-7, 1e-7, saveat=[1.0], maxiters=3)
