@@ -14,8 +14,16 @@ __global__ __launch_bounds__(256) void k_cls_fwd_bwdx(const float* u, const floa
                                                       float Bnorm, float* logits, float* dl, float* loss_b, float* du, ClsOut* out) {
   extern __shared__ __attribute__((aligned(16))) float cls_w[];
   if (WLDS) {
+    // (eight loads in flight per thread before the first LDS store: one after the other — a load, its wait, a store, 31
+    //  times for the MNIST head — this staging was most of the launch's 27 us)
     const int nw = K * (D + 1);
-    for (int i = threadIdx.x; i < nw; i += 256) cls_w[i] = pcg[i];
+    for (int i0 = threadIdx.x; i0 < nw; i0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { const int i = i0 + r * 256; v[r] = i < nw ? pcg[i] : 0.f; }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { const int i = i0 + r * 256; if (i < nw) cls_w[i] = v[r]; }
+    }
     __syncthreads();
   }
   const float* pc = WLDS ? cls_w : pcg;  // (a compile-time choice: the LDS pointer keeps its address space)
@@ -25,11 +33,21 @@ __global__ __launch_bounds__(256) void k_cls_fwd_bwdx(const float* u, const floa
   float lg[16];
 #pragma unroll
   for (int c = 0; c < 16; ++c) lg[c] = 0.f;
-  for (int k = lane; k < D; k += 64) {
-    const float uk = ub[k];
-    const float* wk = pc + (size_t)K * k;
+  // (the lane's u values eight at a time, all requested before the first is used: the rolled loop waited for every one of
+  //  its 13 loads in turn — u comes from memory, the solve's last launch wrote it.  Same k order, same fma chain per lane.)
+  for (int k0 = lane; k0 < D; k0 += 64 * 8) {
+    float uu[8];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) if (c < K) lg[c] = fma_(wk[c], uk, lg[c]);
+    for (int r = 0; r < 8; ++r) { const int k = k0 + 64 * r; uu[r] = k < D ? ub[k] : 0.f; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = k0 + 64 * r;
+      if (k < D) {
+        const float* wk = pc + (size_t)K * k;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) if (c < K) lg[c] = fma_(wk[c], uu[r], lg[c]);
+      }
+    }
   }
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
@@ -40,10 +58,14 @@ __global__ __launch_bounds__(256) void k_cls_fwd_bwdx(const float* u, const floa
       lg[c] = s + pc[(size_t)K * D + c];
     }
   }
+  // (every loop over the classes is unrolled over 16 with a guard: a loop with the runtime bound K indexes lg[] / dlv[]
+  //  dynamically, which put both arrays into scratch memory — a round trip to memory per element, most of the launch's 28 us)
   float mx = lg[0];
-  for (int c = 1; c < K; ++c) mx = fmaxf_(mx, lg[c]);
+#pragma unroll
+  for (int c = 1; c < 16; ++c) if (c < K) mx = fmaxf_(mx, lg[c]);
   float se = 0.f;
-  for (int c = 0; c < K; ++c) se += expf_c(lg[c] - mx);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) if (c < K) se += expf_c(lg[c] - mx);
   const float lse = mx + logf(se);
   int y = labels[b];
   const bool bad = y < 0 || y >= K;
@@ -55,12 +77,16 @@ __global__ __launch_bounds__(256) void k_cls_fwd_bwdx(const float* u, const floa
     if (c < K) dlv[c] = (expf_c(lg[c] - lse) - (c == y ? 1.f : 0.f)) / Bnorm;
   }
   if (lane == 0) {
-    for (int c = 0; c < K; ++c) {
-      if (logits) logits[(size_t)b * K + c] = lg[c];
-      dl[(size_t)b * K + c] = dlv[c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c < K) {
+        if (logits) logits[(size_t)b * K + c] = lg[c];
+        dl[(size_t)b * K + c] = dlv[c];
+      }
     }
     float ly = lg[0];
-    for (int c = 1; c < K; ++c) if (c == y) ly = lg[c];
+#pragma unroll
+    for (int c = 1; c < 16; ++c) if (c < K && c == y) ly = lg[c];
     loss_b[b] = lse - ly;
     if (bad) atomicExch(&out->bad_label, 1);
   }
