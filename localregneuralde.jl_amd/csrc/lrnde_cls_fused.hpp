@@ -9,20 +9,23 @@ struct ClsOut { double loss_sum; int bad_label; int pad; };
 // WLDS: the K x (D+1) parameter block is staged in LDS once per workgroup (coalesced) and both passes read it from
 // there — read straight from memory a lane's ten weights per k are ten 4-byte loads 40 bytes apart from its neighbour's
 // (36 us for 16 MFLOP).  Same values, same order of operations.
-template <bool WLDS>
-__global__ __launch_bounds__(256) void k_cls_fwd_bwdx(const float* u, const float* pcg, const int32_t* labels, int B, int D, int K,
+// KT: the number of classes as a compile-time constant (10: the experiments' heads) or 0 = the runtime K.  With the runtime
+// bound every `if (c < K)` is a branch around one LDS read and one fma — 260 of them in a row per lane, each waited for.
+template <bool WLDS, int KT>
+__global__ __launch_bounds__(256) void k_cls_fwd_bwdx(const float* u, const float* pcg, const int32_t* labels, int B, int D, int K_,
                                                       float Bnorm, float* logits, float* dl, float* loss_b, float* du, ClsOut* out) {
+  const int K = KT ? KT : K_;
   extern __shared__ __attribute__((aligned(16))) float cls_w[];
   if (WLDS) {
-    // (eight loads in flight per thread before the first LDS store: one after the other — a load, its wait, a store, 31
+    // (all of a thread's loads — 31 for the MNIST head — in flight before the first LDS store: one after the other — a load, its wait, a store, 31
     //  times for the MNIST head — this staging was most of the launch's 27 us)
     const int nw = K * (D + 1);
-    for (int i0 = threadIdx.x; i0 < nw; i0 += 256 * 8) {
-      float v[8];
+    for (int i0 = threadIdx.x; i0 < nw; i0 += 256 * 32) {
+      float v[32];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) { const int i = i0 + r * 256; v[r] = i < nw ? pcg[i] : 0.f; }
+      for (int r = 0; r < 32; ++r) { const int i = i0 + r * 256; v[r] = i < nw ? pcg[i] : 0.f; }
 #pragma unroll
-      for (int r = 0; r < 8; ++r) { const int i = i0 + r * 256; if (i < nw) cls_w[i] = v[r]; }
+      for (int r = 0; r < 32; ++r) { const int i = i0 + r * 256; if (i < nw) cls_w[i] = v[r]; }
     }
     __syncthreads();
   }

@@ -4336,8 +4336,9 @@ int cls_enqueue(lrnde_ctx* c, const float* u, int32_t B, const float* pc, int32_
   HIPCHK(c, hipMemsetAsync(out, 0, sizeof(ClsOut), c->stream));
   const size_t wbytes = sizeof(float) * (size_t)K * (D + 1);
   const int wlds = wbytes <= 60 * 1024 ? 1 : 0;  // (the parameter block in LDS when it fits the default dynamic limit)
-  if (wlds) hipLaunchKernelGGL(k_cls_fwd_bwdx<true>, dim3((B + 3) / 4), dim3(256), wbytes, c->stream, u, pc, labels, B, D, K, Bnorm, logits, dl, lb, du, out);
-  else hipLaunchKernelGGL(k_cls_fwd_bwdx<false>, dim3((B + 3) / 4), dim3(256), 0, c->stream, u, pc, labels, B, D, K, Bnorm, logits, dl, lb, du, out);
+  if (wlds && K == 10) hipLaunchKernelGGL((k_cls_fwd_bwdx<true, 10>), dim3((B + 3) / 4), dim3(256), wbytes, c->stream, u, pc, labels, B, D, K, Bnorm, logits, dl, lb, du, out);
+  else if (wlds) hipLaunchKernelGGL((k_cls_fwd_bwdx<true, 0>), dim3((B + 3) / 4), dim3(256), wbytes, c->stream, u, pc, labels, B, D, K, Bnorm, logits, dl, lb, du, out);
+  else hipLaunchKernelGGL((k_cls_fwd_bwdx<false, 0>), dim3((B + 3) / 4), dim3(256), 0, c->stream, u, pc, labels, B, D, K, Bnorm, logits, dl, lb, du, out);
   {  // dW = dl^T u and db = dl^T 1 as ONE batch-reduction GEMM (the parameter-gradient tiles of the adjoint, first form,
      // H := K, no time column) + one extra workgroup that adds the per-sample losses in a fixed order
     PgradArgs g;
