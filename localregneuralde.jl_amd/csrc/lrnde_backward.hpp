@@ -466,6 +466,47 @@ __global__ __launch_bounds__(256) void k_adj_err_dev(AdjErrArgs a, AdjArgs g, in
   float* zn = adj_zb(g, c.cur ^ 1);
   const float dt = c.dt;
   double acc = 0.0;
+  if (((a.n_lam | a.P) & 3) == 0) {
+    // Four elements per lane and two such quads requested before the first is used: the scalar loop below is a chain of
+    // memory round trips (nine 4-byte loads, then the next iteration's; the K's were written by other launches), six of
+    // them per thread for the MNIST field.  Per-thread order of the fp64 adds: quad by quad, x y z w.
+    const size_t nq = cnt >> 2, stride = (size_t)256 * blockDim.x;
+    auto ld = [&](size_t qi, f32x4* kv, f32x4& zv, f32x4& znv) {
+      const size_t i = off + (qi << 2);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) kv[q] = *reinterpret_cast<const f32x4*>(K[q] + i);
+      zv = *reinterpret_cast<const f32x4*>(z + i);
+      if (!second) znv = *reinterpret_cast<const f32x4*>(zn + i);
+    };
+    auto use = [&](size_t qi, const f32x4* kv, const f32x4& zv, f32x4 znv) {
+      const size_t i = off + (qi << 2);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        if (second) {
+          float s = a.A7[0] * kv[0][h];
+#pragma unroll
+          for (int q = 1; q < 6; ++q) s = s + a.A7[q] * kv[q][h];
+          znv[h] = zv[h] + dt * s;
+        }
+        float s = a.BT[0] * kv[0][h];
+#pragma unroll
+        for (int q = 1; q < 7; ++q) s = s + a.BT[q] * kv[q][h];
+        const float ut = 0.f + dt * s;
+        const float sc = a.abstol + fmaxf_(__builtin_fabsf(zv[h]), __builtin_fabsf(znv[h])) * a.reltol;
+        const float r = ut / sc;
+        acc += (double)(r * r);
+      }
+      if (second) *reinterpret_cast<f32x4*>(zn + i) = znv;
+    };
+    for (size_t q0 = bx * (size_t)blockDim.x + threadIdx.x; q0 < nq; q0 += 2 * stride) {
+      const size_t q1 = q0 + stride;
+      f32x4 ka[7], kb[7], za, zb, zna = {0.f, 0.f, 0.f, 0.f}, znb = {0.f, 0.f, 0.f, 0.f};
+      ld(q0, ka, za, zna);
+      if (q1 < nq) ld(q1, kb, zb, znb);
+      use(q0, ka, za, zna);
+      if (q1 < nq) use(q1, kb, zb, znb);
+    }
+  } else
   for (size_t jj = bx * (size_t)blockDim.x + threadIdx.x; jj < cnt; jj += (size_t)256 * blockDim.x) {
     const size_t i = off + jj;
     float kv[7];
