@@ -111,8 +111,6 @@ template <int W> __global__ __launch_bounds__(NT) void k_vjp(VjpArgs a) {
   const int KG2p = ((m.KG2 + SEGK - 1) / SEGK) * SEGK;
   const __amdgpu_buffer_rsrc_t rsU2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.U2p, 0, m.MT2 * KG2p * 1024, 0x00020000);
   // ---- phase 0: y tile (given or interpolated) -> LDS x tile and scratch ----
-  float bw[7];
-  if (!a.y) tsit5_bweights(a.theta, bw);
   __syncthreads();
   tile_foreach<W>(m, b0, nvalid, [&](int row, int nn, bool valid, size_t g) {
     Vec<W> x = vzero<W>();
@@ -121,20 +119,11 @@ template <int W> __global__ __launch_bounds__(NT) void k_vjp(VjpArgs a) {
         x = vload<W>(a.y + g);
       } else {
         const size_t nst = (size_t)a.B * m.D;
+        // the record is in polynomial form: [uprev, k1, P2, P3, P4] (lrnde_math.hpp tsit5_rec_eval)
         const Vec<W> y0 = vload<W>(a.dense + g), v1 = vload<W>(a.dense + nst + g), v2 = vload<W>(a.dense + 2 * nst + g),
-                     v3 = vload<W>(a.dense + 3 * nst + g), v4 = vload<W>(a.dense + 4 * nst + g),
-                     v5 = vload<W>(a.dense + 5 * nst + g), v6 = vload<W>(a.dense + 6 * nst + g),
-                     v7 = vload<W>(a.dense + 7 * nst + g);
+                     v3 = vload<W>(a.dense + 3 * nst + g), v4 = vload<W>(a.dense + 4 * nst + g);
 #pragma unroll
-        for (int h = 0; h < W; ++h) {
-          float sum = v1.v[h] * bw[0] + v2.v[h] * bw[1];
-          sum = sum + v3.v[h] * bw[2];
-          sum = sum + v4.v[h] * bw[3];
-          sum = sum + v5.v[h] * bw[4];
-          sum = sum + v6.v[h] * bw[5];
-          sum = sum + v7.v[h] * bw[6];
-          x.v[h] = y0.v[h] + a.dense_dt * sum;
-        }
+        for (int h = 0; h < W; ++h) x.v[h] = tsit5_rec_eval(y0.v[h], v1.v[h], v2.v[h], v3.v[h], v4.v[h], a.theta, a.dense_dt);
       }
       vstore<W>(a.ysc + g, x);
     }
@@ -856,13 +845,11 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
   // each: the record's (y0, k1..k7), the stage base and six K vectors — before the first store.  As a loop with the
   // stores in program order it was four memory round trips in series (per pass: record, store y, then the lambda terms,
   // whose loads could not move above a store that might alias them): 13.5 k of the launch's 44 k cycles.
-  float bw[7];
-  if (!a.y) tsit5_bweights(a.theta, bw);
   __syncthreads();
   {
     const size_t nst = (size_t)a.B * m.D;
     bool in[2], ok[2]; size_t gg[2]; int li[2];
-    f32x4 dv[2][8], bs[2], kv[2][6];
+    f32x4 dv[2][5], bs[2], kv[2][6];   // the record is in polynomial form: [uprev, k1, P2, P3, P4] (lrnde_math.hpp)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int i = (int)threadIdx.x + r * QNT;
@@ -874,7 +861,7 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
         dv[r][0] = ld4(a.y + g);
       } else {
 #pragma unroll
-        for (int qq = 0; qq < 8; ++qq) dv[r][qq] = ld4(a.dense + (size_t)qq * nst + g);
+        for (int qq = 0; qq < 5; ++qq) dv[r][qq] = ld4(a.dense + (size_t)qq * nst + g);
       }
       if (a.lnk > 0) {
         // the lnk real terms only (lnk is launch-uniform: plain branches, no waits between the loads); the others enter
@@ -896,15 +883,8 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
           x = dv[r][0];
         } else {
 #pragma unroll
-          for (int h = 0; h < 4; ++h) {
-            float sum = dv[r][1][h] * bw[0] + dv[r][2][h] * bw[1];
-            sum = sum + dv[r][3][h] * bw[2];
-            sum = sum + dv[r][4][h] * bw[3];
-            sum = sum + dv[r][5][h] * bw[4];
-            sum = sum + dv[r][6][h] * bw[5];
-            sum = sum + dv[r][7][h] * bw[6];
-            x[h] = dv[r][0][h] + a.dense_dt * sum;
-          }
+          for (int h = 0; h < 4; ++h)
+            x[h] = tsit5_rec_eval(dv[r][0][h], dv[r][1][h], dv[r][2][h], dv[r][3][h], dv[r][4][h], a.theta, a.dense_dt);
         }
         st4(a.ysc + g, x);
         if (a.lnk > 0) {

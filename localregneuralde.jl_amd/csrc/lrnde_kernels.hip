@@ -1376,8 +1376,18 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
       const float* src[8] = {up, k1, a.ks[0], a.ks[1], a.ks[2], a.ks[3], a.ks[4], k7};
       tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
         if (!valid) return;
+        Vec<W> v[8], P2, P3, P4;   // polynomial form [uprev, k1, P2, P3, P4] (lrnde_math.hpp tsit5_rec_poly)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) vstore<W>(dd + (size_t)q * nst + g, vload<W>(src[q] + g));
+        for (int q = 0; q < 8; ++q) v[q] = vload<W>(src[q] + g);
+#pragma unroll
+        for (int h = 0; h < W; ++h) {
+          const float kk[6] = {v[2].v[h], v[3].v[h], v[4].v[h], v[5].v[h], v[6].v[h], v[7].v[h]};
+          float P[3];
+          tsit5_rec_poly(v[1].v[h], kk, P);
+          P2.v[h] = P[0]; P3.v[h] = P[1]; P4.v[h] = P[2];
+        }
+        vstore<W>(dd + g, v[0]); vstore<W>(dd + nst + g, v[1]);
+        vstore<W>(dd + 2 * nst + g, P2); vstore<W>(dd + 3 * nst + g, P3); vstore<W>(dd + 4 * nst + g, P4);
       });
       if (blockIdx.x == 0 && threadIdx.x == 0) { a.dense_t[bc.dense_idx] = bc.tprev; a.dense_dt[bc.dense_idx] = bc.dt_prev; }
     }

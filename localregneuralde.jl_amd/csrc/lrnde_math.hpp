@@ -163,4 +163,31 @@ LRNDE_HD void tsit5_bweights(float th, float* b) {
                       (float)Tsit5::R[4 * i + 1]);
 }
 
+// The dense record of an accepted step in polynomial form: the interpolant's weights are quartics in theta
+// without a constant term, only b_1 has a linear one (R[0] = 1) and sum_i b_i(theta) = theta, so
+//   y(theta) = uprev + dt * (theta * k1 + theta^2 * (P2 + theta * (P3 + theta * P4))),  P_m = sum_{i=2..7} R[4(i-1)+m-1] * (k_i - k1):
+// five arrays per step [uprev, k1, P2, P3, P4] instead of eight, formed from the DIFFERENCES k_i - k1 (the columns of R sum
+// to zero with entries up to 88: formed from the k's themselves the sums would carry 1e-5 |k| of rounding).
+LRNDE_HD void tsit5_rec_poly(float k1, const float* k2to7, float* P) {
+  float d[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) d[i] = k2to7[i] - k1;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    float s = (float)Tsit5::R[4 + m + 1] * d[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) s = s + (float)Tsit5::R[4 * (i + 1) + m + 1] * d[i];
+    P[m] = s;
+  }
+}
+LRNDE_HD float tsit5_rec_eval(float y0, float k1, float P2, float P3, float P4, float th, float ddt) {
+  float s = P4 * th;
+  s = s + P3;
+  s = s * th;
+  s = s + P2;
+  s = s * (th * th);
+  s = s + th * k1;
+  return y0 + ddt * s;
+}
+
 }  // namespace lrnde

@@ -207,11 +207,21 @@ struct EpiFinalQ {
     if (rec) {
       // the attempt's record slot, straight from the operands this lane already holds: uprev (pb[0]), k1..k6 (pb[2..7]),
       // k7 (kv) — eight 16-byte stores per row group instead of a 25-MB copy through global memory in the next prologue
+      // (polynomial form, lrnde_math.hpp tsit5_rec_poly: [uprev, k1, P2, P3, P4] — five stores, were eight)
       const int vd = vo;  // the slot's arrays have the state arrays' (column, row) layout
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pb[0]), rsD, vd, 0, 0);
+      f32x4 P2, P3, P4;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pb[2 + j]), rsD, vd + (1 + j) * nstB, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, kv), rsD, vd + 7 * nstB, 0, 0);
+      for (int r = 0; r < 4; ++r) {
+        const float kk[6] = {pb[3][r], pb[4][r], pb[5][r], pb[6][r], pb[7][r], kv[r]};
+        float P[3];
+        tsit5_rec_poly(pb[2][r], kk, P);
+        P2[r] = P[0]; P3[r] = P[1]; P4[r] = P[2];
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pb[0]), rsD, vd, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pb[2]), rsD, vd + nstB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, P2), rsD, vd + 2 * nstB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, P3), rsD, vd + 3 * nstB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, P4), rsD, vd + 4 * nstB, 0, 0);
     }
     if (sidx >= nvalid || rg * 64 + q * 4 >= D) return;
 #pragma unroll
@@ -749,8 +759,17 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
       if (!a.dense_direct)  // (direct mode: the step wrote this slot itself at its end, EpiFinalQ)
       q_tile_foreach(a.m, b0, nvalid, KQ1, [&](int, int, bool valid, size_t g) {
         if (!valid) return;
+        f32x4 v[8], P2, P3, P4;
 #pragma unroll
-        for (int qq = 0; qq < 8; ++qq) st4(dd + (size_t)qq * nst + g, ld4(src[qq] + g));
+        for (int qq = 0; qq < 8; ++qq) v[qq] = ld4(src[qq] + g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float kk[6] = {v[2][r], v[3][r], v[4][r], v[5][r], v[6][r], v[7][r]};
+          float P[3];
+          tsit5_rec_poly(v[1][r], kk, P);
+          P2[r] = P[0]; P3[r] = P[1]; P4[r] = P[2];
+        }
+        st4(dd + g, v[0]); st4(dd + nst + g, v[1]); st4(dd + 2 * nst + g, P2); st4(dd + 3 * nst + g, P3); st4(dd + 4 * nst + g, P4);
       });
       if (blockIdx.x == 0 && threadIdx.x == 0) { a.dense_t[bc.dense_idx] = bc.tprev; a.dense_dt[bc.dense_idx] = bc.dt_prev; }
     }
