@@ -32,7 +32,7 @@ struct VjpArgs {
   int B;
   float t;
   const float* y;      // (B,D) or NULL -> interpolate from the dense record
-  const float* dense;  // [uprev, k1..k7] of one forward step, 8 arrays of B*D
+  const float* dense;  // [uprev, k1, P2, P3, P4] of one forward step (polynomial form, lrnde_math.hpp), REC_ARRAYS arrays of B*D
   float theta, dense_dt;
   const float* lam;    // (B,D)
   float* dy;           // (B,D)
@@ -713,7 +713,7 @@ __device__ __forceinline__ bool vjp_q_resolve(VjpQArgs& a, const AdjEarly& early
     const size_t nst = g.n_lam;
     const int sidx = a.adj_stage;
     a.y = nullptr;
-    a.dense = g.dense + (size_t)early.lo * 8 * nst; a.theta = early.theta; a.dense_dt = early.ddt; a.t = early.t;
+    a.dense = g.dense + (size_t)early.lo * REC_ARRAYS * nst; a.theta = early.theta; a.dense_dt = early.ddt; a.t = early.t;
     a.lbase = adj_zb(g, cur); a.ldt = early.dt; a.lnk = sidx - 1;
     // row sidx of the tableau; terms beyond the row: the base vector with coefficient 0 (adds +-0, as the host path does)
 #pragma unroll
@@ -758,7 +758,7 @@ __device__ __forceinline__ bool vjp_q_resolve(VjpQArgs& a, const AdjEarly& early
   a.y = nullptr;
   const int sidx = a.adj_mode == ADJ_STAGE ? a.adj_stage : 2;
   const AdjStage* sp = &sh_c.st[sidx - 2];
-  a.dense = g.dense + (size_t)sp->lo * 8 * nst; a.theta = sp->theta; a.dense_dt = sp->ddt; a.t = sp->t;
+  a.dense = g.dense + (size_t)sp->lo * REC_ARRAYS * nst; a.theta = sp->theta; a.dense_dt = sp->ddt; a.t = sp->t;
   if (a.adj_mode == ADJ_STAGE) {
     a.lbase = adj_zb(g, cur); a.ldt = sh_c.dt; a.lnk = sidx - 1;
     // row sidx of the tableau; terms beyond the row: the base vector with coefficient 0 (adds +-0, as the host path does)

@@ -186,7 +186,7 @@ struct StepArgs {
   float* sde_scratch;  // 9 arrays of n_local floats
   const float* sde_uprev;
   float* sde_u;
-  // dense forward record for the adjoint: per accepted step [uprev, k1..k7] (8 * n_local floats)
+  // dense forward record for the adjoint: per accepted step [uprev, k1, P2, P3, P4] (REC_ARRAYS * n_local floats; lrnde_math.hpp)
   float* dense;
   float* dense_t;   // device [dense_cap]
   float* dense_dt;  // device [dense_cap]
@@ -1372,7 +1372,7 @@ template <int W, bool SPEC> __global__ __launch_bounds__(NT) void k_step(StepArg
     }
     if (bc.dense_idx >= 0) {  // dense record of the accepted step (InterpolatingAdjoint keeps u and k1..k7)
       const size_t nst = (size_t)a.n_local;
-      float* dd = a.dense + (size_t)bc.dense_idx * 8 * nst;
+      float* dd = a.dense + (size_t)bc.dense_idx * REC_ARRAYS * nst;
       const float* src[8] = {up, k1, a.ks[0], a.ks[1], a.ks[2], a.ks[3], a.ks[4], k7};
       tile_foreach<W>(a.m, b0, nvalid, [&](int, int, bool valid, size_t g) {
         if (!valid) return;
@@ -3613,7 +3613,7 @@ int adj_rhs(lrnde_ctx* c, const std::vector<float>& dt_, const std::vector<float
   int lo = 0, hi = (int)dt_.size() - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (dt_[mid] <= t) lo = mid; else hi = mid - 1; }
   const float theta = (t - dt_[lo]) / dd_[lo];
-  return launch_vjp(c, nullptr, c->dense + (size_t)lo * 8 * n, theta, dd_[lo], t, zs, B, K, K + n, sin);
+  return launch_vjp(c, nullptr, c->dense + (size_t)lo * REC_ARRAYS * n, theta, dd_[lo], t, zs, B, K, K + n, sin);
 }
 
 struct AdjImpulse { float s; const float* du; };  // a cotangent added to lambda when the reversed solve reaches s = -t_saved
@@ -4101,7 +4101,7 @@ static int node_forward_record_impl(lrnde_ctx* c, const float* x, int32_t B, flo
     if (c->dense_cap == 0 || c->dense_n != n) {
       if (c->dense) { hipFree(c->dense); hipFree(c->dense_t); hipFree(c->dense_dt); c->dense = nullptr; }
       if (c->dense_cap == 0) c->dense_cap = 64;
-      if (hipMalloc(&c->dense, sizeof(float) * (size_t)c->dense_cap * 8 * n) != hipSuccess ||
+      if (hipMalloc(&c->dense, sizeof(float) * (size_t)c->dense_cap * REC_ARRAYS * n) != hipSuccess ||
           hipMalloc(&c->dense_t, sizeof(float) * c->dense_cap) != hipSuccess ||
           hipMalloc(&c->dense_dt, sizeof(float) * c->dense_cap) != hipSuccess)
         return fail(c, LRNDE_HIP_ERROR, "dense record allocation failed");

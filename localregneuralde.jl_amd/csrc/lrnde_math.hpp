@@ -168,6 +168,7 @@ LRNDE_HD void tsit5_bweights(float th, float* b) {
 //   y(theta) = uprev + dt * (theta * k1 + theta^2 * (P2 + theta * (P3 + theta * P4))),  P_m = sum_{i=2..7} R[4(i-1)+m-1] * (k_i - k1):
 // five arrays per step [uprev, k1, P2, P3, P4] instead of eight, formed from the DIFFERENCES k_i - k1 (the columns of R sum
 // to zero with entries up to 88: formed from the k's themselves the sums would carry 1e-5 |k| of rounding).
+constexpr int REC_ARRAYS = 5;  // arrays of B*D floats per recorded step
 LRNDE_HD void tsit5_rec_poly(float k1, const float* k2to7, float* P) {
   float d[6];
 #pragma unroll

@@ -754,7 +754,7 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
     }
     if (bc.dense_idx >= 0) {  // dense record of the accepted step for the adjoint
       const size_t nst = (size_t)a.n_local;
-      float* dd = a.dense + (size_t)bc.dense_idx * 8 * nst;
+      float* dd = a.dense + (size_t)bc.dense_idx * REC_ARRAYS * nst;
       const float* src[8] = {up, k1, a.ks[0], a.ks[1], a.ks[2], a.ks[3], a.ks[4], k7};
       if (!a.dense_direct)  // (direct mode: the step wrote this slot itself at its end, EpiFinalQ)
       q_tile_foreach(a.m, b0, nvalid, KQ1, [&](int, int, bool valid, size_t g) {
@@ -843,8 +843,8 @@ template <bool SPEC, int KT> __global__ __launch_bounds__(QNT) void k_step_q(Ste
   ef.aerr = &aerr; ef.anum = &anum; ef.aden = &aden;
   ef.xl = s.xl; ef.kl = kl; ef.KL = KL; ef.klu = klu; ef.klk = klk;
   ef.rec = a.dense != nullptr && a.dense_direct && bc.dense_slot >= 0; ef.nstB = (int)(a.n_local * 4);
-  ef.rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dense + (size_t)(ef.rec ? bc.dense_slot : 0) * 8 * (size_t)a.n_local), 0,
-                                             (int)(a.n_local * 32), 0x00020000);
+  ef.rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dense + (size_t)(ef.rec ? bc.dense_slot : 0) * REC_ARRAYS * (size_t)a.n_local), 0,
+                                             (int)(a.n_local * 4 * REC_ARRAYS), 0x00020000);
   feval_qs<EpiFinalQ, (QSB * 5) % QRING, KT>(a.m, s, fc, t + dt, ef);
   STAMP(18);
   block_sum3_q(s.red, aerr, anum, aden, a.want_stiff != 0);
