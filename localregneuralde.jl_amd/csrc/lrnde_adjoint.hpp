@@ -36,7 +36,7 @@ struct AdjArgs {
   AdjCtrl* ctl;  // [2]
   float* base;   // the 11-vector allocation: zb0 zb1 zs ut K0..K6, each N floats
   size_t N, n_lam, P;
-  const float* dense; const float* dense_t; const float* dense_dt; int nrec;  // forward record: [uprev,k1..k7] per accepted step
+  const float* dense; const float* dense_t; const float* dense_dt; int nrec;  // forward record: [uprev,k1,P2,P3,P4] per accepted step (lrnde_math.hpp)
   const float* stops; int nstops;  // tstops in reversed time (device, ascending)
   float s0, s1;        // start of the whole solve; end of the CURRENT segment (the next cotangent impulse, or the end)
   float dtmax, dtmin;  // of the whole solve (s_end - s0; eps)

@@ -191,7 +191,7 @@ struct StepArgs {
   float* dense_t;   // device [dense_cap]
   float* dense_dt;  // device [dense_cap]
   int dense_cap;
-  int dense_direct;  // 1 (4-column kernel): every attempted step writes its own record slot [uprev,k1..k7] straight from LDS /
+  int dense_direct;  // 1 (4-column kernel): every attempted step writes its own record slot [uprev,k1,P2,P3,P4] straight from LDS /
                      // registers at its end (slot = accepted steps so far; a rejected attempt's slot is rewritten by the
                      // retry) instead of the next launch's prologue copying eight state arrays through global memory
 };

@@ -188,7 +188,7 @@ struct EpiFinalQ {
   double *aerr, *anum, *aden;
   const f32x4* xl; const f32x4* kl; int KL;  // u is the x tile of this (last) f-eval; uprev, k1..k6 as in EpiStageQ
   const f32x4* klu; const f32x4* klk;
-  // dense record written by the step itself (StepArgs::dense_direct): descriptor over the slot [uprev,k1..k7] of this
+  // dense record written by the step itself (StepArgs::dense_direct): descriptor over the slot [uprev,k1,P2,P3,P4] of this
   // attempt, voff out of range when there is none
   __amdgpu_buffer_rsrc_t rsD; int nstB; bool rec;
   __device__ __forceinline__ void pre(int rg, f32x4 (&pb)[NPRE]) const {
@@ -206,7 +206,7 @@ struct EpiFinalQ {
     qstore(io, vo, off_out, kv);
     if (rec) {
       // the attempt's record slot, straight from the operands this lane already holds: uprev (pb[0]), k1..k6 (pb[2..7]),
-      // k7 (kv) — eight 16-byte stores per row group instead of a 25-MB copy through global memory in the next prologue
+      // k7 (kv) — instead of a 25-MB copy through global memory in the next prologue
       // (polynomial form, lrnde_math.hpp tsit5_rec_poly: [uprev, k1, P2, P3, P4] — five stores, were eight)
       const int vd = vo;  // the slot's arrays have the state arrays' (column, row) layout
       f32x4 P2, P3, P4;
