@@ -441,12 +441,11 @@ __global__ __launch_bounds__(256) void k_adj_err(AdjErrArgs a) {
 }
 
 // the same with z / z_new / K_j / dt taken from the control block of attempt j (device-side controller)
-__global__ __launch_bounds__(256) void k_adj_err_dev(AdjErrArgs a, AdjArgs g, int j) {
+// (block bx of 256 of the lambda part (second = false) or of the mu part: the two halves may run in different launches)
+__device__ __forceinline__ void adj_err_blocks(const AdjErrArgs& a, const AdjArgs& g, int j, const unsigned bx, const bool second) {
   const AdjCtrl c = g.ctl[(j + 1) & 1];
   if (!c.do_step) return;
   __shared__ double red[4];
-  const bool second = blockIdx.x >= 256;
-  const unsigned bx = second ? blockIdx.x - 256 : blockIdx.x;
   const size_t off = second ? a.n_lam : 0, cnt = second ? a.P : a.n_lam;
   const float* K[7];
 #pragma unroll
@@ -524,6 +523,19 @@ __global__ __launch_bounds__(256) void k_adj_err_dev(AdjErrArgs a, AdjArgs g, in
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) a.part[(second ? 256 : 0) + bx] = red[0] + red[1] + red[2] + red[3];
+}
+// 512 blocks: both parts; only_mu: 256 blocks, the mu part alone (the lambda part rode in k_pgrad_adj_err's launch)
+__global__ __launch_bounds__(256) void k_adj_err_dev(AdjErrArgs a, AdjArgs g, int j, int only_mu) {
+  const bool second = only_mu || blockIdx.x >= 256;
+  adj_err_blocks(a, g, j, (!only_mu && second) ? blockIdx.x - 256 : blockIdx.x, second);
+}
+// The last evaluation's parameter-gradient GEMM of an attempt (nt tiles) and, on 256 more workgroups of the same launch,
+// the LAMBDA part of the attempt's error norm: it needs nothing of this GEMM (K7's lambda part and z_new's were written by
+// the VJP launches before it), so it no longer waits for it in a launch of its own.  Same blocks, same sums, same bits.
+__global__ __launch_bounds__(256) void k_pgrad_adj_err(PgradArgs a, AdjArgs g, AdjErrArgs e, int nt, int j) {
+  if ((int)blockIdx.x >= nt) { adj_err_blocks(e, g, j, blockIdx.x - nt, false); return; }
+  if (!pgrad_resolve(a, g)) return;
+  pgrad_tile(a, blockIdx.x);
 }
 
 // the rank's own fp64 sum (256 block partials, fixed order) into slot[rank] of a zeroed per-rank vector: the

@@ -3922,9 +3922,18 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
         const int r = adj_enqueue_eval(c, B, g, ADJ_STAGE, sidx, jj, true, ADJ_STAGE, sidx - 1);
         if (r) return r;
       }
-      const int r = adj_enqueue_pgrad(c, B, g, ADJ_STAGE, 7, jj);
-      if (r) return r;
-      hipLaunchKernelGGL(k_adj_err_dev, dim3(512), dim3(256), 0, c->stream, e, g, jj);
+      static const bool split_off = getenv("LRNDE_ADJ_ERR_ONE_LAUNCH") != nullptr;  // diagnostic: the error norm in one launch of its own
+      if (split_off) {
+        const int r = adj_enqueue_pgrad(c, B, g, ADJ_STAGE, 7, jj);
+        if (r) return r;
+        hipLaunchKernelGGL(k_adj_err_dev, dim3(512), dim3(256), 0, c->stream, e, g, jj, 0);
+      } else {
+        PgradArgs pg = pgrad_args(c, B, 0.f, nullptr, nullptr, c->bw_cur ^ 1);
+        pg.adj_mode = ADJ_STAGE; pg.adj_stage = 7; pg.adj_j = jj;
+        const int nt = pg.ntile1 + pg.ntile2;
+        hipLaunchKernelGGL(k_pgrad_adj_err, dim3(nt + 256), dim3(256), 0, c->stream, pg, g, e, nt, jj);
+        hipLaunchKernelGGL(k_adj_err_dev, dim3(256), dim3(256), 0, c->stream, e, g, jj, 1);
+      }
       HIPCHK(c, hipGetLastError());
       return LRNDE_OK;
     };
