@@ -40,6 +40,12 @@ int lrnde_last_solve_kernel_ms(lrnde_ctx* ctx, float* total_ms_host, int32_t* st
  * control block instead — its fall-back for a platform where no report arrives.  Same results
  * (tests/test_gpu_overlap.py::test_solve_loop_without_reports_gives_the_same_bits). */
 int lrnde_set_reports(lrnde_ctx* ctx, int32_t on);
+/* Diagnostic: the adjoint solves of the following backward calls write one row per ATTEMPTED step — (s, dt) in reversed time
+ * s = -t, the attempt's error estimate, accepted 1/0 — into rows_host (host memory of the caller, cap rows; cap = 0 switches
+ * the trace off); lrnde_adjoint_trace_rows returns how many were written since the last lrnde_set_adjoint_trace.  This is how
+ * tests/test_gpu_backward.py holds the adjoint's controller to the oracle's step sequence attempt by attempt. */
+int lrnde_set_adjoint_trace(lrnde_ctx* ctx, lrnde_trace_row* rows_host, int32_t cap);
+int lrnde_adjoint_trace_rows(lrnde_ctx* ctx, int32_t* n_host);
 /* Diagnostic: mean host-side microseconds per lrnde_node_forward call since the last reset, by phase: [0] entry -> the main
  * solve's init launches enqueued, [1] -> its last report read (the feed loop: the GPU is busy throughout), [2] -> the final
  * synchronisation returned, [3] -> the call returned (local-step results, bookkeeping).  tools/bench/host_phases.py */

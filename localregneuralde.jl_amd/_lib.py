@@ -138,6 +138,8 @@ SYMBOLS = [
     ("lrnde_bench_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _fp]),
     ("lrnde_set_overlap", C.c_int, [_vp, _i32]),
     ("lrnde_set_reports", C.c_int, [_vp, _i32]),
+    ("lrnde_set_adjoint_trace", C.c_int, [_vp, C.POINTER(TraceRow), _i32]),
+    ("lrnde_adjoint_trace_rows", C.c_int, [_vp, C.POINTER(_i32)]),
     ("lrnde_host_phases", C.c_int, [_vp, C.POINTER(C.c_double), _i32]),
     ("lrnde_last_solve_kernel_ms", C.c_int, [_vp, _fp, C.POINTER(_i32)]),
 ]

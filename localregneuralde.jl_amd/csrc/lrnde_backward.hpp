@@ -339,8 +339,16 @@ __global__ void k_pack_t(const float* p, int D, int H, int td, int Dp, int Hp, f
 
 // ---- elementwise kernels on flat vectors (augmented adjoint state, cotangents) ----
 struct AxArgs { float* out; const float* base; const float* k[7]; float c[7]; int nk; float dt; size_t n; };
-// out = base + dt * (c0*k0 + c1*k1 + ...)   (left to right)
+// out = base + dt * (c0*k0 + c1*k1 + ...)   (left to right); ONE term: base + (dt*c0)*k0 — the operation order of the
+// Tsit5 step's second stage (src/perform_step.jl:11-12: `a = dt * a21; uprev + a * k1`), which is also what upstream's own
+// perform_step does in the adjoint's reversed solve
 __global__ void k_axpy(AxArgs a) {
+  if (a.nk == 1) {
+    const float c = a.dt * a.c[0];
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x)
+      a.out[i] = (a.base ? a.base[i] : 0.f) + c * a.k[0][i];
+    return;
+  }
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < a.n; i += (size_t)gridDim.x * blockDim.x) {
     float s = a.c[0] * a.k[0][i];
     for (int j = 1; j < a.nk; ++j) s = s + a.c[j] * a.k[j][i];
@@ -393,7 +401,7 @@ __global__ void k_sweep_join(SweepJoinArgs a) {
     if (a.extra) { x = x + a.extra[i]; a.xb[i] = x; }
 #pragma unroll
     for (int j = 0; j < 5; ++j)
-      if (j < a.nk) a.kb[j][i] = a.kb[j][i] + a.dt * (a.c[j] * x);
+      if (j < a.nk) a.kb[j][i] = a.kb[j][i] + a.c[j] * (a.dt * x);  // pullback of uprev + dt*(sum_j a_sj k_j): through `dt *` first, then a_sj
   }
 }
 
@@ -899,7 +907,12 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
             x[h] = tsit5_rec_eval(dv[r][0][h], dv[r][1][h], dv[r][2][h], dv[r][3][h], dv[r][4][h], a.theta, a.dense_dt);
         }
         st4(a.ysc + g, x);
-        if (a.lnk > 0) {
+        if (a.lnk == 1) {  // one term (stage 2, initdt's Euler step): base + (dt*c0)*k0, the order of k_axpy / perform_step.jl:11-12
+          const float c0 = a.ldt * a.lc[0];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) lv[h] = bs[r][h] + c0 * kv[r][0][h];
+          st4(a.lam_out + g, lv);
+        } else if (a.lnk > 0) {
           f32x4 sacc;
 #pragma unroll
           for (int h = 0; h < 4; ++h) sacc[h] = a.lc[0] * kv[r][0][h];

@@ -1863,6 +1863,8 @@ struct lrnde_ctx {
   std::function<int()> final_hook;
   bool final_hook_fired = false, last_u_end_done = false;
   bool reports_off = false;  // lrnde_set_reports(ctx, 0): the solve loop polls by copies (its fall-back when no report arrives)
+  // lrnde_set_adjoint_trace: per-attempt (s, dt, EEst, accepted) rows of the next adjoint solves, host memory of the caller
+  lrnde_trace_row* adj_trace = nullptr; int adj_trace_cap = 0; int adj_trace_n = 0;
   std::string err;
 };
 
@@ -3737,6 +3739,10 @@ int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, RHSF rhs_fused, bool fuse_
       q = fmaxf(1.0f / qmax, fminf(1.0f / qmin, q / gamma));
     }
     accept = (eest <= 1.0f);
+    if (c->adj_trace && c->adj_trace_n < c->adj_trace_cap) {
+      lrnde_trace_row& r = c->adj_trace[c->adj_trace_n++];
+      r.t = t; r.dt = dt; r.eest = eest; r.accepted = accept;
+    }
     if (accept) {
       st->naccept++;
       const float dtnew = dt / q;
@@ -3917,6 +3923,7 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
     // once the report says the solve goes on (a rejection: the stream idles for one host round trip) — otherwise the
     // solve would always end with eight launches that find nothing to do.
     bool maybe_last = false;
+    int trace_prev = -1, trace_nacc = 0;
     auto enqueue_rest = [&](int jj) -> int {
       for (int sidx = 3; sidx <= 7; ++sidx) {
         const int r = adj_enqueue_eval(c, B, g, ADJ_STAGE, sidx, jj, true, ADJ_STAGE, sidx - 1);
@@ -3956,6 +3963,19 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
           if (q != hipSuccess && q != hipErrorNotReady) return fail(c, LRNDE_HIP_ERROR, "adjoint loop: %s", hipGetErrorString(q));
           if (q == hipSuccess && (int)(__atomic_load_n(hs, __ATOMIC_ACQUIRE) - want) < 0)
             return fail(c, LRNDE_HIP_ERROR, "adjoint loop: the stream drained without the status of attempt %d", j - 1);
+        }
+      }
+      if (c->adj_trace) {
+        // the report of attempt j-1's prologue: its (s, dt), and the error estimate / decision of the attempt before it
+        if (j > 1 && trace_prev >= 0) {
+          lrnde_trace_row& r = c->adj_trace[trace_prev];
+          r.eest = __builtin_bit_cast(float, (int)hs[9]); r.accepted = (hs[6] > trace_nacc);
+        }
+        trace_prev = -1; trace_nacc = hs[6];
+        if (hs[1] == ST_RUNNING && c->adj_trace_n < c->adj_trace_cap) {
+          trace_prev = c->adj_trace_n++;
+          lrnde_trace_row& r = c->adj_trace[trace_prev];
+          r.t = __builtin_bit_cast(float, (int)hs[2]); r.dt = __builtin_bit_cast(float, (int)hs[3]); r.eest = 0.f; r.accepted = -1;
         }
       }
       if (hs[1] != ST_RUNNING) done = true;
@@ -4465,6 +4485,18 @@ int lrnde_opt_update(int32_t kind, float* x, const float* grad, float* state1, f
   hipLaunchKernelGGL(k_opt_update, dim3(nb), dim3(256), 0, (hipStream_t)stream, n, (int)kind, x, grad, state1, state2, eta,
                      rho_or_beta1, beta2, eps, b1t, b2t, weight_decay);
   return hipGetLastError() == hipSuccess ? LRNDE_OK : LRNDE_HIP_ERROR;
+}
+
+int lrnde_set_adjoint_trace(lrnde_ctx* c, lrnde_trace_row* rows_host, int32_t cap) {
+  if (!c || cap < 0) return LRNDE_BADARG;
+  c->adj_trace = cap > 0 ? rows_host : nullptr; c->adj_trace_cap = cap; c->adj_trace_n = 0;
+  return LRNDE_OK;
+}
+
+int lrnde_adjoint_trace_rows(lrnde_ctx* c, int32_t* n_host) {
+  if (!c || !n_host) return LRNDE_BADARG;
+  *n_host = c->adj_trace_n;
+  return LRNDE_OK;
 }
 
 int lrnde_set_reports(lrnde_ctx* c, int32_t on) {

@@ -26,7 +26,7 @@ __global__ void k_reg_seed(RegSeedArgs a) {
       const float scb = -rb * ut / (sc * sc);
       if (__builtin_fabsf(un) > __builtin_fabsf(up)) a.ub[i] += scb * a.reltol * (un >= 0.f ? 1.f : -1.f);
 #pragma unroll
-      for (int j = 1; j < 7; ++j) a.kb[j][i] += a.dt * (float)Tsit5::BT[j] * utb;
+      for (int j = 1; j < 7; ++j) a.kb[j][i] += (float)Tsit5::BT[j] * (a.dt * utb);  // pullback of dt*(sum_j btilde_j k_j): through `dt *` first
     } else if (a.den != 0.f) {  // reg = |num/(den+eps)| / 3.5068
       const float eps = 1.1920929e-7f;
       const float qv = a.num / (a.den + eps);

@@ -232,6 +232,18 @@ class Handle:
                                             C.c_void_p(dp.data_ptr()), C.byref(sf), C.byref(sb)))
         return dict(dx=dx, dp=dp, stats_fwd=sf.asdict(), stats_bwd=sb.asdict())
 
+    def set_adjoint_trace(self, cap):
+        """diagnostic hook (include/lrnde_hooks.h): keep one (s, dt, EEst, accepted) row per attempted step of the adjoint
+        solves that follow; cap = 0 switches it off"""
+        self._adj_rows = (L.TraceRow * int(cap))() if cap else None
+        self._chk(L.lib.lrnde_set_adjoint_trace(self._ctx, self._adj_rows, int(cap)))
+
+    def adjoint_trace(self):
+        n = C.c_int32()
+        self._chk(L.lib.lrnde_adjoint_trace_rows(self._ctx, C.byref(n)))
+        r = self._adj_rows
+        return [(r[i].t, r[i].dt, r[i].eest, r[i].accepted) for i in range(int(n.value))]
+
     def node_forward_record(self, x, t0, t2, abstol, reltol, mode="unbiased", reg_type="error_estimate",
                             t1_or_rand=0.5, maxiters=1000, save_start=False, exact_pow=False):
         """node_forward that keeps the dense record for one `node_backward_recorded`."""

@@ -630,34 +630,61 @@ int lro_solve(const lro_field* f, const float* u0, int B, float t0, float t1, co
                       NULL, 0, NULL);
 }
 
-/* dense recorder: per accepted step t, dt, uprev and k1..k7 (what InterpolatingAdjoint keeps) */
+/* dense recorder: per accepted step t, dt and the Tsit5 interpolant (what InterpolatingAdjoint keeps as uprev, k1..k7) in
+ * POLYNOMIAL form, five arrays [uprev, k1, P2, P3, P4]: the weights b_i(theta) are quartics without a constant term, only
+ * b_1 has a linear one (r11 = 1) and sum_i b_i(theta) = theta, so
+ *   y(theta) = uprev + dt*(theta*k1 + theta^2*(P2 + theta*(P3 + theta*P4))),  P_m = sum_{i=2..7} r_im * (k_i - k1).
+ * Same interpolant, better conditioned (the columns of r sum to zero with entries up to 88), and the
+ * operation order below is the product's (csrc/lrnde_math.hpp tsit5_rec_poly / tsit5_rec_eval), so that the adjoint's
+ * y(t) - and with it every dt of the reversed solve - can be compared bit for bit. */
+#define LRO_REC_ARRAYS 5
 static int dense_push(lro_dense* d, float t, float dt, const float* uprev, const float* const k[7]) {
   if (d->nsteps >= d->cap) {
     int nc = d->cap ? 2 * d->cap : 64;
     d->t = (float*)realloc(d->t, sizeof(float) * nc);
     d->dt = (float*)realloc(d->dt, sizeof(float) * nc);
-    d->data = (float*)realloc(d->data, sizeof(float) * (size_t)nc * 8 * d->n);
+    d->data = (float*)realloc(d->data, sizeof(float) * (size_t)nc * LRO_REC_ARRAYS * d->n);
     if (!d->t || !d->dt || !d->data) return LRO_CAPACITY;
     d->cap = nc;
   }
-  float* dst = d->data + (size_t)d->nsteps * 8 * d->n;
+  float* dst = d->data + (size_t)d->nsteps * LRO_REC_ARRAYS * d->n;
   memcpy(dst, uprev, sizeof(float) * d->n);
-  for (int j = 0; j < 7; ++j) memcpy(dst + (size_t)(1 + j) * d->n, k[j], sizeof(float) * d->n);
+  memcpy(dst + d->n, k[0], sizeof(float) * d->n);
+  float R[28];
+  for (int i = 0; i < 28; ++i) R[i] = (float)TS_R[i];
+  for (long e = 0; e < d->n; ++e) {
+    float df[6];
+    for (int i = 0; i < 6; ++i) df[i] = k[i + 1][e] - k[0][e];
+    for (int m = 0; m < 3; ++m) {
+      float sm = R[4 + m + 1] * df[0];
+      for (int i = 1; i < 6; ++i) sm = sm + R[4 * (i + 1) + m + 1] * df[i];
+      dst[(size_t)(2 + m) * d->n + e] = sm;
+    }
+  }
   d->t[d->nsteps] = t; d->dt[d->nsteps] = dt;
   d->nsteps++;
   return LRO_OK;
 }
 void lro_dense_free(lro_dense* d) { free(d->t); free(d->dt); free(d->data); memset(d, 0, sizeof(*d)); }
 
-/* u(t) from the recorded steps (Tsit5 interpolant of the step containing t) */
+/* u(t) from the recorded steps (Tsit5 interpolant of the step containing t, Horner form of the record) */
 void lro_dense_eval(const lro_dense* d, float t, float* out) {
   int lo = 0, hi = d->nsteps - 1;
   while (lo < hi) { int mid = (lo + hi + 1) / 2; if (d->t[mid] <= t) lo = mid; else hi = mid - 1; }
-  const float* base = d->data + (size_t)lo * 8 * d->n;
-  const float* kk[7];
-  for (int j = 0; j < 7; ++j) kk[j] = base + (size_t)(1 + j) * d->n;
-  const float theta = (t - d->t[lo]) / d->dt[lo];
-  lro_tsit5_interp(theta, d->dt[lo], base, kk, d->n, out);
+  const float* y0 = d->data + (size_t)lo * LRO_REC_ARRAYS * d->n;
+  const float *k1 = y0 + d->n, *P2 = y0 + 2 * d->n, *P3 = y0 + 3 * d->n, *P4 = y0 + 4 * d->n;
+  const float ddt = d->dt[lo];
+  const float th = (t - d->t[lo]) / ddt;
+  const float th2 = th * th;
+  for (long e = 0; e < d->n; ++e) {
+    float sm = P4[e] * th;
+    sm = sm + P3[e];
+    sm = sm * th;
+    sm = sm + P2[e];
+    sm = sm * th2;
+    sm = sm + th * k1[e];
+    out[e] = y0[e] + ddt * sm;
+  }
 }
 
 /* tstops: ascending times strictly inside (t0,t1) the integrator must hit exactly
@@ -1191,22 +1218,40 @@ static void mlp_hidden_pre(const lro_mlp* m, const float* x, float t, float* pre
   for (int o = 0; o < H; ++o) pre[o] = pre[o] + b1[o];
 }
 
-/* dy = (df/dy)^T lam  (B x D);  gp += (df/dp)^T lam  (flat Lux layout; gp may be NULL) */
+/* dy = (df/dy)^T lam  (B x D);  gp += (df/dp)^T lam  (flat Lux layout; gp may be NULL).
+ * What Zygote.pullback(dudt, y, p, t) returns (ZygoteVJP of src/layers/neural_ode.jl:45-48).  The reference
+ * leaves every summation order here to BLAS; this restatement fixes them to the product's (csrc/lrnde_backward.hpp), as
+ * lro_mlp_rhs does for the forward, because at the experiments' tolerances the adjoint's embedded error estimate is
+ * rounding noise of exactly these sums and its step sequence can only be compared bit for bit:
+ *   pre, h          : the forward's canonical dot product (mlp_hidden_pre)
+ *   dh = W2^T lam   : canonical dot product over the D rows (fma chains over segments of 112, partials left to right)
+ *   dy = W1^T dpre  : the same over the H hidden units
+ *   gW = sum_b ...  : the batch in blocks of 32 samples dealt round-robin to 4 chains (one per wave of the GEMM tile), each
+ *                     an fma chain from 0 in increasing sample order, then ((c0 + c1) + c2) + c3; the time column and the
+ *                     bias gradient ride the same chains as the virtual operand columns [t, 1].
+ * The result does not depend on nthreads. */
+static void pgrad_chain4(const float* A, long lda, const float* Bm, long ldb, float bconst, int B, float* out) {
+  /* out = sum_b A[b*lda] * (Bm ? Bm[b*ldb] : bconst) in the order described above */
+  float c[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int nblk = (B + 31) / 32;
+  for (int w = 0; w < 4; ++w)
+    for (int blk = w; blk < nblk; blk += 4) {
+      const int b1 = (blk * 32 + 32 < B) ? blk * 32 + 32 : B;
+      for (int b = blk * 32; b < b1; ++b) c[w] = fmaf(A[(size_t)b * lda], Bm ? Bm[(size_t)b * ldb] : bconst, c[w]);
+    }
+  *out = ((c[0] + c[1]) + c[2]) + c[3];
+}
 void lro_mlp_vjp(const lro_mlp* m, const float* y, float t, const float* lam, int B, float* dy, float* gp) {
   const int D = m->D, H = m->H, td = m->time_dep ? 1 : 0;
   const float* W1 = m->p;
   const float* W2 = W1 + (size_t)H * (D + td) + H;
   const size_t oW1 = 0, ob1 = (size_t)H * (D + td), oW2 = ob1 + H, ob2 = oW2 + (size_t)D * (H + td);
-  const int P = lro_mlp_param_count(D, H, td);
   int nth = m->nthreads > 0 ? m->nthreads : 1;
-  float* gpt = gp ? (float*)calloc((size_t)nth * P, sizeof(float)) : NULL;
+  (void)nth;
+  float* hs = gp ? (float*)malloc(sizeof(float) * 2 * (size_t)B * H) : NULL;   /* h, dpre of every sample (the GEMMs' operands) */
+  float* dps = hs ? hs + (size_t)B * H : NULL;
 #pragma omp parallel num_threads(nth)
   {
-    int tid = 0;
-#ifdef _OPENMP
-    tid = omp_get_thread_num();
-#endif
-    float* g = gpt ? gpt + (size_t)tid * P : NULL;
     float* pre = (float*)malloc(sizeof(float) * 4 * (size_t)H);
     float *tmp = pre + H, *h = pre + 2 * H, *dpre = pre + 3 * H;
 #pragma omp for schedule(static)
@@ -1219,35 +1264,51 @@ void lro_mlp_vjp(const lro_mlp* m, const float* y, float t, const float* lam, in
       /* dh = W2[:, :H]^T lam ; dpre = dh .* act'(pre) */
       for (int o = 0; o < H; ++o) {
         const float* w = W2 + (size_t)o * D;
-        float acc = 0.0f;
-        for (int i = 0; i < D; ++i) acc = fmaf(w[i], ll[i], acc);
-        dpre[o] = acc * act_deriv(m->act, pre[o], h[o]);
+        float tot = 0.0f;
+        for (int k0 = 0; k0 < D; k0 += LRO_KSEG) {
+          const int k1 = (k0 + LRO_KSEG < D) ? k0 + LRO_KSEG : D;
+          float acc = 0.0f;
+          for (int i = k0; i < k1; ++i) acc = fmaf(w[i], ll[i], acc);
+          tot = (k0 == 0) ? acc : tot + acc;
+        }
+        dpre[o] = tot * act_deriv(m->act, pre[o], h[o]);
       }
       /* dy = W1[:, :D]^T dpre */
       for (int k = 0; k < D; ++k) {
         const float* w = W1 + (size_t)k * H;
-        float acc = 0.0f;
-        for (int o = 0; o < H; ++o) acc = fmaf(w[o], dpre[o], acc);
-        dd[k] = acc;
+        float tot = 0.0f;
+        for (int o0 = 0; o0 < H; o0 += LRO_KSEG) {
+          const int o1 = (o0 + LRO_KSEG < H) ? o0 + LRO_KSEG : H;
+          float acc = 0.0f;
+          for (int o = o0; o < o1; ++o) acc = fmaf(w[o], dpre[o], acc);
+          tot = (o0 == 0) ? acc : tot + acc;
+        }
+        dd[k] = tot;
       }
-      if (g) {
-        for (int k = 0; k < H; ++k) { float* gw = g + oW2 + (size_t)k * D; const float hv = h[k];
-          for (int i = 0; i < D; ++i) gw[i] = fmaf(ll[i], hv, gw[i]); }
-        if (td) { float* gw = g + oW2 + (size_t)H * D; for (int i = 0; i < D; ++i) gw[i] = fmaf(ll[i], t, gw[i]); }
-        for (int i = 0; i < D; ++i) g[ob2 + i] += ll[i];
-        for (int k = 0; k < D; ++k) { float* gw = g + oW1 + (size_t)k * H; const float yv = yy[k];
-          for (int o = 0; o < H; ++o) gw[o] = fmaf(dpre[o], yv, gw[o]); }
-        if (td) { float* gw = g + oW1 + (size_t)D * H; for (int o = 0; o < H; ++o) gw[o] = fmaf(dpre[o], t, gw[o]); }
-        for (int o = 0; o < H; ++o) g[ob1 + o] += dpre[o];
-      }
+      if (hs) { memcpy(hs + (size_t)n * H, h, sizeof(float) * H); memcpy(dps + (size_t)n * H, dpre, sizeof(float) * H); }
     }
     free(pre);
+    if (gp) {
+      /* gW1 = dpre^T [y, t, 1] (H x (D+td), b1);  gW2 = lam^T [h, t, 1] (D x (H+td), b2): every entry its own chain set */
+#pragma omp for schedule(static)
+      for (int k = 0; k < D + 2; ++k)
+        for (int o = 0; o < H; ++o) {
+          float v;
+          if (k < D) { pgrad_chain4(dps + o, H, y + k, D, 0.0f, B, &v); gp[oW1 + (size_t)k * H + o] += v; }
+          else if (k == D) { if (td) { pgrad_chain4(dps + o, H, NULL, 0, t, B, &v); gp[oW1 + (size_t)D * H + o] += v; } }
+          else { pgrad_chain4(dps + o, H, NULL, 0, 1.0f, B, &v); gp[ob1 + o] += v; }
+        }
+#pragma omp for schedule(static)
+      for (int k = 0; k < H + 2; ++k)
+        for (int i = 0; i < D; ++i) {
+          float v;
+          if (k < H) { pgrad_chain4(lam + i, D, hs + k, H, 0.0f, B, &v); gp[oW2 + (size_t)k * D + i] += v; }
+          else if (k == H) { if (td) { pgrad_chain4(lam + i, D, NULL, 0, t, B, &v); gp[oW2 + (size_t)H * D + i] += v; } }
+          else { pgrad_chain4(lam + i, D, NULL, 0, 1.0f, B, &v); gp[ob2 + i] += v; }
+        }
+    }
   }
-  if (gp) {
-    for (int th = 0; th < nth; ++th)
-      for (int i = 0; i < P; ++i) gp[i] += gpt[(size_t)th * P + i];
-    free(gpt);
-  }
+  free(hs);
 }
 
 /* adjoint field in reversed time s = -t:  z = [lambda (n); mu (P)],  dz/ds = [J^T lambda; (df/dp)^T lambda] at y(t) */
@@ -1331,7 +1392,7 @@ static int step_reg_grad_generic(const lro_diff_field* df, const float* uprev, c
       const float utb = rb / sc;
       const float scb = -rb * ut[i] / (sc * sc);
       if (fabsf(u[i]) > fabsf(uprev[i])) ub[i] += scb * reltol * (u[i] >= 0.0f ? 1.0f : -1.0f);
-      for (int j = 1; j < 7; ++j) kb[(size_t)j * n + i] += dt * BT[j] * utb;
+      for (int j = 1; j < 7; ++j) kb[(size_t)j * n + i] += BT[j] * (dt * utb);  /* Zygote's order: the pullback of `dt * (...)` first */
     }
     free(ut);
   } else {
@@ -1363,7 +1424,7 @@ static int step_reg_grad_generic(const lro_diff_field* df, const float* uprev, c
     if (s == 6) for (long i = 0; i < n; ++i) xb[i] += g6b[i];
     const int off = (s - 2) * (s - 1) / 2;
     for (int j = 1; j < s - 1; ++j)  /* k_{j+1}, j = 0 is the constant k1 */
-      for (long i = 0; i < n; ++i) kb[(size_t)j * n + i] += dt * A[off + j] * xb[i];
+      for (long i = 0; i < n; ++i) kb[(size_t)j * n + i] += A[off + j] * (dt * xb[i]);
     if (s == 7) { /* u also feeds the next accumulation: xbar_7 already includes ub */ }
   }
   if (reg_val) *reg_val = rv;
@@ -1374,7 +1435,7 @@ static int step_reg_grad_generic(const lro_diff_field* df, const float* uprev, c
 /* full backward of `loss = <du_end, sol.u[end]> + w_reg * reg_val` for the NeuralODE layer */
 static int node_backward_generic(const lro_diff_field* df, const float* x, int B, float t0, float t2, const lro_opts* o, int mode,
                                  int reg_type, float t1_or_rand, const float* du_end, float w_reg, float* dx, float* dp,
-                                 lro_stats* st_fwd, lro_stats* st_bwd) {
+                                 lro_stats* st_fwd, lro_stats* st_bwd, lro_trace_row* btrace, int cap_btrace) {
   const int D = df->field.D;
   const long n = (long)D * B;
   const int P = df->P;
@@ -1426,7 +1487,7 @@ static int node_backward_generic(const lro_diff_field* df, const float* x, int B
   lro_opts ob = *o; ob.save_everystep = 0; ob.save_start = 0;
   float sv[1] = {-t0}; float tsv[2];
   float* zs = (float*)malloc(sizeof(float) * (size_t)N * 2);
-  rc = lro_solve_ex(&af, z0, 1, -t2, -t0, &ob, sv, 1, zs, tsv, 2, st_bwd, NULL, 0, stops, ntst, NULL);
+  rc = lro_solve_ex(&af, z0, 1, -t2, -t0, &ob, sv, 1, zs, tsv, 2, st_bwd, btrace, cap_btrace, stops, ntst, NULL);
   if (rc == LRO_OK) {
     const float* zf = zs + (size_t)(st_bwd->nsaved - 1) * N;
     memcpy(dx, zf, sizeof(float) * n);
@@ -1497,7 +1558,15 @@ int lro_node_backward(const lro_mlp* m, const float* x, int B, float t0, float t
                       int reg_type, float t1_or_rand, const float* du_end, float w_reg, float* dx, float* dp,
                       lro_stats* st_fwd, lro_stats* st_bwd) {
   lro_diff_field d; diff_from_mlp(m, &d);
-  return node_backward_generic(&d, x, B, t0, t2, o, mode, reg_type, t1_or_rand, du_end, w_reg, dx, dp, st_fwd, st_bwd);
+  return node_backward_generic(&d, x, B, t0, t2, o, mode, reg_type, t1_or_rand, du_end, w_reg, dx, dp, st_fwd, st_bwd, NULL, 0);
+}
+/* the same with the adjoint solve's per-attempt trace (t, dt in reversed time s = -t; st_bwd->iters rows are filled) */
+int lro_node_backward_traced(const lro_mlp* m, const float* x, int B, float t0, float t2, const lro_opts* o, int mode,
+                             int reg_type, float t1_or_rand, const float* du_end, float w_reg, float* dx, float* dp,
+                             lro_stats* st_fwd, lro_stats* st_bwd, lro_trace_row* btrace, int cap_btrace) {
+  lro_diff_field d; diff_from_mlp(m, &d);
+  return node_backward_generic(&d, x, B, t0, t2, o, mode, reg_type, t1_or_rand, du_end, w_reg, dx, dp, st_fwd, st_bwd, btrace,
+                               cap_btrace);
 }
 int lro_conv_step_reg_grad(const lro_conv* m, const float* uprev, const float* k1, float t, float dt,
                            float abstol, float reltol, int B, int reg_type, float* gp, float* reg_val) {
@@ -1508,7 +1577,7 @@ int lro_conv_node_backward(const lro_conv* m, const float* x, int B, float t0, f
                            int reg_type, float t1_or_rand, const float* du_end, float w_reg, float* dx, float* dp,
                            lro_stats* st_fwd, lro_stats* st_bwd) {
   lro_diff_field d; diff_from_conv(m, &d);
-  return node_backward_generic(&d, x, B, t0, t2, o, mode, reg_type, t1_or_rand, du_end, w_reg, dx, dp, st_fwd, st_bwd);
+  return node_backward_generic(&d, x, B, t0, t2, o, mode, reg_type, t1_or_rand, du_end, w_reg, dx, dp, st_fwd, st_bwd, NULL, 0);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -202,6 +202,9 @@ int lro_tsit5_step_reg_grad(const lro_mlp* m, const float* uprev, const float* k
 int lro_node_backward(const lro_mlp* m, const float* x, int B, float t0, float t2, const lro_opts* o, int mode,
                       int reg_type, float t1_or_rand, const float* du_end, float w_reg, float* dx, float* dp,
                       lro_stats* st_fwd, lro_stats* st_bwd);
+int lro_node_backward_traced(const lro_mlp* m, const float* x, int B, float t0, float t2, const lro_opts* o, int mode,
+                             int reg_type, float t1_or_rand, const float* du_end, float w_reg, float* dx, float* dp,
+                             lro_stats* st_fwd, lro_stats* st_bwd, lro_trace_row* btrace, int cap_btrace);
 
 /* ---- SDE: adaptive Euler-Heun local step with supplied dW (src/perform_step.jl:172-206) ---- */
 /* ---- layers around the CIFAR10 NeuralODE (experiments/src/construct.jl:224-227) ----

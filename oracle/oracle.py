@@ -129,6 +129,7 @@ def lib():
                                               C.c_int, C.c_int, fp, fp]
         L.lro_node_backward.argtypes = [C.POINTER(Mlp), fp, C.c_int, C.c_float, C.c_float, C.POINTER(Opts), C.c_int,
                                         C.c_int, C.c_float, fp, C.c_float, fp, fp, C.POINTER(Stats), C.POINTER(Stats)]
+        L.lro_node_backward_traced.argtypes = L.lro_node_backward.argtypes + [C.POINTER(TraceRow), C.c_int]
         _lib = L
     return _lib
 
@@ -372,13 +373,21 @@ def step_reg_grad(fld, uprev, k1, t, dt, abstol, reltol, reg_type="error_estimat
 
 
 def node_backward(fld, x, t0, t2, abstol, reltol, du_end, mode="unbiased", reg_type="error_estimate",
-                  t1_or_rand=0.5, w_reg=0.0, maxiters=10000, save_start=False):
+                  t1_or_rand=0.5, w_reg=0.0, maxiters=10000, save_start=False, trace=False):
     x = _f32(x); du_end = _f32(du_end)
     B = x.size // fld.D
     o = make_opts(abstol, reltol, maxiters, save_start, False, False)
     dx = np.empty_like(x)
     dp = np.zeros(fld.params.size, np.float32)
     sf, sb = Stats(), Stats()
+    if trace and not isinstance(fld, ConvField):
+        cap = maxiters + 2
+        rows = (TraceRow * cap)()
+        rc = lib().lro_node_backward_traced(C.byref(fld.m), _fp(x), B, float(t0), float(t2), C.byref(o), MODE[mode],
+                                            REG[reg_type], float(t1_or_rand), _fp(du_end), float(w_reg), _fp(dx), _fp(dp),
+                                            C.byref(sf), C.byref(sb), rows, cap)
+        tr = [(rows[i].t, rows[i].dt, rows[i].eest, rows[i].accepted) for i in range(min(cap, sb.iters))]
+        return dict(retcode=rc, dx=dx, dp=dp, stats_fwd=sf.asdict(), stats_bwd=sb.asdict(), trace_bwd=tr)
     fn = lib().lro_conv_node_backward if isinstance(fld, ConvField) else lib().lro_node_backward
     rc = fn(C.byref(fld.m), _fp(x), B, float(t0), float(t2), C.byref(o), MODE[mode],
                                  REG[reg_type], float(t1_or_rand), _fp(du_end), float(w_reg), _fp(dx), _fp(dp),
