@@ -5,7 +5,7 @@ Mirrors (reference paths): NeuralODE — src/layers/neural_ode.jl; TDChain —
 src/layers/common.jl:2-45; diffeqsol_to_array / diffeqsol_to_timeseries —
 src/utils.jl:37-46.  PyTorch is used only for device memory and streams.
 """
-from ._lib import LIB_PATH, LrndeError  # noqa: F401  (raises if liblrnde.so is missing)
+from ._lib import LIB_PATH, LrndeError, set_option  # noqa: F401  (raises if liblrnde.so is missing)
 from .layers import (Chain, Dense, Handle, NeuralODE, ODESolution, TDChain,  # noqa: F401
                      diffeqsol_to_array, diffeqsol_to_timeseries, flatten_params,
                      glorot_params)

@@ -138,6 +138,7 @@ SYMBOLS = [
     ("lrnde_bench_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _fp]),
     ("lrnde_set_overlap", C.c_int, [_vp, _i32]),
     ("lrnde_set_reports", C.c_int, [_vp, _i32]),
+    ("lrnde_set_option", C.c_int, [C.c_char_p, _i32]),
     ("lrnde_set_adjoint_trace", C.c_int, [_vp, C.POINTER(TraceRow), _i32]),
     ("lrnde_adjoint_trace_rows", C.c_int, [_vp, C.POINTER(_i32)]),
     ("lrnde_host_phases", C.c_int, [_vp, C.POINTER(C.c_double), _i32]),
@@ -167,3 +168,10 @@ def check(ctx, rc):
     if rc != 0:
         msg = lib.lrnde_last_error(ctx)
         raise LrndeError(rc, msg.decode() if msg else "")
+
+
+def set_option(name, value):
+    """diagnostic hook lrnde_set_option (include/lrnde_hooks.h): override a process-wide switch by its environment-variable name"""
+    rc = lib.lrnde_set_option(name.encode(), int(value))
+    if rc != 0:
+        raise LrndeError(rc, f"unknown option {name}")

@@ -1736,7 +1736,7 @@ struct DevBuf {
 inline size_t state_n(const lrnde_conv* c, int B) { return (size_t)B * c->d.width * c->d.height * c->d.channels; }
 inline int strip_rows(const lrnde_conv* c) {
   // largest TR dividing H with TR*W <= 128 pixels (8 M tiles)
-  static const int maxpx = getenv("LRNDE_CONV_STRIP_PX") ? atoi(getenv("LRNDE_CONV_STRIP_PX")) : 16 * MAXMT;
+  const int maxpx = 16 * MAXMT;
   int best = 0;
   for (int tr = 1; tr <= c->d.height; ++tr)
     if (c->d.height % tr == 0 && tr * c->d.width <= maxpx) best = tr;
@@ -1767,7 +1767,7 @@ int check_ready(lrnde_conv* c, int B) {
 }
 
 ConvArgs base_args(const lrnde_conv* c, int B) {
-  ConvArgs a;
+  ConvArgs a{};
   memset(&a, 0, sizeof(a));
   a.W = c->d.width; a.H = c->d.height; a.B = B; a.TR = strip_rows(c);
   a.TP = a.TR * a.W; a.MT = (a.TP + 15) / 16;
@@ -1785,8 +1785,7 @@ ConvArgs base_args(const lrnde_conv* c, int B) {
 template <int MT> void launch_one(lrnde_conv* c, int which, const ConvArgs& a, size_t sm) {
   if (c->d.compute_dtype == LRNDE_BF16 && !c->force_f32) {
     if (which == 0) {
-      static const bool f32in = getenv("LRNDE_CONV_BF16_F32IN") != nullptr;  // conv1 in fp32 math (bf16 output) instead
-      if (f32in || !a.wpk2) LRNDE_CONV_LAUNCH((k_conv_wide_f32<8, MT, true>), a);
+      if (!a.wpk2) LRNDE_CONV_LAUNCH((k_conv_wide_f32<8, MT, true>), a);
       else { ConvArgs b = a; b.wpk = a.wpk2; b.CINP = 8; LRNDE_CONV_LAUNCH(k_conv_in_bf16<MT>, b); }
     }
     else if (which == 1) LRNDE_CONV_LAUNCH(k_conv_wide_bf16<MT>, a);
@@ -1807,8 +1806,6 @@ template <int MT> void launch_one(lrnde_conv* c, int which, const ConvArgs& a, s
 }
 #undef LRNDE_CONV_LAUNCH
 void launch_mt(lrnde_conv* c, int which, const ConvArgs& a, size_t sm) {
-  static const size_t lds_min = getenv("LRNDE_CONV_LDS_MIN") ? (size_t)atoi(getenv("LRNDE_CONV_LDS_MIN")) : 0;  // occupancy experiments
-  if (sm < lds_min) sm = lds_min;
   switch (a.MT) {
     case 1: launch_one<1>(c, which, a, sm); break;
     case 2: launch_one<2>(c, which, a, sm); break;
@@ -1841,9 +1838,8 @@ int launch_rhs_ex(lrnde_conv* c, const float* u, float t, int B, float* du, bool
   if (c->split) { a.wpk = c->w1h; a.wpk2 = c->w1l; }
   a.part = train ? c->part : nullptr;
   const size_t stg_bytes = sizeof(float) * (size_t)a.TP * 68;  // epilogue transpose buffer (aliases the tile)
-  static const bool bf_f32in = getenv("LRNDE_CONV_BF16_F32IN") != nullptr;
   // bf16 kernels: [9][64] t-plane table + tile, no transpose buffer (direct epilogue)
-  if (bf && !bf_f32in && a.wpk2) launch_mt(c, 0, a, TSL_BYTES + 2 * (size_t)rows * WP * 8);
+  if (bf && a.wpk2) launch_mt(c, 0, a, TSL_BYTES + 2 * (size_t)rows * WP * 8);
   else launch_mt(c, 0, a, std::max(sizeof(float) * rows * WP * a.CINP, stg_bytes));
   CHK(c, hipGetLastError());
   float* rs = (train && last) ? c->bn_state : nullptr;  // the VJP's recompute does not advance the running statistics
@@ -1929,7 +1925,7 @@ int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, 
   ConvArgs a = base_args(c, B);
   const int rows = a.TR + 2, WP = a.W + 2;
   auto bn_bwd = [&](float* g, const float* araw, int layer) -> int {
-    BnBwdArgs b;
+    BnBwdArgs b{};
     b.g = g; b.a = araw; b.npix = npix; b.mean = c->stat + 2 * layer * Hc; b.inv = c->stat + (2 * layer + 1) * Hc;
     b.scale = c->bn + 2 * layer * Hc; b.bias = c->bn + (2 * layer + 1) * Hc; b.act = c->d.act; b.part = c->part_bw;
     hipLaunchKernelGGL(k_bn_bwd1, dim3(NBW1), dim3(256), 0, c->stream, b);
@@ -1941,10 +1937,10 @@ int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, 
   };
   auto wgrad = [&](int GM, int IM, const float* g, const float* graw, int glayer, const float* in, int ilayer, int CINr, int COUTr,
                    float* gw) -> int {
-    WgradArgs w;
+    WgradArgs w{};
     memset(&w, 0, sizeof(w));
-    // strips of <= LRNDE_WGRAD_PX pixels (128; 64 gives two workgroups per CU and measured the same)
-    static const int wpx = getenv("LRNDE_WGRAD_PX") ? atoi(getenv("LRNDE_WGRAD_PX")) : 128;
+    // strips of <= 128 pixels (64 gives two workgroups per CU and measured the same)
+    const int wpx = 128;
     int trw = 1;
     for (int tr = 1; tr <= H; ++tr) if (H % tr == 0 && tr * W <= wpx) trw = tr;
     const int nstrips_w = B * (H / trw);
@@ -1995,7 +1991,7 @@ int launch_vjp(lrnde_conv* c, const float* y, float t, const float* lam, int B, 
 }
 
 int lincomb(lrnde_conv* c, float* out, const float* base, float dt, int nk, const float* const* k, const float* coef, size_t n) {
-  LinArgs a;
+  LinArgs a{};
   a.out = out; a.base = base; a.dt = dt; a.nk = nk; a.n = n;
   for (int j = 0; j < 7; ++j) { a.k[j] = j < nk ? k[j] : nullptr; a.c[j] = j < nk ? coef[j] : 0.f; }
   bool vec = n % 4 == 0 && ((uintptr_t)out % 16) == 0 && (!base || ((uintptr_t)base % 16) == 0);
@@ -2071,7 +2067,7 @@ int tsit5_step_g(lrnde_conv* c, size_t n, RHS&& rhs, const float* uprev, const f
     else if ((rc = lincomb(c, x, uprev, dt, s - 1, K, A + off, n))) return rc;
     if ((rc = rhs(x, t + cs[s - 2] * dt, Kw[s - 1]))) return rc;
   }
-  ErrArgs e;
+  ErrArgs e{};
   e.uprev = uprev; e.u = u; for (int j = 0; j < 7; ++j) e.k[j] = K[j];
   e.g6 = g6; e.dt = dt; e.abstol = abstol; e.reltol = reltol; e.n = n; e.part = c->sums;
   bool v4 = n % 4 == 0 && ((uintptr_t)uprev % 16) == 0 && ((uintptr_t)u % 16) == 0 && ((uintptr_t)g6 % 16) == 0;
@@ -2530,7 +2526,7 @@ int step_reg_grad(lrnde_conv* c, const float* uprev, const float* k1, int B, flo
   float *ub = A0 + 6 * n, *g6b = A0 + 7 * n, *xs = A0 + 8 * n, *xb = A0 + 9 * n, *gtmp = A0 + 11 * n;
   CHK(c, hipMemsetAsync(A0, 0, sizeof(float) * 8 * n, c->stream));
   CHK(c, hipMemsetAsync(gp, 0, sizeof(float) * P, c->stream));
-  RegSeedArgs sa;
+  RegSeedArgs sa{};
   sa.n = n; sa.n_norm = n; sa.uprev = uprev; sa.u = u; sa.g6 = g6;
   for (int j = 0; j < 7; ++j) sa.k[j] = kk[j];
   sa.kb[0] = nullptr;

@@ -38,6 +38,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <string>
 #include <functional>
 #include <vector>
@@ -1010,7 +1011,7 @@ struct PrologueArgs {
   unsigned long long* prog; Ctrl* fin_host;
 };
 __device__ __forceinline__ PrologueArgs pin_args(const StepArgs& a) {
-  PrologueArgs p;
+  PrologueArgs p{};
   p.mode = pin_v(a.mode); p.maxiters = pin_v(a.maxiters); p.nsave = pin_v(a.nsave); p.cap_saved = pin_v(a.cap_saved);
   p.save_everystep = pin_v(a.save_everystep); p.exact_pow = pin_v(a.exact_pow); p.nwg_global = pin_v(a.nwg_global);
   p.dense_cap = pin_v(a.dense_cap); p.dense_direct = pin_v(a.dense_direct); p.force_store_k = pin_v(a.force_store_k);
@@ -1870,6 +1871,37 @@ struct lrnde_ctx {
 
 namespace {
 
+// ---- diagnostic switches -------------------------------------------------------------------------
+// One process-wide table: each entry starts from its environment variable (read once) and can be set from the host
+// language with the hook lrnde_set_option(name, value) — which is how tests/test_gpu_switches.py runs every alternative
+// path in the same process as the default one and holds the two to the same bits.
+enum {
+  OPT_NO_QTILE, OPT_QTILE_MAX_B, OPT_NO_FUSE, OPT_DENSE_COPY, OPT_NO_OVERLAP, OPT_NO_SDE_FAST, OPT_SDE_HOST_LOOP, OPT_NO_QVJP,
+  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_HOST, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
+};
+struct OptDef { const char* name; int dflt; bool flag; };   // flag: present in the environment = 1
+const OptDef g_optdef[N_OPT] = {
+    {"LRNDE_NO_QTILE", 0, true}, {"LRNDE_QTILE_MAX_B", 2048, false}, {"LRNDE_NO_FUSE", 0, true}, {"LRNDE_DENSE_COPY", 0, true},
+    {"LRNDE_NO_OVERLAP", 0, true}, {"LRNDE_NO_SDE_FAST", 0, true}, {"LRNDE_SDE_HOST_LOOP", 0, true}, {"LRNDE_NO_QVJP", 0, true},
+    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
+    {"LRNDE_FEED_M", 2, false}, {"LRNDE_GATHER_TILES", 0, true}, {"LRNDE_FORCE_COMM", 0, true}};
+int g_opt[N_OPT];
+bool g_opt_set[N_OPT];     // set by the hook: the environment no longer counts
+std::once_flag g_opt_once;
+void opt_init() {
+  for (int i = 0; i < N_OPT; ++i) {
+    const char* e = getenv(g_optdef[i].name);
+    g_opt[i] = e ? (g_optdef[i].flag ? 1 : atoi(e)) : g_optdef[i].dflt;
+  }
+  if (const char* e = getenv("LRNDE_FEED")) sscanf(e, "%d,%d,%d", &g_opt[OPT_FEED_T], &g_opt[OPT_FEED_E], &g_opt[OPT_FEED_M]);
+}
+int opt(int i) {
+  std::call_once(g_opt_once, opt_init);
+  // (the two communicator switches are read when a communicator is made and tests flip them through the environment)
+  if ((i == OPT_GATHER_TILES || i == OPT_FORCE_COMM) && !g_opt_set[i]) return getenv(g_optdef[i].name) != nullptr;
+  return g_opt[i];
+}
+
 int fail(lrnde_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -1929,12 +1961,12 @@ inline int vecw(const lrnde_ctx* c) { return (c->desc.state_dim % 4 == 0) ? 4 : 
 // Which tile shape runs this batch: the 4-column family (lrnde_qtile.hpp) when there would be too
 // few 16-column workgroups to fill the chip, the 16-column family otherwise.
 bool use_qtile(const lrnde_ctx* c, int B) {
-  static const int qmax = getenv("LRNDE_QTILE_MAX_B") ? atoi(getenv("LRNDE_QTILE_MAX_B")) : 2048;  // two rounds of 4-column workgroups (97 us at B=2048) beat one of 16-column ones (114 us)
+  const int qmax = opt(OPT_QTILE_MAX_B);  // two rounds of 4-column workgroups (97 us at B=2048) beat one of 16-column ones (114 us)
   const int D = c->desc.state_dim, H = c->desc.hidden_dim;
   // streaming path shape limits: one Dense-1 segment and one Dense-2 pass per wave
   const bool shape_ok = (D % 4 == 0) && (H <= 112) && (c->m.KQ1p / QSEG <= QNW) && (c->m.RG1 <= 2) &&
                         (c->m.RG2 <= 2 * QNW);
-  static const bool no_qtile = getenv("LRNDE_NO_QTILE") != nullptr;
+  const bool no_qtile = opt(OPT_NO_QTILE) != 0;
   return shape_ok && ((double)B * D * 40.0 < 2147483000.0) && B <= qmax && !no_qtile;
 }
 inline int tile_nb(const lrnde_ctx* c, int B) { return use_qtile(c, B) ? QNB : NB; }
@@ -1986,7 +2018,7 @@ void fill_args(lrnde_ctx* c, StepArgs& a, int B, int force_nb = 0) {
   const int nwg = (B + nb - 1) / nb;
   a.m = c->m;
   a.state = c->state; a.n_local = (long)n;
-  static const bool no_fuse = getenv("LRNDE_NO_FUSE") != nullptr;
+  const bool no_fuse = opt(OPT_NO_FUSE) != 0;
   a.fused = (c->desc.state_dim % 16 == 0) && ((double)n * 40.0 < 2147483000.0) && !no_fuse;
   a.ubuf[0] = c->state; a.ubuf[1] = c->state + n;
   a.kfsal[0] = c->state + 2 * n; a.kfsal[1] = c->state + 3 * n;
@@ -2279,7 +2311,7 @@ int lrnde_rhs(lrnde_ctx* c, const float* u, float t, int32_t B, float* du) {
   int rc = check_ready(c, B);
   if (rc) return rc;
   if (!u || !du) return fail(c, LRNDE_BADARG, "null state pointer");
-  StepArgs a;
+  StepArgs a{};
   memset(&a, 0, sizeof(a));
   a.m = c->m; a.B = B;
   if (use_qtile(c, B)) {
@@ -2303,7 +2335,7 @@ int lrnde_init_dt(lrnde_ctx* c, const float* u0, int32_t B, float t0, float tend
   if (!(tend > t0)) return fail(c, LRNDE_BADARG, "tspan must be increasing");
   if ((rc = ensure_workspace(c, B))) return rc;
   c->rec_valid = false;
-  StepArgs a;
+  StepArgs a{};
   fill_args(c, a, B);
   a.t0 = t0; a.t1 = tend; a.abstol = abstol; a.reltol = reltol; a.mode = MODE_SINGLE_INIT_DT;
   const size_t n = (size_t)B * c->desc.state_dim;
@@ -2361,7 +2393,7 @@ int lrnde_perform_step(lrnde_ctx* c, const float* uprev, const float* k1, int32_
   if (!uprev || !k1) return fail(c, LRNDE_BADARG, "null state pointer");
   if ((rc = ensure_workspace(c, B))) return rc;
   c->rec_valid = false;  // the state workspace a recorded forward left for its backward is overwritten
-  StepArgs a;
+  StepArgs a{};
   fill_args(c, a, B);
   a.t0 = t; a.t1 = t + 1.0f; a.abstol = abstol; a.reltol = reltol; a.mode = MODE_SINGLE_GIVEN_DT;
   a.want_stiff = 1; a.maxiters = 1;
@@ -2423,14 +2455,14 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
     HIPCHK(c, hipMalloc(&c->trace_dev, sizeof(lrnde_trace_row) * cap_trace));
     c->trace_cap = cap_trace;
   }
-  StepArgs a;
+  StepArgs a{};
   fill_args(c, a, B);
   a.t0 = t0; a.t1 = t1; a.abstol = o->abstol; a.reltol = o->reltol;
   a.maxiters = o->maxiters; a.save_everystep = o->save_everystep; a.exact_pow = o->exact_pow;
   a.want_stiff = 0; a.mode = MODE_SOLVE;
   if (c->dense_on) {
     a.dense = c->dense; a.dense_t = c->dense_t; a.dense_dt = c->dense_dt; a.dense_cap = c->dense_cap;
-    static const bool no_direct = getenv("LRNDE_DENSE_COPY") != nullptr;  // diagnostic: round 1's prologue copy
+    const bool no_direct = opt(OPT_DENSE_COPY) != 0;  // diagnostic: round 1's prologue copy
     a.dense_direct = (use_qtile(c, B) && !no_direct) ? 1 : 0;
   }
   a.cap_saved = cap_saved; a.u_saved = u_saved; a.t_saved = c->tsaved_dev;
@@ -2494,8 +2526,7 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
       // (rem + 1 is exact when dt stays put; while the controller still grows dt the estimate is high and every launch
       //  enqueued on its strength beyond the real end is a 6-us launch with nothing to do — seven of them per pass on the
       //  MNIST field.  Far from the end half the estimate plus two keeps the queue two launches deep at the least.)
-      static int fT = -1, fE = 1, fM = 2;
-      if (fT < 0) { fT = 3; if (const char* e = getenv("LRNDE_FEED")) sscanf(e, "%d,%d,%d", &fT, &fE, &fM); }
+      const int fT = opt(OPT_FEED_T), fE = opt(OPT_FEED_E), fM = opt(OPT_FEED_M);
       int ahead = rem <= fT ? rem + fE : rem / 2 + fE + 1;
       if (ahead < fM) ahead = fM;
       if (ahead > 16) ahead = 16;
@@ -2659,7 +2690,7 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
   };
   // _get_ode_integrator (neural_ode.jl:33-38): fresh init on (t1, t2); then _perform_step (:77).  `L` is the context the
   // step runs on: the handle itself, or its companion (own stream) while the main solve is still going.
-  StepArgs a;
+  StepArgs a{};
   auto enqueue_local = [&](lrnde_ctx* L, const float* u_at_t1, float t1v) -> int {
     int r;
     fill_args(L, a, B);
@@ -2715,7 +2746,7 @@ static int node_forward_impl(lrnde_ctx* c, const float* x, int32_t B, float t0, 
     // the local step is enqueued on the companion's stream — and, recording, the regulariser's reverse sweep once the
     // step's scalars have come back — while this stream goes on with [t1, t2].  LRNDE_NO_OVERLAP=1: everything in order
     // on the handle's stream (the results are the same bits either way: same kernels, same inputs).
-    static const bool no_overlap = getenv("LRNDE_NO_OVERLAP") != nullptr;
+    const bool no_overlap = opt(OPT_NO_OVERLAP) != 0;
     lrnde_ctx* sd = nullptr;
     int side_state = 0;  // 0: nothing enqueued, 1: local step enqueued, 2: + sweep
     // save slot of the LAST saveat entry equal to t1: its index among the entries inside the span (those at or before t0 are
@@ -2841,11 +2872,11 @@ int lrnde_comm_init(lrnde_ctx* c, const void* uid, int32_t rank, int32_t nranks)
   c->lcomm = nullptr;
   c->rank = rank; c->nranks = nranks;
   c->wsB = 0;  // partial vectors are sized by nranks
-  if (nranks > 1 || getenv("LRNDE_FORCE_COMM")) {
+  if (nranks > 1 || opt(OPT_FORCE_COMM)) {
     ncclUniqueId id;
     memcpy(&id, uid, sizeof(id));
     NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));
-    c->prered = getenv("LRNDE_GATHER_TILES") == nullptr;
+    c->prered = !opt(OPT_GATHER_TILES);
   }
   return LRNDE_OK;
 }
@@ -2893,7 +2924,7 @@ int lrnde_comm_init_local(lrnde_ctx* c, lrnde_local_comm* lc, int32_t rank) {
     lc->joined[rank] = true;
   }
   c->lcomm = lc; c->rank = rank; c->nranks = lc->n;
-  c->prered = getenv("LRNDE_GATHER_TILES") == nullptr;
+  c->prered = !opt(OPT_GATHER_TILES);
   c->wsB = 0;  // partial vectors are sized by nranks
   return LRNDE_OK;
 }
@@ -2912,7 +2943,7 @@ int lrnde_bench_step(lrnde_ctx* c, const float* uprev, const float* k1, int32_t 
   if (rc) return rc;
   if (!uprev || !k1 || reps < 1 || !avg_us_host) return fail(c, LRNDE_BADARG, "bad bench arguments");
   if ((rc = ensure_workspace(c, B))) return rc;
-  StepArgs a;
+  StepArgs a{};
   fill_args(c, a, B);
   a.t0 = t; a.t1 = t + 1.0f; a.bench_dt = dt; a.abstol = abstol; a.reltol = reltol; a.mode = MODE_BENCH;
   const size_t n = (size_t)B * c->desc.state_dim;
@@ -3013,16 +3044,16 @@ static int sde_step_enqueue(lrnde_sde* s, int which, const float* uprev, const f
                             float abstol, float reltol, float delta, float* u, Ctrl* rec, Ctrl* rec_dev = nullptr) {
   lrnde_ctx* c = s->drift;
   int rc;
-  StepArgs a;
+  StepArgs a{};
   fill_args(c, a, B, NB);
   a.m2 = s->diff->m;
   a.t0 = t; a.bench_dt = dt; a.abstol = abstol; a.reltol = reltol; a.delta = delta;
   a.dW = dW; a.sde_scratch = c->state; a.sde_uprev = uprev; a.sde_u = u;
   const int nwg = (B + NB - 1) / NB;
   // the MNIST-SDE shape (state 32, hidden 64, no time input) has a one-launch small-latency kernel (lrnde_sde_fast.hpp)
-  static const bool no_fast = getenv("LRNDE_NO_SDE_FAST") != nullptr;
+  const bool no_fast = opt(OPT_NO_SDE_FAST) != 0;
   if (which == 0 && !no_fast && !sharded(c) && c->desc.state_dim == 32 && c->desc.hidden_dim == 64 && !c->desc.time_dep) {
-    SdeFastArgs f;
+    SdeFastArgs f{};
     memset(&f, 0, sizeof(f));
     f.W1p = c->m.W1p; f.KG1 = c->m.KG1;
     f.W2p = c->m.W2p; f.KG2p = ((c->m.KG2 + SEGK - 1) / SEGK) * SEGK;
@@ -3161,9 +3192,9 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
   hipLaunchKernelGGL(k_sde_ctl_init, dim3(1), dim3(1), 0, c->stream, s->ad_ctl, m0);
   volatile unsigned long long* pw = s->ad_prog;
   *pw = 0ull;
-  StepArgs a;
+  StepArgs a{};
   fill_args(c, a, B, NB);
-  SdeFastArgs f;
+  SdeFastArgs f{};
   memset(&f, 0, sizeof(f));
   f.W1p = c->m.W1p; f.KG1 = c->m.KG1;
   f.W2p = c->m.W2p; f.KG2p = ((c->m.KG2 + SEGK - 1) / SEGK) * SEGK;
@@ -3235,8 +3266,8 @@ int lrnde_sde_solve_adaptive(lrnde_sde* s, const float* u0, const float* W, int3
   }
   float *ua = s->ad_ws, *ub = s->ad_ws + n, *dW = s->ad_ws + 2 * n;
   {
-    static const bool no_fast = getenv("LRNDE_NO_SDE_FAST") != nullptr;
-    static const bool host_loop = getenv("LRNDE_SDE_HOST_LOOP") != nullptr;  // diagnostic: the host-controlled loop below
+    const bool no_fast = opt(OPT_NO_SDE_FAST) != 0;
+    const bool host_loop = opt(OPT_SDE_HOST_LOOP) != 0;  // diagnostic: the host-controlled loop below
     if (!no_fast && !host_loop && !sharded(c) && c->desc.state_dim == 32 && c->desc.hidden_dim == 64 && !c->desc.time_dep)
       return sde_adaptive_device(s, u0, W, nfine, B, t0, t1, o, u_end, st, trace_host, cap_trace, ua, ub);
   }
@@ -3418,7 +3449,7 @@ static int ensure_bw(lrnde_ctx* c, int B) {
 
 // (df/dp)^T lam from the scratch left by the last VJP launch (y, h, dpre); gp may be NULL
 static PgradArgs pgrad_args(const lrnde_ctx* c, int B, float t, const float* lam, float* gp, int set) {
-  PgradArgs g;
+  PgradArgs g{};
   memset(&g, 0, sizeof(g));  // adj_mode = ADJ_HOST: t / lam / gp as given here
   g.accumulate = c->pg_accumulate ? 1 : 0;
   g.D = c->m.D; g.H = c->m.H; g.Hp = c->m.Hp; g.td = c->m.td; g.B = B; g.t = t;
@@ -3458,7 +3489,7 @@ struct StageIn { const float* base; float dt; int nk; const float* k[6]; float c
 
 // dy = J^T lam at (y or the interpolated dense step, t);  gp (optional) = (df/dp)^T lam
 static bool vjp_uses_qtile(const lrnde_ctx* c, int B) {
-  static const bool no_qvjp = getenv("LRNDE_NO_QVJP") != nullptr;
+  const bool no_qvjp = opt(OPT_NO_QVJP) != 0;
   return use_qtile(c, B) && !no_qvjp;
 }
 static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float theta, float dense_dt, float t,
@@ -3466,7 +3497,7 @@ static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float th
   int rc = ensure_bw(c, B);
   if (rc) return rc;
   if (vjp_uses_qtile(c, B)) {
-    VjpQArgs a;
+    VjpQArgs a{};
     memset(&a, 0, sizeof(a));
     a.m = c->m; a.V1q = c->V1q; a.U2q = c->U2q;
     a.B = B; a.t = t; a.y = y; a.dense = dense; a.theta = theta; a.dense_dt = dense_dt; a.lam = lam; a.dy = dy;
@@ -3505,7 +3536,7 @@ static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float th
     return launch_pgrad(c, B, t, lam, gp);
   }
   if (sin) return fail(c, LRNDE_BADARG, "fused stage input needs the 4-column VJP kernel");
-  VjpArgs a;
+  VjpArgs a{};
   memset(&a, 0, sizeof(a));
   a.m = c->m; a.V1p = reinterpret_cast<const f32x4*>(c->V1p); a.U2p = reinterpret_cast<const f32x4*>(c->U2p);
   a.B = B; a.t = t; a.y = y; a.dense = dense; a.theta = theta; a.dense_dt = dense_dt; a.lam = lam; a.dy = dy;
@@ -3555,7 +3586,7 @@ int adj_alloc(lrnde_ctx* c, size_t N, AdjVec& v) {
 }
 
 int vec_axpy(lrnde_ctx* c, float* out, const float* base, float dt, int nk, const float* const* k, const float* coef, size_t n) {
-  AxArgs a;
+  AxArgs a{};
   a.out = out; a.base = base; a.dt = dt; a.nk = nk; a.n = n;
   for (int j = 0; j < 7; ++j) { a.k[j] = j < nk ? k[j] : nullptr; a.c[j] = j < nk ? coef[j] : 0.f; }
   int nb = (int)((n + 255) / 256); if (nb > 2048) nb = 2048;
@@ -3570,7 +3601,7 @@ int vec_axpy(lrnde_ctx* c, float* out, const float* base, float dt, int nk, cons
 int norm_readback(lrnde_ctx* c, size_t n_lam, size_t P, float* out);
 int vec_norm(lrnde_ctx* c, const float* num, const float* num2, const float* sa, const float* sb, float abstol,
              float reltol, size_t n_lam, size_t P, float* out) {
-  NormArgs a;
+  NormArgs a{};
   a.num = num; a.num2 = num2; a.sa = sa; a.sb = sb; a.abstol = abstol; a.reltol = reltol; a.n = n_lam; a.part = c->adj_part;
   if (P) {  // one launch for both parts (same per-block sums as two k_norm launches)
     NormArgs b = a;
@@ -3701,7 +3732,7 @@ int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, RHSF rhs_fused, bool fuse_
         // k_axpy) and left for the parameter-gradient GEMM, which is deferred into the next stage's launch; the stage
         // lambdas therefore alternate between v.zs and v.ut (free until the error estimate), stage 7's is zn itself.
         // The mu part of a stage state is never needed; zn's is formed after the last GEMM.
-        StageIn sin;
+        StageIn sin{};
         sin.base = z; sin.dt = dt; sin.nk = sidx - 1; sin.lam_out = (sidx == 7) ? zn : ((sidx & 1) ? v.ut : v.zs);
         for (int j = 0; j < sidx - 1; ++j) { sin.k[j] = K[j]; sin.c[j] = A[off + j]; }
         if ((rc = rhs_fused(sin, t + cs[sidx - 2] * dt, K[sidx - 1]))) return rc;
@@ -3716,7 +3747,7 @@ int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, RHSF rhs_fused, bool fuse_
       if ((rc = flush_pgrad(c))) return rc;
       c->pg_defer = false;
       // mu part of u_{n+1}, utilde and the error norm's sums in one launch (k_adj_err: the values of k_axpy + k_norm2)
-      AdjErrArgs e;
+      AdjErrArgs e{};
       for (int j = 0; j < 7; ++j) { e.K[j] = K[j]; e.BT[j] = BT[j]; }
       for (int j = 0; j < 6; ++j) e.A7[j] = A[15 + j];
       e.dt = dt; e.z = z; e.zn = zn; e.n_lam = v.n_lam; e.P = v.P; e.abstol = abstol; e.reltol = reltol; e.part = c->adj_part;
@@ -3778,7 +3809,7 @@ int adj_enqueue_eval(lrnde_ctx* c, int B, const AdjArgs& g, int mode, int stage,
                      int prev_mode, int prev_stage) {
   // one VJP launch in device-resolved form; with_prev_pgrad: the launch also carries the parameter-gradient GEMM of the
   // previous evaluation (prev_mode / prev_stage of the same attempt), whose scratch set is the one written last
-  VjpQArgs a;
+  VjpQArgs a{};
   memset(&a, 0, sizeof(a));
   a.m = c->m; a.V1q = c->V1q; a.U2q = c->U2q; a.B = B;
   a.adj_mode = mode; a.adj_stage = stage; a.adj_j = j; a.adj = g;
@@ -3821,7 +3852,7 @@ int adj_enqueue_slots(lrnde_ctx* c, double* part) {
 
 int adj_norm_into(lrnde_ctx* c, const float* num, const float* num2, const float* sa, float abstol, float reltol, size_t n_lam,
                   size_t P, double* part) {
-  NormArgs a;
+  NormArgs a{};
   a.num = num; a.num2 = num2; a.sa = sa; a.sb = nullptr; a.abstol = abstol; a.reltol = reltol; a.n = n_lam; a.part = part;
   NormArgs b = a;
   b.num = num + n_lam; b.num2 = num2 ? num2 + n_lam : nullptr; b.sa = sa + n_lam; b.n = P; b.part = part + 256;
@@ -3855,7 +3886,7 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
   const bool one_begin = c->adj_init_src != nullptr && tstops.size() <= 8;
   if (!tstops.empty() && !one_begin)
     HIPCHK(c, hipMemcpyAsync(c->adj_stops, tstops.data(), sizeof(float) * tstops.size(), hipMemcpyHostToDevice, c->stream));
-  AdjArgs g;
+  AdjArgs g{};
   memset(&g, 0, sizeof(g));
   g.ctl = c->adj_ctl; g.base = c->adj; g.N = v.N; g.n_lam = v.n_lam; g.P = v.P;
   g.dense = c->dense; g.dense_t = c->dense_t; g.dense_dt = c->dense_dt; g.nrec = nrec;
@@ -3865,14 +3896,14 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
   g.part = c->adj_part; g.ipart = c->adj_ipart; g.nranks = 1; g.use_slots = 0;
   const size_t N = v.N, n = v.n_lam;
   float* const zb0 = c->adj; float* const K0 = c->adj + 4 * N; float* const K1 = c->adj + 5 * N;
-  AdjErrArgs e;
+  AdjErrArgs e{};
   memset(&e, 0, sizeof(e));
   for (int q = 0; q < 7; ++q) e.BT[q] = (float)Tsit5::BT[q];
   for (int q = 0; q < 6; ++q) e.A7[q] = (float)Tsit5::A[15 + q];
   e.n_lam = v.n_lam; e.P = v.P; e.abstol = abstol; e.reltol = reltol; e.part = c->adj_part;
 
   if (one_begin) {
-    AdjBegin b;
+    AdjBegin b{};
     memset(&b, 0, sizeof(b));
     b.z = v.z; b.src = c->adj_init_src; b.n = v.n_lam; b.N = v.N; b.ctl = c->adj_ctl; b.s0 = s0;
     b.stops = c->adj_stops; b.nstops = (int)tstops.size();
@@ -3929,7 +3960,7 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
         const int r = adj_enqueue_eval(c, B, g, ADJ_STAGE, sidx, jj, true, ADJ_STAGE, sidx - 1);
         if (r) return r;
       }
-      static const bool split_off = getenv("LRNDE_ADJ_ERR_ONE_LAUNCH") != nullptr;  // diagnostic: the error norm in one launch of its own
+      const bool split_off = opt(OPT_ADJ_ERR_ONE_LAUNCH) != 0;  // diagnostic: the error norm in one launch of its own
       if (split_off) {
         const int r = adj_enqueue_pgrad(c, B, g, ADJ_STAGE, 7, jj);
         if (r) return r;
@@ -4065,7 +4096,7 @@ static int step_reg_sweep(lrnde_ctx* c, const float* uprev, int32_t B, float t, 
   float* gtmp = c->adj + 10 * N;
   HIPCHK(c, hipMemsetAsync(c->adj, 0, sizeof(float) * 8 * N, c->stream));
   HIPCHK(c, hipMemsetAsync(gp, 0, sizeof(float) * P, c->stream));
-  RegSeedArgs sa;
+  RegSeedArgs sa{};
   sa.n = n; sa.n_norm = n * (size_t)(sharded(c) ? c->nranks : 1); sa.uprev = uprev; sa.u = u; sa.g6 = g6;
   for (int j = 0; j < 7; ++j) sa.k[j] = kk[j];
   for (int j = 1; j < 7; ++j) sa.kb[j] = kb[j];
@@ -4094,7 +4125,7 @@ static int step_reg_sweep(lrnde_ctx* c, const float* uprev, int32_t B, float t, 
       c->pg_accumulate = false;
       if (rc) return rc;
     }
-    SweepJoinArgs ja;
+    SweepJoinArgs ja{};
     ja.n = n; ja.xb = xb; ja.extra = (sidx == 7) ? ub : ((sidx == 6) ? g6b : nullptr); ja.dt = dt; ja.nk = sidx - 2;
     for (int j = 1; j < 6; ++j) { ja.kb[j - 1] = (j < sidx - 1) ? kb[j] : nullptr; ja.c[j - 1] = (j < sidx - 1) ? A[off + j] : 0.f; }
     if (ja.nk > 0 || ja.extra) {
@@ -4216,7 +4247,7 @@ static int node_backward_recorded_impl(lrnde_ctx* c, int32_t B, const float* du_
   AdjVec v;
   if ((rc = adj_alloc(c, N, v))) return rc;
   v.n_lam = n; v.P = P;
-  static const bool adj_host = getenv("LRNDE_ADJ_HOST") != nullptr;  // diagnostic: the round-1 host-controlled loop
+  const bool adj_host = opt(OPT_ADJ_HOST) != 0;  // diagnostic: the round-1 host-controlled loop
   const bool dev_loop = vjp_uses_qtile(c, B) && !sharded(c) && !adj_host;
   const bool begin_in_solve = dev_loop && !du_series;  // the device loop's first launch sets z = [du_end; 0] itself
   if (!begin_in_solve) HIPCHK(c, hipMemsetAsync(v.z, 0, sizeof(float) * N, c->stream));
@@ -4380,7 +4411,7 @@ int cls_enqueue(lrnde_ctx* c, const float* u, int32_t B, const float* pc, int32_
   else hipLaunchKernelGGL((k_cls_fwd_bwdx<false, 0>), dim3((B + 3) / 4), dim3(256), 0, c->stream, u, pc, labels, B, D, K, Bnorm, logits, dl, lb, du, out);
   {  // dW = dl^T u and db = dl^T 1 as ONE batch-reduction GEMM (the parameter-gradient tiles of the adjoint, first form,
      // H := K, no time column) + one extra workgroup that adds the per-sample losses in a fixed order
-    PgradArgs g;
+    PgradArgs g{};
     memset(&g, 0, sizeof(g));
     g.D = D; g.H = K; g.Hp = K; g.td = 0; g.B = B; g.t = 0.f; g.dpre = dl; g.y = u; g.gp = dpc;
     g.nt1c = (D + 2 + 15) / 16; g.ntile1 = ((K + 15) / 16) * g.nt1c; g.ntile2 = 0; g.nt2c = 1;
@@ -4497,6 +4528,14 @@ int lrnde_adjoint_trace_rows(lrnde_ctx* c, int32_t* n_host) {
   if (!c || !n_host) return LRNDE_BADARG;
   *n_host = c->adj_trace_n;
   return LRNDE_OK;
+}
+
+int lrnde_set_option(const char* name, int32_t value) {
+  if (!name) return LRNDE_BADARG;
+  opt(0);
+  for (int i = 0; i < N_OPT; ++i)
+    if (strcmp(name, g_optdef[i].name) == 0) { g_opt[i] = value; g_opt_set[i] = true; return LRNDE_OK; }
+  return LRNDE_BADARG;
 }
 
 int lrnde_set_reports(lrnde_ctx* c, int32_t on) {

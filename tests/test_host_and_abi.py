@@ -133,3 +133,23 @@ def test_product_path_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in txt and "lrnde_oracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_kernel_argument_structs_are_value_initialised():
+    """Two GPU faults of round 2 were a kernel-argument struct that gained a field its host-side filler did not set
+    (PgradArgs::adj_mode; a stale LDS record base).  Every local of a kernel-argument struct type (`*Args`, `AdjBegin`,
+    `StageIn`) in the host code must be declared with an initialiser — `T a{};`, a copy, or a function result — so a new
+    field starts at zero everywhere."""
+    import re
+    csrc = os.path.join(ROOT, "localregneuralde.jl_amd", "csrc")
+    bare = re.compile(r"^\s*(?:const\s+)?([A-Z][A-Za-z0-9]*(?:Args|Begin)|StageIn)\s+([a-z_][A-Za-z0-9_]*)\s*;", re.M)
+    bad = []
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".hpp")):
+            continue
+        txt = open(os.path.join(csrc, f)).read()
+        # struct members (declarations inside `struct X { ... };`) are not locals: drop struct bodies first
+        body = re.sub(r"struct\s+\w+\s*\{[^{}]*(?:\{[^{}]*\}[^{}]*)*\}\s*;", "", txt)
+        for m in bare.finditer(body):
+            bad.append(f"{f}: {m.group(1)} {m.group(2)};")
+    assert not bad, bad
