@@ -150,6 +150,10 @@ int lrnde_node_forward(lrnde_ctx* ctx, const float* x, int32_t B, float t0, floa
 int lrnde_comm_unique_id(void* unique_id_128_host);
 int lrnde_comm_init(lrnde_ctx* ctx, const void* unique_id_128_host, int32_t rank, int32_t nranks);
 int lrnde_comm_destroy(lrnde_ctx* ctx);
+/* The size of the communicator the handle actually holds (ncclCommCount; 1 for an unsharded handle) and, optionally, its
+ * kind (0 none, 1 RCCL, 2 the in-process local communicator of lrnde_hooks.h): what a launcher checks against the number
+ * of ranks it asked for. */
+int lrnde_comm_count(lrnde_ctx* ctx, int32_t* nranks_host, int32_t* kind_host);
 
 /* ---- SDE: `_perform_step(integrator, cache::LambaEulerHeunConstantCache, p)`,
  * src/perform_step.jl:172-206 (residual :214-216), as called by NeuralDSDE,

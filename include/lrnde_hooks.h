@@ -1,8 +1,8 @@
 /*
  * lrnde_hooks.h — entry points of liblrnde that are NOT part of the drop-in boundary (include/lrnde.h): the timing
  * hooks bench.py uses for its roofline leg, and the in-process local communicator that lets the batch-sharded
- * (nranks > 1) code of the library run inside one process — several handles, one host thread each, on one GPU or
- * on several — where RCCL cannot (it refuses two ranks on one device).  Nothing in the reference corresponds to
+ * (nranks > 1) code of the library run inside one process — several handles, one host thread each, on ONE GPU —
+ * where RCCL cannot (it refuses two ranks on one device).  Nothing in the reference corresponds to
  * these (it has neither a benchmark harness nor a collective: SURVEY.md §2 rows 16-18).
  */
 #ifndef LRNDE_HOOKS_H
@@ -32,6 +32,10 @@ int lrnde_comm_init_local(lrnde_ctx* ctx, lrnde_local_comm* lc, int32_t rank);
  * with HIP events on the handle's stream; avg_us_host = microseconds per launch (roofline leg). */
 int lrnde_bench_step(lrnde_ctx* ctx, const float* uprev, const float* k1, int32_t B, float t, float dt,
                      float abstol, float reltol, int32_t reps, float* avg_us_host);
+/* `reps` back-to-back exchanges of the per-step kind (the SUM all-reduce of the error norm's partial sums, the buffers
+ * and count of a solve at batch B) between two HIP events on the handle's stream: microseconds per exchange.  Collective
+ * (every rank calls it); 0 for an unsharded handle.  bench.py --gpus N reports it as allreduce_us_per_step. */
+int lrnde_bench_exchange(lrnde_ctx* ctx, int32_t B, int32_t reps, float* avg_us_host);
 /* HIP events on the handle's stream around the kernels of the last solve (ms), and its step-kernel launches.  The first call
  * ARMS the clock (solves record their two events from then on — each a marker packet in the queue — and this call returns
  * 0 ms): call it once, run a solve, call it again. */

@@ -78,6 +78,8 @@ SYMBOLS = [
     ("lrnde_comm_unique_id", C.c_int, [_vp]),
     ("lrnde_comm_init", C.c_int, [_vp, _vp, _i32, _i32]),
     ("lrnde_comm_destroy", C.c_int, [_vp]),
+    ("lrnde_comm_count", C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    ("lrnde_bench_exchange", C.c_int, [_vp, _i32, _i32, _fp]),
     ("lrnde_local_comm_create", C.c_int, [C.POINTER(_vp), _i32]),
     ("lrnde_local_comm_destroy", C.c_int, [_vp]),
     ("lrnde_comm_init_local", C.c_int, [_vp, _vp, _i32]),

@@ -3,7 +3,7 @@
 //   * RCCL (`ncclAllReduce` on the handle's stream) when the handle joined a communicator with lrnde_comm_init —
 //     one process per GPU, the product path;
 //   * the in-process LOCAL communicator (lrnde_local_comm_*, include/lrnde_hooks.h) when several handles of one
-//     process — driven by one host thread each, on the same device or on different ones — were joined with
+//     process — driven by one host thread each, all on ONE device (lrnde_comm_init_local refuses a second device: the sum kernel reads peers' buffers directly and no peer access is set up) — were joined with
 //     lrnde_comm_init_local.  It performs the same reduction with stream-ordered kernels and events, so that the
 //     nranks > 1 code of the library (offsets into the partial-sum vectors, receive buffers, the sharded adjoint's
 //     norm and parameter-cotangent sums) runs on a one-GPU box, where RCCL refuses two ranks on one device.

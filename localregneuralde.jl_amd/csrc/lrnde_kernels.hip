@@ -1863,6 +1863,7 @@ struct lrnde_ctx {
   const float* adj_init_src = nullptr;  // adj_solve_device: its first launch also sets z = [this; 0] (k_adj_begin)
   std::function<int()> final_hook;
   bool final_hook_fired = false, last_u_end_done = false;
+  bool hung = false;         // a host loop waited LRNDE_SPIN_DEADLINE_S for a report while the queue stayed busy: only lrnde_destroy is safe
   bool reports_off = false;  // lrnde_set_reports(ctx, 0): the solve loop polls by copies (its fall-back when no report arrives)
   // lrnde_set_adjoint_trace: per-attempt (s, dt, EEst, accepted) rows of the next adjoint solves, host memory of the caller
   lrnde_trace_row* adj_trace = nullptr; int adj_trace_cap = 0; int adj_trace_n = 0;
@@ -1938,6 +1939,17 @@ inline bool spin_stalled(long spin) {
   t_last = now;
   return true;
 }
+
+// ... and the bound on such a wait: the loops spin while hipStreamQuery says "not ready", which a hung queue says for ever.
+// After LRNDE_SPIN_DEADLINE_S of one wait the call fails, the handle is marked (check_ready refuses it) and nothing is
+// restarted in place.
+constexpr int LRNDE_SPIN_DEADLINE_S = 90;  // (above the local communicator's 60-s rendezvous timeout)
+struct SpinDeadline {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void restart() { t0 = std::chrono::steady_clock::now(); }
+  bool expired() const { return std::chrono::steady_clock::now() - t0 > std::chrono::seconds(LRNDE_SPIN_DEADLINE_S); }
+};
+#define LRNDE_HUNG(c, what) ((c)->hung = true, fail((c), LRNDE_HIP_ERROR, "%s: no report for %d s while the queue stayed busy (hung queue); destroy the handle", (what), LRNDE_SPIN_DEADLINE_S))
 
 // a batch-sharded handle: its collectives run (RCCL or the in-process local communicator, lrnde_comm.hpp)
 inline bool sharded(const lrnde_ctx* c) { return c->comm != nullptr || c->lcomm != nullptr; }
@@ -2135,6 +2147,7 @@ int set_smem_attr() {
 
 int check_ready(lrnde_ctx* c, int B) {
   if (!c) return LRNDE_BADARG;
+  if (c->hung) return fail(c, LRNDE_HIP_ERROR, "the handle's queue stopped making progress in an earlier call: destroy the handle");
   if (!c->have_params) return fail(c, LRNDE_BADARG, "lrnde_set_params has not been called");
   if (B <= 0) return fail(c, LRNDE_BADARG, "batch must be positive (got %d)", B);
   HIPCHK(c, hipSetDevice(c->device));
@@ -2541,6 +2554,7 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
       // the report of launch `seen` (it carries seen + 1 as its launch count)
       volatile unsigned long long* slot = pw + (seen & (PROG_RING - 1));
       unsigned long long w = *slot;
+      const SpinDeadline deadline;
       for (long spin = 1; (int)(w & 0xffffffull) != seen + 1; ++spin) {
         // bounded: a faulted queue must not hang the caller.  The query is kept for a report that is LATE (the runtime
         // answers it by putting a marker packet into the queue: asked every few thousand spins, one landed between two
@@ -2548,6 +2562,7 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
         if ((spin & 0x3fff) == 0 && spin_stalled(spin)) {
           const hipError_t qe = hipStreamQuery(c->stream);
           if (qe != hipSuccess && qe != hipErrorNotReady) return fail(c, LRNDE_HIP_ERROR, "solve loop: %s", hipGetErrorString(qe));
+          if (qe == hipErrorNotReady && deadline.expired()) return LRNDE_HUNG(c, "solve loop");
           if (qe == hipSuccess) {
             w = *slot;
             if ((int)(w & 0xffffffull) != seen + 1) word_ok = false;  // the stream drained and no report came: poll by copies
@@ -2889,6 +2904,48 @@ int lrnde_comm_destroy(lrnde_ctx* c) {
   return LRNDE_OK;
 }
 
+// how many ranks the handle's communicator really has: ncclCommCount for RCCL, the rendezvous size for the local
+// communicator, 1 for an unsharded handle — what bench.py prints as `rccl_nranks` (WORLD_SIZE says what was asked for,
+// this says what was built)
+int lrnde_comm_count(lrnde_ctx* c, int32_t* nranks_host, int32_t* kind_host) {
+  if (!c || !nranks_host) return LRNDE_BADARG;
+  int n = 1, kind = 0;
+  if (c->comm) { NCCLCHK(c, ncclCommCount(c->comm, &n)); kind = 1; }
+  else if (c->lcomm) { n = c->lcomm->n; kind = 2; }
+  *nranks_host = n;
+  if (kind_host) *kind_host = kind;  // 0 none, 1 RCCL, 2 in-process local communicator
+  return LRNDE_OK;
+}
+
+// bench.py --gpus N: `reps` back-to-back exchanges of the per-step kind (the all-reduce of the error norm's partial sums,
+// same buffers and count as inside a solve of batch B) between two HIP events on the handle's stream -> microseconds per
+// exchange.  Collective: every rank must call it.  An unsharded handle reports 0.
+int lrnde_bench_exchange(lrnde_ctx* c, int32_t B, int32_t reps, float* avg_us_host) {
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (reps < 1 || !avg_us_host) return fail(c, LRNDE_BADARG, "bad bench arguments");
+  *avg_us_host = 0.f;
+  if (!sharded(c)) return LRNDE_OK;
+  if ((rc = ensure_workspace(c, B))) return rc;
+  StepArgs a{};
+  fill_args(c, a, B);
+  const size_t cnt = (size_t)a.nwg_global * PSTRIDE;
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  for (int i = 0; i < 3 && !rc; ++i) rc = exchange(c, c->part, c->part_rx, cnt);  // warm-up (first collective builds its channels)
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  for (int i = 0; i < reps && !rc; ++i) rc = exchange(c, c->part + (size_t)(i & 1) * cnt, c->part_rx + (size_t)(i & 1) * cnt, cnt);
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  if (rc) return rc;
+  *avg_us_host = ms * 1e3f / (float)reps;
+  return LRNDE_OK;
+}
+
 // ---- in-process local communicator (include/lrnde_hooks.h; lrnde_comm.hpp) ----
 int lrnde_local_comm_create(lrnde_local_comm** out, int32_t nranks) {
   if (!out || nranks < 1 || nranks > LRNDE_LC_MAXR) return LRNDE_BADARG;
@@ -2918,6 +2975,11 @@ int lrnde_comm_init_local(lrnde_ctx* c, lrnde_local_comm* lc, int32_t rank) {
   {
     std::lock_guard<std::mutex> lk(lc->mu);
     if (lc->joined[rank]) return fail(c, LRNDE_BADARG, "rank %d has already joined this local communicator", rank);
+    // one device only: the sum kernel reads the peers' send buffers directly, and no peer access is set up between devices
+    for (int r = 0; r < lc->n; ++r)
+      if (lc->joined[r] && lc->device[r] != c->device)
+        return fail(c, LRNDE_UNSUPPORTED, "the in-process local communicator is single-device (rank %d is on device %d, rank %d on %d); "
+                    "use lrnde_comm_init (RCCL) across devices", r, lc->device[r], rank, c->device);
     HIPCHK(c, hipEventCreateWithFlags(&lc->ready[rank], hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&lc->done[rank], hipEventDisableTiming));
     lc->device[rank] = c->device;
@@ -3221,6 +3283,7 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
     }
     HIPCHK(c, hipGetLastError());
     const unsigned want = (unsigned)(j - 4);
+    const SpinDeadline deadline;
     for (long spin = 1;; ++spin) {
       const unsigned long long w = *pw;
       if ((unsigned)(w >> 32) != (unsigned)ST_RUNNING) { done = true; break; }
@@ -3228,6 +3291,7 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
       if ((spin & 0x3fff) == 0 && spin_stalled(spin)) {  // (a stream query is a marker packet in the queue: only when the report is late)
         const hipError_t qe = hipStreamQuery(c->stream);
         if (qe != hipSuccess && qe != hipErrorNotReady) return fail(c, LRNDE_HIP_ERROR, "adaptive SDE loop: %s", hipGetErrorString(qe));
+        if (qe == hipErrorNotReady && deadline.expired()) return LRNDE_HUNG(c, "adaptive SDE loop");
         if (qe == hipSuccess) break;  // everything enqueued has run: look at the word again, enqueue more
       }
     }
@@ -3949,6 +4013,14 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
     volatile int* hs = c->adj_hstat;
     int j = 0;
     bool done = false;
+    // every early exit of this segment: nothing of it stays in flight, and the sequence numbers its launches may still have
+    // written (up to seq0 + j + 1) are retired, so the next solve's first wait cannot be satisfied by a stale report
+    auto bail = [&](int code) -> int {
+      hipStreamSynchronize(c->stream);
+      c->adj_seq += j + 1;
+      c->after_first_attempt = nullptr;
+      return code;
+    };
     // maybe_last: the attempt whose prologue reported last reaches the end of the segment if it is accepted.  The next
     // attempt is then enqueued as its FIRST launch only (whose prologue takes that decision); its other seven follow
     // once the report says the solve goes on (a rejection: the stream idles for one host round trip) — otherwise the
@@ -3976,24 +4048,26 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
       return LRNDE_OK;
     };
     while (!done) {
-      if ((rc = adj_enqueue_eval(c, B, g, ADJ_STAGE, 2, j, false, ADJ_STAGE, 1))) return rc;
+      if ((rc = adj_enqueue_eval(c, B, g, ADJ_STAGE, 2, j, false, ADJ_STAGE, 1))) return bail(rc);
       const bool rest_ahead = !maybe_last;
-      if (rest_ahead && (rc = enqueue_rest(j))) return rc;
+      if (rest_ahead && (rc = enqueue_rest(j))) return bail(rc);
       if (c->after_first_attempt) {  // (the handle's stream now holds ~150 us of work: time for the caller's side enqueues)
         auto fn = std::move(c->after_first_attempt);
         c->after_first_attempt = nullptr;
-        if ((rc = fn())) return rc;
+        if ((rc = fn())) return bail(rc);
       }
       ++j;
-      // wait for the prologue of the attempt just enqueued (bounded: a faulted queue must not hang the caller)
+      // wait for the prologue of the attempt just enqueued (bounded: a faulted or hung queue must not hang the caller)
       const int want = g.seq0 + j;
       long spins = 0;
+      const SpinDeadline deadline;
       while ((int)(__atomic_load_n(hs, __ATOMIC_ACQUIRE) - want) < 0) {
         if (((++spins) & 0xFFFFF) == 0) {
           const hipError_t q = hipStreamQuery(c->stream);
-          if (q != hipSuccess && q != hipErrorNotReady) return fail(c, LRNDE_HIP_ERROR, "adjoint loop: %s", hipGetErrorString(q));
+          if (q != hipSuccess && q != hipErrorNotReady) return bail(fail(c, LRNDE_HIP_ERROR, "adjoint loop: %s", hipGetErrorString(q)));
           if (q == hipSuccess && (int)(__atomic_load_n(hs, __ATOMIC_ACQUIRE) - want) < 0)
-            return fail(c, LRNDE_HIP_ERROR, "adjoint loop: the stream drained without the status of attempt %d", j - 1);
+            return bail(fail(c, LRNDE_HIP_ERROR, "adjoint loop: the stream drained without the status of attempt %d", j - 1));
+          if (q == hipErrorNotReady && deadline.expired()) { c->adj_seq += j + 1; return LRNDE_HUNG(c, "adjoint loop"); }
         }
       }
       if (c->adj_trace) {
@@ -4011,7 +4085,7 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
       }
       if (hs[1] != ST_RUNNING) done = true;
       else {
-        if (!rest_ahead && (rc = enqueue_rest(j - 1))) return rc;
+        if (!rest_ahead && (rc = enqueue_rest(j - 1))) return bail(rc);
         const float te = __builtin_bit_cast(float, (int)hs[2]) + __builtin_bit_cast(float, (int)hs[3]);
         maybe_last = fabsf(te - g.s1) <= 100.0f * eps_f(fmaxf(fabsf(te), fabsf(g.s1)));
       }

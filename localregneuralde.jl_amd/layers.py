@@ -345,6 +345,18 @@ class Handle:
                                          float(t), float(dt), float(abstol), float(reltol), int(reps), C.byref(us)))
         return float(us.value)
 
+    def comm_count(self):
+        """(nranks, kind) of the communicator the handle holds: kind 0 none, 1 RCCL, 2 in-process local (lrnde_comm_count)"""
+        n, k = C.c_int32(), C.c_int32()
+        self._chk(L.lib.lrnde_comm_count(self._ctx, C.byref(n), C.byref(k)))
+        return int(n.value), int(k.value)
+
+    def bench_exchange(self, B, reps=100):
+        """microseconds per per-step exchange (collective: every rank calls it); 0.0 on an unsharded handle"""
+        us = C.c_float()
+        self._chk(L.lib.lrnde_bench_exchange(self._ctx, int(B), int(reps), C.byref(us)))
+        return float(us.value)
+
     def set_reports(self, on):
         """diagnostic (lrnde_hooks.h): False makes the solve loop poll by copies instead of reading the per-launch reports"""
         self._chk(L.lib.lrnde_set_reports(self._ctx, 1 if on else 0))

@@ -40,7 +40,7 @@ def init_comm(handle, rank, nranks, group=None):
 
 class LocalComm:
     """In-process communicator (include/lrnde_hooks.h): several handles of ONE process, one host thread each, run the
-    library's nranks > 1 code — on one GPU or on several — where RCCL cannot (it refuses two ranks on one device).
+    library's nranks > 1 code — on one GPU (single-device by construction) — where RCCL cannot (it refuses two ranks on one device).
     `join(handle, rank)` replaces `init_comm`; the sharded calls must then be issued by all ranks concurrently
     (`run_ranks`)."""
 

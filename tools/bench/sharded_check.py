@@ -23,13 +23,16 @@ try:
 except Exception as e:
     print(f"rank {rank}: init_comm failed: {e}", flush=True)
     dist.destroy_process_group(); sys.exit(2)  # a communicator that cannot be built is a FAILURE of this check
+nr, kind = h.comm_count()
+comm_ok = (nr == world and kind == 1)   # the library's communicator is RCCL and has WORLD_SIZE ranks
+print(f"rank {rank}: lrnde_comm_count = {nr} (kind {kind}) for WORLD_SIZE {world} -> {'OK' if comm_ok else 'MISMATCH'}", flush=True)
 x = torch.from_numpy(np.ascontiguousarray(P.shard_columns(xg, rank, world))).cuda()
 r = h.node_forward(x, 0.0, 1.0, 1e-5, 1e-5, mode="unbiased", t1_or_rand=0.37, maxiters=2000)
 import oracle as O
 fld = O.MlpField(D, H, p, nthreads=4)
 ref = O.node_forward(fld, xg, 0.0, 1.0, 1e-5, 1e-5, mode="unbiased", t1_or_rand=0.37, maxiters=2000)
 mine = ref["u_end"][rank * Bl:(rank + 1) * Bl]
-ok = r["nfe"] == ref["nfe"] and r["reg_val"] == ref["reg_val"] and np.array_equal(r["u_end"].cpu().numpy(), mine)
+ok = comm_ok and r["nfe"] == ref["nfe"] and r["reg_val"] == ref["reg_val"] and np.array_equal(r["u_end"].cpu().numpy(), mine)
 print(f"rank {rank}: nfe {r['nfe']} vs {ref['nfe']}, reg {r['reg_val']} vs {ref['reg_val']}, u_end equal {np.array_equal(r['u_end'].cpu().numpy(), mine)} -> {'OK' if ok else 'MISMATCH'}", flush=True)
 # sharded adjoint
 g = np.random.default_rng(4).standard_normal(xg.shape).astype(np.float32)
