@@ -363,6 +363,36 @@ int lrnde_sde_solve_fixed_backward(lrnde_sde* sde, const float* u0, const float*
 int lrnde_sde_euler_heun_reg_grad(lrnde_sde* sde, const float* uprev, const float* dW, int32_t B, float t, float dt, float abstol,
                                   float reltol, float delta, float* dp_drift, float* dp_diff, float* reg_val_host);
 
+/* The NeuralDSDE layer itself, forward and pullback: `(n::NeuralDSDE{R})(x, ps, st)` (src/layers/neural_sde.jl:74-123) =
+ * `_solve_neuraldsde_generic` (:50-72: ADAPTIVE solve of drift / diffusion from x over tspan with the layer's saveat rules,
+ * src/layers/neural_ode.jl:102-116) + for R = unbiased / biased in training mode the local step: a fresh integrator at
+ * (sol(t1), t1) over (t1, t2) and one `_perform_step` (:94-98, :116-118; src/perform_step.jl:172-206) whose EEst*dt is
+ * reg_val — and what `Zygote.gradient` of the reference's tests takes through it (test/runtests.jl:340-433: TrackerAdjoint
+ * tapes the solve's own steps; reg_val w.r.t. the parameters only, neural_sde.jl:42).
+ *   forward : x (B x D, device); W: the caller's Brownian path on a uniform grid of nfine intervals over (t0, t2), as for
+ *     lrnde_sde_solve_adaptive (device, must stay alive until the backward call); opts: tolerances, delta and the
+ *     controller's constants; opts->dt0 <= 0 selects the automatic initial dt (StochasticDiffEq's sde_determine_initdt
+ *     restated, UPSTREAM-RECALL), for the main solve (rounded down to whole grid intervals) and for the local step.
+ *     mode LRNDE_MODE_* (pass NONE for test mode); t1_or_rand: t1 itself (unbiased; the caller's host RNG draw
+ *     rand*(t2-t0)+t0, :92) or the uniform draw r in [0,1) that picks sol.t[floor(r*(len-1))] (biased, :114).
+ *     z_local (B x D, device, standard normal): the local step's increment is sqrt(dt_local) * z_local.
+ *     save_start: 1 / 0, or -1 for DiffEq's default rule; saveat_host / nsave: the layer's `saveat` kwarg (ascending, may be
+ *     empty).  Saved values between step ends come from the SDE solvers' linear interpolant.
+ *     u_series (device, cap_series x B x D), t_series_host, nseries_host: sol.u / sol.t as the layer's caller sees them —
+ *     after `_CorrectedDESolution` when the layer added t1 to a user saveat (the reference's own method is typed for
+ *     ODESolution only, src/utils.jl:31; the behaviour here is the ODE layer's).  sol.u[end] is the last entry.
+ *     nfe_drift_host / nfe_diffusion_host: the closures' call counts (:55-65).  stats: the main solve's.
+ *   backward: du_series (device, nseries x B x D) = the cotangent of every state of that series; loss = sum_j <du_j, u_j> +
+ *     w_reg * reg_val.  dx (B x D), dp_drift (flat drift parameters), dp_diff ([vec(Wg); bg]): device.  The reverse sweep walks
+ *     the recorded accepted steps with their own dt and dW. */
+int lrnde_sde_node_forward_record(lrnde_sde* sde, const float* x, const float* W, int32_t nfine, int32_t B, float t0, float t2,
+                                  const lrnde_sde_adapt_opts* opts, int32_t mode, float t1_or_rand, const float* z_local,
+                                  int32_t save_start, const float* saveat_host, int32_t nsave, float* u_series,
+                                  float* t_series_host, int32_t cap_series, int32_t* nseries_host, float* reg_val_host,
+                                  int32_t* nfe_drift_host, int32_t* nfe_diffusion_host, lrnde_stats* stats_host, float* t1_used_host);
+int lrnde_sde_node_backward_recorded(lrnde_sde* sde, int32_t B, const float* du_series, int32_t nseries, float w_reg, float* dx,
+                                     float* dp_drift, float* dp_diff);
+
 /* `_perform_step(integrator, cache::FourStageSRIConstantCache, p)`, src/perform_step.jl:49-106 — the step the
  * reference's default SDE solver SOSRI runs — diagonal noise: four drift and four diffusion evaluations, the
  * increments dW and dZ of the caller's noise process (device, B x D each), u, EEst from the 7-argument

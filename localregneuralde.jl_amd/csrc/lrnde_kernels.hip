@@ -3023,7 +3023,10 @@ int lrnde_bench_step(lrnde_ctx* c, const float* uprev, const float* k1, int32_t 
 }
 
 // ---- SDE (src/layers/neural_sde.jl, src/perform_step.jl:172-206) ----
+namespace { struct SdeNodeRecord; }   // the layer's forward record (lrnde_sde_node.hpp)
 struct lrnde_sde {
+  SdeNodeRecord* node = nullptr;
+  double *idt_part = nullptr, *idt_part_host = nullptr;   // sde_init_dt's norm partials (device / pinned)
   lrnde_ctx* drift = nullptr;
   lrnde_ctx* diff = nullptr;
   float* p2 = nullptr;  // expanded diffusion parameters
@@ -3054,8 +3057,12 @@ int lrnde_sde_create(lrnde_sde** out, const lrnde_model_desc* drift, int32_t dif
   return LRNDE_OK;
 }
 
+namespace { void sde_node_release(lrnde_sde* s); }
 int lrnde_sde_destroy(lrnde_sde* s) {
   if (!s) return LRNDE_OK;
+  sde_node_release(s);
+  if (s->idt_part) hipFree(s->idt_part);
+  if (s->idt_part_host) hipHostFree(s->idt_part_host);
   lrnde_destroy(s->drift);
   lrnde_destroy(s->diff);
   if (s->p2) hipFree(s->p2);
@@ -3090,6 +3097,19 @@ int lrnde_sde_set_params(lrnde_sde* s, const float* p_drift, size_t n_drift, con
 
 static int sde_step_impl(lrnde_sde* s, int which, const float* uprev, const float* dW, int32_t B, float t, float dt,
                          float abstol, float reltol, float delta, float* u, float* eest_host, float* reg_val_host);
+// the one-launch Euler-Heun kernel (lrnde_sde_fast.hpp) serves this handle: unsharded, no time input, D <= 64, H <= 128
+static bool sde_uses_fast(const lrnde_sde* s) {
+  const lrnde_ctx* c = s->drift;
+  return !opt(OPT_NO_SDE_FAST) && !sharded(c) && !c->desc.time_dep && sde_fast_shape(c->desc.state_dim, c->desc.hidden_dim);
+}
+static void sde_fast_args(lrnde_sde* s, SdeFastArgs& f) {
+  lrnde_ctx* c = s->drift;
+  memset(&f, 0, sizeof(f));
+  f.W1p = c->m.W1p; f.KG1 = c->m.KG1;
+  f.W2p = c->m.W2p; f.KG2p = ((c->m.KG2 + SEGK - 1) / SEGK) * SEGK;
+  f.Wgp = s->diff->m.W2p; f.KGgp = ((s->diff->m.KG2 + SEGK - 1) / SEGK) * SEGK;
+  f.b1 = c->m.b1; f.b2 = c->m.b2; f.bg = s->diff->m.b2; f.act = c->m.act; f.D = c->desc.state_dim;
+}
 int lrnde_sde_euler_heun_step(lrnde_sde* s, const float* uprev, const float* dW, int32_t B, float t, float dt,
                               float abstol, float reltol, float delta, float* u, float* eest_host,
                               float* reg_val_host) {
@@ -3113,26 +3133,21 @@ static int sde_step_enqueue(lrnde_sde* s, int which, const float* uprev, const f
   a.dW = dW; a.sde_scratch = c->state; a.sde_uprev = uprev; a.sde_u = u;
   const int nwg = (B + NB - 1) / NB;
   // the MNIST-SDE shape (state 32, hidden 64, no time input) has a one-launch small-latency kernel (lrnde_sde_fast.hpp)
-  const bool no_fast = opt(OPT_NO_SDE_FAST) != 0;
-  if (which == 0 && !no_fast && !sharded(c) && c->desc.state_dim == 32 && c->desc.hidden_dim == 64 && !c->desc.time_dep) {
+  if (which == 0 && sde_uses_fast(s)) {
     SdeFastArgs f{};
-    memset(&f, 0, sizeof(f));
-    f.W1p = c->m.W1p; f.KG1 = c->m.KG1;
-    f.W2p = c->m.W2p; f.KG2p = ((c->m.KG2 + SEGK - 1) / SEGK) * SEGK;
-    f.Wgp = s->diff->m.W2p; f.KGgp = ((s->diff->m.KG2 + SEGK - 1) / SEGK) * SEGK;
-    f.b1 = c->m.b1; f.b2 = c->m.b2; f.bg = s->diff->m.b2; f.act = c->m.act;
+    sde_fast_args(s, f);
     f.u = uprev; f.dW = dW; f.un = u; f.B = B; f.dt = dt; f.abstol = abstol; f.reltol = reltol; f.delta = delta;
     f.part = c->part + (size_t)a.nwg_global * PSTRIDE;  // the parity-1 block k_finalize reads
     f.n_norm = a.n_global;
     if (rec_dev) {  // fixed-grid solve: the step writes its own record (no footer launch)
       if (!s->arrive) { HIPCHK(c, hipMalloc(&s->arrive, sizeof(int))); HIPCHK(c, hipMemsetAsync(s->arrive, 0, sizeof(int), c->stream)); }
       f.arrive = s->arrive; f.rec = rec_dev;
-      hipLaunchKernelGGL(k_sde_eh_fast<false>, dim3(nwg), dim3(SF_NT), 0, c->stream, f);
+      sde_fast_launch(f.D, c->desc.hidden_dim, nwg, c->stream, f);
       HIPCHK(c, hipGetLastError());
       return LRNDE_OK;
     }
     hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t, dt, 0, 0);
-    hipLaunchKernelGGL(k_sde_eh_fast<false>, dim3(nwg), dim3(SF_NT), 0, c->stream, f);
+    sde_fast_launch(f.D, c->desc.hidden_dim, nwg, c->stream, f);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, a, 1);
     HIPCHK(c, hipGetLastError());
     if (rec) HIPCHK(c, hipMemcpyAsync(rec, c->ctrl + 1, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
@@ -3217,20 +3232,22 @@ __global__ void k_sde_dw(size_t n, const float* Wlo, const float* Whi, float* dW
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dW[i] = Whi[i] - Wlo[i];
 }
 
-__global__ void k_sde_ctl_init(SdeCtl* ctl, int m0) {
+__global__ void k_sde_ctl_init(SdeCtl* ctl, int m0, float dtc0) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   SdeCtl c;
   c.status = ST_RUNNING; c.i = 0; c.m = m0; c.cur = 0; c.naccept = 0; c.nreject = 0; c.iters = 1; c.nf = 0;
-  c.qold = 1e-4f; c.eest_last = 0.f;
+  c.qold = 1e-4f; c.eest_last = 0.f; c.dtc = dtc0;
   *ctl = c;
 }
 
 // lrnde_sde_solve_adaptive on the one-launch kernel's shape: the controller runs in the step kernel's footer (SdeCtl,
 // lrnde_sde_fast.hpp), the host only keeps launches enqueued and watches a pinned progress word — one launch per attempted
 // step, no synchronisation inside the solve (the host-controlled loop below paid one per step: ~45 us for a 10-us step).
+// rec_u / rec_im / rec_cap: the layer's dense record of the accepted steps (device; NULL / 0 for a plain solve)
 static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
                                const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
-                               int32_t cap_trace, float* ua, float* ub) {
+                               int32_t cap_trace, float* ua, float* ub, float* rec_u = nullptr, int2* rec_im = nullptr,
+                               int rec_cap = 0) {
   lrnde_ctx* c = s->drift;
   const size_t n = (size_t)B * c->desc.state_dim;
   if (!s->ad_ctl) {
@@ -3251,17 +3268,14 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
   if (m0 > nfine) m0 = nfine;
   if (1 > o->maxiters) { st->iters = 1; st->retcode = LRNDE_MAXITERS; return fail(c, LRNDE_MAXITERS, "adaptive SDE solve stopped with retcode %d at t=%g", LRNDE_MAXITERS, (double)t0); }
   HIPCHK(c, hipMemcpyAsync(ua, u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(k_sde_ctl_init, dim3(1), dim3(1), 0, c->stream, s->ad_ctl, m0);
+  hipLaunchKernelGGL(k_sde_ctl_init, dim3(1), dim3(1), 0, c->stream, s->ad_ctl, m0, o->dt0);
   volatile unsigned long long* pw = s->ad_prog;
   *pw = 0ull;
   StepArgs a{};
   fill_args(c, a, B, NB);
   SdeFastArgs f{};
-  memset(&f, 0, sizeof(f));
-  f.W1p = c->m.W1p; f.KG1 = c->m.KG1;
-  f.W2p = c->m.W2p; f.KG2p = ((c->m.KG2 + SEGK - 1) / SEGK) * SEGK;
-  f.Wgp = s->diff->m.W2p; f.KGgp = ((s->diff->m.KG2 + SEGK - 1) / SEGK) * SEGK;
-  f.b1 = c->m.b1; f.b2 = c->m.b2; f.bg = s->diff->m.b2; f.act = c->m.act;
+  sde_fast_args(s, f);
+  f.rec_u = rec_u; f.rec_im = rec_im; f.rec_cap = rec_cap;
   f.B = B; f.abstol = o->abstol; f.reltol = o->reltol; f.delta = o->delta;
   f.part = c->part + (size_t)a.nwg_global * PSTRIDE;
   f.n_norm = a.n_global;
@@ -3279,7 +3293,7 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
   while (!done && j <= cap) {
     for (int k = 0; k < 8; ++k, ++j) {
       f.jlaunch = j;
-      hipLaunchKernelGGL(k_sde_eh_fast<true>, dim3(nwg), dim3(SF_NT), 0, c->stream, f);
+      sde_fast_launch(f.D, c->desc.hidden_dim, nwg, c->stream, f);
     }
     HIPCHK(c, hipGetLastError());
     const unsigned want = (unsigned)(j - 4);
@@ -3313,9 +3327,19 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
   return LRNDE_OK;
 }
 
+// rec_u (device, rec_cap x B x D) / rec_im_dev (device) / rec_im_host (host): the dense record of the accepted steps —
+// end state, (start index, length) on the path's grid — for the layer's recorded forward; all NULL for a plain solve
+static int sde_solve_adaptive_impl(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
+                                   const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
+                                   int32_t cap_trace, float* rec_u, int2* rec_im_dev, int2* rec_im_host, int rec_cap);
 int lrnde_sde_solve_adaptive(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
                              const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
                              int32_t cap_trace) {
+  return sde_solve_adaptive_impl(s, u0, W, nfine, B, t0, t1, o, u_end, st, trace_host, cap_trace, nullptr, nullptr, nullptr, 0);
+}
+static int sde_solve_adaptive_impl(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
+                                   const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
+                                   int32_t cap_trace, float* rec_u, int2* rec_im_dev, int2* rec_im_host, int rec_cap) {
   int rc = sde_check(s, u0, W, u_end, B, 1.0f);
   if (rc) return rc;
   lrnde_ctx* c = s->drift;
@@ -3330,10 +3354,13 @@ int lrnde_sde_solve_adaptive(lrnde_sde* s, const float* u0, const float* W, int3
   }
   float *ua = s->ad_ws, *ub = s->ad_ws + n, *dW = s->ad_ws + 2 * n;
   {
-    const bool no_fast = opt(OPT_NO_SDE_FAST) != 0;
     const bool host_loop = opt(OPT_SDE_HOST_LOOP) != 0;  // diagnostic: the host-controlled loop below
-    if (!no_fast && !host_loop && !sharded(c) && c->desc.state_dim == 32 && c->desc.hidden_dim == 64 && !c->desc.time_dep)
-      return sde_adaptive_device(s, u0, W, nfine, B, t0, t1, o, u_end, st, trace_host, cap_trace, ua, ub);
+    if (sde_uses_fast(s) && !host_loop) {
+      rc = sde_adaptive_device(s, u0, W, nfine, B, t0, t1, o, u_end, st, trace_host, cap_trace, ua, ub, rec_u, rec_im_dev, rec_cap);
+      if (!rc && rec_im_host && st->naccept > 0)
+        HIPCHK(c, hipMemcpy(rec_im_host, rec_im_dev, sizeof(int2) * (size_t)(st->naccept < rec_cap ? st->naccept : rec_cap), hipMemcpyDeviceToHost));
+      return rc;
+    }
   }
   HIPCHK(c, hipMemcpyAsync(ua, u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   const float h = (t1 - t0) / (float)nfine;
@@ -3341,6 +3368,7 @@ int lrnde_sde_solve_adaptive(lrnde_sde* s, const float* u0, const float* W, int3
   int i = 0;                                                  // position on the path's grid
   int m = (int)(o->dt0 / h); if (m < 1) m = 1;                // step length in grid intervals
   float qold = qoldinit;
+  float dtc = o->dt0;   // the controller's proposal as a real number; the step taken is its floor on the grid (SdeCtl::dtc)
   int nb = (int)((n + 255) / 256); if (nb > 1024) nb = 1024;
   while (i < nfine) {
     if (m > nfine - i) m = nfine - i;
@@ -3363,9 +3391,15 @@ int lrnde_sde_solve_adaptive(lrnde_sde* s, const float* u0, const float* W, int3
     const int accepted = eest <= 1.0f;
     const int ntr = st->naccept + st->nreject;
     if (trace_host && ntr < cap_trace) { trace_host[ntr].t = t; trace_host[ntr].dt = dt; trace_host[ntr].eest = eest; trace_host[ntr].accepted = accepted; }
-    int mnew = (int)((dt / q) / h);
+    dtc = (accepted ? fmaxf(dtc, dt) : dt) / q;
+    int mnew = (int)(dtc / h);
     if (mnew < 1) mnew = 1;
     if (accepted) {
+      if (rec_u) {
+        if (st->naccept >= rec_cap) { st->retcode = LRNDE_CAPACITY; break; }
+        HIPCHK(c, hipMemcpyAsync(rec_u + (size_t)st->naccept * n, ub, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+        rec_im_host[st->naccept] = make_int2(i, m);
+      }
       st->naccept++;
       qold = fmaxf(eest, qoldinit);
       i += m;
@@ -3622,6 +3656,7 @@ int lrnde_vjp(lrnde_ctx* c, const float* y, float t, const float* lam, int32_t B
 
 }  // extern "C"
 #include "lrnde_sde_bwd.hpp"
+#include "lrnde_sde_node.hpp"
 extern "C" {
 // ---- backward drivers -----------------------------------------------------------------------
 }  // extern "C"

@@ -1,100 +1,156 @@
-// lrnde_sde_fast.hpp — the Lamba Euler-Heun step (src/perform_step.jl:172-206) for the MNIST-SDE shape
-// (experiments/src/construct.jl:204-205: state 32, drift Dense(32=>64,tanh)->Dense(64=>32), diagonal diffusion
-// Dense(32=>32)) as ONE small-latency launch.  Included by lrnde_kernels.hip inside its anonymous namespace.
+// lrnde_sde_fast.hpp — the Lamba Euler-Heun step (src/perform_step.jl:172-206) as ONE small-latency launch, for every
+// NeuralDSDE whose drift is Chain(Dense(D => H, act), Dense(H => D)) without a time input and whose diffusion is
+// Dense(D => D) (src/layers/neural_sde.jl:50-72; experiments/src/construct.jl:204-205 is D = 32, H = 64) with D <= 64 and
+// H <= 128.  Included by lrnde_kernels.hip inside its anonymous namespace.
 //
 // k_sde_step (the generic kernel) runs the step's six field evaluations through feval_tile: per evaluation it restages
 // the biases, reloads the resident weight fragments from L2, and passes every intermediate (du1, L, K, tmp, ...) through
 // global memory between evaluations — 28 us for 15.7 MFLOP.  Here a workgroup is four waves on 16 columns and nothing
 // leaves the CU between the first load of (u, dW) and the store of u_new:
-//   * the three weight matrices (24 KB) are MFMA A fragments in registers for the whole launch (wave w: hidden tile w of
-//     Dense-1; waves 0,1: output tile of Dense-2; waves 2,3: output tile of the diffusion);
-//   * a round = [drift Dense-1 + tanh on all four waves] barrier [drift Dense-2 on waves 0,1 || diffusion on waves 2,3]
-//     barrier; the step is three rounds: (f,g)(u) -> (f,g)(tmp) -> f(K), g(utilde);
-//   * the elementwise algebra of the step stays in the C-fragment registers of waves 0,1 (4 rows x 1 column per lane).
+//   * the three weight matrices (24 KB at 32/64) are MFMA A fragments in registers for the whole launch: wave w holds the
+//     hidden tiles w, w + 4 of Dense-1; the 2 DT output-tile jobs of the second phase — DT tiles of Dense-2, DT tiles of
+//     the diffusion — go round-robin to the waves (job j = wave + 4 r: Dense-2 tile j for j < DT, diffusion tile j - DT
+//     otherwise; a wave owns at most one of each);
+//   * a round = [drift Dense-1 + activation, and this wave's diffusion tile] barrier [drift Dense-2 of this wave's tile +
+//     the elementwise algebra] barrier; the step is three rounds: (f,g)(u) -> (f,g)(tmp) -> f(K), g(utilde);
+//   * the elementwise algebra of the step stays in the C-fragment registers of the wave that owns the Dense-2 tile
+//     (4 rows x 1 column per lane).
 // Arithmetic: the canonical dot products (k-ordered fma chains = v_mfma_f32_16x16x4_f32 chains over the k-groups in
-// order), the same activation polynomial and the same elementwise expressions as k_sde_step, so results are bit-identical
-// to it and to the oracle (tests/test_gpu_parity.py::test_sde_*).  Shape: D = 32, H = 64, no time dependence.
+// order, segments of 112 rows added left to right — H = 128 has two), the same activation polynomial and the same
+// elementwise expressions as k_sde_step, so results are bit-identical to it and to the oracle
+// (tests/test_gpu_parity.py::test_sde_*, tests/test_gpu_switches.py).  Rows beyond D / H are zero-padded fragments.
+//
+// The adaptive solve's controller (lrnde_sde_solve_adaptive, lrnde_sde_node_forward_record) runs in this kernel's footer
+// (last workgroup to arrive): PI controller on EEst, position on the caller's Brownian grid, state buffer flip, and — for
+// the layer's recorded forward — the dense record of the accepted steps (start index, length, end state) that the
+// reverse sweep of lrnde_sde_node_backward_recorded walks.
 
-constexpr int SF_DT = 2;   // D / 16
-constexpr int SF_HT = 4;   // H / 16
 constexpr int SF_NT = 256;
+constexpr int SF_MAXD = 64, SF_MAXH = 128;
 
 struct SdeFastArgs {
   const f32x4* W1p; int KG1;         // drift Dense-1 fragments [MT1p][KG1][64]
   const f32x4* W2p; int KG2p;        // drift Dense-2 fragments [MT2][KG2p][64]
   const f32x4* Wgp; int KGgp;        // diffusion (second layer of the identity+Dense form) [MT2][KGgp][64]
-  const float *b1, *b2, *bg;
-  int act;
-  const float* u; const float* dW; float* un;   // (B, 32)
+  const float *b1, *b2, *bg;         // zero-padded to the tile sizes
+  int act, D;
+  const float* u; const float* dW; float* un;   // (B, D)
   int B;
   float dt, abstol, reltol, delta;
   double* part;      // per-workgroup fp64 sums of the squared residual (PSTRIDE doubles each)
   int* arrive;       // fixed-grid solve: arrival counter of the step's footer, or NULL
   Ctrl* rec;         //   ... and the record slot the last workgroup fills (EEst, EEst*dt)
-  double n_norm;     // elements of the norm (B * 32)
-  // ADAPT (lrnde_sde_solve_adaptive on this shape): the controller lives on the device.  The launch reads the control
-  // block (grid position i, step length m in grid intervals, which of the two state buffers is current), forms dW from the
-  // caller's path itself, and its last workgroup runs the PI controller and writes the block for the next launch.
+  double n_norm;     // elements of the norm (B * D)
+  // adaptive solves: the controller lives on the device.  The launch reads the control block (grid position i, step
+  // length m in grid intervals, which of the two state buffers is current), forms dW from the caller's path itself, and
+  // its last workgroup runs the PI controller and writes the block for the next launch.
   struct SdeCtl* ctl; const float* Wpath; float* ua; float* ub; int nfine; float t0, h;
   float gamma, qmin, qmax, beta1, beta2; int maxiters;
   lrnde_trace_row* trace; int cap_trace;
   unsigned long long* prog;  // pinned host word: (launches whose footer ran) | status << 32
   int jlaunch;
+  // the layer's recorded forward: end state of accepted step k -> rec_u[k] (slot = accepted steps so far; a rejected
+  // attempt's slot is rewritten by the retry), its (i, m) -> rec_im[k]
+  float* rec_u; int2* rec_im; int rec_cap;
 };
-struct SdeCtl { int status, i, m, cur, naccept, nreject, iters, nf; float qold, eest_last; };
+// dtc: the controller's step proposal as a REAL number; the step taken is its floor on the path's grid (m intervals, at least
+// one).  Growth accumulates in dtc — with qmax = 1.125 a proposal quantised after every step could never leave m = 1.
+struct SdeCtl { int status, i, m, cur, naccept, nreject, iters, nf; float qold, eest_last, dtc; };
 
-__device__ __forceinline__ f32x4 sf_chain(const f32x4* frag, int nkg, const f32x4* xb, int lane) {
+// canonical dot product over NKG k-groups of 16 rows: fma chains over segments of SEGK k-groups, partials left to right
+template <int NKG>
+__device__ __forceinline__ f32x4 sf_chain(const f32x4 (&frag)[NKG], const f32x4* xb, int lane) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int kg = 0; kg < nkg; ++kg) acc = mfma4(frag[kg], xb[kg * 64 + lane], acc);
+#pragma unroll
+  for (int kg = 0; kg < (NKG < SEGK ? NKG : SEGK); ++kg) acc = mfma4(frag[kg], xb[kg * 64 + lane], acc);
+  if constexpr (NKG > SEGK) {
+    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kg = SEGK; kg < NKG; ++kg) acc2 = mfma4(frag[kg], xb[kg * 64 + lane], acc2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = acc[r] + acc2[r];
+  }
   return acc;
 }
 
-template <bool ADAPT>
+template <int DT, int HT>
 __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
-  int ad_i = 0, ad_m = 0, ad_cur = 0;
-  if (ADAPT) {
+  static_assert(DT >= 1 && DT <= 4 && HT >= 1 && HT <= 8, "D <= 64, H <= 128");
+  constexpr int NJ = (HT + 3) / 4;   // hidden tiles per wave
+  const bool adapt = a.ctl != nullptr;
+  int ad_i = 0, ad_m = 0, ad_slot = 0;
+  if (adapt) {
     const SdeCtl cc = *a.ctl;   // written by the previous launch's last workgroup (kernel boundary in between)
     if (cc.status != ST_RUNNING) return;
-    ad_i = cc.i; ad_m = cc.m; ad_cur = cc.cur;
+    ad_i = cc.i; ad_m = cc.m; ad_slot = cc.naccept;
     a.dt = (float)ad_m * a.h;
-    a.u = ad_cur ? a.ub : a.ua;
-    a.un = ad_cur ? a.ua : a.ub;
+    a.u = cc.cur ? a.ub : a.ua;
+    a.un = cc.cur ? a.ua : a.ub;
   }
-  // LDS: three x tiles in B-operand layout (32 rows x 16 columns each: [kg][64 lanes] float4), the h tile (64 rows), the
-  // diffusion results of waves 2,3 in C-fragment order, the reduction scratch
-  __shared__ f32x4 xA[SF_DT * 64], xB[SF_DT * 64], xC[SF_DT * 64], hl[SF_HT * 64], gl[2 * 64];
-  __shared__ double red[2];
+  // LDS: three x tiles in B-operand layout (16 DT rows x 16 columns each: [kg][64 lanes] float4), the h tile, the
+  // diffusion results in C-fragment order, the reduction scratch
+  __shared__ f32x4 xA[DT * 64], xB[DT * 64], xC[DT * 64], hl[HT * 64], gl[DT * 64];
+  __shared__ double red[4];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, rq = lane >> 4;
   const int b0 = blockIdx.x * 16;
   const bool colok = b0 + n < a.B;
+  const int D = a.D;
+  // jobs of this wave: Dense-2 tile t (wave < DT), diffusion tile tg (job wave or wave + 4 in [DT, 2 DT))
+  const bool has_d2 = wave < DT;
+  const int t = has_d2 ? wave : 0;
+  const int tg = (wave >= DT && wave < 2 * DT) ? wave - DT : ((wave + 4 >= DT && wave + 4 < 2 * DT) ? wave + 4 - DT : -1);
   // resident A fragments
-  f32x4 w1[SF_DT], w2[SF_HT], wg[SF_DT];
-#pragma unroll
-  for (int kg = 0; kg < SF_DT; ++kg) w1[kg] = a.W1p[((size_t)wave * a.KG1 + kg) * 64 + lane];
-  const int t = wave & 1;  // output tile of Dense-2 (waves 0,1) / of the diffusion (waves 2,3)
-#pragma unroll
-  for (int kg = 0; kg < SF_HT; ++kg) w2[kg] = a.W2p[((size_t)t * a.KG2p + kg) * 64 + lane];
-#pragma unroll
-  for (int kg = 0; kg < SF_DT; ++kg) wg[kg] = a.Wgp[((size_t)t * a.KGgp + kg) * 64 + lane];
-  const f32x4 b1v = *reinterpret_cast<const f32x4*>(a.b1 + wave * 16 + rq * 4);
-  const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2 + t * 16 + rq * 4);
-  const f32x4 bgv = *reinterpret_cast<const f32x4*>(a.bg + t * 16 + rq * 4);
-  // this lane's four rows (16 t + 4 rq + r) of column n: state and increments (waves 0,1 own the elementwise work)
+  f32x4 w1[NJ][DT], w2[HT], wg[DT];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int ht = wave + 4 * j;
+#pragma unroll
+    for (int kg = 0; kg < DT; ++kg) w1[j][kg] = ht < HT ? a.W1p[((size_t)ht * a.KG1 + kg) * 64 + lane] : zero4;
+  }
+#pragma unroll
+  for (int kg = 0; kg < HT; ++kg) w2[kg] = has_d2 ? a.W2p[((size_t)t * a.KG2p + kg) * 64 + lane] : zero4;
+#pragma unroll
+  for (int kg = 0; kg < DT; ++kg) wg[kg] = tg >= 0 ? a.Wgp[((size_t)tg * a.KGgp + kg) * 64 + lane] : zero4;
+  f32x4 b1v[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) b1v[j] = (wave + 4 * j < HT) ? *reinterpret_cast<const f32x4*>(a.b1 + (wave + 4 * j) * 16 + rq * 4) : zero4;
+  const f32x4 b2v = has_d2 ? *reinterpret_cast<const f32x4*>(a.b2 + t * 16 + rq * 4) : zero4;
+  const f32x4 bgv = tg >= 0 ? *reinterpret_cast<const f32x4*>(a.bg + tg * 16 + rq * 4) : zero4;
+  // this lane's four rows (16 t + 4 rq + r) of column n: state and increments (the Dense-2 waves own the elementwise work)
+  const int row0 = t * 16 + rq * 4;
+  const bool vec = (D & 3) == 0;                 // rows in whole quads: one 16-byte access per lane
+  const bool live = has_d2 && colok && row0 < D;
+  const size_t g = (size_t)(b0 + n) * D + row0;
+  const size_t nn = (size_t)a.B * D;
+  auto ld4s = [&](const float* p) {
+    f32x4 v = zero4;
+    if (vec) v = *reinterpret_cast<const f32x4*>(p + g);
+    else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (row0 + r < D) v[r] = p[g + r];
+    }
+    return v;
+  };
+  auto st4s = [&](float* p, const f32x4& v) {
+    if (vec) *reinterpret_cast<f32x4*>(p + g) = v;
+    else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (row0 + r < D) p[g + r] = v[r];
+    }
+  };
   f32x4 u4 = zero4, w4 = zero4;
-  const size_t g = (size_t)(b0 + n) * 32 + t * 16 + rq * 4;
-  if (wave < 2 && colok) {
-    u4 = *reinterpret_cast<const f32x4*>(a.u + g);
-    if (ADAPT) {  // dW = W[i + m] - W[i], the path's own increment (the expression of k_sde_dw)
-      const size_t nn = (size_t)a.B * 32;
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(a.Wpath + (size_t)ad_i * nn + g);
-      const f32x4 hi = *reinterpret_cast<const f32x4*>(a.Wpath + (size_t)(ad_i + ad_m) * nn + g);
+  if (live) {
+    u4 = ld4s(a.u);
+    if (adapt) {  // dW = W[i + m] - W[i], the path's own increment (the expression of k_sde_dw)
+      const f32x4 lo = ld4s(a.Wpath + (size_t)ad_i * nn);
+      const f32x4 hi = ld4s(a.Wpath + (size_t)(ad_i + ad_m) * nn);
 #pragma unroll
       for (int r = 0; r < 4; ++r) w4[r] = hi[r] - lo[r];
     } else {
-      w4 = *reinterpret_cast<const f32x4*>(a.dW + g);
+      w4 = ld4s(a.dW);
     }
   }
   // B-operand image of rows 16 t + 4 rq + r, column n: float4 index t*64 + r*16 + n, component rq
@@ -103,25 +159,32 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) p[r * 64] = v[r];
   };
-  if (wave < 2) put(xA, u4);
+  if (has_d2) put(xA, u4);
   __syncthreads();
   const float dt = a.dt, hdt = dt / 2.0f, sqdt = __builtin_sqrtf(dt);
 
-  // drift Dense-1 + activation of hidden tile `wave` on the x tile xs -> hl
+  // drift Dense-1 + activation of this wave's hidden tiles on the x tile xs -> hl
   auto dense1 = [&](const f32x4* xs) {
-    const f32x4 acc = sf_chain(w1, SF_DT, xs, lane);
-    float* p = reinterpret_cast<float*>(hl) + ((wave * 64 + n) << 2) + rq;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) p[r * 64] = act_apply(a.act, acc[r] + b1v[r]);
+    for (int j = 0; j < NJ; ++j) {
+      const int ht = wave + 4 * j;
+      if (ht < HT) {
+        const f32x4 acc = sf_chain<DT>(w1[j], xs, lane);
+        float* p = reinterpret_cast<float*>(hl) + ((ht * 64 + n) << 2) + rq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r * 64] = act_apply(a.act, acc[r] + b1v[j][r]);
+      }
+    }
   };
-  auto diffusion = [&](const f32x4* xs) {  // waves 2,3: tile t of g(xs) -> gl (C-fragment order)
-    f32x4 acc = sf_chain(wg, SF_DT, xs, lane);
+  auto diffusion = [&](const f32x4* xs) {  // tile tg of g(xs) -> gl (C-fragment order)
+    if (tg < 0) return;
+    f32x4 acc = sf_chain<DT>(wg, xs, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = acc[r] + bgv[r];
-    gl[t * 64 + lane] = acc;
+    gl[tg * 64 + lane] = acc;
   };
-  auto dense2 = [&]() {  // waves 0,1: tile t of f = W2 h + b2
-    f32x4 acc = sf_chain(w2, SF_HT, hl, lane);
+  auto dense2 = [&]() {  // tile t of f = W2 h + b2
+    f32x4 acc = sf_chain<HT>(w2, hl, lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = acc[r] + b2v[r];
     return acc;
@@ -129,10 +192,10 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
 
   // ---- round 1: du1 = f(u), L = g(u) (:174-176) ----
   dense1(xA);
-  if (wave >= 2) diffusion(xA);
+  diffusion(xA);
   __syncthreads();
   f32x4 du1 = zero4, L = zero4, Kv = zero4;
-  if (wave < 2) {
+  if (has_d2) {
     du1 = dense2();
     L = gl[t * 64 + lane];
     f32x4 tmp, ut;
@@ -147,10 +210,10 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
   __syncthreads();
   // ---- round 2: g(tmp), f(tmp) at t + dt (:184, :191) ----
   dense1(xB);
-  if (wave >= 2) diffusion(xB);
+  diffusion(xB);
   __syncthreads();
   f32x4 un = zero4;
-  if (wave < 2) {
+  if (has_d2) {
     const f32x4 f2 = dense2();
     const f32x4 g2 = gl[t * 64 + lane];
 #pragma unroll
@@ -159,21 +222,25 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
       const float noise2 = gtmp2 * w4[r];
       un[r] = (u4[r] + hdt * (du1[r] + f2[r])) + noise2;   // :191
     }
-    if (colok) *reinterpret_cast<f32x4*>(a.un + g) = un;
+    if (live) {
+      st4s(a.un, un);
+      if (a.rec_u && ad_slot < a.rec_cap) st4s(a.rec_u + (size_t)ad_slot * nn, un);
+    }
     put(xA, Kv);   // xA is free: every wave has read it (barrier above)
   }
   __syncthreads();
   // ---- round 3: du2 = f(K, t + dt) (:193), g(utilde, t) (:197) ----
   dense1(xA);
-  if (wave >= 2) diffusion(xC);
+  diffusion(xC);
   __syncthreads();
   double acc = 0.0;
-  if (wave < 2) {
+  if (has_d2) {
     const f32x4 du2 = dense2();
     const f32x4 g3 = gl[t * 64 + lane];
-    if (colok) {
+    if (live) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        if (row0 + r >= D) continue;
         const float Ed = (dt * (du2[r] - du1[r])) / 2.0f;                        // :194
         const float ggp = (g3[r] - L[r]) / sqdt;                                 // :197
         const float En = (ggp * (w4[r] * w4[r])) / 2.0f;                         // :198
@@ -188,12 +255,14 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
   }
   __syncthreads();
   if (threadIdx.x < 64) {
-    const double tot = red[0] + red[1];
+    double tot = red[0];
+#pragma unroll
+    for (int w = 1; w < DT; ++w) tot += red[w];
     if (!a.arrive) {
       if (lane == 0) { double* p = a.part + (size_t)blockIdx.x * PSTRIDE; p[0] = tot; p[1] = 0.0; p[2] = 0.0; }
       return;
     }
-    // fixed-grid solve: the step's own footer — the last workgroup to arrive reduces the partials and fills the record
+    // the step's own footer — the last workgroup to arrive reduces the partials and fills the record / runs the controller
     int last = 0;
     if (lane == 0) {
       double* p = a.part + (size_t)blockIdx.x * PSTRIDE;
@@ -207,7 +276,7 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
     const Sum3 s = reduce_partials3(a.part, (int)gridDim.x);
     if (lane == 0) {
       const float eest = rms_from(s.a, a.n_norm);
-      if (!ADAPT) {
+      if (!adapt) {
         a.rec->eest_last = eest;
         a.rec->reg_error = eest * dt;
         a.rec->status = ST_DONE;
@@ -232,15 +301,20 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
             lrnde_trace_row r; r.t = a.t0 + (float)c.i * a.h; r.dt = dt; r.eest = eest; r.accepted = accepted;
             a.trace[ntr] = r;
           }
-          int mnew = (int)((dt / q) / a.h);
+          c.dtc = (accepted ? fmaxf_(c.dtc, dt) : dt) / q;
+          int mnew = (int)(c.dtc / a.h);
           if (mnew < 1) mnew = 1;
           if (accepted) {
+            if (a.rec_im) {
+              if (c.naccept < a.rec_cap) a.rec_im[c.naccept] = make_int2(c.i, c.m);
+              else c.status = LRNDE_CAPACITY;
+            }
             c.naccept++;
             c.qold = fmaxf_(eest, qoldinit);
             c.i += c.m;
             c.cur ^= 1;
             c.m = mnew;
-            if (c.i >= a.nfine) c.status = ST_DONE;
+            if (c.i >= a.nfine && c.status == ST_RUNNING) c.status = ST_DONE;
           } else {
             c.nreject++;
             if (c.m == 1) c.status = LRNDE_DT_LESS_THAN_MIN;  // the path's grid cannot be refined further
@@ -257,5 +331,29 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
       }
       __hip_atomic_store(a.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+  }
+}
+
+// launch by shape: DT = ceil(D / 16) in 1..4, HT = ceil(H / 16) in 1..8
+inline bool sde_fast_shape(int D, int H) { return D >= 1 && D <= SF_MAXD && H >= 1 && H <= SF_MAXH; }
+template <int DT> inline void sde_fast_launch_h(int HT, int nwg, hipStream_t st, const SdeFastArgs& f) {
+  switch (HT) {
+    case 1: hipLaunchKernelGGL((k_sde_eh_fast<DT, 1>), dim3(nwg), dim3(SF_NT), 0, st, f); break;
+    case 2: hipLaunchKernelGGL((k_sde_eh_fast<DT, 2>), dim3(nwg), dim3(SF_NT), 0, st, f); break;
+    case 3: hipLaunchKernelGGL((k_sde_eh_fast<DT, 3>), dim3(nwg), dim3(SF_NT), 0, st, f); break;
+    case 4: hipLaunchKernelGGL((k_sde_eh_fast<DT, 4>), dim3(nwg), dim3(SF_NT), 0, st, f); break;
+    case 5: hipLaunchKernelGGL((k_sde_eh_fast<DT, 5>), dim3(nwg), dim3(SF_NT), 0, st, f); break;
+    case 6: hipLaunchKernelGGL((k_sde_eh_fast<DT, 6>), dim3(nwg), dim3(SF_NT), 0, st, f); break;
+    case 7: hipLaunchKernelGGL((k_sde_eh_fast<DT, 7>), dim3(nwg), dim3(SF_NT), 0, st, f); break;
+    default: hipLaunchKernelGGL((k_sde_eh_fast<DT, 8>), dim3(nwg), dim3(SF_NT), 0, st, f); break;
+  }
+}
+inline void sde_fast_launch(int D, int H, int nwg, hipStream_t st, const SdeFastArgs& f) {
+  const int DT = (D + 15) / 16, HT = (H + 15) / 16;
+  switch (DT) {
+    case 1: sde_fast_launch_h<1>(HT, nwg, st, f); break;
+    case 2: sde_fast_launch_h<2>(HT, nwg, st, f); break;
+    case 3: sde_fast_launch_h<3>(HT, nwg, st, f); break;
+    default: sde_fast_launch_h<4>(HT, nwg, st, f); break;
   }
 }

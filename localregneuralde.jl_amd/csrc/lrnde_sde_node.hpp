@@ -1,0 +1,364 @@
+// lrnde_sde_node.hpp — the NeuralDSDE layer as the reference runs it (src/layers/neural_sde.jl:50-123): ADAPTIVE solve of
+// dudt / g from x over tspan, sol(t1) / `saveat` values, a fresh integrator at (sol(t1), t1) and one local Euler-Heun step
+// for reg_val (:88-105, :109-123) — and its pullback (the reference tapes the solver's own arithmetic with TrackerAdjoint,
+// :12; reg_val is differentiated w.r.t. the parameters only, :42).  Included by lrnde_kernels.hip after lrnde_sde_bwd.hpp.
+//
+// What is restated from un-vendored StochasticDiffEq (UPSTREAM-RECALL, not readable in this image):
+//   * the adaptive loop: PI controller on the step's EEst (lrnde_sde_solve_adaptive), on the CALLER's Brownian path given on
+//     a uniform grid — steps are whole grid intervals, a rejected step retries a shorter piece of the same path;
+//   * saveat values between steps by the SDE solvers' linear interpolant  (1 - theta) uprev + theta u ;
+//   * the automatic initial dt (sde_determine_initdt: the ODE heuristic with the diffusion entering as +-3 g).
+// The forward keeps a dense record of the accepted steps (start index and length on the grid, end state); the backward is
+// the reverse sweep over exactly those steps with their own dt and dW = W[i + m] - W[i] (discretise-then-differentiate:
+// what a tape of the solve gives), cotangents of interpolated saveat values split (1 - theta, theta) onto the two step ends.
+
+namespace {
+
+struct SdeSeriesEntry { float t; int k; float theta; };  // value = (1-theta) * state_before(step k) + theta * rec_u[k]; k = -1: the start value
+struct SdeNodeRecord {
+  bool valid = false;
+  int B = 0, nfine = 0, K = 0, mode = 0;
+  float t0 = 0.f, t2 = 0.f, h = 0.f;
+  lrnde_sde_adapt_opts o{};
+  const float* W = nullptr;        // the caller's path (must stay alive until the backward call)
+  float* x = nullptr;              // copy of the input state
+  float* rec_u = nullptr; int2* rec_im_dev = nullptr; size_t rec_floats = 0; int rec_cap = 0;
+  std::vector<int2> im;            // (i, m) of every accepted step
+  std::vector<SdeSeriesEntry> series;  // the caller's view of the solution (after the _CorrectedDESolution filter)
+  float* u1 = nullptr; float* dWloc = nullptr; float* tmp = nullptr; size_t n_alloc = 0;
+  float t1 = 0.f, dt_loc = 0.f;
+  float* gdr = nullptr; float* gdf = nullptr; size_t pf = 0, pg = 0;
+};
+
+// out = (1 - theta) * a + theta * b   (StochasticDiffEq's linear sde_interpolant)
+__global__ void k_sde_lerp(size_t n, const float* a, const float* b, float theta, float* out) {
+  const float om = 1.0f - theta;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = om * a[i] + theta * b[i];
+}
+// acc += c * g
+__global__ void k_sde_axpy(size_t n, float* acc, const float* g, float c) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc[i] = acc[i] + c * g[i];
+}
+// dW = sqrt(dt) * z
+__global__ void k_sde_scale(size_t n, const float* z, float c, float* out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = c * z[i];
+}
+// partial sums of sde_determine_initdt's three norms (fp64, one per block):
+//  phase 0: d0 = ||u / sk||, d1 = ||max(|f0 + 3 g0|, |f0 - 3 g0|) / sk||      (sk = abstol + |u| reltol)
+//  phase 1: d2 = ||max(|df + dg|, |df - dg|) / sk||, df = f1 - f0, dg = max(|3g0 - 3g1|, |3g0 + 3g1|)
+__global__ __launch_bounds__(256) void k_sde_initdt(size_t n, const float* u, const float* f0, const float* g0, const float* f1,
+                                                   const float* g1, float abstol, float reltol, int phase, double* part) {
+  __shared__ double red[2][4];
+  double a0 = 0.0, a1 = 0.0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float sk = abstol + __builtin_fabsf(u[i]) * reltol;
+    const float G0 = 3.0f * g0[i];
+    if (phase == 0) {
+      const float r0 = u[i] / sk;
+      const float r1 = fmaxf_(__builtin_fabsf(f0[i] + G0), __builtin_fabsf(f0[i] - G0)) / sk;
+      a0 += (double)(r0 * r0); a1 += (double)(r1 * r1);
+    } else {
+      const float G1 = 3.0f * g1[i];
+      const float dg = fmaxf_(__builtin_fabsf(G0 - G1), __builtin_fabsf(G0 + G1));
+      const float df = f1[i] - f0[i];
+      const float r2 = fmaxf_(__builtin_fabsf(df + dg), __builtin_fabsf(df - dg)) / sk;
+      a0 += (double)(r2 * r2);
+    }
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a0; red[1][threadIdx.x >> 6] = a1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    part[64 + blockIdx.x] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+  }
+}
+
+// StochasticDiffEq.sde_determine_initdt (UPSTREAM-RECALL): 2 drift + 2 diffusion evaluations.  order: the solver's strong
+// order (1/2 for Euler-Heun).  ws: 5 state-sized device vectors.  Host synchronisations: two (init only).
+int sde_init_dt(lrnde_sde* s, const float* u, int B, float t, float tend, float abstol, float reltol, float order, float* ws,
+                float* dt_out) {
+  lrnde_ctx* c = s->drift; lrnde_ctx* cg = s->diff;
+  const size_t n = (size_t)B * c->desc.state_dim;
+  float *f0 = ws, *g0 = ws + n, *u1 = ws + 2 * n, *f1 = ws + 3 * n, *g1 = ws + 4 * n;
+  int rc;
+  if (!s->idt_part) {
+    HIPCHK(c, hipMalloc(&s->idt_part, sizeof(double) * 128));
+    HIPCHK(c, hipHostMalloc(&s->idt_part_host, sizeof(double) * 128));
+  }
+  const float dtmax = tend - t;
+  if ((rc = lrnde_rhs(c, u, t, B, f0))) return rc;
+  if ((rc = lrnde_rhs(cg, u, t, B, g0))) return rc;
+  hipLaunchKernelGGL(k_sde_initdt, dim3(64), dim3(256), 0, c->stream, n, u, (const float*)f0, (const float*)g0, (const float*)nullptr,
+                     (const float*)nullptr, abstol, reltol, 0, s->idt_part);
+  HIPCHK(c, hipMemcpyAsync(s->idt_part_host, s->idt_part, sizeof(double) * 128, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = 0; i < 64; ++i) { s0 += s->idt_part_host[i]; s1 += s->idt_part_host[64 + i]; }
+  const float d0 = (float)sqrt(s0 / (double)n), d1 = (float)sqrt(s1 / (double)n);
+  float dt0 = ((double)d0 < 1e-5 || (double)d1 < 1e-5) ? 1e-6f : (d0 / d1) / 100.0f;
+  dt0 = fminf(dt0, dtmax);
+  HIPCHK(c, hipMemcpyAsync(u1, u, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_sde_axpy, dim3(sde_nb(n)), dim3(256), 0, c->stream, n, u1, (const float*)f0, dt0);  // u1 = u + dt0 * f0
+  if ((rc = lrnde_rhs(c, u1, t + dt0, B, f1))) return rc;
+  if ((rc = lrnde_rhs(cg, u1, t + dt0, B, g1))) return rc;
+  hipLaunchKernelGGL(k_sde_initdt, dim3(64), dim3(256), 0, c->stream, n, u, (const float*)f0, (const float*)g0, (const float*)f1,
+                     (const float*)g1, abstol, reltol, 1, s->idt_part);
+  HIPCHK(c, hipMemcpyAsync(s->idt_part_host, s->idt_part, sizeof(double) * 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double s2 = 0.0;
+  for (int i = 0; i < 64; ++i) s2 += s->idt_part_host[i];
+  const float d2 = (float)sqrt(s2 / (double)n) / dt0;
+  const float maxd = fmaxf(d1, d2);
+  float dt1;
+  if ((double)maxd <= 1e-15) dt1 = fmaxf(1e-6f, dt0 * 1e-3f);
+  else {
+    const float l10 = (float)log10((double)maxd);
+    const float e = (-(2.0f + l10)) / (order + 0.5f);
+    dt1 = (float)pow(10.0, (double)e);
+  }
+  *dt_out = fminf(fminf(100.0f * dt0, dt1), dtmax);
+  return LRNDE_OK;
+}
+
+int sde_node_alloc(lrnde_sde* s, SdeNodeRecord& r, int B, int nfine) {
+  lrnde_ctx* c = s->drift;
+  const size_t n = (size_t)B * c->desc.state_dim;
+  if (r.n_alloc != n) {
+    for (float** p : {&r.x, &r.u1, &r.dWloc, &r.tmp}) { if (*p) hipFree(*p); *p = nullptr; }
+    r.n_alloc = 0;
+    HIPCHK(c, hipMalloc(&r.x, sizeof(float) * n));
+    HIPCHK(c, hipMalloc(&r.u1, sizeof(float) * n));
+    HIPCHK(c, hipMalloc(&r.dWloc, sizeof(float) * n));
+    HIPCHK(c, hipMalloc(&r.tmp, sizeof(float) * 6 * n));
+    r.n_alloc = n;
+  }
+  if (r.rec_floats < (size_t)nfine * n || r.rec_cap < nfine) {
+    if (r.rec_u) hipFree(r.rec_u);
+    if (r.rec_im_dev) hipFree(r.rec_im_dev);
+    r.rec_u = nullptr; r.rec_im_dev = nullptr; r.rec_floats = 0; r.rec_cap = 0;
+    HIPCHK(c, hipMalloc(&r.rec_u, sizeof(float) * (size_t)nfine * n));
+    HIPCHK(c, hipMalloc(&r.rec_im_dev, sizeof(int2) * (size_t)nfine));
+    r.rec_floats = (size_t)nfine * n; r.rec_cap = nfine;
+  }
+  const size_t Pf = lrnde_param_count(&c->desc), Pg = (size_t)c->desc.state_dim * c->desc.state_dim + (s->diff_bias ? c->desc.state_dim : 0);
+  if (r.pf != Pf || r.pg != Pg) {
+    if (r.gdr) hipFree(r.gdr);
+    if (r.gdf) hipFree(r.gdf);
+    r.gdr = r.gdf = nullptr;
+    HIPCHK(c, hipMalloc(&r.gdr, sizeof(float) * Pf));
+    HIPCHK(c, hipMalloc(&r.gdf, sizeof(float) * Pg));
+    r.pf = Pf; r.pg = Pg;
+  }
+  return LRNDE_OK;
+}
+
+void sde_node_release(lrnde_sde* s) {
+  if (!s->node) return;
+  SdeNodeRecord& r = *s->node;
+  for (float** p : {&r.x, &r.u1, &r.dWloc, &r.tmp, &r.rec_u, &r.gdr, &r.gdf}) { if (*p) hipFree(*p); *p = nullptr; }
+  if (r.rec_im_dev) hipFree(r.rec_im_dev);
+  delete s->node;
+  s->node = nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, int32_t nfine, int32_t B, float t0, float t2,
+                                  const lrnde_sde_adapt_opts* o, int32_t mode, float t1_or_rand, const float* z_local,
+                                  int32_t save_start, const float* saveat_host, int32_t nsave, float* u_series,
+                                  float* t_series_host, int32_t cap_series, int32_t* nseries_host, float* reg_val_host,
+                                  int32_t* nfe_drift_host, int32_t* nfe_diffusion_host, lrnde_stats* st, float* t1_used_host) {
+  if (!s) return LRNDE_BADARG;
+  lrnde_ctx* c = s->drift;
+  int rc = sde_check(s, x, W, u_series, B, 1.0f);
+  if (rc) return rc;
+  if (!o || !st || !t_series_host || !nseries_host || !reg_val_host || nfine < 1 || !(t2 > t0) || nsave < 0 || cap_series < 1)
+    return fail(c, LRNDE_BADARG, "bad arguments (nfine >= 1, t2 > t0, non-null outputs)");
+  if (mode < LRNDE_MODE_NONE || mode > LRNDE_MODE_BIASED) return fail(c, LRNDE_BADARG, "mode");
+  if (mode != LRNDE_MODE_NONE && !z_local) return fail(c, LRNDE_BADARG, "z_local (the local step's standard-normal draw) is required when regularising");
+  for (int i = 0; i < nsave; ++i)
+    if (!(saveat_host[i] >= t0 && saveat_host[i] <= t2) || (i > 0 && saveat_host[i] < saveat_host[i - 1]))
+      return fail(c, LRNDE_BADARG, "saveat must be ascending and inside tspan");
+  if (!s->node) s->node = new SdeNodeRecord();
+  SdeNodeRecord& r = *s->node;
+  r.valid = false;
+  if ((rc = sde_node_alloc(s, r, B, nfine))) return rc;
+  const int D = c->desc.state_dim;
+  const size_t n = (size_t)B * D;
+  const float h = (t2 - t0) / (float)nfine;
+  int nfe_f = 0, nfe_g = 0;
+  HIPCHK(c, hipMemcpyAsync(r.x, x, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  // the main solve (src/layers/neural_sde.jl:50-72): dt0 <= 0 -> automatic initial dt
+  lrnde_sde_adapt_opts oo = *o;
+  if (!(oo.dt0 > 0.f)) {
+    if ((rc = sde_init_dt(s, r.x, B, t0, t2, oo.abstol, oo.reltol, 0.5f, r.tmp, &oo.dt0))) return rc;
+    nfe_f += 2; nfe_g += 2;
+  }
+  r.im.assign((size_t)nfine, make_int2(0, 0));
+  float* u_end = r.tmp;  // (scratch: the end state is also the record's last slot)
+  rc = sde_solve_adaptive_impl(s, r.x, W, nfine, B, t0, t2, &oo, u_end, st, nullptr, 0, r.rec_u, r.rec_im_dev, r.im.data(), r.rec_cap);
+  if (rc) return rc;
+  const int K = st->naccept;
+  nfe_f += 3 * (st->naccept + st->nreject); nfe_g += 3 * (st->naccept + st->nreject);
+  // sol.t / sol.u as StochasticDiffEq would hold them (UPSTREAM-RECALL): saveat values by linear interpolation inside the
+  // accepted step that contains them; saveat = [] saves every step; save_start < 0: DiffEq's default rule
+  auto tk = [&](int k) { return t0 + (float)r.im[k].x * h; };                       // start of accepted step k
+  auto tk1 = [&](int k) { return (r.im[k].x + r.im[k].y >= nfine) ? t2 : t0 + (float)(r.im[k].x + r.im[k].y) * h; };
+  auto entry_at = [&](float ts) {
+    SdeSeriesEntry e; e.t = ts; e.k = -1; e.theta = 0.f;
+    if (!(ts > t0)) return e;
+    int k = 0;
+    while (k < K - 1 && tk1(k) < ts) ++k;
+    e.k = k;
+    e.theta = (ts >= tk1(k)) ? 1.0f : (ts - tk(k)) / ((float)r.im[k].y * h);
+    return e;
+  };
+  float t1 = t2;
+  std::vector<float> sv;   // the solve's saveat
+  bool needs_correction = false, everystep = false;
+  if (mode == LRNDE_MODE_UNBIASED) {
+    t1 = t1_or_rand;
+    if (!(t1 >= t0 && t1 <= t2)) return fail(c, LRNDE_BADARG, "t1 outside tspan");
+    if (nsave > 0) { sv.assign(saveat_host, saveat_host + nsave); sv.push_back(t1); std::stable_sort(sv.begin(), sv.end()); needs_correction = true; }
+    else { sv = {t1, t2}; }
+  } else if (nsave > 0) sv.assign(saveat_host, saveat_host + nsave);
+  else if (mode == LRNDE_MODE_BIASED) everystep = true;
+  else sv = {t2};
+  bool with_start = save_start > 0;
+  if (save_start < 0) with_start = everystep || (!sv.empty() && sv.front() == t0);   // DiffEq: save_everystep || isempty(saveat) || tspan[1] in saveat
+  std::vector<SdeSeriesEntry> sol;
+  if (with_start) { SdeSeriesEntry e; e.t = t0; e.k = -1; e.theta = 0.f; sol.push_back(e); }
+  if (everystep) {
+    for (int k = 0; k < K; ++k) { SdeSeriesEntry e; e.t = tk1(k); e.k = k; e.theta = 1.0f; sol.push_back(e); }
+  } else {
+    for (float ts : sv) { if (ts == t0 && with_start) continue; sol.push_back(entry_at(ts)); }
+  }
+  if (sol.empty()) return fail(c, LRNDE_BADARG, "the solve saves nothing");
+  SdeSeriesEntry e1; e1.t = t2; e1.k = K - 1; e1.theta = 1.0f;
+  if (mode == LRNDE_MODE_BIASED) {      // :114-115  t1 = rand(rng, sol.t[1:(end - 1)])
+    const int m = (int)sol.size() - 1;
+    if (m < 1) return fail(c, LRNDE_BADARG, ":biased needs at least two saved times");
+    int idx = (int)(t1_or_rand * (float)m);
+    if (idx >= m) idx = m - 1;
+    if (idx < 0) idx = 0;
+    e1 = sol[idx]; t1 = e1.t;
+  } else if (mode == LRNDE_MODE_UNBIASED) {
+    e1 = entry_at(t1);
+  }
+  auto value_of = [&](const SdeSeriesEntry& e, float* out) -> int {
+    const int nb = sde_nb(n);
+    if (e.k < 0) { HIPCHK(c, hipMemcpyAsync(out, r.x, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream)); return LRNDE_OK; }
+    const float* b = r.rec_u + (size_t)e.k * n;
+    if (e.theta == 1.0f) { HIPCHK(c, hipMemcpyAsync(out, b, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream)); return LRNDE_OK; }
+    const float* a = e.k == 0 ? r.x : r.rec_u + (size_t)(e.k - 1) * n;
+    hipLaunchKernelGGL(k_sde_lerp, dim3(nb), dim3(256), 0, c->stream, n, a, b, e.theta, out);
+    HIPCHK(c, hipGetLastError());
+    return LRNDE_OK;
+  };
+  // the local step (:94-98, :116-118): fresh integrator at (sol(t1), t1) on (t1, t2) -> its own initial dt; one Euler-Heun
+  // step with a fresh increment sqrt(dt) z
+  *reg_val_host = 0.f;
+  r.t1 = t1; r.dt_loc = 0.f;
+  if (mode != LRNDE_MODE_NONE) {
+    if (!(t1 < t2)) return fail(c, LRNDE_BADARG, "t1 must lie before the end of tspan");
+    if ((rc = value_of(e1, r.u1))) return rc;
+    float dtl = o->dt0;
+    if (!(dtl > 0.f)) {
+      if ((rc = sde_init_dt(s, r.u1, B, t1, t2, o->abstol, o->reltol, 0.5f, r.tmp, &dtl))) return rc;
+      nfe_f += 2; nfe_g += 2;
+    }
+    dtl = fminf(dtl, t2 - t1);
+    hipLaunchKernelGGL(k_sde_scale, dim3(sde_nb(n)), dim3(256), 0, c->stream, n, z_local, sqrtf(dtl), r.dWloc);
+    float ee = 0.f, rv = 0.f;
+    if ((rc = sde_step_impl(s, 0, r.u1, r.dWloc, B, t1, dtl, o->abstol, o->reltol, o->delta, r.tmp, &ee, &rv))) return rc;
+    *reg_val_host = rv;
+    nfe_f += 3; nfe_g += 3;
+    r.dt_loc = dtl;
+  }
+  // the caller's view: _CorrectedDESolution drops the entries at t1 (src/utils.jl:31-33: `sol.u[t1 .!= sol.t]`)
+  r.series.clear();
+  for (const SdeSeriesEntry& e : sol) if (!(needs_correction && e.t == t1)) r.series.push_back(e);
+  const int ns = (int)r.series.size();
+  *nseries_host = ns;
+  if (ns > cap_series) return fail(c, LRNDE_CAPACITY, "series buffer too small (%d > %d)", ns, cap_series);
+  for (int i = 0; i < ns; ++i) {
+    if ((rc = value_of(r.series[i], u_series + (size_t)i * n))) return rc;
+    t_series_host[i] = r.series[i].t;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (nfe_drift_host) *nfe_drift_host = nfe_f;
+  if (nfe_diffusion_host) *nfe_diffusion_host = nfe_g;
+  if (t1_used_host) *t1_used_host = t1;
+  r.valid = true; r.B = B; r.nfine = nfine; r.K = K; r.mode = mode; r.t0 = t0; r.t2 = t2; r.h = h; r.o = *o; r.W = W;
+  return LRNDE_OK;
+}
+
+int lrnde_sde_node_backward_recorded(lrnde_sde* s, int32_t B, const float* du_series, int32_t nseries, float w_reg, float* dx,
+                                     float* dp_drift, float* dp_diff) {
+  if (!s) return LRNDE_BADARG;
+  lrnde_ctx* c = s->drift; lrnde_ctx* cg = s->diff;
+  int rc = check_ready(c, B);
+  if (rc) return rc;
+  if (!du_series || !dx || !dp_drift || !dp_diff) return fail(c, LRNDE_BADARG, "null pointer");
+  if (!s->node) return fail(c, LRNDE_BADARG, "no forward record (call lrnde_sde_node_forward_record first)");
+  SdeNodeRecord& r = *s->node;
+  if (!r.valid || r.B != B) return fail(c, LRNDE_BADARG, "no forward record for this batch (call lrnde_sde_node_forward_record first)");
+  if (nseries != (int)r.series.size()) return fail(c, LRNDE_BADARG, "%d cotangents for a series of %zu states", nseries, r.series.size());
+  if (cg->stream != c->stream) return fail(c, LRNDE_BADARG, "drift and diffusion contexts must share a stream");
+  const int D = c->desc.state_dim;
+  const size_t n = (size_t)B * D, Pf = lrnde_param_count(&c->desc), Pg2 = lrnde_param_count(&cg->desc);
+  const size_t Pg = (size_t)D * D + (s->diff_bias ? D : 0), goff = (size_t)D * D + D;
+  float* v[13]; float* gpf[2]; float* gpg[2];
+  if ((rc = sde_bwd_ws(s, n, Pf, Pg2, v, 13, gpf, gpg))) return rc;
+  float *du1 = v[0], *L = v[1], *tmp = v[2], *fb2 = v[3], *gb2 = v[4], *dtf = v[5], *dtg = v[6], *du1b = v[7], *Lb = v[8],
+        *up = v[9], *duf = v[10], *dug = v[11], *w = v[12];
+  const int nb = sde_nb(n);
+  HIPCHK(c, hipMemsetAsync(dx, 0, sizeof(float) * n, c->stream));   // dx doubles as ub, the cotangent of the current step's end state
+  HIPCHK(c, hipMemsetAsync(dp_drift, 0, sizeof(float) * Pf, c->stream));
+  HIPCHK(c, hipMemsetAsync(dp_diff, 0, sizeof(float) * Pg, c->stream));
+  for (int k = r.K - 1; k >= 0; --k) {
+    // cotangents of the series values taken inside step k: theta of each onto the step's end state ...
+    for (int j = 0; j < nseries; ++j)
+      if (r.series[j].k == k && r.series[j].theta != 0.f)
+        hipLaunchKernelGGL(k_sde_axpy, dim3(nb), dim3(256), 0, c->stream, n, dx, du_series + (size_t)j * n, r.series[j].theta);
+    const int i0 = r.im[k].x, m = r.im[k].y;
+    const float t = r.t0 + (float)i0 * r.h, dt = (float)m * r.h;
+    const float* u = (k == 0) ? r.x : r.rec_u + (size_t)(k - 1) * n;
+    hipLaunchKernelGGL(k_sde_dw, dim3(nb), dim3(256), 0, c->stream, n, r.W + (size_t)i0 * n, r.W + (size_t)(i0 + m) * n, w);
+    if ((rc = lrnde_rhs(c, u, t, B, du1))) return rc;
+    if ((rc = lrnde_rhs(cg, u, t, B, L))) return rc;
+    hipLaunchKernelGGL(k_sdeb_seed, dim3(nb), dim3(256), 0, c->stream, n, u, (const float*)du1, (const float*)L, (const float*)w, (const float*)dx, dt, tmp, fb2, gb2);
+    if ((rc = launch_vjp(c, tmp, nullptr, 0.f, 0.f, t + dt, fb2, B, dtf, gpf[0]))) return rc;
+    if ((rc = launch_vjp(cg, tmp, nullptr, 0.f, 0.f, t + dt, gb2, B, dtg, gpg[0]))) return rc;
+    hipLaunchKernelGGL(k_sdeb_mid, dim3(nb), dim3(256), 0, c->stream, n, (const float*)dtf, (const float*)dtg, (const float*)w, (const float*)dx, dt, du1b, Lb, up);
+    if ((rc = launch_vjp(c, u, nullptr, 0.f, 0.f, t, du1b, B, duf, gpf[1]))) return rc;
+    if ((rc = launch_vjp(cg, u, nullptr, 0.f, 0.f, t, Lb, B, dug, gpg[1]))) return rc;
+    hipLaunchKernelGGL(k_sdeb_end, dim3(nb), dim3(256), 0, c->stream, n, (const float*)up, (const float*)duf, (const float*)dug, dx);
+    hipLaunchKernelGGL(k_sdeb_acc, dim3(sde_nb(Pf)), dim3(256), 0, c->stream, Pf, dp_drift, (const float*)gpf[0], (const float*)gpf[1]);
+    hipLaunchKernelGGL(k_sdeb_acc, dim3(sde_nb(Pg)), dim3(256), 0, c->stream, Pg, dp_diff, (const float*)(gpg[0] + goff), (const float*)(gpg[1] + goff));
+    // ... and 1 - theta onto its start state
+    for (int j = 0; j < nseries; ++j)
+      if (r.series[j].k == k && r.series[j].theta != 1.0f)
+        hipLaunchKernelGGL(k_sde_axpy, dim3(nb), dim3(256), 0, c->stream, n, dx, du_series + (size_t)j * n, 1.0f - r.series[j].theta);
+    HIPCHK(c, hipGetLastError());
+  }
+  for (int j = 0; j < nseries; ++j)   // a saved start value is the input itself
+    if (r.series[j].k < 0) hipLaunchKernelGGL(k_sde_axpy, dim3(nb), dim3(256), 0, c->stream, n, dx, du_series + (size_t)j * n, 1.0f);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // the regulariser (w.r.t. the parameters only: the local step's integrator is a constant of the tape, neural_sde.jl:42)
+  if (r.mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
+    float rv = 0.f;
+    if ((rc = lrnde_sde_euler_heun_reg_grad(s, r.u1, r.dWloc, B, r.t1, r.dt_loc, r.o.abstol, r.o.reltol, r.o.delta, r.gdr, r.gdf, &rv))) return rc;
+    hipLaunchKernelGGL(k_sde_axpy, dim3(sde_nb(Pf)), dim3(256), 0, c->stream, Pf, dp_drift, (const float*)r.gdr, w_reg);
+    hipLaunchKernelGGL(k_sde_axpy, dim3(sde_nb(Pg)), dim3(256), 0, c->stream, Pg, dp_diff, (const float*)r.gdf, w_reg);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return LRNDE_OK;
+}
+
+}  // extern "C"

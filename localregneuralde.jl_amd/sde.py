@@ -1,11 +1,12 @@
 """NeuralDSDE mirror (src/layers/neural_sde.jl) on the liblrnde SDE entry points.
 
-What is built: the adaptive Euler-Heun local step with its error estimate
-(`_perform_step(::LambaEulerHeunConstantCache)`, src/perform_step.jl:172-206) on the device, and a
-NeuralDSDE-shaped forward that integrates with that step on a FIXED grid with caller-visible
-Brownian increments (BASELINE config 5).  The four-stage SRI step SOSRI runs (`_perform_step(::FourStageSRIConstantCache)`, :49-106) is on
-the device too (`SdeHandle.sri_step`) with a caller-supplied tableau: SOSRI's coefficients and its RSWM adaptive
-noise process live in un-vendored StochasticDiffEq and are not restated, so `solver="SOSRI"` still raises.
+The layer runs what the reference's runs (src/layers/neural_sde.jl:50-123): an ADAPTIVE solve — the Lamba Euler-Heun step
+(`_perform_step(::LambaEulerHeunConstantCache)`, src/perform_step.jl:172-206) under a PI controller on its error estimate,
+on a Brownian path drawn up front on a uniform grid (`lrnde_sde_node_forward_record`) — the local step at (sol(t1), t1) for
+reg_val, user `saveat` with the `_CorrectedDESolution` filter, and the pullback as the reverse sweep over the recorded
+accepted steps (`lrnde_sde_node_backward_recorded`).  `adaptive=False` keeps the fixed-grid integrator of rounds 1-2 (also the
+only mode of the Milstein and four-stage SRI steps, :108-170 and :49-106).  SOSRI's tableau and its RSWM noise process live in
+un-vendored StochasticDiffEq and are not restated: `solver="SOSRI"` raises, `solver="SRI"` takes the tableau from the caller.
 """
 import copy
 import ctypes as C
@@ -124,6 +125,47 @@ class SdeHandle:
     def _pcounts(self):
         return self._keep[0].numel(), self._keep[1].numel()
 
+    def node_forward_record(self, x, W, t0, t2, abstol, reltol, mode="unbiased", t1_or_rand=0.5, z_local=None, saveat=(),
+                            save_start=-1, delta=1.0 / 6.0, dt0=0.0, gamma=0.9, qmin=0.2, qmax=1.125, beta1=7.0 / 50.0,
+                            beta2=2.0 / 25.0, maxiters=10000):
+        """the NeuralDSDE layer forward (lrnde_sde_node_forward_record): adaptive solve on the path W ((nfine+1, B, D), W[0] = 0),
+        sol.u / sol.t as the layer's caller sees them, reg_val of the local step; keeps the record for one
+        `node_backward_recorded`.  dt0 = 0: automatic initial dt."""
+        nfine = int(W.shape[0]) - 1
+        B = x.numel() // self.D
+        W = W.contiguous()
+        sv = np.ascontiguousarray(saveat, dtype=np.float32)
+        o = L.SdeAdaptOpts(float(abstol), float(reltol), float(delta), float(dt0), float(gamma), float(qmin), float(qmax),
+                           float(beta1), float(beta2), int(maxiters))
+        cap = int(sv.size) + 3 + (nfine + 1 if (mode == "biased" and not sv.size) else 0)
+        us = torch.empty((cap,) + tuple(x.shape), dtype=torch.float32, device=x.device)
+        ts = np.empty(cap, dtype=np.float32)
+        ns, reg, nf, ng, st, t1u = C.c_int32(), C.c_float(), C.c_int32(), C.c_int32(), L.Stats(), C.c_float()
+        if z_local is not None:
+            z_local = z_local.contiguous()
+        self._chk(L.lib.lrnde_sde_node_forward_record(
+            self._h, _dev_ptr(x, "x", self.D), _dev_ptr(W, "W"), nfine, B, float(t0), float(t2), C.byref(o), L.MODE[mode],
+            float(t1_or_rand), None if z_local is None else _dev_ptr(z_local, "z_local", self.D), int(save_start),
+            sv.ctypes.data_as(C.POINTER(C.c_float)) if sv.size else None, int(sv.size), C.c_void_p(us.data_ptr()),
+            ts.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(ns), C.byref(reg), C.byref(nf), C.byref(ng), C.byref(st), C.byref(t1u)))
+        self._node_keep = (W, x)   # the record refers to the caller's path: keep it alive until the backward
+        n = int(ns.value)
+        return dict(u=us[:n], t=ts[:n].copy(), u_end=us[n - 1], reg_val=np.float32(reg.value), nfe_drift=int(nf.value),
+                    nfe_diffusion=int(ng.value), stats=st.asdict(), t1=np.float32(t1u.value))
+
+    def node_backward_recorded(self, du_series, w_reg=0.0):
+        """pullback of sum_j <du_j, sol.u[j]> + w_reg * reg_val from the record of `node_forward_record`"""
+        du_series = du_series.contiguous()
+        nser = int(du_series.shape[0])
+        B = du_series[0].numel() // self.D
+        nf, ng = self._pcounts()
+        dx = torch.empty_like(du_series[0])
+        dpf = torch.empty(nf, dtype=torch.float32, device=dx.device)
+        dpg = torch.empty(ng, dtype=torch.float32, device=dx.device)
+        self._chk(L.lib.lrnde_sde_node_backward_recorded(self._h, B, _dev_ptr(du_series, "du_series", self.D), nser, float(w_reg),
+                                                         _dev_ptr(dx, "dx"), C.c_void_p(dpf.data_ptr()), C.c_void_p(dpg.data_ptr())))
+        return dict(dx=dx, dp_drift=dpf, dp_diff=dpg)
+
     def solve_fixed_backward(self, u0, u_traj, dW, t0, dt, du_end):
         """pullback of solve_fixed (Euler-Heun) for <du_end, u_traj[-1]>: dict(dx, dp_drift, dp_diff)"""
         nsteps = int(dW.shape[0])
@@ -153,10 +195,13 @@ class SdeHandle:
 
 class NeuralDSDE:
     """`(sol, st) = nsde(x, ps, st)`; ps = dict(drift=flat, diffusion=[vec(Wg); bg]).
-    src/layers/neural_sde.jl:1-123 with a fixed-grid Euler-Heun integrator (see module docstring)."""
+    src/layers/neural_sde.jl:1-123.  Default (solver="EulerHeun", adaptive=True): the ADAPTIVE solve on a Brownian path of
+    `nfine` grid intervals drawn from st["rng"] (or given as `noise=` / `path=`), kwargs `abstol`, `reltol`, `saveat`, `save_start`
+    as the reference's; `adaptive=False` (and the Milstein / SRI steps): the fixed grid of `nsteps` steps."""
 
     def __init__(self, drift, diffusion, *, solver="EulerHeun", sensealg=None, tspan=(0.0, 1.0),
-                 regularize="unbiased", maxiters=1000, nsteps=20, delta=1.0 / 6.0, tableau=None, **kwargs):
+                 regularize="unbiased", maxiters=1000, nsteps=20, delta=1.0 / 6.0, tableau=None, adaptive=None, nfine=256,
+                 dt0=0.0, **kwargs):
         regularize = _sym(regularize)
         _check_valid_regularize(regularize)
         if solver in ("SRI", "FourStageSRI"):
@@ -177,8 +222,13 @@ class NeuralDSDE:
             raise ValueError("drift and diffusion state sizes differ")
         self.tspan = (np.float32(tspan[0]), np.float32(tspan[1]))
         self.regularize, self.maxiters, self.nsteps, self.delta = regularize, int(maxiters), int(nsteps), float(delta)
+        self.adaptive = (self.solver == "EulerHeun") if adaptive is None else bool(adaptive)
+        if self.adaptive and self.solver != "EulerHeun":
+            raise NotImplementedError("the adaptive solve is built on the Euler-Heun step (src/perform_step.jl:172-206)")
+        self.nfine, self.dt0 = int(nfine), float(dt0)
         self.kwargs = dict(kwargs)
         self._handle = None
+        self._last_adaptive = None
 
     def initialstates(self, rng):
         rng.standard_normal()  # :23
@@ -190,7 +240,44 @@ class NeuralDSDE:
             self._handle = SdeHandle(self.desc)
         return self._handle
 
-    def __call__(self, x, ps, st, noise=None):
+    def _draw_path(self, rng, shape, device):
+        """W on the uniform grid (nfine + 1, B, D), W[0] = 0, and the local step's standard-normal draw, from the host stream"""
+        t0, t2 = self.tspan
+        h = np.float32((t2 - t0) / np.float32(self.nfine))
+        inc = rng.standard_normal((self.nfine,) + tuple(shape)).astype(np.float32) * np.float32(np.sqrt(h))
+        W = np.concatenate([np.zeros((1,) + tuple(shape), np.float32), np.cumsum(inc, axis=0, dtype=np.float32)], axis=0)
+        z = rng.standard_normal(tuple(shape)).astype(np.float32)
+        return torch.from_numpy(W).to(device), torch.from_numpy(z).to(device)
+
+    def _call_adaptive(self, x, ps, st, path=None, z_local=None):
+        h = self.handle()
+        h.set_params(ps["drift"], ps["diffusion"])
+        t0, t2 = self.tspan
+        abstol, reltol = self.kwargs.get("abstol", 1e-2), self.kwargs.get("reltol", 1e-2)
+        rng = copy.deepcopy(st["rng"])
+        if path is None:
+            path, z_draw = self._draw_path(rng, x.shape, x.device)
+            z_local = z_draw if z_local is None else z_local
+        else:
+            path = torch.as_tensor(path, dtype=torch.float32).to(x.device)
+            if z_local is None:
+                z_local = torch.from_numpy(rng.standard_normal(tuple(x.shape)).astype(np.float32)).to(x.device)
+        mode = self.regularize if st["training"] else "none"
+        r01 = np.float32(rng.random(dtype=np.float32)) if mode != "none" else np.float32(0)
+        t1_or_rand = np.float32(r01 * (t2 - t0) + t0) if mode == "unbiased" else r01     # :92 / :114
+        saveat = self.kwargs.get("saveat", ())
+        r = h.node_forward_record(x, path, t0, t2, abstol, reltol, mode=mode, t1_or_rand=float(t1_or_rand), z_local=z_local,
+                                  saveat=() if saveat is None else saveat, save_start=int(self.kwargs.get("save_start", -1)),
+                                  delta=self.delta, dt0=self.dt0, maxiters=self.maxiters)
+        self._last_adaptive = dict(nseries=int(r["u"].shape[0]), mode=mode)
+        sol = ODESolution([r["u"][i] for i in range(r["u"].shape[0])], [np.float32(t) for t in r["t"]], r["nfe_drift"])
+        sol.stats = r["stats"]
+        return sol, dict(drift=st["drift"], diffusion=st["diffusion"], nfe_drift=r["nfe_drift"], nfe_diffusion=r["nfe_diffusion"],
+                         reg_val=r["reg_val"], rng=rng, training=st["training"])
+
+    def __call__(self, x, ps, st, noise=None, path=None, z_local=None):
+        if self.adaptive:
+            return self._call_adaptive(x, ps, st, path=path if path is not None else noise, z_local=z_local)
         h = self.handle()
         h.set_params(ps["drift"], ps["diffusion"])
         t0, t2 = self.tspan
@@ -257,6 +344,8 @@ class NeuralDSDE:
         w.r.t. the parameters only (info['dx_reg'] is None: `gs_x === nothing` in the reference)."""
         if self.solver != "EulerHeun":
             raise NotImplementedError("the gradient path is built for the Euler-Heun step (src/perform_step.jl:172-206)")
+        if self.adaptive:
+            return self.pullback_series(x, ps, st, None, du_end=du_end, w_reg=w_reg, path=noise)
         sol, st2 = self(x, ps, st, noise=noise)
         h = self.handle()
         fs = self._last_solve
@@ -270,3 +359,15 @@ class NeuralDSDE:
             dpf = dpf + np.float32(w_reg) * rg["dp_drift"]
             dpg = dpg + np.float32(w_reg) * rg["dp_diff"]
         return bw["dx"], dict(drift=dpf, diffusion=dpg), dict(sol=sol, st=st2, dx_reg=None)
+
+    def pullback_series(self, x, ps, st, du_series, du_end=None, w_reg=0.0, path=None, z_local=None):
+        """adaptive layer: pullback of  sum_j <du_series[j], sol.u[j]> + w_reg * reg_val  (du_end alone = a cotangent on
+        sol.u[end], what `diffeqsol_to_array` passes back).  The forward is re-run with the same draws; the backward is the
+        reverse sweep over its recorded accepted steps (lrnde_sde_node_backward_recorded)."""
+        sol, st2 = self._call_adaptive(x, ps, st, path=path, z_local=z_local)
+        ns = self._last_adaptive["nseries"]
+        if du_series is None:
+            du_series = torch.zeros((ns,) + tuple(x.shape), dtype=torch.float32, device=x.device)
+            du_series[ns - 1] = du_end
+        bw = self.handle().node_backward_recorded(du_series, w_reg=w_reg)
+        return bw["dx"], dict(drift=bw["dp_drift"], diffusion=bw["dp_diff"]), dict(sol=sol, st=st2, dx_reg=None)

@@ -338,6 +338,144 @@ def euler_heun_step(drift, diffusion, uprev, dW, t, dt, abstol, reltol, delta):
     return dict(u=u, eest=np.float32(ee.value), reg_val=np.float32(rv.value))
 
 
+# ---------------------------------------------------------------------------------------------
+# NeuralDSDE layer (src/layers/neural_sde.jl:50-123): the oracle counterpart of lrnde_sde_node_forward_record.  The step is
+# the C oracle's lro_euler_heun_step; around it, in float32 numpy, the loop StochasticDiffEq runs (UPSTREAM-RECALL: that
+# package is neither vendored nor readable here — "parity unpinned" for everything in this block but the step): automatic
+# initial dt (sde_determine_initdt: the ODE heuristic with the diffusion entering as +-3 g), the PI controller on EEst with
+# steps of whole grid intervals of the caller's Brownian path, saveat values by the linear interpolant, the layer's saveat /
+# t1 rules (src/layers/neural_ode.jl:102-116, neural_sde.jl:88-123) and the local step at (sol(t1), t1).
+# ---------------------------------------------------------------------------------------------
+def sde_init_dt(drift, diffusion, u, t, tend, abstol, reltol, order=0.5):
+    f32 = np.float32
+    u = _f32(u); abstol, reltol, t, tend = f32(abstol), f32(reltol), f32(t), f32(tend)
+    n = u.size
+    rms = lambda r: f32(np.sqrt(np.sum((r * r).astype(np.float64)) / n))
+    sk = abstol + np.abs(u) * reltol
+    f0, g0 = drift.rhs(u, t), diffusion.rhs(u, t)
+    G0 = f32(3) * g0
+    d0 = rms(u / sk)
+    d1 = rms(np.maximum(np.abs(f0 + G0), np.abs(f0 - G0)) / sk)
+    dtmax = f32(tend - t)
+    dt0 = f32(1e-6) if (float(d0) < 1e-5 or float(d1) < 1e-5) else f32(f32(d0 / d1) / f32(100))
+    dt0 = min(dt0, dtmax)
+    u1 = (u + dt0 * f0).astype(f32)
+    f1, g1 = drift.rhs(u1, f32(t + dt0)), diffusion.rhs(u1, f32(t + dt0))
+    G1 = f32(3) * g1
+    dg = np.maximum(np.abs(G0 - G1), np.abs(G0 + G1))
+    df = f1 - f0
+    d2 = f32(rms(np.maximum(np.abs(df + dg), np.abs(df - dg)) / sk) / dt0)
+    md = max(d1, d2)
+    if float(md) <= 1e-15:
+        dt1 = max(f32(1e-6), f32(dt0 * f32(1e-3)))
+    else:
+        e = f32(f32(-(f32(2) + f32(np.log10(float(md))))) / f32(f32(order) + f32(0.5)))
+        dt1 = f32(10.0 ** float(e))
+    return min(f32(f32(100) * dt0), dt1, dtmax)
+
+
+def sde_node_forward(drift, diffusion, x, W, t0, t2, abstol, reltol, mode="unbiased", t1_or_rand=0.5, z_local=None, saveat=(),
+                     save_start=-1, delta=1.0 / 6.0, dt0=0.0, gamma=0.9, qmin=0.2, qmax=1.125, beta1=7.0 / 50.0, beta2=2.0 / 25.0,
+                     maxiters=10000):
+    """dict(u (nseries,B,D), t, reg_val, nfe_drift, nfe_diffusion, naccept, nreject, steps [(i, m)], t1, dt_local, u1, dW_local)"""
+    f32 = np.float32
+    x = _f32(x); W = _f32(W)
+    nfine = W.shape[0] - 1
+    t0, t2 = f32(t0), f32(t2)
+    h = f32(f32(t2 - t0) / f32(nfine))
+    fp = lambda a, b: f32(lib().lro_fastpow(float(a), float(b)))
+    gamma, qmin, qmax, beta1, beta2 = f32(gamma), f32(qmin), f32(qmax), f32(beta1), f32(beta2)
+    nff = ngg = 0
+    d0 = f32(dt0)
+    if not d0 > 0:
+        d0 = sde_init_dt(drift, diffusion, x, t0, t2, abstol, reltol); nff += 2; ngg += 2
+    i, m, qold, u, dtc = 0, max(int(f32(d0 / h)), 1), f32(1e-4), x, f32(d0)
+    steps, states, nacc, nrej, iters = [], [], 0, 0, 0
+    while i < nfine:
+        m = min(m, nfine - i)
+        iters += 1
+        assert iters <= maxiters
+        t, dt = f32(t0 + f32(i) * h), f32(f32(m) * h)
+        r = euler_heun_step(drift, diffusion, u, (W[i + m] - W[i]).astype(f32), t, dt, abstol, reltol, delta)
+        ee = r["eest"]
+        q = f32(f32(1) / qmax) if ee == 0 else max(f32(f32(1) / qmax), min(f32(f32(1) / qmin), f32(f32(fp(ee, beta1) / fp(qold, beta2)) / gamma)))
+        dtc = f32((max(dtc, dt) if ee <= 1 else dt) / q)   # the proposal stays a real number; the step is its floor on the grid
+        mnew = max(int(f32(dtc / h)), 1)
+        if ee <= 1:
+            nacc += 1; steps.append((i, m)); states.append(r["u"])
+            qold, i, u, m = max(ee, f32(1e-4)), i + m, r["u"], mnew
+        else:
+            nrej += 1
+            assert m > 1, "DtLessThanMin: the path's grid cannot be refined further"
+            m = mnew if mnew < m else m - 1
+    nff += 3 * (nacc + nrej); ngg += 3 * (nacc + nrej)
+    K = len(steps)
+    tk = lambda k: f32(t0 + f32(steps[k][0]) * h)
+    tk1 = lambda k: t2 if steps[k][0] + steps[k][1] >= nfine else f32(t0 + f32(steps[k][0] + steps[k][1]) * h)
+
+    def entry(ts):
+        ts = f32(ts)
+        if not ts > t0:
+            return (ts, -1, f32(0))
+        k = 0
+        while k < K - 1 and tk1(k) < ts:
+            k += 1
+        th = f32(1) if ts >= tk1(k) else f32(f32(ts - tk(k)) / f32(f32(steps[k][1]) * h))
+        return (ts, k, th)
+
+    def value(e):
+        ts, k, th = e
+        if k < 0:
+            return x
+        if th == 1:
+            return states[k]
+        a = x if k == 0 else states[k - 1]
+        return (f32(f32(1) - th) * a + th * states[k]).astype(f32)
+
+    sv_user = [f32(v) for v in saveat]
+    needs_corr = everystep = False
+    t1 = t2
+    if mode == "unbiased":
+        t1 = f32(t1_or_rand)
+        if sv_user:
+            sv = sorted(sv_user + [t1]); needs_corr = True
+        else:
+            sv = [t1, t2]
+    elif sv_user:
+        sv = sv_user
+    elif mode == "biased":
+        sv, everystep = [], True
+    else:
+        sv = [t2]
+    with_start = save_start > 0 if save_start >= 0 else (everystep or (len(sv) > 0 and sv[0] == t0))
+    sol = [(t0, -1, f32(0))] if with_start else []
+    if everystep:
+        sol += [(tk1(k), k, f32(1)) for k in range(K)]
+    else:
+        sol += [entry(ts) for ts in sv if not (ts == t0 and with_start)]
+    e1 = None
+    if mode == "biased":
+        mm = len(sol) - 1
+        idx = min(max(int(f32(t1_or_rand) * f32(mm)), 0), mm - 1)
+        e1 = sol[idx]; t1 = e1[0]
+    elif mode == "unbiased":
+        e1 = entry(t1)
+    reg, dtl, u1, dwl = f32(0), f32(0), None, None
+    if mode != "none":
+        u1 = value(e1)
+        dtl = f32(dt0)
+        if not dtl > 0:
+            dtl = sde_init_dt(drift, diffusion, u1, t1, t2, abstol, reltol); nff += 2; ngg += 2
+        dtl = min(dtl, f32(t2 - t1))
+        dwl = (f32(np.sqrt(dtl)) * _f32(z_local)).astype(f32)
+        reg = euler_heun_step(drift, diffusion, u1, dwl, t1, dtl, abstol, reltol, delta)["reg_val"]
+        nff += 3; ngg += 3
+    series = [e for e in sol if not (needs_corr and e[0] == t1)]
+    return dict(u=np.stack([value(e) for e in series]), t=np.array([e[0] for e in series], f32), reg_val=reg, nfe_drift=nff,
+                nfe_diffusion=ngg, naccept=nacc, nreject=nrej, steps=steps, t1=t1, dt_local=dtl, u1=u1, dW_local=dwl, series=series,
+                dt0=d0)
+
+
 def glorot_mlp_params(D, H, time_dep=True, seed=0):
     """Lux Dense init: W ~ glorot_uniform = (rand-0.5)*sqrt(24/(in+out)), b = 0
     (SURVEY.md §3.5); numpy stream (the Julia RNG streams cannot be reproduced here)."""

@@ -333,7 +333,7 @@ def test_neural_dsde_forward_behaviour(oracle, gpu_pkg):
     pd, pg, drift, diff = _sde_fields(oracle, D, H, seed=3)
     x = np.random.default_rng(1).standard_normal((B, D)).astype(np.float32)
     mk = lambda reg: gpu_pkg.NeuralDSDE(gpu_pkg.Chain(gpu_pkg.Dense(D, H, "tanh"), gpu_pkg.Dense(H, D)), gpu_pkg.Dense(D, D),
-                                        regularize=reg, nsteps=n, abstol=0.14, reltol=0.14)
+                                        regularize=reg, nsteps=n, abstol=0.14, reltol=0.14, adaptive=False)
     noise = (np.random.default_rng(2).standard_normal((n + 1, B, D)) * np.sqrt(1.0 / n)).astype(np.float32)
     ps = dict(drift=pd, diffusion=pg)
     outs = {}

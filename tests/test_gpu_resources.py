@@ -121,7 +121,7 @@ def test_conv_and_sde_handles_release_their_memory(gpu_pkg):
         assert np.isfinite(loss)
         node._handle.close()
         sde = P.NeuralDSDE(P.Chain(P.Dense(Ds, Hs, "tanh"), P.Dense(Hs, Ds)), P.Dense(Ds, Ds), regularize="unbiased", nsteps=8,
-                           abstol=0.14, reltol=0.14)
+                           abstol=0.14, reltol=0.14, nfine=32)
         sts = sde.initialstates(np.random.default_rng(i))
         dx, dps, info = sde.pullback(xs, dict(drift=pd, diffusion=pg), sts, torch.ones_like(xs), w_reg=1.0)
         assert torch.isfinite(dx).all()

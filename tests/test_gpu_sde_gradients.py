@@ -113,7 +113,7 @@ def test_neural_dsde_pullback_behaviour(gpu_pkg, regularize):
     pd, pg = _params(D, H, 5)
     x = np.random.default_rng(2).standard_normal((B, D)).astype(np.float32)
     node = P.NeuralDSDE(P.Chain(P.Dense(D, H, "tanh"), P.Dense(H, D)), P.Dense(D, D), regularize=regularize, nsteps=n,
-                        abstol=0.14, reltol=0.14)
+                        abstol=0.14, reltol=0.14, adaptive=False)
     st = node.initialstates(np.random.default_rng(0))
     ps = dict(drift=pd, diffusion=pg)
     xd = torch.from_numpy(x).cuda()
@@ -156,7 +156,7 @@ def test_adaptive_euler_heun_solve_equals_the_oracle_step_loop(oracle, gpu_pkg, 
     got = hd.solve_adaptive(torch.from_numpy(x).cuda(), torch.from_numpy(W).cuda(), 0.0, 1.0, tol, tol, dt0=8 * float(h))
     # the same loop on the host over the oracle's step
     gamma, qmin, qmax, b1, b2 = f32(0.9), f32(0.2), f32(1.125), f32(7.0 / 50.0), f32(2.0 / 25.0)
-    i, m, qold, u = 0, 8, f32(1e-4), x
+    i, m, qold, u, dtc = 0, 8, f32(1e-4), x, f32(8 * float(h))
     rows = []
     while i < nfine:
         m = min(m, nfine - i)
@@ -167,7 +167,8 @@ def test_adaptive_euler_heun_solve_equals_the_oracle_step_loop(oracle, gpu_pkg, 
         q = f32(1) / qmax if ee == 0 else max(f32(1) / qmax, min(f32(1) / qmin, f32(f32(R.fastpow(ee, b1) / R.fastpow(qold, b2)) / gamma)))
         acc = bool(ee <= 1)
         rows.append((t, dt, ee, acc))
-        mnew = max(int(f32(f32(dt / q) / h)), 1)
+        dtc = f32((max(dtc, dt) if acc else dt) / q)    # the proposal is kept as a real number (SdeCtl::dtc)
+        mnew = max(int(f32(dtc / h)), 1)
         if acc:
             qold, i, u, m = max(ee, f32(1e-4)), i + m, r["u"], mnew
         else:
