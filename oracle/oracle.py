@@ -456,12 +456,14 @@ def sde_node_forward(drift, diffusion, x, W, t0, t2, abstol, reltol, mode="unbia
     e1 = None
     if mode == "biased":
         mm = len(sol) - 1
+        assert mm >= 1, ":biased needs at least two saved times"
         idx = min(max(int(f32(t1_or_rand) * f32(mm)), 0), mm - 1)
         e1 = sol[idx]; t1 = e1[0]
     elif mode == "unbiased":
         e1 = entry(t1)
     reg, dtl, u1, dwl = f32(0), f32(0), None, None
     if mode != "none":
+        assert t1 < t2, "t1 must lie before the end of tspan"
         u1 = value(e1)
         dtl = f32(dt0)
         if not dtl > 0:

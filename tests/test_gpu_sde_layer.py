@@ -187,3 +187,37 @@ def test_layer_draws_are_reproducible_and_fixed_grid_mode_remains(gpu_pkg):
     fixed = P.NeuralDSDE(P.Chain(P.Dense(D, H, "tanh"), P.Dense(H, D)), P.Dense(D, D), abstol=0.14, reltol=0.14, adaptive=False, nsteps=8)
     c, sc = fixed(x, ps, fixed.initialstates(np.random.default_rng(0)))
     assert sc["nfe_drift"] == 3 * 8 + 3 and torch.isfinite(c.u[-1]).all()
+
+
+import os as _os
+
+
+@pytest.mark.parametrize("seed", list(range(int(_os.environ.get("LRNDE_SOAK_SEEDS", "8")))))
+def test_adaptive_layer_soak_bit_exact(oracle, gpu_pkg, seed):
+    """random shape (inside and outside the one-launch kernel's range), batch, grid, tolerance, mode, saveat list, save_start, t1
+    draw, explicit or automatic initial dt: forward == the oracle loop bit for bit; LRNDE_SOAK_SEEDS=N runs N seeds"""
+    rng = np.random.default_rng(90_000 + seed)
+    D = int(rng.choice([1, 2, 7, 16, 32, 33, 48, 64, 70]))
+    H = int(rng.choice([3, 16, 40, 64, 100, 113, 128, 130]))
+    B = int(rng.choice([1, 3, 16, 17, 64, 130]))
+    nfine = int(rng.choice([16, 64, 200]))
+    tol = float(rng.choice([0.14, 0.05, 0.5]))
+    mode = str(rng.choice(["unbiased", "biased", "none"]))
+    act = str(rng.choice(["tanh", "gelu"]))
+    nsv = int(rng.integers(0, 4))
+    saveat = tuple(sorted(float(f32(v)) for v in rng.random(nsv))) if nsv else ()
+    if nsv and rng.random() < 0.5:
+        saveat = saveat + (1.0,)
+    save_start = int(rng.choice([-1, 0, 1]))
+    dt0 = float(rng.choice([0.0, 0.0, 0.05, 0.3]))
+    h, drift, diff, pd, pg, x, W, z = _setup(gpu_pkg, oracle, D, H, B, nfine, seed=seed, act=act, scale=float(rng.choice([1.0, 2.5])))
+    kw = dict(mode=mode, t1_or_rand=float(f32(rng.random())), saveat=saveat, save_start=save_start, dt0=dt0)
+    what = f"seed={seed} D={D} H={H} B={B} nfine={nfine} tol={tol} {act} {kw}"
+    try:
+        ref = oracle.sde_node_forward(drift, diff, x, W, 0.0, 1.0, tol, tol, z_local=z, **kw)
+    except AssertionError as e:    # the oracle loop's own DtLessThanMin / ":biased needs two saved times": the library must refuse too
+        with pytest.raises(gpu_pkg.LrndeError):
+            h.node_forward_record(torch.from_numpy(x).cuda(), torch.from_numpy(W).cuda(), 0.0, 1.0, tol, tol, z_local=torch.from_numpy(z).cuda(), **kw)
+        return
+    got = h.node_forward_record(torch.from_numpy(x).cuda(), torch.from_numpy(W).cuda(), 0.0, 1.0, tol, tol, z_local=torch.from_numpy(z).cuda(), **kw)
+    _check_forward(got, ref, what)
