@@ -393,6 +393,15 @@ int lrnde_sde_node_forward_record(lrnde_sde* sde, const float* x, const float* W
 int lrnde_sde_node_backward_recorded(lrnde_sde* sde, int32_t B, const float* du_series, int32_t nseries, float w_reg, float* dx,
                                      float* dp_drift, float* dp_diff);
 
+/* Which recorded forward a handle's record belongs to: the count of successful lrnde_*_forward_record* calls on it (0 = no
+ * usable record).  A binding's pullback closure keeps the value it saw after ITS forward and compares before calling
+ * lrnde_*_backward_recorded*: a later forward on the same handle (an evaluation pass between forward and pullback, nested
+ * AD) has replaced the record, and the backward would silently differentiate the other input.  julia/LRNDELayer.jl re-runs
+ * its forward in that case. */
+int lrnde_record_generation(lrnde_ctx* ctx, uint64_t* gen_host);
+int lrnde_conv_record_generation(lrnde_conv* c, uint64_t* gen_host);
+int lrnde_sde_record_generation(lrnde_sde* sde, uint64_t* gen_host);
+
 /* `_perform_step(integrator, cache::FourStageSRIConstantCache, p)`, src/perform_step.jl:49-106 — the step the
  * reference's default SDE solver SOSRI runs — diagonal noise: four drift and four diffusion evaluations, the
  * increments dW and dZ of the caller's noise process (device, B x D each), u, EEst from the 7-argument

@@ -10,9 +10,13 @@
 module LRNDEBackend
 
 import ChainRulesCore
+import Libdl
 using ChainRulesCore: NoTangent
 
 const lib = get(ENV, "LRNDE_LIB", "liblrnde.so")
+# entry points chosen at run time (a Symbol in a variable): `ccall((name, lib), ...)` needs a constant tuple, so these go
+# through dlsym
+sym(name::Symbol) = Libdl.dlsym(Libdl.dlopen(lib), name)
 
 # ---- structs of include/lrnde.h ----
 struct ModelDesc; state_dim::Int32; hidden_dim::Int32; time_dep::Int32; act::Int32; end
@@ -54,7 +58,7 @@ const DTYPE = Dict(:f32 => Int32(0), :bf16 => Int32(1), :f32_split => Int32(2))
 
 function check(ctx, rc; last_error=:lrnde_last_error)
     rc == 0 && return nothing
-    msg = unsafe_string(ccall((last_error, lib), Cstring, (Ptr{Cvoid},), ctx))
+    msg = unsafe_string(ccall(sym(last_error), Cstring, (Ptr{Cvoid},), ctx))
     rc == 4 ? throw(ArgumentError(msg)) : error("lrnde status $rc: $msg")
 end
 nbatch(x) = Int32(size(x, ndims(x)))
@@ -151,7 +155,7 @@ end
 function conv_node_forward(ctx, x, t0, t2, opts::SolveOpts, mode::Symbol, reg_type::Symbol, t1_or_rand; record=false)
     u_end = similar(x); reg = Ref{Float32}(); nfe = Ref{Int32}(); st = Stats(); t1 = Ref{Float32}()
     f = record ? :lrnde_conv_node_forward_record : :lrnde_conv_node_forward
-    conv_check(ctx, ccall((f, lib), Cint,
+    conv_check(ctx, ccall(sym(f), Cint,
         (Ptr{Cvoid}, Ptr{Float32}, Int32, Float32, Float32, Ref{SolveOpts}, Int32, Int32, Float32,
          Ptr{Float32}, Ptr{Float32}, Ptr{Int32}, Ref{Stats}, Ptr{Float32}),
         ctx, pointer(x), nbatch(x), t0, t2, opts, MODE[mode], REG_TYPE[reg_type], t1_or_rand, pointer(u_end), reg, nfe, st, t1))

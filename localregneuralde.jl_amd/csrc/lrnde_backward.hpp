@@ -601,6 +601,7 @@ struct VjpQArgs {
   // dt, the z / K buffers) are filled in from the control block (lrnde_adjoint.hpp) at the head of the kernel
   int adj_mode, adj_stage, adj_j;
   AdjArgs adj;
+  int qcols;   // batch columns per workgroup: QNB (4), or 2 to put a B <= 512 launch on all 256 CUs (0 = QNB)
 };
 
 constexpr int VQB = 3 * QSB1;  // stream blocks of one VJP (QSB2 == QSB1)
@@ -831,7 +832,8 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sidx = lane & 3, q = lane >> 2;
-  const int b0 = blockIdx.x * QNB, nvalid = min(QNB, a.B - b0);
+  const int qc = a.qcols > 0 ? a.qcols : QNB;
+  const int b0 = blockIdx.x * qc, nvalid = min(qc, a.B - b0);
   const int KQ1 = m.D / 4;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   StreamV st;

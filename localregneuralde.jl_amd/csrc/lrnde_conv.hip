@@ -1700,6 +1700,7 @@ struct lrnde_conv {
   bool dense_on = false; size_t dense_n = 0;
   std::vector<float*> dense; std::vector<float> dense_t, dense_dt;
   float* rec_u1 = nullptr; size_t rec_n = 0;
+  unsigned long long rec_gen = 0;
   bool rec_valid = false; int rec_B = 0, rec_mode = 0, rec_reg_type = 0; float rec_t0 = 0.f, rec_t2 = 0.f, rec_t1 = 0.f; lrnde_solve_opts rec_opts;
   float* adj = nullptr; size_t adj_elems = 0;
 };
@@ -2656,7 +2657,7 @@ int lrnde_conv_node_forward_record(lrnde_conv* c, const float* x, int32_t B, flo
   c->dense_on = false;
   if (rc) return rc;
   if (t1_used_host) *t1_used_host = t1;
-  c->rec_valid = true; c->rec_B = B; c->rec_t0 = t0; c->rec_t2 = t2; c->rec_t1 = t1; c->rec_opts = *o; c->rec_mode = mode;
+  c->rec_valid = true; ++c->rec_gen; c->rec_B = B; c->rec_t0 = t0; c->rec_t2 = t2; c->rec_t1 = t1; c->rec_opts = *o; c->rec_mode = mode;
   c->rec_reg_type = reg_type;
   return LRNDE_OK;
 }
@@ -2681,6 +2682,11 @@ int lrnde_conv_node_backward(lrnde_conv* c, const float* x, int32_t B, float t0,
 }
 
 // backward of  loss = <du_end, sol.u[end]> + w_reg * reg_val  from the record of the last lrnde_conv_node_forward_record
+int lrnde_conv_record_generation(lrnde_conv* c, uint64_t* gen_host) {   // see lrnde_record_generation
+  if (!c || !gen_host) return LRNDE_BADARG;
+  *gen_host = c->rec_valid ? c->rec_gen : 0;
+  return LRNDE_OK;
+}
 int lrnde_conv_node_backward_recorded(lrnde_conv* c, int32_t B, const float* du_end, float w_reg, float* dx, float* dp,
                                       lrnde_stats* st_bwd) {
   int rc = check_ready(c, B);

@@ -1804,6 +1804,7 @@ struct lrnde_ctx {
   float loc_dt = 0.f, loc_eest = 0.f, loc_snum = 0.f, loc_sden = 0.f;    // the same of the LAST layer forward
   // arguments of the last lrnde_node_forward_record (what lrnde_node_backward_recorded differentiates)
   bool rec_valid = false; int rec_B = 0, rec_mode = 0, rec_reg_type = 0, rec_naccept = 0;
+  unsigned long long rec_gen = 0;  // counts the recorded forwards of this handle (lrnde_record_generation)
   float rec_t0 = 0.f, rec_t2 = 0.f, rec_t1 = 0.f; lrnde_solve_opts rec_opts{};
   int wsNB = 0;  // tile width the workspace (partial-sum vectors) was sized for
   // workspace
@@ -1878,13 +1879,13 @@ namespace {
 // path in the same process as the default one and holds the two to the same bits.
 enum {
   OPT_NO_QTILE, OPT_QTILE_MAX_B, OPT_NO_FUSE, OPT_DENSE_COPY, OPT_NO_OVERLAP, OPT_NO_SDE_FAST, OPT_SDE_HOST_LOOP, OPT_NO_QVJP,
-  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_HOST, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
+  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
 };
 struct OptDef { const char* name; int dflt; bool flag; };   // flag: present in the environment = 1
 const OptDef g_optdef[N_OPT] = {
     {"LRNDE_NO_QTILE", 0, true}, {"LRNDE_QTILE_MAX_B", 2048, false}, {"LRNDE_NO_FUSE", 0, true}, {"LRNDE_DENSE_COPY", 0, true},
     {"LRNDE_NO_OVERLAP", 0, true}, {"LRNDE_NO_SDE_FAST", 0, true}, {"LRNDE_SDE_HOST_LOOP", 0, true}, {"LRNDE_NO_QVJP", 0, true},
-    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
+    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
     {"LRNDE_FEED_M", 2, false}, {"LRNDE_GATHER_TILES", 0, true}, {"LRNDE_FORCE_COMM", 0, true}};
 int g_opt[N_OPT];
 bool g_opt_set[N_OPT];     // set by the hook: the environment no longer counts
@@ -1901,6 +1902,12 @@ int opt(int i) {
   // (the two communicator switches are read when a communicator is made and tests flip them through the environment)
   if ((i == OPT_GATHER_TILES || i == OPT_FORCE_COMM) && !g_opt_set[i]) return getenv(g_optdef[i].name) != nullptr;
   return g_opt[i];
+}
+
+// batch columns per workgroup of the 4-column VJP kernel: LRNDE_VJP_QCOLS = 2 spreads a B <= 512 launch over all 256 CUs
+inline int vjp_qcols(int B) {
+  const int q = opt(OPT_VJP_QCOLS);
+  return (q == 1 || q == 2) && B <= 256 * q ? q : QNB;
 }
 
 int fail(lrnde_ctx* c, int code, const char* fmt, ...) {
@@ -3057,7 +3064,7 @@ int lrnde_sde_create(lrnde_sde** out, const lrnde_model_desc* drift, int32_t dif
   return LRNDE_OK;
 }
 
-namespace { void sde_node_release(lrnde_sde* s); }
+namespace { void sde_node_release(lrnde_sde* s); unsigned long long sde_node_generation(const lrnde_sde* s); }
 int lrnde_sde_destroy(lrnde_sde* s) {
   if (!s) return LRNDE_OK;
   sde_node_release(s);
@@ -3608,7 +3615,8 @@ static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float th
       lam = sin->lam_out;  // what the parameter-gradient GEMM reads
     }
     const size_t smq = smem_bytes_vq(c->m.KQ1p, c->m.KQ2p, c->m.RG1, c->m.RG2);
-    const int nvjp = (B + QNB - 1) / QNB;
+    const int qcv = vjp_qcols(B); a.qcols = qcv;
+    const int nvjp = (B + qcv - 1) / qcv;
     const bool kt1 = (c->desc.hidden_dim + 3) / 4 == (QSB2 - 1) * QSQ + 1;  // real k-quads in the last phase-3 block (see launch_step)
     if (c->pg_defer) {
       // this VJP's launch carries the GEMM of the previous evaluation; its own GEMM waits for the next launch (or flush_pgrad)
@@ -3915,7 +3923,8 @@ int adj_enqueue_eval(lrnde_ctx* c, int B, const AdjArgs& g, int mode, int stage,
   const int set = c->bw_cur;
   a.ysc = c->bw_y + (size_t)set * B * c->desc.state_dim; a.hsc = c->bw_h + (size_t)set * B * c->m.Hp; a.dpsc = c->bw_dp + (size_t)set * B * c->m.Hp;
   const size_t smq = smem_bytes_vq(c->m.KQ1p, c->m.KQ2p, c->m.RG1, c->m.RG2);
-  const int nvjp = (B + QNB - 1) / QNB;
+  const int qcv = vjp_qcols(B); a.qcols = qcv;
+    const int nvjp = (B + qcv - 1) / qcv;
   const bool kt1 = (c->desc.hidden_dim + 3) / 4 == (QSB2 - 1) * QSQ + 1;
   if (with_prev_pgrad) {
     PgradArgs pg = pgrad_args(c, B, 0.f, nullptr, nullptr, set ^ 1);
@@ -4289,7 +4298,7 @@ static int node_forward_record_impl(lrnde_ctx* c, const float* x, int32_t B, flo
     // kept here: the regulariser's reverse sweep starts from them without re-running the step or asking the device again
     c->rec_dt1 = c->loc_dt; c->rec_eest = c->loc_eest; c->rec_snum = c->loc_snum; c->rec_sden = c->loc_sden;
   }
-  c->rec_valid = true; c->rec_B = B; c->rec_t0 = t0; c->rec_t2 = t2; c->rec_opts = *o; c->rec_mode = mode;
+  c->rec_valid = true; ++c->rec_gen; c->rec_B = B; c->rec_t0 = t0; c->rec_t2 = t2; c->rec_opts = *o; c->rec_mode = mode;
   c->rec_reg_type = reg_type; c->rec_t1 = t1; c->rec_naccept = st->naccept;
   return LRNDE_OK;
 }
@@ -4636,6 +4645,21 @@ int lrnde_set_adjoint_trace(lrnde_ctx* c, lrnde_trace_row* rows_host, int32_t ca
 int lrnde_adjoint_trace_rows(lrnde_ctx* c, int32_t* n_host) {
   if (!c || !n_host) return LRNDE_BADARG;
   *n_host = c->adj_trace_n;
+  return LRNDE_OK;
+}
+
+// which recorded forward the handle's record belongs to: it counts the successful lrnde_node_forward_record* calls.  A
+// binding whose pullback closure captured generation g checks it before lrnde_node_backward_recorded*: a later forward of
+// the same layer (an evaluation pass, a second pullback in flight) has replaced the record, and the backward would
+// return the gradients of the OTHER input without an error (the C side can only see that some record is valid).
+int lrnde_record_generation(lrnde_ctx* c, uint64_t* gen_host) {
+  if (!c || !gen_host) return LRNDE_BADARG;
+  *gen_host = c->rec_valid ? c->rec_gen : 0;   // 0: no usable record
+  return LRNDE_OK;
+}
+int lrnde_sde_record_generation(lrnde_sde* s, uint64_t* gen_host) {
+  if (!s || !gen_host) return LRNDE_BADARG;
+  *gen_host = sde_node_generation(s);
   return LRNDE_OK;
 }
 

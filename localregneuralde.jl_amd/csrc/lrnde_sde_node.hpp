@@ -17,6 +17,7 @@ namespace {
 struct SdeSeriesEntry { float t; int k; float theta; };  // value = (1-theta) * state_before(step k) + theta * rec_u[k]; k = -1: the start value
 struct SdeNodeRecord {
   bool valid = false;
+  unsigned long long gen = 0;
   int B = 0, nfine = 0, K = 0, mode = 0;
   float t0 = 0.f, t2 = 0.f, h = 0.f;
   lrnde_sde_adapt_opts o{};
@@ -153,6 +154,7 @@ int sde_node_alloc(lrnde_sde* s, SdeNodeRecord& r, int B, int nfine) {
   return LRNDE_OK;
 }
 
+unsigned long long sde_node_generation(const lrnde_sde* s) { return (s->node && s->node->valid) ? s->node->gen : 0ull; }
 void sde_node_release(lrnde_sde* s) {
   if (!s->node) return;
   SdeNodeRecord& r = *s->node;
@@ -292,7 +294,7 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
   if (nfe_drift_host) *nfe_drift_host = nfe_f;
   if (nfe_diffusion_host) *nfe_diffusion_host = nfe_g;
   if (t1_used_host) *t1_used_host = t1;
-  r.valid = true; r.B = B; r.nfine = nfine; r.K = K; r.mode = mode; r.t0 = t0; r.t2 = t2; r.h = h; r.o = *o; r.W = W;
+  r.valid = true; ++r.gen; r.B = B; r.nfine = nfine; r.K = K; r.mode = mode; r.t0 = t0; r.t2 = t2; r.h = h; r.o = *o; r.W = W;
   return LRNDE_OK;
 }
 

@@ -258,6 +258,12 @@ class Handle:
         return dict(u_end=u_end, reg_val=np.float32(reg.value), nfe=int(nfe.value), stats=st.asdict(),
                     t1=np.float32(t1u.value))
 
+    def record_generation(self):
+        """which recorded forward the handle's record belongs to (lrnde_record_generation); 0 = no usable record"""
+        g = C.c_uint64()
+        self._chk(L.lib.lrnde_record_generation(self._ctx, C.byref(g)))
+        return int(g.value)
+
     def node_backward_recorded(self, du_end, w_reg=0.0):
         B = du_end.numel() // self.D
         dx = torch.empty_like(du_end)

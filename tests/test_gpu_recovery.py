@@ -77,3 +77,29 @@ def test_forward_and_backward_after_failures(gpu_pkg, t1, reg_type):
     _same(h.node_forward_record(x, 0.0, 1.0, 1e-5, 1e-5, maxiters=10000, **kw), want_r)
     _same(h.node_backward_recorded(du, w_reg=2.5), want_b)
     _same(h.node_forward(x, 0.0, 1.0, 1e-5, 1e-5, maxiters=10000, **kw), want_f)
+
+
+@pytest.mark.gpu
+def test_record_generation_tells_a_stale_record_from_the_callers_own(gpu_pkg):
+    """a binding's pullback closure must be able to see that ANOTHER forward of the same layer replaced the record
+    it was made for (the C side can only see that some record is valid).  lrnde_record_generation counts the recorded
+    forwards; 0 = no usable record (none yet, or consumed by a backward)."""
+    import numpy as np
+    import torch
+    from localregneuralde_jl_amd.layers import Handle, _mlp_desc
+    P = gpu_pkg
+    D, H, B = 32, 16, 8
+    model = P.TDChain(P.Chain(P.Dense(D + 1, H, "tanh"), P.Dense(H + 1, D)))
+    h = Handle(_mlp_desc(model))
+    h.set_params(torch.from_numpy(P.glorot_params(model, seed=0)))
+    x = torch.from_numpy(np.random.default_rng(0).random((B, D), dtype=np.float32)).cuda()
+    assert h.record_generation() == 0
+    h.node_forward_record(x, 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.3)
+    g1 = h.record_generation()
+    assert g1 == 1
+    h.node_forward_record(x * 2, 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.3)   # "an evaluation pass in between"
+    assert h.record_generation() == 2 != g1          # the first closure sees that its record is gone
+    h.node_backward_recorded(torch.ones_like(x), w_reg=1.0)
+    assert h.record_generation() == 0                # consumed
+    h.node_forward(x, 0.0, 1.0, 1e-3, 1e-3, mode="unbiased", t1_or_rand=0.3)               # an unrecorded forward makes none
+    assert h.record_generation() == 0

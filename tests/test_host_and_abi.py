@@ -55,7 +55,7 @@ def test_julia_binding_matches_the_header():
     calls = re.findall(r"ccall\(\(:?(\w+), (?:LRNDEBackend\.)?lib\), \w+,\s*\((.*?)\),\s*\n?", src + layer, flags=re.S)
     seen = set()
     for name, types in calls:
-        if name in ("last_error", "f"):   # dispatched through a variable: checked below
+        if name in ("last_error", "f"):   # dispatched through a variable: checked below / by name further down
             continue
         assert name in arity, f"{name} is not declared in include/lrnde.h"
         nargs = len([t for t in re.split(r",(?![^{]*})", types) if t.strip()])
@@ -65,7 +65,15 @@ def test_julia_binding_matches_the_header():
         assert name in arity, name
     assert {"lrnde_create", "lrnde_node_forward", "lrnde_node_forward_record", "lrnde_node_backward_recorded", "lrnde_conv_create",
             "lrnde_sde_sri_step", "lrnde_comm_init", "lrnde_node_forward_record_ts", "lrnde_node_backward_recorded_ts",
-            "lrnde_sde_solve_fixed_backward", "lrnde_sde_euler_heun_reg_grad"} <= seen
+            "lrnde_sde_solve_fixed_backward", "lrnde_sde_euler_heun_reg_grad",
+            # round 3: the other two layers behind the reference's own call + the record-generation check
+            "lrnde_conv_node_backward_recorded", "lrnde_conv_set_bn_mode", "lrnde_conv_get_bn_state", "lrnde_conv_set_bn_state",
+            "lrnde_sde_node_forward_record", "lrnde_sde_node_backward_recorded"} <= seen
+    for name in ("lrnde_record_generation", "lrnde_conv_record_generation", "lrnde_sde_record_generation"):
+        assert ":" + name in layer and name in arity, name     # passed through a keyword (f=:...): one (ctx, Ptr{UInt64}) signature
+    assert "function (n::NeuralDSDE)(x::AbstractMatrix{Float32}, ps, st::NamedTuple)" in layer and "CRC_.rrule(n::NeuralDSDE" in layer
+    assert "function (n::NeuralODE)(x::AbstractArray{Float32, 4}, ps, st::NamedTuple)" in layer
+    assert len(re.findall(r"::(?:Int32|Float32)", re.search(r"struct SdeAdaptOpts\b(.*?)\bend\b", layer, re.S).group(1))) == len(_lib.SdeAdaptOpts._fields_) == 10
     fields = lambda name: len(re.findall(r"::(?:Int32|Float32)", re.search(r"struct %s\b(.*?)\bend\b" % name, src, re.S).group(1)))
     assert fields("ModelDesc") == 4 and fields("SolveOpts") == 6 and fields("Stats") == 10 and fields("ConvDesc") == 8
     assert fields("SriTableau") == len(_lib.SRI_FIELDS) == 51
