@@ -362,6 +362,12 @@ int lrnde_sde_solve_fixed_backward(lrnde_sde* sde, const float* u0, const float*
                                    float dt, int32_t nsteps, const float* du_end, float* dx, float* dp_drift, float* dp_diff);
 int lrnde_sde_euler_heun_reg_grad(lrnde_sde* sde, const float* uprev, const float* dW, int32_t B, float t, float dt, float abstol,
                                   float reltol, float delta, float* dp_drift, float* dp_diff, float* reg_val_host);
+/* The same two for the Milstein step (src/perform_step.jl:108-170; `solver = RKMilCommute()`): pullback of
+ * lrnde_sde_solve_fixed(which = 1) and d (EEst*dt) / d parameters of one local step (EEst from the 4-argument residual). */
+int lrnde_sde_solve_fixed_backward_rkmil(lrnde_sde* sde, const float* u0, const float* u_traj, const float* dW, int32_t B, float t0,
+                                         float dt, int32_t nsteps, const float* du_end, float* dx, float* dp_drift, float* dp_diff);
+int lrnde_sde_rkmil_reg_grad(lrnde_sde* sde, const float* uprev, const float* dW, int32_t B, float t, float dt, float abstol,
+                             float reltol, float* dp_drift, float* dp_diff, float* reg_val_host);
 
 /* The NeuralDSDE layer itself, forward and pullback: `(n::NeuralDSDE{R})(x, ps, st)` (src/layers/neural_sde.jl:74-123) =
  * `_solve_neuraldsde_generic` (:50-72: ADAPTIVE solve of drift / diffusion from x over tspan with the layer's saveat rules,

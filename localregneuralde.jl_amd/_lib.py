@@ -100,6 +100,8 @@ SYMBOLS = [
     ("lrnde_record_generation", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     ("lrnde_conv_record_generation", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     ("lrnde_sde_record_generation", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    ("lrnde_sde_solve_fixed_backward_rkmil", C.c_int, [_vp, _vp, _vp, _vp, _i32, _f, _f, _i32, _vp, _vp, _vp, _vp]),
+    ("lrnde_sde_rkmil_reg_grad", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _vp, _vp, _fp]),
     ("lrnde_sde_sri_step", C.c_int, [_vp, C.POINTER(SriTableau), _vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _vp, _fp, _fp]),
     ("lrnde_vjp", C.c_int, [_vp, _vp, _f, _vp, _i32, _vp, _vp]),
     ("lrnde_step_reg_grad", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _i32, _vp, _fp]),

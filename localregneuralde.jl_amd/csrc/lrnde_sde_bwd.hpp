@@ -87,6 +87,44 @@ __global__ void k_sdeb_acc1(size_t n, float* acc, const float* a) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc[i] = acc[i] + a[i];
 }
 
+// ---- Milstein step (src/perform_step.jl:108-170, diagonal noise, Ito): u' = K + L dW + Dgj J,  K = u + dt du1,
+//      tmp = K + sqdt L, Dgj = (g(tmp) - L) / sqdt, J = dW^2/2 - dt/2.  Reverse sweep for a cotangent ub of u' ----
+__global__ void k_mil_tmp(size_t n, const float* u, const float* du1, const float* L, float dt, float sqdt, float* tmp) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) tmp[i] = (u[i] + dt * du1[i]) + sqdt * L[i];
+}
+// gtb = cotangent of g(tmp) = ub J / sqdt ;  Lb0 = ub dW - ub J / sqdt
+__global__ void k_mil_seed(size_t n, const float* dW, const float* ub, float dt, float sqdt, float* gtb, float* Lb0) {
+  const float hdt = dt / 2.0f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float J = (0.5f * dW[i]) * dW[i] - hdt;
+    const float gb = (ub[i] * J) / sqdt;
+    gtb[i] = gb;
+    Lb0[i] = ub[i] * dW[i] - gb;
+  }
+}
+// tb = cotangent of tmp (from the VJP of g at tmp): Kb = ub + tb -> up ; du1b = dt Kb ; Lb = Lb0 + sqdt tb
+__global__ void k_mil_mid(size_t n, const float* ub, const float* tb, const float* Lb0, float dt, float sqdt, float* du1b, float* Lb, float* up) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float kb = ub[i] + tb[i];
+    up[i] = kb;
+    du1b[i] = dt * kb;
+    Lb[i] = Lb0[i] + sqdt * tb[i];
+  }
+}
+// regulariser of the Milstein step: reg = dt sqrt(mean r^2), r = (u' - u) / (abstol + max(|u|, |u'|) reltol)  (:166-169, the
+// 4-argument residual :218-220); cotangent of u' with u constant
+__global__ void k_mil_reg_seed(size_t n, const float* u, const float* un, float dt, float abstol, float reltol, float eest, float nf, float* unb) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float sc = abstol + fmaxf_(__builtin_fabsf(u[i]), __builtin_fabsf(un[i])) * reltol;
+    const float num = un[i] - u[i];
+    const float r = num / sc;
+    const float rb = (eest > 0.f) ? dt * r / (nf * eest) : 0.f;
+    float b = rb / sc;
+    if (__builtin_fabsf(un[i]) > __builtin_fabsf(u[i])) b += (-rb * num / (sc * sc)) * reltol * (un[i] >= 0.f ? 1.f : -1.f);
+    unb[i] = b;
+  }
+}
+
 inline int sde_nb(size_t n) { int nb = (int)((n + 255) / 256); return nb > 1024 ? 1024 : (nb < 1 ? 1 : nb); }
 
 // workspace of the SDE backward entry points: `cnt` state-sized vectors + the parameter-sized ones
@@ -147,6 +185,85 @@ int lrnde_sde_solve_fixed_backward(lrnde_sde* s, const float* u0, const float* u
     hipLaunchKernelGGL(k_sdeb_acc, dim3(sde_nb(Pg)), dim3(256), 0, c->stream, Pg, dp_diff, (const float*)(gpg[0] + goff), (const float*)(gpg[1] + goff));
     HIPCHK(c, hipGetLastError());
   }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRNDE_OK;
+}
+
+// reverse sweep of ONE Milstein step from the cotangent in `ub` (overwritten with the cotangent of u when want_dx), parameter
+// cotangents ADDED to dp_drift / dp_diff.  v: 9 state-sized scratch vectors.
+static int sde_rkmil_step_sweep(lrnde_sde* s, const float* u, const float* w, int B, float t, float dt, float* ub, float** v,
+                                float** gpf, float** gpg, float* dp_drift, float* dp_diff) {
+  lrnde_ctx* c = s->drift; lrnde_ctx* cg = s->diff;
+  const int D = c->desc.state_dim;
+  const size_t n = (size_t)B * D, Pf = lrnde_param_count(&c->desc);
+  const size_t Pg = (size_t)D * D + (s->diff_bias ? D : 0), goff = (size_t)D * D + D;
+  float *du1 = v[0], *L = v[1], *tmp = v[2], *gtb = v[3], *Lb0 = v[4], *tb = v[5], *du1b = v[6], *Lb = v[7], *up = v[8];
+  float *duf = v[3], *dug = v[5];   // gtb / tb are free again by then
+  const int nb = sde_nb(n);
+  const float sqdt = sqrtf(dt);
+  int rc;
+  if ((rc = lrnde_rhs(c, u, t, B, du1))) return rc;
+  if ((rc = lrnde_rhs(cg, u, t, B, L))) return rc;
+  hipLaunchKernelGGL(k_mil_tmp, dim3(nb), dim3(256), 0, c->stream, n, u, (const float*)du1, (const float*)L, dt, sqdt, tmp);
+  hipLaunchKernelGGL(k_mil_seed, dim3(nb), dim3(256), 0, c->stream, n, w, (const float*)ub, dt, sqdt, gtb, Lb0);
+  if ((rc = launch_vjp(cg, tmp, nullptr, 0.f, 0.f, t, gtb, B, tb, gpg[0]))) return rc;     // g(tmp, p, t): :138
+  hipLaunchKernelGGL(k_mil_mid, dim3(nb), dim3(256), 0, c->stream, n, (const float*)ub, (const float*)tb, (const float*)Lb0, dt, sqdt, du1b, Lb, up);
+  if ((rc = launch_vjp(c, u, nullptr, 0.f, 0.f, t, du1b, B, duf, gpf[0]))) return rc;
+  if ((rc = launch_vjp(cg, u, nullptr, 0.f, 0.f, t, Lb, B, dug, gpg[1]))) return rc;
+  hipLaunchKernelGGL(k_sdeb_end, dim3(nb), dim3(256), 0, c->stream, n, (const float*)up, (const float*)duf, (const float*)dug, ub);
+  hipLaunchKernelGGL(k_sdeb_acc1, dim3(sde_nb(Pf)), dim3(256), 0, c->stream, Pf, dp_drift, (const float*)gpf[0]);
+  hipLaunchKernelGGL(k_sdeb_acc, dim3(sde_nb(Pg)), dim3(256), 0, c->stream, Pg, dp_diff, (const float*)(gpg[0] + goff), (const float*)(gpg[1] + goff));
+  HIPCHK(c, hipGetLastError());
+  return LRNDE_OK;
+}
+
+// Pullback of lrnde_sde_solve_fixed(which = 1, Milstein): the reference tapes whatever n.solver is
+// (src/layers/neural_sde.jl:12,68-69); same contract as lrnde_sde_solve_fixed_backward.
+int lrnde_sde_solve_fixed_backward_rkmil(lrnde_sde* s, const float* u0, const float* u_traj, const float* dW, int32_t B, float t0,
+                                         float dt, int32_t nsteps, const float* du_end, float* dx, float* dp_drift, float* dp_diff) {
+  int rc = sde_check(s, u0, dW, u_traj, B, dt);
+  if (rc) return rc;
+  lrnde_ctx* c = s->drift; lrnde_ctx* cg = s->diff;
+  if (!du_end || !dx || !dp_drift || !dp_diff || nsteps <= 0) return fail(c, LRNDE_BADARG, "null pointer / nsteps");
+  if (cg->stream != c->stream) return fail(c, LRNDE_BADARG, "drift and diffusion contexts must share a stream");
+  const int D = c->desc.state_dim;
+  const size_t n = (size_t)B * D, Pf = lrnde_param_count(&c->desc), Pg2 = lrnde_param_count(&cg->desc);
+  const size_t Pg = (size_t)D * D + (s->diff_bias ? D : 0);
+  float* v[9]; float* gpf[2]; float* gpg[2];
+  if ((rc = sde_bwd_ws(s, n, Pf, Pg2, v, 9, gpf, gpg))) return rc;
+  HIPCHK(c, hipMemcpyAsync(dx, du_end, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dp_drift, 0, sizeof(float) * Pf, c->stream));
+  HIPCHK(c, hipMemsetAsync(dp_diff, 0, sizeof(float) * Pg, c->stream));
+  for (int i = nsteps - 1; i >= 0; --i) {
+    const float* u = (i == 0) ? u0 : u_traj + (size_t)(i - 1) * n;
+    if ((rc = sde_rkmil_step_sweep(s, u, dW + (size_t)i * n, B, t0 + (float)i * dt, dt, dx, v, gpf, gpg, dp_drift, dp_diff))) return rc;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRNDE_OK;
+}
+
+// d (EEst*dt) / d (p_drift, p_diffusion) of one local Milstein step (src/perform_step.jl:108-170) with uprev, dW, dt constant
+int lrnde_sde_rkmil_reg_grad(lrnde_sde* s, const float* uprev, const float* dW, int32_t B, float t, float dt, float abstol,
+                             float reltol, float* dp_drift, float* dp_diff, float* reg_val_host) {
+  lrnde_ctx* c0 = s ? s->drift : nullptr;
+  if (!s || !dp_drift || !dp_diff) return c0 ? fail(c0, LRNDE_BADARG, "null pointer") : LRNDE_BADARG;
+  int rc = sde_check(s, uprev, dW, dp_drift, B, dt);
+  if (rc) return rc;
+  lrnde_ctx* c = s->drift; lrnde_ctx* cg = s->diff;
+  if (cg->stream != c->stream) return fail(c, LRNDE_BADARG, "drift and diffusion contexts must share a stream");
+  const int D = c->desc.state_dim;
+  const size_t n = (size_t)B * D, Pf = lrnde_param_count(&c->desc), Pg2 = lrnde_param_count(&cg->desc);
+  const size_t Pg = (size_t)D * D + (s->diff_bias ? D : 0);
+  float* v[11]; float* gpf[2]; float* gpg[2];
+  if ((rc = sde_bwd_ws(s, n, Pf, Pg2, v, 11, gpf, gpg))) return rc;
+  float *un = v[9], *unb = v[10];
+  float ee = 0.f, rv = 0.f;
+  if ((rc = sde_step_impl(s, 1, uprev, dW, B, t, dt, abstol, reltol, 0.f, un, &ee, &rv))) return rc;
+  if (reg_val_host) *reg_val_host = rv;
+  hipLaunchKernelGGL(k_mil_reg_seed, dim3(sde_nb(n)), dim3(256), 0, c->stream, n, uprev, (const float*)un, dt, abstol, reltol, ee, (float)n, unb);
+  HIPCHK(c, hipMemsetAsync(dp_drift, 0, sizeof(float) * Pf, c->stream));
+  HIPCHK(c, hipMemsetAsync(dp_diff, 0, sizeof(float) * Pg, c->stream));
+  if ((rc = sde_rkmil_step_sweep(s, uprev, dW, B, t, dt, unb, v, gpf, gpg, dp_drift, dp_diff))) return rc;   // (the cotangent of uprev is discarded: a constant)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRNDE_OK;
 }

@@ -166,19 +166,32 @@ class SdeHandle:
                                                          _dev_ptr(dx, "dx"), C.c_void_p(dpf.data_ptr()), C.c_void_p(dpg.data_ptr())))
         return dict(dx=dx, dp_drift=dpf, dp_diff=dpg)
 
-    def solve_fixed_backward(self, u0, u_traj, dW, t0, dt, du_end):
-        """pullback of solve_fixed (Euler-Heun) for <du_end, u_traj[-1]>: dict(dx, dp_drift, dp_diff)"""
+    def solve_fixed_backward(self, u0, u_traj, dW, t0, dt, du_end, solver="EulerHeun"):
+        """pullback of solve_fixed (Euler-Heun, or solver="RKMil": the Milstein step) for <du_end, u_traj[-1]>:
+        dict(dx, dp_drift, dp_diff)"""
         nsteps = int(dW.shape[0])
         B = u0.numel() // self.D
         nf, ng = self._pcounts()
         dx = torch.empty_like(u0)
         dpf = torch.empty(nf, dtype=torch.float32, device=u0.device)
         dpg = torch.empty(ng, dtype=torch.float32, device=u0.device)
-        self._chk(L.lib.lrnde_sde_solve_fixed_backward(self._h, _dev_ptr(u0, "u0", self.D), _dev_ptr(u_traj.contiguous(), "u_traj"),
+        fn = L.lib.lrnde_sde_solve_fixed_backward_rkmil if solver.startswith("RKMil") else L.lib.lrnde_sde_solve_fixed_backward
+        self._chk(fn(self._h, _dev_ptr(u0, "u0", self.D), _dev_ptr(u_traj.contiguous(), "u_traj"),
                                                        _dev_ptr(dW.contiguous(), "dW"), B, float(t0), float(dt), nsteps,
                                                        _dev_ptr(du_end, "du_end", self.D), _dev_ptr(dx, "dx"),
                                                        C.c_void_p(dpf.data_ptr()), C.c_void_p(dpg.data_ptr())))
         return dict(dx=dx, dp_drift=dpf, dp_diff=dpg)
+
+    def rkmil_reg_grad(self, uprev, dW, t, dt, abstol, reltol):
+        """d (EEst*dt) / d (p_drift, p_diffusion) of one local Milstein step (src/perform_step.jl:108-170), uprev / dW / dt constant"""
+        B = uprev.numel() // self.D
+        nf, ng = self._pcounts()
+        dpf = torch.empty(nf, dtype=torch.float32, device=uprev.device)
+        dpg = torch.empty(ng, dtype=torch.float32, device=uprev.device)
+        rv = C.c_float()
+        self._chk(L.lib.lrnde_sde_rkmil_reg_grad(self._h, _dev_ptr(uprev, "uprev", self.D), _dev_ptr(dW, "dW", self.D), B, float(t), float(dt),
+                                                 float(abstol), float(reltol), C.c_void_p(dpf.data_ptr()), C.c_void_p(dpg.data_ptr()), C.byref(rv)))
+        return dict(dp_drift=dpf, dp_diff=dpg, reg_val=np.float32(rv.value))
 
     def euler_heun_reg_grad(self, uprev, dW, t, dt, abstol, reltol, delta):
         """d (EEst*dt) / d (p_drift, p_diffusion) of one local Euler-Heun step, uprev / dW / dt constant"""
@@ -342,19 +355,23 @@ class NeuralDSDE:
         (test/runtests.jl:361-365, 386-397): (dx, dict(drift=, diffusion=), info).  The forward is re-run with the same
         draws as `__call__` (st['rng']; `noise` if given); the solve is differentiated through its own steps, reg_val
         w.r.t. the parameters only (info['dx_reg'] is None: `gs_x === nothing` in the reference)."""
-        if self.solver != "EulerHeun":
-            raise NotImplementedError("the gradient path is built for the Euler-Heun step (src/perform_step.jl:172-206)")
+        if self.solver == "SRI":
+            raise NotImplementedError("the gradient path is built for the Euler-Heun (src/perform_step.jl:172-206) and Milstein (:108-170) "
+                                      "steps; the four-stage SRI step's reverse sweep is not")
         if self.adaptive:
             return self.pullback_series(x, ps, st, None, du_end=du_end, w_reg=w_reg, path=noise)
         sol, st2 = self(x, ps, st, noise=noise)
         h = self.handle()
         fs = self._last_solve
-        bw = h.solve_fixed_backward(x, fs["u_traj"], fs["dW"].contiguous(), fs["t0"], fs["dt"], du_end)
+        bw = h.solve_fixed_backward(x, fs["u_traj"], fs["dW"].contiguous(), fs["t0"], fs["dt"], du_end, solver=self.solver)
         dpf, dpg = bw["dp_drift"], bw["dp_diff"]
         mode = self.regularize if st["training"] else "none"
         if mode != "none" and w_reg != 0.0:
             lo = self._last_local
-            rg = h.euler_heun_reg_grad(lo["u1"], lo["dW"], lo["t1"], lo["dt"], lo["abstol"], lo["reltol"], self.delta)
+            if self.solver == "RKMil":
+                rg = h.rkmil_reg_grad(lo["u1"], lo["dW"], lo["t1"], lo["dt"], lo["abstol"], lo["reltol"])
+            else:
+                rg = h.euler_heun_reg_grad(lo["u1"], lo["dW"], lo["t1"], lo["dt"], lo["abstol"], lo["reltol"], self.delta)
             assert rg["reg_val"] == st2["reg_val"]
             dpf = dpf + np.float32(w_reg) * rg["dp_drift"]
             dpg = dpg + np.float32(w_reg) * rg["dp_diff"]
