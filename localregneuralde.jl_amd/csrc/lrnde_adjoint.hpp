@@ -50,7 +50,13 @@ struct AdjArgs {
   // host driver reads the integrator's progress from it without putting copy packets between the kernels
   int* hstat;
   int seq0;             // seq written by attempt j is seq0 + j + 1
+  // mu part of the ATTEMPT's error norm: 0 = the 256 per-block sums at part[256..512) (k_adj_err_dev / k_adj_err);
+  // > 0 = one partial per tile of the last parameter-gradient GEMM at part[ADJ_MU_TILE_OFF ..) (k_pgrad_adj_err, which
+  // then also forms the mu part of z_new: no launch of its own for the end of an adjoint step)
+  int mu_tiles;
 };
+constexpr int ADJ_MU_TILE_OFF = 576;   // behind [256 lambda][256 mu blocks][64 rank slots]
+constexpr int ADJ_MU_TILE_MAX = 2048;
 
 // how a backward kernel gets its per-launch arguments: from the host (round-1 path, single calls), or from AdjCtrl:
 // ADJ_FSAL = K1 := rhs(z, t) at the state of ctl[0] (init phase A; re-evaluation after an impulse), ADJ_INIT_B = initdt's
@@ -72,7 +78,7 @@ __device__ __forceinline__ float* adj_stage_lam(const AdjArgs& g, int sidx, int 
 
 // sum of the norm's partial sums (wave 0, all lanes return the total): lambda part = the 256 block sums, or, on a sharded
 // handle, the per-rank sums in rank order; then the 256 mu block sums.  Fixed order: lane-strided, DPP/readlane tree.
-__device__ __forceinline__ double adj_norm_sum(const double* p, int use_slots, int nranks, bool has_mu) {
+__device__ __forceinline__ double adj_norm_sum(const double* p, int use_slots, int nranks, bool has_mu, int mu_tiles = 0) {
   const int lane = threadIdx.x & 63;
   double s = 0.0;
   if (use_slots) {
@@ -83,7 +89,11 @@ __device__ __forceinline__ double adj_norm_sum(const double* p, int use_slots, i
     for (int u = 0; u < 4; ++u) v[u] = __hip_atomic_load(p + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s = ((v[0] + v[1]) + v[2]) + v[3];
   }
-  if (has_mu) {
+  if (has_mu && mu_tiles > 0) {   // per-tile partials of the last GEMM launch: lane-strided, in tile order per lane
+    double m = 0.0;
+    for (int i = lane; i < mu_tiles; i += 64) m += __hip_atomic_load(p + ADJ_MU_TILE_OFF + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s += m;
+  } else if (has_mu) {
     double v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = __hip_atomic_load(p + 256 + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -189,7 +199,7 @@ __device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
     dt = c.dtpropose;
     c.resume = 0;
   } else {
-    const float eest = (float)sqrt(adj_norm_sum(g.part, g.use_slots, g.nranks, g.P != 0) / ntot);
+    const float eest = (float)sqrt(adj_norm_sum(g.part, g.use_slots, g.nranks, g.P != 0, g.mu_tiles) / ntot);
     c.eest_last = eest;
     if (eest != eest) {
       c.status = LRNDE_DT_NAN;

@@ -230,7 +230,11 @@ __device__ __forceinline__ bool pgrad_resolve(PgradArgs& a, const AdjArgs& g) {
   return true;
 }
 
-__device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile) {  // one output tile per workgroup, the batch (K) split over its 4 waves
+// the end of an adjoint step folded into the last GEMM's tiles (fold != nullptr): the lane that holds an entry of K7's mu part
+// forms z_new's and the residual's entry on the spot (K1..K6 and z at the same index; the arithmetic of k_adj_err) and the
+// tile leaves ONE fp64 partial — no launch of its own for the mu part of the error norm
+struct AdjMuFold { const float* K[6]; const float* z; float* zn; float A7[6], BT[7]; float dt, abstol, reltol; double* part; };
+__device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, const AdjMuFold* fold = nullptr) {  // one output tile per workgroup, the batch (K) split over its 4 waves
   __shared__ f32x4 red[3][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -295,15 +299,67 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile) {
   float* gW = a.gp + (first ? (size_t)0 : oW2);
   float* gb = a.gp + (first ? ob1 : ob2);
   const int c = tj * 16 + li;
+  double esum = 0.0;
+  float* dsts[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int rr = ti * 16 + lk * 4 + r;
-    if (rr >= M) continue;
     float* dst = nullptr;
-    if (c < N) dst = gW + (size_t)rr + (size_t)M * c;
-    else if (c == N) { if (a.td) dst = gW + (size_t)rr + (size_t)M * N; }
-    else if (c == N + 1) dst = gb + rr;
+    if (rr < M) {
+      if (c < N) dst = gW + (size_t)rr + (size_t)M * c;
+      else if (c == N) { if (a.td) dst = gW + (size_t)rr + (size_t)M * N; }
+      else if (c == N + 1) dst = gb + rr;
+    }
+    dsts[r] = dst;
     if (dst) *dst = a.accumulate ? *dst + acc[r] : acc[r];
+  }
+  if (fold) {
+    // all loads of the lane's (up to) four entries first: K1..K6 and z at the entry's index of the mu part.  The four entries
+    // are consecutive rows of one column: one 16-byte load per array when the layout allows it (M % 4 == 0, as for the MNIST
+    // field) — as scalar loads a tile touched 2048 cache lines for 1024 entries and the launch got 14 us longer
+    float kv[4][6], zv[4];
+    const bool vec4 = (M & 3) == 0 && dsts[0] && dsts[3] == dsts[0] + 3 && ((dsts[0] - a.gp) & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(fold->z) | reinterpret_cast<uintptr_t>(fold->K[0])) & 15) == 0;
+    if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(vec4 || !dsts[0])) == 64)) {
+      const size_t i = dsts[0] ? (size_t)(dsts[0] - a.gp) : 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(fold->K[q] + i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kv[r][q] = v[r];
+      }
+      const f32x4 zz = *reinterpret_cast<const f32x4*>(fold->z + i);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zv[r] = zz[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t i = dsts[r] ? (size_t)(dsts[r] - a.gp) : 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) kv[r][q] = fold->K[q][i];
+        zv[r] = fold->z[i];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (!dsts[r]) continue;
+      const size_t i = (size_t)(dsts[r] - a.gp);
+      float sacc = fold->A7[0] * kv[r][0];
+#pragma unroll
+      for (int q = 1; q < 6; ++q) sacc = sacc + fold->A7[q] * kv[r][q];
+      const float znv = zv[r] + fold->dt * sacc;
+      fold->zn[i] = znv;
+      float sb = fold->BT[0] * kv[r][0];
+#pragma unroll
+      for (int q = 1; q < 6; ++q) sb = sb + fold->BT[q] * kv[r][q];
+      sb = sb + fold->BT[6] * acc[r];
+      const float ut = 0.f + fold->dt * sb;
+      const float sc = fold->abstol + fmaxf_(__builtin_fabsf(zv[r]), __builtin_fabsf(znv)) * fold->reltol;
+      const float rres = ut / sc;
+      esum += (double)(rres * rres);
+    }
+    esum = wave_sum_dpp(esum);
+    if (lane == 0) fold->part[tile] = esum;
   }
 }
 
@@ -540,10 +596,22 @@ __global__ __launch_bounds__(256) void k_adj_err_dev(AdjErrArgs a, AdjArgs g, in
 // The last evaluation's parameter-gradient GEMM of an attempt (nt tiles) and, on 256 more workgroups of the same launch,
 // the LAMBDA part of the attempt's error norm: it needs nothing of this GEMM (K7's lambda part and z_new's were written by
 // the VJP launches before it), so it no longer waits for it in a launch of its own.  Same blocks, same sums, same bits.
-__global__ __launch_bounds__(256) void k_pgrad_adj_err(PgradArgs a, AdjArgs g, AdjErrArgs e, int nt, int j) {
+// fold_mu: the GEMM's tiles also form the mu part of z_new and of the error norm (AdjMuFold; g.mu_tiles = nt tells the next
+// prologue where the partials are) — then k_adj_err_dev is not launched at all
+__global__ __launch_bounds__(256) void k_pgrad_adj_err(PgradArgs a, AdjArgs g, AdjErrArgs e, int nt, int j, int fold_mu) {
   if ((int)blockIdx.x >= nt) { adj_err_blocks(e, g, j, blockIdx.x - nt, false); return; }
   if (!pgrad_resolve(a, g)) return;
-  pgrad_tile(a, blockIdx.x);
+  if (!fold_mu) { pgrad_tile(a, blockIdx.x); return; }
+  const AdjCtrl* cp = g.ctl + ((j + 1) & 1);
+  const int cur = cp->cur;
+  AdjMuFold f;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) { f.K[q] = adj_K(g, q, cur) + g.n_lam; f.A7[q] = e.A7[q]; }
+#pragma unroll
+  for (int q = 0; q < 7; ++q) f.BT[q] = e.BT[q];
+  f.z = adj_zb(g, cur) + g.n_lam; f.zn = adj_zb(g, cur ^ 1) + g.n_lam;
+  f.dt = cp->dt; f.abstol = e.abstol; f.reltol = e.reltol; f.part = const_cast<double*>(g.part) + ADJ_MU_TILE_OFF;
+  pgrad_tile(a, blockIdx.x, &f);
 }
 
 // the rank's own fp64 sum (256 block partials, fixed order) into slot[rank] of a zeroed per-rank vector: the

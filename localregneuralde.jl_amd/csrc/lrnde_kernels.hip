@@ -1879,13 +1879,13 @@ namespace {
 // path in the same process as the default one and holds the two to the same bits.
 enum {
   OPT_NO_QTILE, OPT_QTILE_MAX_B, OPT_NO_FUSE, OPT_DENSE_COPY, OPT_NO_OVERLAP, OPT_NO_SDE_FAST, OPT_SDE_HOST_LOOP, OPT_NO_QVJP,
-  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
+  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
 };
 struct OptDef { const char* name; int dflt; bool flag; };   // flag: present in the environment = 1
 const OptDef g_optdef[N_OPT] = {
     {"LRNDE_NO_QTILE", 0, true}, {"LRNDE_QTILE_MAX_B", 2048, false}, {"LRNDE_NO_FUSE", 0, true}, {"LRNDE_DENSE_COPY", 0, true},
     {"LRNDE_NO_OVERLAP", 0, true}, {"LRNDE_NO_SDE_FAST", 0, true}, {"LRNDE_SDE_HOST_LOOP", 0, true}, {"LRNDE_NO_QVJP", 0, true},
-    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
+    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
     {"LRNDE_FEED_M", 2, false}, {"LRNDE_GATHER_TILES", 0, true}, {"LRNDE_FORCE_COMM", 0, true}};
 int g_opt[N_OPT];
 bool g_opt_set[N_OPT];     // set by the hook: the environment no longer counts
@@ -3684,7 +3684,7 @@ int adj_alloc(lrnde_ctx* c, size_t N, AdjVec& v) {
     c->adj_elems = 11 * N;
   }
   if (!c->adj_part) {  // [256 lambda partials][256 mu partials][64 per-rank lambda sums]
-    HIPCHK(c, hipMalloc(&c->adj_part, sizeof(double) * (512 + 64)));
+    HIPCHK(c, hipMalloc(&c->adj_part, sizeof(double) * (512 + 64 + ADJ_MU_TILE_MAX)));  // + the per-tile mu partials (ADJ_MU_TILE_OFF)
     HIPCHK(c, hipHostMalloc(&c->adj_part_host, sizeof(double) * (512 + 64)));
   }
   v.N = N; v.n_lam = N; v.P = 0; v.z = c->adj; v.zn = c->adj + N; v.zs = c->adj + 2 * N; v.ut = c->adj + 3 * N;
@@ -4002,6 +4002,16 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
   g.s0 = s0; g.dtmax = s1 - s0; g.dtmin = fmaxf(eps_f(s1), eps_f(s0));
   g.abstol = abstol; g.reltol = reltol; g.maxiters = maxiters; g.exact_pow = exact_pow;
   g.part = c->adj_part; g.ipart = c->adj_ipart; g.nranks = 1; g.use_slots = 0;
+  // LRNDE_ADJ_MU_FOLD=1: the mu part of an attempt's error norm and of z_new rides in the last GEMM's tiles (no launch of its
+  // own).  Built as DESIGN 4.4's "next lever" and measured (round 3): the tiles' tail — a dependent round trip for K1..K6 and
+  // z after the GEMM — makes that launch longer than k_adj_err_dev was (+6.5 us per attempt net), so it stays opt-in.
+  bool fold_mu = false;
+  {
+    const PgradArgs pg0 = pgrad_args(c, B, 0.f, nullptr, nullptr, 0);
+    const int nt0 = pg0.ntile1 + pg0.ntile2;
+    fold_mu = v.P != 0 && !opt(OPT_ADJ_ERR_ONE_LAUNCH) && opt(OPT_ADJ_MU_FOLD) && nt0 <= ADJ_MU_TILE_MAX;
+    g.mu_tiles = fold_mu ? nt0 : 0;
+  }
   const size_t N = v.N, n = v.n_lam;
   float* const zb0 = c->adj; float* const K0 = c->adj + 4 * N; float* const K1 = c->adj + 5 * N;
   AdjErrArgs e{};
@@ -4085,8 +4095,8 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
         PgradArgs pg = pgrad_args(c, B, 0.f, nullptr, nullptr, c->bw_cur ^ 1);
         pg.adj_mode = ADJ_STAGE; pg.adj_stage = 7; pg.adj_j = jj;
         const int nt = pg.ntile1 + pg.ntile2;
-        hipLaunchKernelGGL(k_pgrad_adj_err, dim3(nt + 256), dim3(256), 0, c->stream, pg, g, e, nt, jj);
-        hipLaunchKernelGGL(k_adj_err_dev, dim3(256), dim3(256), 0, c->stream, e, g, jj, 1);
+        hipLaunchKernelGGL(k_pgrad_adj_err, dim3(nt + 256), dim3(256), 0, c->stream, pg, g, e, nt, jj, fold_mu ? 1 : 0);
+        if (!fold_mu) hipLaunchKernelGGL(k_adj_err_dev, dim3(256), dim3(256), 0, c->stream, e, g, jj, 1);
       }
       HIPCHK(c, hipGetLastError());
       return LRNDE_OK;
