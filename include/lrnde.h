@@ -422,6 +422,15 @@ typedef struct lrnde_sri_tableau {
 int lrnde_sde_sri_step(lrnde_sde* sde, const lrnde_sri_tableau* tab, const float* uprev, const float* dW, const float* dZ,
                        int32_t B, float t, float dt, float abstol, float reltol, float delta, float* u, float* eest_host,
                        float* reg_val_host);
+/* Reverse sweep of ONE four-stage SRI step (src/perform_step.jl:49-106; lrnde_sde_sri_step with the same arguments):
+ * loss = <du_new, u'> + w_reg * EEst*dt.  du_new (device, may be NULL = 0): cotangent of the step's result; dx (device, may be
+ * NULL): cotangent of uprev — NULL when uprev is a constant of the tape, as for the local step's regulariser
+ * (src/layers/neural_sde.jl:42); dp_drift / dp_diff (device): the parameter cotangents are ADDED (zero them first; a solve's
+ * pullback calls this once per step, newest first).  dW, dZ, dt are constants.  reg_val_host (may be NULL): EEst*dt. */
+int lrnde_sde_sri_step_backward(lrnde_sde* sde, const lrnde_sri_tableau* tab, const float* uprev, const float* dW, const float* dZ,
+                                int32_t B, float t, float dt, float abstol, float reltol, float delta, const float* du_new,
+                                float w_reg, float* dx, float* dp_drift, float* dp_diff, float* reg_val_host);
+
 
 /* ---- backward pass ----
  * lrnde_vjp: the vector-Jacobian product Zygote.pullback(dudt, y, p, t) computes inside the adjoint

@@ -97,6 +97,7 @@ SYMBOLS = [
     ("lrnde_sde_node_forward_record", C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _f, C.POINTER(SdeAdaptOpts), _i32, _f, _vp, _i32, _fp, _i32,
                                                 _vp, _fp, _i32, C.POINTER(_i32), _fp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(Stats), _fp]),
     ("lrnde_sde_node_backward_recorded", C.c_int, [_vp, _i32, _vp, _i32, _f, _vp, _vp, _vp]),
+    ("lrnde_sde_sri_step_backward", C.c_int, [_vp, C.POINTER(SriTableau), _vp, _vp, _vp, _i32, _f, _f, _f, _f, _f, _vp, _f, _vp, _vp, _vp, _fp]),
     ("lrnde_record_generation", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     ("lrnde_conv_record_generation", C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     ("lrnde_sde_record_generation", C.c_int, [_vp, C.POINTER(C.c_uint64)]),

@@ -364,3 +364,129 @@ int lrnde_sde_node_backward_recorded(lrnde_sde* s, int32_t B, const float* du_se
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Reverse sweep of the four-stage SRI step (src/perform_step.jl:49-106, diagonal noise; the reference differentiates the
+// solve with whatever n.solver is — SOSRI by default — through TrackerAdjoint, src/layers/neural_sde.jl:12).
+// loss = <du_new, u'> + w_reg * EEst*dt  ->  dx (cotangent of uprev; NULL when uprev is a constant, as for the local
+// step's regulariser), dp_drift / dp_diff ADDED to (the caller zeroes them).  Eight vector-Jacobian products.
+// =====================================================================================================================
+namespace {
+struct SriBwd {
+  const float *up, *dW, *chi1, *chi2, *chi3, *un, *du_new;
+  const float* k[4]; const float* g[4];
+  float* kb[4]; float* gb[4]; float* upb;
+  float dt, sqdt, abstol, reltol, delta, eest, w_reg, nf;
+};
+// seeds: cotangents of k1..k4, g1..g4 and the direct part of uprev's from u' (:90-94) and from EEst*dt (:96-103)
+__global__ void k_sri_bseed(size_t n, SriBwd a, lrnde_sri_tableau T) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float k1 = a.k[0][i], k2 = a.k[1][i], k3 = a.k[2][i], k4 = a.k[3][i];
+    const float g1 = a.g[0][i], g2 = a.g[1][i], g3 = a.g[2][i], g4 = a.g[3][i];
+    const float up = a.up[i], un = a.un[i];
+    float unb = a.du_new ? a.du_new[i] : 0.f;
+    float numb = 0.f;
+    if (a.w_reg != 0.f && a.eest > 0.f) {
+      const float s3 = ((T.beta31 * g1 + T.beta32 * g2) + T.beta33 * g3) + T.beta34 * g4;
+      const float s4 = ((T.beta41 * g1 + T.beta42 * g2) + T.beta43 * g3) + T.beta44 * g4;
+      const float E2 = a.chi2[i] * s3 + a.chi3[i] * s4;
+      const float E1 = a.dt * (((k1 + k2) + k3) + k4);
+      const float sc = a.abstol + fmaxf_(__builtin_fabsf(up), __builtin_fabsf(un)) * a.reltol;
+      const float num = a.delta * E1 + E2;
+      const float r = num / sc;
+      const float rb = a.w_reg * a.dt * r / (a.nf * a.eest);     // reg = dt * sqrt(mean r^2)
+      numb = rb / sc;
+      if (__builtin_fabsf(un) > __builtin_fabsf(up)) unb += (-rb * num / (sc * sc)) * a.reltol * (un >= 0.f ? 1.f : -1.f);
+    }
+    const float e1b = a.delta * numb;            // cotangent of E1
+    const float e2b = unb + numb;                // cotangent of E2 (u' contains E2)
+    const float kc = a.dt * unb, ke = a.dt * e1b;
+    a.kb[0][i] = T.alpha1 * kc + ke; a.kb[1][i] = T.alpha2 * kc + ke; a.kb[2][i] = T.alpha3 * kc + ke; a.kb[3][i] = T.alpha4 * kc + ke;
+    const float w1 = unb * a.dW[i], w2 = unb * a.chi1[i], w3 = e2b * a.chi2[i], w4 = e2b * a.chi3[i];
+    a.gb[0][i] = ((T.beta11 * w1 + T.beta21 * w2) + T.beta31 * w3) + T.beta41 * w4;
+    a.gb[1][i] = ((T.beta12 * w1 + T.beta22 * w2) + T.beta32 * w3) + T.beta42 * w4;
+    a.gb[2][i] = ((T.beta13 * w1 + T.beta23 * w2) + T.beta33 * w3) + T.beta43 * w4;
+    a.gb[3][i] = ((T.beta14 * w1 + T.beta24 * w2) + T.beta34 * w3) + T.beta44 * w4;
+    a.upb[i] = unb;
+  }
+}
+// after the VJPs of stage st (k_{st+1} = f(H0_st), g_{st+1} = g(H1_st)): ha / hb = cotangents of H0_st / H1_st
+__global__ void k_sri_bjoin(size_t n, SriBwd a, lrnde_sri_tableau T, int st, const float* ha, const float* hb) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float x = ha[i], y = hb[i];
+    a.upb[i] = (a.upb[i] + x) + y;
+    if (st == 0) continue;   // k1 = f(uprev), g1 = g(uprev)
+    const float dx = a.dt * x, dy = a.dt * y, cx = a.chi2[i] * x, sy = a.sqdt * y;
+    if (st == 1) {
+      a.kb[0][i] += T.a021 * dx + T.a121 * dy; a.gb[0][i] += T.b021 * cx + T.b121 * sy;
+    } else if (st == 2) {
+      a.kb[0][i] += T.a031 * dx + T.a131 * dy; a.gb[0][i] += T.b031 * cx + T.b131 * sy;
+      a.kb[1][i] += T.a032 * dx + T.a132 * dy; a.gb[1][i] += T.b032 * cx + T.b132 * sy;
+    } else {
+      a.kb[0][i] += T.a041 * dx + T.a141 * dy; a.gb[0][i] += T.b041 * cx + T.b141 * sy;
+      a.kb[1][i] += T.a042 * dx + T.a142 * dy; a.gb[1][i] += T.b042 * cx + T.b142 * sy;
+      a.kb[2][i] += T.a043 * dx + T.a143 * dy; a.gb[2][i] += T.b043 * cx + T.b143 * sy;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int lrnde_sde_sri_step_backward(lrnde_sde* s, const lrnde_sri_tableau* tab, const float* uprev, const float* dW, const float* dZ,
+                                           int32_t B, float t, float dt, float abstol, float reltol, float delta, const float* du_new,
+                                           float w_reg, float* dx, float* dp_drift, float* dp_diff, float* reg_val_host) {
+  int rc = sde_check(s, uprev, dW, dp_drift, B, dt);
+  if (rc) return rc;
+  lrnde_ctx* c = s->drift; lrnde_ctx* cg = s->diff;
+  if (!tab || !dZ || !dp_drift || !dp_diff) return fail(c, LRNDE_BADARG, "null pointer");
+  if (cg->stream != c->stream) return fail(c, LRNDE_BADARG, "drift and diffusion contexts must share a stream");
+  const int D = c->desc.state_dim;
+  const size_t n = (size_t)B * D, Pf = lrnde_param_count(&c->desc), Pg2 = lrnde_param_count(&cg->desc);
+  const size_t Pg = (size_t)D * D + (s->diff_bias ? D : 0), goff = (size_t)D * D + D;
+  // the step itself (u', EEst) through the forward entry point, then its stages again keeping every H0 / H1
+  if (!s->node) s->node = new SdeNodeRecord();
+  SdeNodeRecord& r = *s->node;
+  if ((rc = sde_node_alloc(s, r, B, r.rec_cap > 0 ? r.rec_cap : 1))) return rc;
+  float* un = r.u1;   // (scratch of the layer record: a recorded adaptive forward and this sweep do not interleave)
+  r.valid = false;
+  float ee = 0.f, rv = 0.f;
+  if ((rc = lrnde_sde_sri_step(s, tab, uprev, dW, dZ, B, t, dt, abstol, reltol, delta, un, &ee, &rv))) return rc;
+  if (reg_val_host) *reg_val_host = rv;
+  float* v[20]; float* gpf[2]; float* gpg[2];
+  if ((rc = sde_bwd_ws(s, n, Pf, Pg2, v, 20, gpf, gpg))) return rc;
+  // lrnde_sde_sri_step left k1..k4, g1..g4, chi1..3 in its workspace (13 n floats); H0 / H1 of the three stages are recomputed
+  const float* w = s->sri_ws;
+  SriBwd a{};
+  a.up = uprev; a.dW = dW; a.un = un; a.du_new = du_new;
+  for (int j = 0; j < 4; ++j) { a.k[j] = w + (size_t)j * n; a.g[j] = w + (size_t)(4 + j) * n; a.kb[j] = v[j]; a.gb[j] = v[4 + j]; }
+  a.chi1 = w + 10 * n; a.chi2 = w + 11 * n; a.chi3 = w + 12 * n; a.upb = v[8];
+  float* H0[3] = {v[9], v[10], v[11]}; float* H1[3] = {v[12], v[13], v[14]};
+  float *ha = v[15], *hb = v[16];
+  const float sqdt = sqrtf(fabsf(dt));
+  a.dt = dt; a.sqdt = sqdt; a.abstol = abstol; a.reltol = reltol; a.delta = delta; a.eest = ee; a.w_reg = w_reg; a.nf = (float)n;
+  const lrnde_sri_tableau& T = *tab;
+  const int nb = sde_nb(n);
+  SriPtrs p;
+  p.uprev = uprev; p.dW = dW; p.dZ = dZ;
+  for (int j = 0; j < 4; ++j) { p.k[j] = const_cast<float*>(a.k[j]); p.g[j] = const_cast<float*>(a.g[j]); }
+  p.chi1 = const_cast<float*>(a.chi1); p.chi2 = const_cast<float*>(a.chi2); p.chi3 = const_cast<float*>(a.chi3);
+  for (int st = 1; st <= 3; ++st) {   // the stage inputs, from the k's and g's the step left (same kernel, same arithmetic)
+    p.H0 = H0[st - 1]; p.H1 = H1[st - 1];
+    hipLaunchKernelGGL(k_sri_stage, dim3(nb), dim3(256), 0, c->stream, n, p, T, st, dt, sqdt);
+  }
+  hipLaunchKernelGGL(k_sri_bseed, dim3(nb), dim3(256), 0, c->stream, n, a, T);
+  HIPCHK(c, hipGetLastError());
+  const float cf[3] = {T.c02, T.c03, T.c04}, cgt[3] = {T.c12, T.c13, T.c14};
+  for (int st = 3; st >= 0; --st) {
+    const float* xf = st ? H0[st - 1] : uprev; const float* xg = st ? H1[st - 1] : uprev;
+    const float tf = st ? t + cf[st - 1] * dt : t, tg = st ? t + cgt[st - 1] * dt : t + T.c11 * dt;
+    if ((rc = launch_vjp(c, xf, nullptr, 0.f, 0.f, tf, a.kb[st], B, ha, gpf[0]))) return rc;
+    if ((rc = launch_vjp(cg, xg, nullptr, 0.f, 0.f, tg, a.gb[st], B, hb, gpg[0]))) return rc;
+    hipLaunchKernelGGL(k_sri_bjoin, dim3(nb), dim3(256), 0, c->stream, n, a, T, st, (const float*)ha, (const float*)hb);
+    hipLaunchKernelGGL(k_sdeb_acc1, dim3(sde_nb(Pf)), dim3(256), 0, c->stream, Pf, dp_drift, (const float*)gpf[0]);
+    hipLaunchKernelGGL(k_sdeb_acc1, dim3(sde_nb(Pg)), dim3(256), 0, c->stream, Pg, dp_diff, (const float*)(gpg[0] + goff));
+    HIPCHK(c, hipGetLastError());
+  }
+  if (dx) HIPCHK(c, hipMemcpyAsync(dx, a.upb, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRNDE_OK;
+}

@@ -182,6 +182,23 @@ class SdeHandle:
                                                        C.c_void_p(dpf.data_ptr()), C.c_void_p(dpg.data_ptr())))
         return dict(dx=dx, dp_drift=dpf, dp_diff=dpg)
 
+    def sri_step_backward(self, tableau, uprev, dW, dZ, t, dt, abstol, reltol, delta, du_new=None, w_reg=0.0, want_dx=True,
+                          dp_drift=None, dp_diff=None):
+        """reverse sweep of one four-stage SRI step (lrnde_sde_sri_step_backward) for <du_new, u'> + w_reg * EEst*dt:
+        dict(dx, dp_drift, dp_diff, reg_val); dp_* are accumulated into the given tensors (fresh zeros by default)"""
+        B = uprev.numel() // self.D
+        tab = tableau if isinstance(tableau, L.SriTableau) else L.SriTableau(*[float(v) for v in tableau])
+        nf, ng = self._pcounts()
+        dpf = torch.zeros(nf, dtype=torch.float32, device=uprev.device) if dp_drift is None else dp_drift
+        dpg = torch.zeros(ng, dtype=torch.float32, device=uprev.device) if dp_diff is None else dp_diff
+        dx = torch.empty_like(uprev) if want_dx else None
+        rv = C.c_float()
+        self._chk(L.lib.lrnde_sde_sri_step_backward(
+            self._h, C.byref(tab), _dev_ptr(uprev, "uprev", self.D), _dev_ptr(dW, "dW", self.D), _dev_ptr(dZ, "dZ", self.D), B, float(t),
+            float(dt), float(abstol), float(reltol), float(delta), None if du_new is None else _dev_ptr(du_new.contiguous(), "du_new", self.D),
+            float(w_reg), None if dx is None else _dev_ptr(dx, "dx"), C.c_void_p(dpf.data_ptr()), C.c_void_p(dpg.data_ptr()), C.byref(rv)))
+        return dict(dx=dx, dp_drift=dpf, dp_diff=dpg, reg_val=np.float32(rv.value))
+
     def rkmil_reg_grad(self, uprev, dW, t, dt, abstol, reltol):
         """d (EEst*dt) / d (p_drift, p_diffusion) of one local Milstein step (src/perform_step.jl:108-170), uprev / dW / dt constant"""
         B = uprev.numel() // self.D
@@ -309,6 +326,7 @@ class NeuralDSDE:
             for i in range(n):
                 u = step(u, i, np.float32(t0 + np.float32(i) * dt))["u"]
                 us.append(u)
+            self._last_solve = dict(us=us, dW=noise, dZ=dz, t0=t0, dt=dt, abstol=abstol, reltol=reltol)
         else:
             if self.solver == "RKMil":
                 step = lambda uu, i, tt: h.rkmil_step(uu, noise[i].contiguous(), tt, dt, abstol, reltol)
@@ -345,7 +363,8 @@ class NeuralDSDE:
                 r = h.euler_heun_step(u1, noise[n].contiguous(), t1, dt_loc, abstol, reltol, self.delta)
             reg_val = r["reg_val"]
             nfe += per_step[0]; nfe_g += per_step[1]
-            self._last_local = dict(t1=t1, dt=dt_loc, u1=u1, dW=noise[n].contiguous(), abstol=abstol, reltol=reltol)
+            self._last_local = dict(t1=t1, dt=dt_loc, u1=u1, dW=noise[n].contiguous(), abstol=abstol, reltol=reltol,
+                                    dZ=dz[n].contiguous() if self.solver == "SRI" else None)
         sol = ODESolution([us[-1]], [t2], nfe)
         return sol, dict(drift=st["drift"], diffusion=st["diffusion"], nfe_drift=nfe, nfe_diffusion=nfe_g,
                          reg_val=reg_val, rng=rng, training=st["training"])
@@ -355,9 +374,25 @@ class NeuralDSDE:
         (test/runtests.jl:361-365, 386-397): (dx, dict(drift=, diffusion=), info).  The forward is re-run with the same
         draws as `__call__` (st['rng']; `noise` if given); the solve is differentiated through its own steps, reg_val
         w.r.t. the parameters only (info['dx_reg'] is None: `gs_x === nothing` in the reference)."""
-        if self.solver == "SRI":
-            raise NotImplementedError("the gradient path is built for the Euler-Heun (src/perform_step.jl:172-206) and Milstein (:108-170) "
-                                      "steps; the four-stage SRI step's reverse sweep is not")
+        if self.solver == "SRI":   # the fixed-grid loop of four-stage SRI steps, newest first (lrnde_sde_sri_step_backward)
+            sol, st2 = self(x, ps, st, noise=noise)
+            h = self.handle()
+            fs = self._last_solve
+            n = len(fs["us"])
+            ub, dpf, dpg = du_end.contiguous(), None, None
+            for i in range(n - 1, -1, -1):
+                ui = x if i == 0 else fs["us"][i - 1]
+                r = h.sri_step_backward(self.tableau, ui, fs["dW"][i].contiguous(), fs["dZ"][i].contiguous(),
+                                        np.float32(fs["t0"] + np.float32(i) * fs["dt"]), fs["dt"], fs["abstol"], fs["reltol"], self.delta,
+                                        du_new=ub, dp_drift=dpf, dp_diff=dpg)
+                ub, dpf, dpg = r["dx"], r["dp_drift"], r["dp_diff"]
+            mode = self.regularize if st["training"] else "none"
+            if mode != "none" and w_reg != 0.0:
+                lo = self._last_local
+                rg = h.sri_step_backward(self.tableau, lo["u1"], lo["dW"], lo["dZ"], lo["t1"], lo["dt"], lo["abstol"], lo["reltol"], self.delta,
+                                         du_new=None, w_reg=w_reg, want_dx=False, dp_drift=dpf, dp_diff=dpg)
+                assert rg["reg_val"] == st2["reg_val"]
+            return ub, dict(drift=dpf, diffusion=dpg), dict(sol=sol, st=st2, dx_reg=None)
         if self.adaptive:
             return self.pullback_series(x, ps, st, None, du_end=du_end, w_reg=w_reg, path=noise)
         sol, st2 = self(x, ps, st, noise=noise)

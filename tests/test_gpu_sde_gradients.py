@@ -295,3 +295,95 @@ def test_rkmil_solve_and_regulariser_gradients_match_float64_autograd(gpu_pkg, D
     dx1, dps1, info = node.pullback(xd, ps, st, torch.ones_like(xd), w_reg=2.0)
     assert torch.isfinite(dx0).all() and (dx0 != 0).all() and torch.equal(dx0, dx1) and info["dx_reg"] is None
     assert not torch.equal(dps0["drift"], dps1["drift"]) and info["st"]["reg_val"] != 0
+
+
+def _sri_step64(f, g, T, u, dW, dZ, dt, abstol, reltol, delta):
+    """src/perform_step.jl:49-106 in float64 torch; T: dict of the 51 tableau coefficients.  Returns (u', EEst*dt)."""
+    sq = np.sqrt(dt)
+    chi1 = (dW ** 2 - abs(dt)) / (2 * sq)
+    chi2 = (dW + dZ / np.sqrt(3.0)) / 2
+    chi3 = (dW ** 3 - 3 * dW * dt) / (6 * dt)
+    k1 = f(u); g1 = g(u)
+    H01 = u + dt * T["a021"] * k1 + T["b021"] * chi2 * g1
+    H11 = u + dt * T["a121"] * k1 + sq * T["b121"] * g1
+    k2 = f(H01); g2 = g(H11)
+    H02 = u + dt * (T["a031"] * k1 + T["a032"] * k2) + chi2 * (T["b031"] * g1 + T["b032"] * g2)
+    H12 = u + dt * (T["a131"] * k1 + T["a132"] * k2) + sq * (T["b131"] * g1 + T["b132"] * g2)
+    k3 = f(H02); g3 = g(H12)
+    H03 = u + dt * (T["a041"] * k1 + T["a042"] * k2 + T["a043"] * k3) + chi2 * (T["b041"] * g1 + T["b042"] * g2 + T["b043"] * g3)
+    H13 = u + dt * (T["a141"] * k1 + T["a142"] * k2 + T["a143"] * k3) + sq * (T["b141"] * g1 + T["b142"] * g2 + T["b143"] * g3)
+    k4 = f(H03); g4 = g(H13)
+    E2 = chi2 * (T["beta31"] * g1 + T["beta32"] * g2 + T["beta33"] * g3 + T["beta34"] * g4) + \
+        chi3 * (T["beta41"] * g1 + T["beta42"] * g2 + T["beta43"] * g3 + T["beta44"] * g4)
+    un = u + dt * (T["alpha1"] * k1 + T["alpha2"] * k2 + T["alpha3"] * k3 + T["alpha4"] * k4) + E2 + \
+        dW * (T["beta11"] * g1 + T["beta12"] * g2 + T["beta13"] * g3 + T["beta14"] * g4) + \
+        chi1 * (T["beta21"] * g1 + T["beta22"] * g2 + T["beta23"] * g3 + T["beta24"] * g4)
+    E1 = dt * (k1 + k2 + k3 + k4)
+    r = (delta * E1 + E2) / (abstol + torch.maximum(u.abs(), un.abs()) * reltol)
+    return un, torch.sqrt((r * r).mean()) * dt
+
+
+@pytest.mark.parametrize("D,H,B,n", [(32, 64, 16, 4), (20, 48, 5, 3), (2, 4, 3, 4)])
+def test_sri_solve_and_regulariser_gradients_match_float64_autograd(gpu_pkg, D, H, B, n):
+    """the four-stage SRI step (src/perform_step.jl:49-106 — what SOSRI, the reference's default solver, runs; the tableau is the
+    caller's): reverse sweep of a fixed-grid solve and of the local step's EEst*dt against float64 autograd of the same
+    expressions with the same (random, order-1) tableau; then the layer-level pullback's assertions"""
+    P = gpu_pkg
+    from localregneuralde_jl_amd import _lib as L
+    from localregneuralde_jl_amd.layers import _mlp_desc
+    rng = np.random.default_rng(41)
+    T = {k: float(np.float32(rng.uniform(-0.6, 0.9))) for k in L.SRI_FIELDS}
+    tab = [T[k] for k in L.SRI_FIELDS]
+    pd, pg = _params(D, H, 6)
+    x = rng.standard_normal((B, D)).astype(np.float32)
+    dt = np.float32(0.5 / n)
+    dW = (rng.standard_normal((n, B, D)) * np.sqrt(dt)).astype(np.float32)
+    dZ = (rng.standard_normal((n, B, D)) * np.sqrt(dt)).astype(np.float32)
+    gend = rng.standard_normal((B, D)).astype(np.float32)
+    h = P.SdeHandle(_mlp_desc(P.Chain(P.Dense(D, H, "tanh"), P.Dense(H, D))))
+    h.set_params(pd, pg)
+    xd = torch.from_numpy(x).cuda()
+    us, u = [], xd
+    for i in range(n):
+        u = h.sri_step(tab, u, torch.from_numpy(dW[i]).cuda(), torch.from_numpy(dZ[i]).cuda(), i * float(dt), dt, 0.14, 0.14, 1.0 / 6.0)["u"]
+        us.append(u)
+    ub, dpf, dpg = torch.from_numpy(gend).cuda(), None, None
+    for i in range(n - 1, -1, -1):
+        r = h.sri_step_backward(tab, xd if i == 0 else us[i - 1], torch.from_numpy(dW[i]).cuda(), torch.from_numpy(dZ[i]).cuda(), i * float(dt), dt,
+                                0.14, 0.14, 1.0 / 6.0, du_new=ub, dp_drift=dpf, dp_diff=dpg)
+        ub, dpf, dpg = r["dx"], r["dp_drift"], r["dp_diff"]
+    pdt = torch.tensor(pd, dtype=torch.float64, requires_grad=True)
+    pgt = torch.tensor(pg, dtype=torch.float64, requires_grad=True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    f, g = _fields64(pdt, pgt, D, H)
+    u64 = xt
+    for i in range(n):
+        u64 = _sri_step64(f, g, T, u64, torch.tensor(dW[i], dtype=torch.float64), torch.tensor(dZ[i], dtype=torch.float64), float(dt), 0.14, 0.14, 1.0 / 6.0)[0]
+    assert _rel(us[-1].cpu().numpy(), u64.detach().numpy()) < 1e-5
+    (u64 * torch.tensor(gend, dtype=torch.float64)).sum().backward()
+    for name, got, ref in (("dx", ub, xt.grad), ("dp_drift", dpf, pdt.grad), ("dp_diff", dpg, pgt.grad)):
+        e = _rel(got.cpu().numpy(), ref.numpy())
+        print(f"sri solve backward {name}: rel err {e:.2e}")
+        assert e < 1e-5, (name, e)
+    # the local step's regulariser, parameters only
+    u1 = us[n // 2].contiguous()
+    rg = h.sri_step_backward(tab, u1, torch.from_numpy(dW[0]).cuda(), torch.from_numpy(dZ[1]).cuda(), 0.2, dt, 0.14, 0.14, 1.0 / 6.0,
+                             du_new=None, w_reg=1.0, want_dx=False)
+    pdt.grad = None; pgt.grad = None
+    val = _sri_step64(f, g, T, torch.tensor(u1.cpu().numpy(), dtype=torch.float64), torch.tensor(dW[0], dtype=torch.float64),
+                      torch.tensor(dZ[1], dtype=torch.float64), float(dt), 0.14, 0.14, 1.0 / 6.0)[1]
+    assert abs(float(val.detach()) - float(rg["reg_val"])) < 5e-5 * abs(float(val.detach()))
+    val.backward()
+    for name, got, ref in (("dp_drift", rg["dp_drift"], pdt.grad), ("dp_diff", rg["dp_diff"], pgt.grad)):
+        e = _rel(got.cpu().numpy(), ref.numpy())
+        print(f"sri reg gradient {name}: rel err {e:.2e}")
+        assert e < 5e-5, (name, e)
+    # the layer
+    node = P.NeuralDSDE(P.Chain(P.Dense(D, H, "tanh"), P.Dense(H, D)), P.Dense(D, D), solver="SRI", tableau=tab, regularize="unbiased",
+                        nsteps=n, abstol=0.14, reltol=0.14)
+    st = node.initialstates(np.random.default_rng(0))
+    ps = dict(drift=pd, diffusion=pg)
+    dx0, dps0, _ = node.pullback(xd, ps, st, torch.ones_like(xd), w_reg=0.0)
+    dx1, dps1, info = node.pullback(xd, ps, st, torch.ones_like(xd), w_reg=2.0)
+    assert torch.isfinite(dx0).all() and (dx0 != 0).all() and torch.equal(dx0, dx1) and info["dx_reg"] is None
+    assert not torch.equal(dps0["drift"], dps1["drift"]) and info["st"]["reg_val"] != 0
