@@ -54,6 +54,11 @@ struct AdjArgs {
   // > 0 = one partial per tile of the last parameter-gradient GEMM at part[ADJ_MU_TILE_OFF ..) (k_pgrad_adj_err, which
   // then also forms the mu part of z_new: no launch of its own for the end of an adjoint step)
   int mu_tiles;
+  // OVERLAPPED stage launches (LRNDE_ADJ_OVERLAP, adj_solve_device): device words shared by the stage launches of one solve —
+  // sync[0] = attempt whose control block is published (seq numbering of hstat), sync[1] = a wait timed out,
+  // sync[8 + (id & 7)] = VJP workgroups of stage launch `id` that have stored their outputs.  NULL: launches run one after
+  // the other and none of this is touched.
+  int* sync;
 };
 constexpr int ADJ_MU_TILE_OFF = 576;   // behind [256 lambda][256 mu blocks][64 rank slots]
 constexpr int ADJ_MU_TILE_MAX = 2048;
@@ -72,8 +77,41 @@ __device__ __forceinline__ float* adj_K(const AdjArgs& g, int j, int cur) {
   return g.base + (size_t)(4 + slot) * g.N;
 }
 // lambda part of the stage state of stage sidx (2..7): the buffers the host loop of round 1 alternated between
+// (overlapped launches: THREE stage buffers in rotation — the tiles of launch s still read lambda_{s-1} while launch s+1
+//  forms lambda_{s+1}; the third is the 12th vector of the allocation)
 __device__ __forceinline__ float* adj_stage_lam(const AdjArgs& g, int sidx, int cur) {
-  return (sidx == 7) ? adj_zb(g, cur ^ 1) : ((sidx & 1) ? adj_ut(g) : adj_zs(g));
+  if (sidx == 7) return adj_zb(g, cur ^ 1);
+  if (g.sync) { const int r = sidx % 3; return r == 0 ? g.base + 11 * g.N : (r == 1 ? adj_ut(g) : adj_zs(g)); }
+  return (sidx & 1) ? adj_ut(g) : adj_zs(g);
+}
+
+// ---- overlapped launches: L2-bypassing accesses (agent scope: the per-XCD L2s are not coherent with each other inside a
+// kernel) and the bounded wait.  Pattern measured in tools/xchg_probe.hip: relaxed agent-scope stores / loads, no fences.
+__device__ __forceinline__ float ldcc(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ldcc(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16-byte forms: one sc1 instruction per lane (four scalar agent-scope accesses cost four address-path slots)
+__device__ __forceinline__ f32x4 ld4cc(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void stwt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stwt(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st4wt(float* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+// wait until *w - want >= 0 (30 ms at most: a wait that long is a lost launch, not a slow one; sync[1] tells the host)
+__device__ __forceinline__ bool adj_spin(const int* w, int want, int* err) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+  for (;;) {
+    if (ldcc(w) - want >= 0) return true;
+    __builtin_amdgcn_s_sleep(4);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000ull) { stwt(err, 1); return false; }
+  }
+}
+// all of this workgroup's stores have been acknowledged -> one arrival on the launch's counter (every wave, then thread 0)
+__device__ __forceinline__ void adj_arrive(int* sync, int id) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + 8 + (id & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // sum of the norm's partial sums (wave 0, all lanes return the total): lambda part = the 256 block sums, or, on a sharded
@@ -156,6 +194,25 @@ __device__ __forceinline__ void adj_hstat_fill(int* hs, const AdjCtrl& c) {
   hs[9] = __builtin_bit_cast(int, c.eest_last); hs[10] = __builtin_bit_cast(int, c.dt_init);
 }
 
+// overlapped launches: the control block of attempt j is read by the stage-3 launch WHILE this (stage-2) launch runs, from
+// other XCDs — field by field through the L2 (agent-scope stores), then the attempt's number in sync[0]
+__device__ __forceinline__ void adj_publish(const AdjArgs& g, AdjCtrl* cout, const AdjCtrl& c, int j) {
+  int* d = reinterpret_cast<int*>(cout);
+#define LRNDE_PUB(f) stwt(d + offsetof(AdjCtrl, f) / 4, __builtin_bit_cast(int, c.f))
+  LRNDE_PUB(status); LRNDE_PUB(first); LRNDE_PUB(do_step); LRNDE_PUB(resume); LRNDE_PUB(iter); LRNDE_PUB(naccept); LRNDE_PUB(nreject);
+  LRNDE_PUB(nf); LRNDE_PUB(cur); LRNDE_PUB(istop); LRNDE_PUB(t); LRNDE_PUB(dt); LRNDE_PUB(tstop); LRNDE_PUB(qold); LRNDE_PUB(q11);
+  LRNDE_PUB(dtpropose); LRNDE_PUB(eest_last); LRNDE_PUB(dt_init); LRNDE_PUB(dt0);
+#undef LRNDE_PUB
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    int* sp = d + (offsetof(AdjCtrl, st) + q * sizeof(AdjStage)) / 4;
+    stwt(sp + 0, c.st[q].lo); stwt(sp + 1, __builtin_bit_cast(int, c.st[q].theta)); stwt(sp + 2, __builtin_bit_cast(int, c.st[q].ddt));
+    stwt(sp + 3, __builtin_bit_cast(int, c.st[q].t));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stwt(g.sync, g.seq0 + j + 1);
+}
+
 // footer of attempt j-1 + header of attempt j (wave 0 of every workgroup; identical inputs => identical results).
 // Returns the control block of attempt j; block 0 also publishes it to ctl[(j+1)&1].
 __device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
@@ -166,9 +223,11 @@ __device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
   c.do_step = 0;
   if (c.status != ST_RUNNING) {
     if (blockIdx.x == 0 && lane == 0) {
-      *cout = c;
+      if (g.sync) adj_publish(g, cout, c, j);
+      else *cout = c;
       if (g.hstat) {
         adj_hstat_fill(g.hstat, c);
+        if (g.sync) g.hstat[11] = ldcc(g.sync + 1);   // a wait of an overlapped launch timed out: the results are not to be used
         __hip_atomic_store(g.hstat, g.seq0 + j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
@@ -251,9 +310,11 @@ __device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
   }
   c.t = t; c.dt = dt; c.first = 0;
   if (blockIdx.x == 0 && lane == 0) {
-    *cout = c;
+    if (g.sync) adj_publish(g, cout, c, j);
+    else *cout = c;
     if (g.hstat) {
       adj_hstat_fill(g.hstat, c);
+      if (g.sync) g.hstat[11] = ldcc(g.sync + 1);
       __hip_atomic_store(g.hstat, g.seq0 + j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }

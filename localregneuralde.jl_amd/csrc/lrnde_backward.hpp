@@ -204,10 +204,13 @@ struct PgradArgs {
   const float* h;     // (B,Hp)
   const float* dpre;  // (B,Hp)
   float* gp;          // flat (P)
-  int ntile1, ntile2, nt1c, nt2c;  // tiles of gW1: ceil(H/16) x ceil(D/16); gW2: ceil(D/16) x ceil(H/16)
+  int ntile1, ntile2, nt1c, nt2c;  // tiles of gW1: ceil(H/16ts) x ceil((D+2)/16ts); gW2: ceil(D/16ts) x ceil((H+2)/16ts)
+  int ts;          // a workgroup's output tile is 16ts x 16ts (1 or 2)
   // device-resolved form (lrnde_adjoint.hpp): t, lam and gp of the evaluation come from the control block
   int adj_mode, adj_stage, adj_j;
   int accumulate;  // 1: gp += result (the regulariser's reverse sweep sums six evaluations' cotangents), 0: overwrite
+  int cc;          // 1: operands (scratch y / h / dpre, lam) were written by a launch that is still running elsewhere on the
+                   // chip (overlapped stage launches): read them past the L2 (agent scope)
 };
 
 // t / lam / gp of a parameter-gradient GEMM that belongs to the adjoint loop's evaluation (mode, stage) of attempt j
@@ -222,9 +225,14 @@ __device__ __forceinline__ bool pgrad_resolve(PgradArgs& a, const AdjArgs& g) {
   }
   // (fields read through the pointer: a private copy of the block indexed by the runtime stage would live in scratch)
   const AdjCtrl* cp = g.ctl + ((a.adj_j + 1) & 1);
-  if (!cp->do_step) return false;
-  const int cur = cp->cur;
-  a.t = cp->st[a.adj_stage - 2].t;
+  int do_step, cur; float tt;
+  if (g.sync) {   // published by a launch that may still be running: past the L2
+    const int* d = reinterpret_cast<const int*>(cp);
+    do_step = ldcc(d + offsetof(AdjCtrl, do_step) / 4); cur = ldcc(d + offsetof(AdjCtrl, cur) / 4);
+    tt = __builtin_bit_cast(float, ldcc(d + (offsetof(AdjCtrl, st) + (a.adj_stage - 2) * sizeof(AdjStage) + offsetof(AdjStage, t)) / 4));
+  } else { do_step = cp->do_step; cur = cp->cur; tt = cp->st[a.adj_stage - 2].t; }
+  if (!do_step) return false;
+  a.t = tt;
   a.lam = adj_stage_lam(g, a.adj_stage, cur);
   a.gp = adj_K(g, a.adj_stage - 1, cur) + g.n_lam;
   return true;
@@ -234,6 +242,10 @@ __device__ __forceinline__ bool pgrad_resolve(PgradArgs& a, const AdjArgs& g) {
 // forms z_new's and the residual's entry on the spot (K1..K6 and z at the same index; the arithmetic of k_adj_err) and the
 // tile leaves ONE fp64 partial — no launch of its own for the mu part of the error norm
 struct AdjMuFold { const float* K[6]; const float* z; float* zn; float A7[6], BT[7]; float dt, abstol, reltol; double* part; };
+// TS x TS MFMA tiles of 16 x 16 per workgroup (a.ts: 1 or 2).  A wave's loads per k-step are TS A values + TS B values for
+// TS*TS MFMAs: at TS = 1 the GEMM re-read its operands 45 MB per launch at B = 512 through the L2 (700 workgroups, two loads
+// per MFMA), at TS = 2 half of that with 200 workgroups.  The sums are the same chains in the same order either way.
+template <bool CC = false, int TS = 1>
 __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, const AdjMuFold* fold = nullptr) {  // one output tile per workgroup, the batch (K) split over its 4 waves
   __shared__ f32x4 red[3][64];
   const int lane = threadIdx.x & 63;
@@ -251,19 +263,30 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, c
   const float* Bm = first ? a.y : a.h;
   const int lda = first ? a.Hp : a.D, ldb = first ? a.D : a.Hp;
   const int M = first ? a.H : a.D, N = first ? a.D : a.H;
-  const int row = ti * 16 + li, col = tj * 16 + li;
-  const bool rok = row < M, cok = col < N;
-  const float cconst = (col == N) ? a.t : ((col == N + 1) ? 1.0f : 0.0f);
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const float* Ap = A + (rok ? row : 0);
-  const float* Bp = Bm + (cok ? col : 0);
+  bool rok[TS], cok[TS];
+  float cconst[TS];
+  const float* Ap[TS];
+  const float* Bp[TS];
+#pragma unroll
+  for (int s = 0; s < TS; ++s) {
+    const int row = (ti * TS + s) * 16 + li, col = (tj * TS + s) * 16 + li;
+    rok[s] = row < M; cok[s] = col < N;
+    cconst[s] = (col == N) ? a.t : ((col == N + 1) ? 1.0f : 0.0f);
+    Ap[s] = A + (rok[s] ? row : 0);
+    Bp[s] = Bm + (cok[s] ? col : 0);
+  }
+  f32x4 acc[TS][TS];
+#pragma unroll
+  for (int si = 0; si < TS; ++si)
+#pragma unroll
+    for (int sj = 0; sj < TS; ++sj) acc[si][sj] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int UN = 8;   // 8 MFMA k-steps (32 samples) per block
-  constexpr int GB = 4;   // blocks whose loads are all in flight before the first MFMA (64 independent loads per lane):
-                          // at B = 512 a wave's whole share; block after block the kernel paid one L2 round trip per block
+  constexpr int GB = TS == 1 ? 4 : 2;   // blocks whose loads are all in flight before the first MFMA (64 independent loads per lane):
+                          // at B = 512 and TS = 1 a wave's whole share; block after block the kernel paid one L2 round trip per block
   // blocks of 32 samples go round-robin to the 4 waves (fixed, so the summation order is fixed)
   const int nblk = (a.B + 4 * UN - 1) / (4 * UN);
   for (int blk0 = wave < 4 ? wave : nblk; blk0 < nblk; blk0 += 4 * GB) {  // waves beyond the fourth (512-thread launch) only join the barrier
-    float av[GB][UN], bv[GB][UN];
+    float av[GB][UN][TS], bv[GB][UN][TS];
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
       const int b0 = (blk0 + 4 * g) * 4 * UN;
@@ -271,39 +294,63 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, c
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
           const size_t b = (size_t)(b0 + 4 * u + lk);
-          av[g][u] = rok ? Ap[b * lda] : 0.f;
-          bv[g][u] = cok ? Bp[b * ldb] : cconst;
+#pragma unroll
+          for (int s = 0; s < TS; ++s) {
+            if constexpr (CC) { av[g][u][s] = rok[s] ? ldcc(Ap[s] + b * lda) : 0.f; bv[g][u][s] = cok[s] ? ldcc(Bp[s] + b * ldb) : cconst[s]; }
+            else { av[g][u][s] = rok[s] ? Ap[s][b * lda] : 0.f; bv[g][u][s] = cok[s] ? Bp[s][b * ldb] : cconst[s]; }
+          }
         }
       } else {  // the ragged last block, or no block at all (zeros add nothing)
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
           const int b = b0 + 4 * u + lk;
           const bool bok = b < a.B;
-          av[g][u] = (rok && bok) ? Ap[(size_t)b * lda] : 0.f;
-          bv[g][u] = bok ? (cok ? Bp[(size_t)b * ldb] : cconst) : 0.f;
+#pragma unroll
+          for (int s = 0; s < TS; ++s) {
+            if constexpr (CC) { av[g][u][s] = (rok[s] && bok) ? ldcc(Ap[s] + (size_t)b * lda) : 0.f; bv[g][u][s] = bok ? (cok[s] ? ldcc(Bp[s] + (size_t)b * ldb) : cconst[s]) : 0.f; }
+            else { av[g][u][s] = (rok[s] && bok) ? Ap[s][(size_t)b * lda] : 0.f; bv[g][u][s] = bok ? (cok[s] ? Bp[s][(size_t)b * ldb] : cconst[s]) : 0.f; }
+          }
         }
       }
     }
 #pragma unroll
     for (int g = 0; g < GB; ++g)
 #pragma unroll
-      for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][u], bv[g][u], acc, 0, 0, 0);
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int si = 0; si < TS; ++si)
+#pragma unroll
+          for (int sj = 0; sj < TS; ++sj) acc[si][sj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][u][si], bv[g][u][sj], acc[si][sj], 0, 0, 0);
   }
-  if (wave > 0 && wave < 4) red[wave - 1][lane] = acc;
-  __syncthreads();
+  // chains 1..3 join chain 0 in wave 0, sub-tile by sub-tile through the one staging array
+#pragma unroll
+  for (int si = 0; si < TS; ++si)
+#pragma unroll
+    for (int sj = 0; sj < TS; ++sj) {
+      if (TS > 1 && (si | sj)) __syncthreads();
+      if (wave > 0 && wave < 4) red[wave - 1][lane] = acc[si][sj];
+      __syncthreads();
+      if (wave == 0) {
+        acc[si][sj] = acc[si][sj] + red[0][lane];
+        acc[si][sj] = acc[si][sj] + red[1][lane];
+        acc[si][sj] = acc[si][sj] + red[2][lane];
+      }
+    }
   if (wave > 0) return;
-  acc = acc + red[0][lane];
-  acc = acc + red[1][lane];
-  acc = acc + red[2][lane];
   // D fragment: row = ti*16 + lk*4 + r, col = tj*16 + li ; flat weight index = row + M*col
   float* gW = a.gp + (first ? (size_t)0 : oW2);
   float* gb = a.gp + (first ? ob1 : ob2);
-  const int c = tj * 16 + li;
   double esum = 0.0;
+#pragma unroll
+  for (int si = 0; si < TS; ++si)
+#pragma unroll
+  for (int sj = 0; sj < TS; ++sj) {
+  const f32x4 accv = acc[si][sj];
+  const int c = (tj * TS + sj) * 16 + li;
   float* dsts[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int rr = ti * 16 + lk * 4 + r;
+    const int rr = (ti * TS + si) * 16 + lk * 4 + r;
     float* dst = nullptr;
     if (rr < M) {
       if (c < N) dst = gW + (size_t)rr + (size_t)M * c;
@@ -311,7 +358,7 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, c
       else if (c == N + 1) dst = gb + rr;
     }
     dsts[r] = dst;
-    if (dst) *dst = a.accumulate ? *dst + acc[r] : acc[r];
+    if (dst) *dst = a.accumulate ? *dst + accv[r] : accv[r];
   }
   if (fold) {
     // all loads of the lane's (up to) four entries first: K1..K6 and z at the entry's index of the mu part.  The four entries
@@ -352,21 +399,30 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, c
       float sb = fold->BT[0] * kv[r][0];
 #pragma unroll
       for (int q = 1; q < 6; ++q) sb = sb + fold->BT[q] * kv[r][q];
-      sb = sb + fold->BT[6] * acc[r];
+      sb = sb + fold->BT[6] * accv[r];
       const float ut = 0.f + fold->dt * sb;
       const float sc = fold->abstol + fmaxf_(__builtin_fabsf(zv[r]), __builtin_fabsf(znv)) * fold->reltol;
       const float rres = ut / sc;
       esum += (double)(rres * rres);
     }
+  }
+  }
+  if (fold) {
     esum = wave_sum_dpp(esum);
     if (lane == 0) fold->part[tile] = esum;
   }
 }
+// the tile shape is the launch's (PgradArgs::ts, set with the tile counts by pgrad_args)
+template <bool CC = false>
+__device__ __forceinline__ void pgrad_tile_any(const PgradArgs& a, const int tile, const AdjMuFold* fold = nullptr) {
+  if (a.ts == 2) pgrad_tile<CC, 2>(a, tile, fold);
+  else pgrad_tile<CC, 1>(a, tile, fold);
+}
 
-__global__ __launch_bounds__(256) void k_pgrad(PgradArgs a) { pgrad_tile(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_pgrad(PgradArgs a) { pgrad_tile_any(a, blockIdx.x); }
 __global__ __launch_bounds__(256) void k_pgrad_adj(PgradArgs a, AdjArgs g) {
   if (!pgrad_resolve(a, g)) return;
-  pgrad_tile(a, blockIdx.x);
+  pgrad_tile_any(a, blockIdx.x);
 }
 
 // W2^T / W1^T in the forward fragment layouts (see k_pack)
@@ -601,7 +657,7 @@ __global__ __launch_bounds__(256) void k_adj_err_dev(AdjErrArgs a, AdjArgs g, in
 __global__ __launch_bounds__(256) void k_pgrad_adj_err(PgradArgs a, AdjArgs g, AdjErrArgs e, int nt, int j, int fold_mu) {
   if ((int)blockIdx.x >= nt) { adj_err_blocks(e, g, j, blockIdx.x - nt, false); return; }
   if (!pgrad_resolve(a, g)) return;
-  if (!fold_mu) { pgrad_tile(a, blockIdx.x); return; }
+  if (!fold_mu) { pgrad_tile_any(a, blockIdx.x); return; }
   const AdjCtrl* cp = g.ctl + ((j + 1) & 1);
   const int cur = cp->cur;
   AdjMuFold f;
@@ -611,7 +667,7 @@ __global__ __launch_bounds__(256) void k_pgrad_adj_err(PgradArgs a, AdjArgs g, A
   for (int q = 0; q < 7; ++q) f.BT[q] = e.BT[q];
   f.z = adj_zb(g, cur) + g.n_lam; f.zn = adj_zb(g, cur ^ 1) + g.n_lam;
   f.dt = cp->dt; f.abstol = e.abstol; f.reltol = e.reltol; f.part = const_cast<double*>(g.part) + ADJ_MU_TILE_OFF;
-  pgrad_tile(a, blockIdx.x, &f);
+  pgrad_tile_any(a, blockIdx.x, &f);
 }
 
 // the rank's own fp64 sum (256 block partials, fixed order) into slot[rank] of a zeroed per-rank vector: the
@@ -670,6 +726,10 @@ struct VjpQArgs {
   int adj_mode, adj_stage, adj_j;
   AdjArgs adj;
   int qcols;   // batch columns per workgroup: QNB (4), or 2 to put a B <= 512 launch on all 256 CUs (0 = QNB)
+  // overlapped stage launches (adj.sync != NULL): this launch's id (its arrival counter is sync[8 + (id & 7)]); ovl = 1: the
+  // launch started while its producer (id - 1) was still running — it forms y, h and act' first, then waits for the
+  // producer's arrivals before it touches lambda and the newest K
+  int sync_id, ovl;
 };
 
 constexpr int VQB = 3 * QSB1;  // stream blocks of one VJP (QSB2 == QSB1)
@@ -786,6 +846,17 @@ __device__ __forceinline__ AdjEarly adj_early_load(const VjpQArgs& a) {
   e.do_step = 1; e.cur = 0; e.dt = 0.f; e.lo = 0; e.theta = 0.f; e.ddt = 0.f; e.t = 0.f;
   if (a.adj_mode == ADJ_STAGE && a.adj_stage > 2) {
     const AdjCtrl* cp = a.adj.ctl + ((a.adj_j + 1) & 1);
+    if (a.adj.sync) {
+      // the stage-2 launch of this attempt may not have published yet (it runs beside us), and it sits on other XCDs
+      if (!adj_spin(a.adj.sync, a.adj.seq0 + a.adj_j + 1, a.adj.sync + 1)) { e.do_step = 0; return e; }
+      const int* d = reinterpret_cast<const int*>(cp);
+      const int so = (offsetof(AdjCtrl, st) + (a.adj_stage - 2) * sizeof(AdjStage)) / 4;
+      e.do_step = ldcc(d + offsetof(AdjCtrl, do_step) / 4); e.cur = ldcc(d + offsetof(AdjCtrl, cur) / 4);
+      e.dt = __builtin_bit_cast(float, ldcc(d + offsetof(AdjCtrl, dt) / 4));
+      e.lo = ldcc(d + so); e.theta = __builtin_bit_cast(float, ldcc(d + so + 1)); e.ddt = __builtin_bit_cast(float, ldcc(d + so + 2));
+      e.t = __builtin_bit_cast(float, ldcc(d + so + 3));
+      return e;
+    }
     const AdjStage* sp = &cp->st[a.adj_stage - 2];
     e.do_step = cp->do_step; e.cur = cp->cur; e.dt = cp->dt;
     e.lo = sp->lo; e.theta = sp->theta; e.ddt = sp->ddt; e.t = sp->t;
@@ -885,11 +956,17 @@ __device__ unsigned long long g_vstamps[16];  // tools/vjp_probe: phases of a st
 #else
 #define VSTAMP(i) do { } while (0)
 #endif
-template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
+template <int KT, bool SYNC = false> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
 #ifdef LRNDE_STAMPS
   const bool vst_on = a.adj_mode == ADJ_STAGE && a.adj_stage == 5;
 #endif
   VSTAMP(0);
+  // SYNC: a stage launch of the overlapped adjoint loop (compile-time: a run-time flag around every store and in the operand
+  // loads cost the one-stream path 40 % — the loads of a phase no longer went out together)
+  int* const sync = SYNC ? a.adj.sync : nullptr;
+  constexpr bool wt = SYNC;              // outputs past the L2: a consumer on another XCD reads them while this launch runs
+  const bool ovl = SYNC && a.ovl != 0;
+  if (SYNC && blockIdx.x == 0 && threadIdx.x == 0) stwt(sync + 8 + ((a.sync_id + 2) & 7), 0);   // the launch after next's counter
   const AdjEarly early = adj_early_load(a);
   const ModelDev& m = a.m;
   const BiasPreQ bpre = bias_issue_q(m);  // in flight while the weight stream is set up; written to LDS below
@@ -902,6 +979,7 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
   const int sidx = lane & 3, q = lane >> 2;
   const int qc = a.qcols > 0 ? a.qcols : QNB;
   const int b0 = blockIdx.x * qc, nvalid = min(qc, a.B - b0);
+  const int nprod = (a.B + qc - 1) / qc;   // VJP workgroups of a stage launch (the producer's arrival count)
   const int KQ1 = m.D / 4;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   StreamV st;
@@ -936,6 +1014,66 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
   // stores in program order it was four memory round trips in series (per pass: record, store y, then the lambda terms,
   // whose loads could not move above a store that might alias them): 13.5 k of the launch's 44 k cycles.
   __syncthreads();
+  // the lambda half of phase 0, by itself (overlapped launches run it AFTER phase 1, once the producer has arrived):
+  // lambda_s = base + dt * sum a_sj K_j, the newest K past the L2
+  auto lambda_tile = [&]() {
+    f32x4 bs[2], kv[2][6]; bool in[2], ok[2]; size_t gg[2]; int li[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int i = (int)threadIdx.x + r * QNT;
+      const int sx = i & 3, kq = i >> 2;
+      in[r] = i < KQ1 * 4; ok[r] = in[r] && sx < nvalid; li[r] = i;
+      gg[r] = ok[r] ? (size_t)(b0 + sx) * m.D + kq * 4 : 0;
+      const size_t g = gg[r];
+      bs[r] = ld4(a.lbase + g);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) kv[r][j] = (j < a.lnk) ? (j == a.lnk - 1 ? ld4cc(a.lk[j] + g) : ld4(a.lk[j] + g)) : zero4;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (!in[r]) continue;
+      f32x4 lv = zero4;
+      if (ok[r]) {
+        if (a.lnk == 1) {
+          const float c0 = a.ldt * a.lc[0];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) lv[h] = bs[r][h] + c0 * kv[r][0][h];
+        } else {
+          f32x4 sacc;
+#pragma unroll
+          for (int h = 0; h < 4; ++h) sacc[h] = a.lc[0] * kv[r][0][h];
+#pragma unroll
+          for (int j = 1; j < 6; ++j)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) sacc[h] = sacc[h] + a.lc[j] * kv[r][j][h];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) lv[h] = bs[r][h] + a.ldt * sacc[h];
+        }
+        st4wt(a.lam_out + gg[r], lv);
+      }
+      ll[li[r]] = lv;
+    }
+  };
+  if (ovl) {   // y tile alone: record -> y -> LDS x tile and scratch
+    const size_t nst = (size_t)a.B * m.D;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int i = (int)threadIdx.x + r * QNT;
+      const int sx = i & 3, kq = i >> 2;
+      if (i >= KQ1 * 4) continue;
+      f32x4 x = zero4;
+      if (sx < nvalid) {
+        const size_t g = (size_t)(b0 + sx) * m.D + kq * 4;
+        f32x4 dv[5];
+#pragma unroll
+        for (int qq = 0; qq < 5; ++qq) dv[qq] = ld4(a.dense + (size_t)qq * nst + g);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) x[h] = tsit5_rec_eval(dv[0][h], dv[1][h], dv[2][h], dv[3][h], dv[4][h], a.theta, a.dense_dt);
+        st4wt(a.ysc + g, x);
+      }
+      s.xl[i] = x;
+    }
+  } else
   {
     const size_t nst = (size_t)a.B * m.D;
     bool in[2], ok[2]; size_t gg[2]; int li[2];
@@ -976,12 +1114,12 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
           for (int h = 0; h < 4; ++h)
             x[h] = tsit5_rec_eval(dv[r][0][h], dv[r][1][h], dv[r][2][h], dv[r][3][h], dv[r][4][h], a.theta, a.dense_dt);
         }
-        st4(a.ysc + g, x);
+        if constexpr (wt) st4wt(a.ysc + g, x); else st4(a.ysc + g, x);
         if (a.lnk == 1) {  // one term (stage 2, initdt's Euler step): base + (dt*c0)*k0, the order of k_axpy / perform_step.jl:11-12
           const float c0 = a.ldt * a.lc[0];
 #pragma unroll
           for (int h = 0; h < 4; ++h) lv[h] = bs[r][h] + c0 * kv[r][0][h];
-          st4(a.lam_out + g, lv);
+          if constexpr (wt) st4wt(a.lam_out + g, lv); else st4(a.lam_out + g, lv);
         } else if (a.lnk > 0) {
           f32x4 sacc;
 #pragma unroll
@@ -992,7 +1130,7 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
             for (int h = 0; h < 4; ++h) sacc[h] = sacc[h] + a.lc[j] * kv[r][j][h];
 #pragma unroll
           for (int h = 0; h < 4; ++h) lv[h] = bs[r][h] + a.ldt * sacc[h];
-          st4(a.lam_out + g, lv);
+          if constexpr (wt) st4wt(a.lam_out + g, lv); else st4(a.lam_out + g, lv);
         } else {
           lv = bs[r];
         }
@@ -1023,7 +1161,14 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
     pre = pre + b1[o];
     const float h = act_apply(m.act, pre);
     dact[e] = act_deriv_c(m.act, pre, h);
-    if (sx < nvalid && o < m.Hp) a.hsc[(size_t)(b0 + sx) * m.Hp + o] = h;
+    if (sx < nvalid && o < m.Hp) { float* hp_ = a.hsc + (size_t)(b0 + sx) * m.Hp + o; if constexpr (wt) stwt(hp_, h); else *hp_ = h; }
+  }
+  if (ovl) {
+    // everything above needed the record only.  Now the producer (launch id - 1: the previous stage) must have stored its
+    // K and lambda: one thread waits for its arrivals, then the lambda tile is formed (phase 0's other half)
+    if (threadIdx.x == 0) adj_spin(sync + 8 + ((a.sync_id - 1) & 7), nprod, sync + 1);
+    __syncthreads();
+    lambda_tile();
   }
   q_barrier();
   VSTAMP(5);
@@ -1038,7 +1183,7 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
     const float v = q_segment_sum(plf, ne, e, nseg1);
     const float dpre = (o < m.H) ? v * dact[e] : 0.f;
     hlf[((o >> 2) * 4 + sx) * 4 + r] = dpre;
-    if (sx < nvalid && o < m.Hp) a.dpsc[(size_t)(b0 + sx) * m.Hp + o] = dpre;
+    if (sx < nvalid && o < m.Hp) { float* dp_ = a.dpsc + (size_t)(b0 + sx) * m.Hp + o; if constexpr (wt) stwt(dp_, dpre); else *dp_ = dpre; }
   }
   q_barrier();
   VSTAMP(7);
@@ -1057,23 +1202,39 @@ template <int KT> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
     const int g0 = wave, g1 = wave + QNW;
     if (sidx < nvalid) {
       float* dst = a.dy + (size_t)(b0 + sidx) * m.D + q * 4;
-      if (g0 < m.RG2 && g0 * 64 + q * 4 < m.D) st4(dst + g0 * 64, acc0);
-      if (g1 < m.RG2 && g1 * 64 + q * 4 < m.D) st4(dst + g1 * 64, acc1);
+      if (g0 < m.RG2 && g0 * 64 + q * 4 < m.D) { if constexpr (wt) st4wt(dst + g0 * 64, acc0); else st4(dst + g0 * 64, acc0); }
+      if (g1 < m.RG2 && g1 * 64 + q * 4 < m.D) { if constexpr (wt) st4wt(dst + g1 * 64, acc1); else st4(dst + g1 * 64, acc1); }
     }
   }
   VSTAMP(8);
+  if constexpr (wt) adj_arrive(sync, a.sync_id);   // this workgroup's K, lambda and scratch are out: the next stage may read them
 }
 
-template <int KT> __global__ __launch_bounds__(QNT) void k_vjp_q(VjpQArgs a) { vjp_q_body<KT>(a); }
+#ifndef LRNDE_OVL_TILE_CC
+#define LRNDE_OVL_TILE_CC false
+#endif
+template <int KT, bool SYNC = false> __global__ __launch_bounds__(QNT) void k_vjp_q(VjpQArgs a) { vjp_q_body<KT, SYNC>(a); }
 
 // The VJP of one adjoint RHS evaluation and, on the CUs it leaves idle (it has B/4 workgroups: 128 at B = 512), the
 // parameter-gradient GEMM of the PREVIOUS evaluation (its tiles are workgroups nvjp, nvjp+1, ...).  The two touch
 // disjoint buffers: the scratch (y, h, dpre) and the stage lambda are double buffered by the host (launch_vjp).
-template <int KT> __global__ __launch_bounds__(QNT) void k_vjp_q_pg(VjpQArgs a, PgradArgs pg, int nvjp) {
+template <int KT, bool SYNC = false> __global__ __launch_bounds__(QNT) void k_vjp_q_pg(VjpQArgs a, PgradArgs pg, int nvjp) {
   if ((int)blockIdx.x >= nvjp) {
+    constexpr bool synced = SYNC;
+    if (synced) {   // the attempt's control block may not be published yet (its stage-2 launch runs beside this one)
+      if (threadIdx.x == 0) adj_spin(a.adj.sync, a.adj.seq0 + a.adj_j + 1, a.adj.sync + 1);
+      __syncthreads();
+    }
     if (!pgrad_resolve(pg, a.adj)) return;
-    pgrad_tile(pg, (int)blockIdx.x - nvjp);
+    if (synced) {
+      // the scratch set and lambda these tiles read belong to launch id - 1, which may still be running elsewhere on the chip
+      if (threadIdx.x == 0) adj_spin(a.adj.sync + 8 + ((a.sync_id - 1) & 7), nvjp, a.adj.sync + 1);
+      __syncthreads();
+      pgrad_tile_any<LRNDE_OVL_TILE_CC>(pg, (int)blockIdx.x - nvjp);
+      return;
+    }
+    pgrad_tile_any(pg, (int)blockIdx.x - nvjp);
     return;
   }
-  vjp_q_body<KT>(a);
+  vjp_q_body<KT, SYNC>(a);
 }

@@ -1794,6 +1794,9 @@ struct lrnde_ctx {
   // device-side adjoint controller (lrnde_adjoint.hpp): control blocks, initdt partial sums, tstops, pinned read-back slots
   AdjCtrl* adj_ctl = nullptr; AdjCtrl* adj_ctl_host = nullptr; double* adj_ipart = nullptr; float* adj_stops = nullptr; int adj_stops_cap = 0;
   hipEvent_t adj_ev[2] = {nullptr, nullptr};
+  // overlapped stage launches of the adjoint loop (LRNDE_ADJ_OVERLAP): second stream, cross-stream events, device sync words
+  hipStream_t adj_stream2 = nullptr; hipEvent_t adj_evA[2] = {nullptr, nullptr}, adj_evB[2] = {nullptr, nullptr};
+  int* adj_sync = nullptr; int adj_launch_id = 0;
   int* adj_hstat = nullptr; int* adj_hstat_dev = nullptr; int adj_seq = 0;  // pinned progress word of the adjoint loop (host / device view)
   std::vector<float> last_ts;  // sol.t of the last node_forward (cotangent times of the adjoint)
   std::vector<int> series_idx; std::vector<float> series_t;  // the caller's view of that solution: save slots and times
@@ -1879,13 +1882,13 @@ namespace {
 // path in the same process as the default one and holds the two to the same bits.
 enum {
   OPT_NO_QTILE, OPT_QTILE_MAX_B, OPT_NO_FUSE, OPT_DENSE_COPY, OPT_NO_OVERLAP, OPT_NO_SDE_FAST, OPT_SDE_HOST_LOOP, OPT_NO_QVJP,
-  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
+  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_OVERLAP, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_PGRAD_TS, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
 };
 struct OptDef { const char* name; int dflt; bool flag; };   // flag: present in the environment = 1
 const OptDef g_optdef[N_OPT] = {
     {"LRNDE_NO_QTILE", 0, true}, {"LRNDE_QTILE_MAX_B", 2048, false}, {"LRNDE_NO_FUSE", 0, true}, {"LRNDE_DENSE_COPY", 0, true},
     {"LRNDE_NO_OVERLAP", 0, true}, {"LRNDE_NO_SDE_FAST", 0, true}, {"LRNDE_SDE_HOST_LOOP", 0, true}, {"LRNDE_NO_QVJP", 0, true},
-    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
+    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_OVERLAP", 0, false}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_PGRAD_TS", 0, false}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
     {"LRNDE_FEED_M", 2, false}, {"LRNDE_GATHER_TILES", 0, true}, {"LRNDE_FORCE_COMM", 0, true}};
 int g_opt[N_OPT];
 bool g_opt_set[N_OPT];     // set by the hook: the environment no longer counts
@@ -2291,6 +2294,9 @@ int lrnde_destroy(lrnde_ctx* c) {
   if (c->adj_ctl) hipFree(c->adj_ctl);
   if (c->adj_ctl_host) hipHostFree(c->adj_ctl_host);
   if (c->adj_hstat) hipHostFree(c->adj_hstat);
+  if (c->adj_stream2) hipStreamDestroy(c->adj_stream2);
+  for (int i = 0; i < 2; ++i) { if (c->adj_evA[i]) hipEventDestroy(c->adj_evA[i]); if (c->adj_evB[i]) hipEventDestroy(c->adj_evB[i]); }
+  if (c->adj_sync) hipFree(c->adj_sync);
   if (c->adj_ipart) hipFree(c->adj_ipart);
   if (c->adj_stops) hipFree(c->adj_stops);
   if (c->adj_ev[0]) hipEventDestroy(c->adj_ev[0]);
@@ -3545,15 +3551,19 @@ static int ensure_bw(lrnde_ctx* c, int B) {
   if (c->bw_h) HIPCHK(c, hipFree(c->bw_h));
   if (c->bw_dp) HIPCHK(c, hipFree(c->bw_dp));
   c->bw_y = c->bw_h = c->bw_dp = nullptr;
-  HIPCHK(c, hipMalloc(&c->bw_y, sizeof(float) * 2 * (size_t)B * c->desc.state_dim));
-  HIPCHK(c, hipMalloc(&c->bw_h, sizeof(float) * 2 * (size_t)B * c->m.Hp));
-  HIPCHK(c, hipMalloc(&c->bw_dp, sizeof(float) * 2 * (size_t)B * c->m.Hp));
+  // (three sets: two alternate between consecutive evaluations; overlapped stage launches rotate through all three)
+  HIPCHK(c, hipMalloc(&c->bw_y, sizeof(float) * 3 * (size_t)B * c->desc.state_dim));
+  HIPCHK(c, hipMalloc(&c->bw_h, sizeof(float) * 3 * (size_t)B * c->m.Hp));
+  HIPCHK(c, hipMalloc(&c->bw_dp, sizeof(float) * 3 * (size_t)B * c->m.Hp));
   c->bwB = B;
   return LRNDE_OK;
 }
 
 // (df/dp)^T lam from the scratch left by the last VJP launch (y, h, dpre); gp may be NULL
-static PgradArgs pgrad_args(const lrnde_ctx* c, int B, float t, const float* lam, float* gp, int set) {
+// riding: the tiles share a VJP launch's grid (k_vjp_q_pg) — 32 x 32 tiles there (half the operand traffic beside the VJP's weight
+// stream: the stage launch went 22.5 -> 18.9 us at B = 512), 16 x 16 in a launch of their own (700 workgroups instead of 200
+// hide the loads' latency better: 9.5 vs 11.2 us).  LRNDE_PGRAD_TS = 1 | 2 forces one shape everywhere.
+static PgradArgs pgrad_args(const lrnde_ctx* c, int B, float t, const float* lam, float* gp, int set, bool riding = false) {
   PgradArgs g{};
   memset(&g, 0, sizeof(g));  // adj_mode = ADJ_HOST: t / lam / gp as given here
   g.accumulate = c->pg_accumulate ? 1 : 0;
@@ -3561,8 +3571,11 @@ static PgradArgs pgrad_args(const lrnde_ctx* c, int B, float t, const float* lam
   g.lam = lam; g.gp = gp;
   g.y = c->bw_y + (size_t)set * B * c->desc.state_dim; g.h = c->bw_h + (size_t)set * B * c->m.Hp; g.dpre = c->bw_dp + (size_t)set * B * c->m.Hp;
   // output tiles incl. the two virtual columns (time column, bias): gW1 is H x (D+2), gW2 is D x (H+2)
-  const int th = (g.H + 15) / 16, td16 = (g.D + 15) / 16;
-  g.nt1c = (g.D + 2 + 15) / 16; g.nt2c = (g.H + 2 + 15) / 16;
+  const int ots = opt(OPT_PGRAD_TS);
+  g.ts = (ots == 1 || ots == 2) ? ots : (riding ? 2 : 1);
+  const int e = 16 * g.ts;
+  const int th = (g.H + e - 1) / e, td16 = (g.D + e - 1) / e;
+  g.nt1c = (g.D + 2 + e - 1) / e; g.nt2c = (g.H + 2 + e - 1) / e;
   g.ntile1 = th * g.nt1c; g.ntile2 = td16 * g.nt2c;
   return g;
 }
@@ -3632,7 +3645,7 @@ static int launch_vjp(lrnde_ctx* c, const float* y, const float* dense, float th
       HIPCHK(c, hipGetLastError());
       if (had && sharded(c)) { const int rcc = comm_allreduce(c, prev.gp, prev.gp, lrnde_param_count(&c->desc), false); if (rcc) return rcc; }
       c->pg_pending = gp != nullptr;
-      if (gp) c->pg_args = pgrad_args(c, B, t, lam, gp, set);
+      if (gp) c->pg_args = pgrad_args(c, B, t, lam, gp, set, true);
       c->bw_cur ^= 1;
       return LRNDE_OK;
     }
@@ -3677,11 +3690,11 @@ struct AdjVec {  // device vectors of the augmented adjoint state [lambda (local
 };
 
 int adj_alloc(lrnde_ctx* c, size_t N, AdjVec& v) {
-  if (c->adj_elems < 11 * N) {
+  if (c->adj_elems < 12 * N) {   // (the 12th vector: third stage-lambda buffer of the overlapped launches)
     if (c->adj) HIPCHK(c, hipFree(c->adj));
     c->adj = nullptr;
-    HIPCHK(c, hipMalloc(&c->adj, sizeof(float) * 11 * N));
-    c->adj_elems = 11 * N;
+    HIPCHK(c, hipMalloc(&c->adj, sizeof(float) * 12 * N));
+    c->adj_elems = 12 * N;
   }
   if (!c->adj_part) {  // [256 lambda partials][256 mu partials][64 per-rank lambda sums]
     HIPCHK(c, hipMalloc(&c->adj_part, sizeof(double) * (512 + 64 + ADJ_MU_TILE_MAX)));  // + the per-tile mu partials (ADJ_MU_TILE_OFF)
@@ -3913,30 +3926,44 @@ int vec_tsit5_solve(lrnde_ctx* c, AdjVec& v, RHS rhs, RHSF rhs_fused, bool fuse_
 // to a (B, D) cotangent) pairs in ascending s; each ends a segment: the host waits for it, adds the impulse, has K1
 // re-evaluated at the modified state (what a callback's u_modified! does upstream) and lets the integrator go on.
 int adj_enqueue_eval(lrnde_ctx* c, int B, const AdjArgs& g, int mode, int stage, int j, bool with_prev_pgrad,
-                     int prev_mode, int prev_stage) {
+                     int prev_mode, int prev_stage, hipStream_t st = nullptr, int ovl = 0) {
   // one VJP launch in device-resolved form; with_prev_pgrad: the launch also carries the parameter-gradient GEMM of the
   // previous evaluation (prev_mode / prev_stage of the same attempt), whose scratch set is the one written last
   VjpQArgs a{};
   memset(&a, 0, sizeof(a));
   a.m = c->m; a.V1q = c->V1q; a.U2q = c->U2q; a.B = B;
   a.adj_mode = mode; a.adj_stage = stage; a.adj_j = j; a.adj = g;
-  const int set = c->bw_cur;
+  if (!st) st = c->stream;
+  // scratch sets: two alternate; with overlapped stage launches (g.sync) three rotate, because launch id + 1 writes its set while
+  // the tiles of launch id still read the set of launch id - 1
+  const bool rot3 = g.sync != nullptr && mode == ADJ_STAGE;
+  const int set = c->bw_cur, prev_set = rot3 ? (set + 2) % 3 : set ^ 1;
   a.ysc = c->bw_y + (size_t)set * B * c->desc.state_dim; a.hsc = c->bw_h + (size_t)set * B * c->m.Hp; a.dpsc = c->bw_dp + (size_t)set * B * c->m.Hp;
+  if (rot3) { a.sync_id = c->adj_launch_id++; a.ovl = ovl; }
   const size_t smq = smem_bytes_vq(c->m.KQ1p, c->m.KQ2p, c->m.RG1, c->m.RG2);
   const int qcv = vjp_qcols(B); a.qcols = qcv;
-    const int nvjp = (B + qcv - 1) / qcv;
+  const int nvjp = (B + qcv - 1) / qcv;
   const bool kt1 = (c->desc.hidden_dim + 3) / 4 == (QSB2 - 1) * QSQ + 1;
   if (with_prev_pgrad) {
-    PgradArgs pg = pgrad_args(c, B, 0.f, nullptr, nullptr, set ^ 1);
+    PgradArgs pg = pgrad_args(c, B, 0.f, nullptr, nullptr, prev_set, true);
     pg.adj_mode = prev_mode; pg.adj_stage = prev_stage; pg.adj_j = j;
-    if (kt1) hipLaunchKernelGGL(k_vjp_q_pg<1>, dim3(nvjp + pg.ntile1 + pg.ntile2), dim3(QNT), smq, c->stream, a, pg, nvjp);
-    else hipLaunchKernelGGL(k_vjp_q_pg<4>, dim3(nvjp + pg.ntile1 + pg.ntile2), dim3(QNT), smq, c->stream, a, pg, nvjp);
+    const dim3 grid(nvjp + pg.ntile1 + pg.ntile2);
+    if (rot3) {
+      if (kt1) hipLaunchKernelGGL((k_vjp_q_pg<1, true>), grid, dim3(QNT), smq, st, a, pg, nvjp);
+      else hipLaunchKernelGGL((k_vjp_q_pg<4, true>), grid, dim3(QNT), smq, st, a, pg, nvjp);
+    } else {
+      if (kt1) hipLaunchKernelGGL(k_vjp_q_pg<1>, grid, dim3(QNT), smq, st, a, pg, nvjp);
+      else hipLaunchKernelGGL(k_vjp_q_pg<4>, grid, dim3(QNT), smq, st, a, pg, nvjp);
+    }
+  } else if (rot3) {
+    if (kt1) hipLaunchKernelGGL((k_vjp_q<1, true>), dim3(nvjp), dim3(QNT), smq, st, a);
+    else hipLaunchKernelGGL((k_vjp_q<4, true>), dim3(nvjp), dim3(QNT), smq, st, a);
   } else {
-    if (kt1) hipLaunchKernelGGL(k_vjp_q<1>, dim3(nvjp), dim3(QNT), smq, c->stream, a);
-    else hipLaunchKernelGGL(k_vjp_q<4>, dim3(nvjp), dim3(QNT), smq, c->stream, a);
+    if (kt1) hipLaunchKernelGGL(k_vjp_q<1>, dim3(nvjp), dim3(QNT), smq, st, a);
+    else hipLaunchKernelGGL(k_vjp_q<4>, dim3(nvjp), dim3(QNT), smq, st, a);
   }
   HIPCHK(c, hipGetLastError());
-  c->bw_cur ^= 1;
+  c->bw_cur = rot3 ? (set + 1) % 3 : set ^ 1;
   return LRNDE_OK;
 }
 
@@ -4012,6 +4039,26 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
     fold_mu = v.P != 0 && !opt(OPT_ADJ_ERR_ONE_LAUNCH) && opt(OPT_ADJ_MU_FOLD) && nt0 <= ADJ_MU_TILE_MAX;
     g.mu_tiles = fold_mu ? nt0 : 0;
   }
+  // LRNDE_ADJ_OVERLAP=1: the stage launches of an attempt alternate between the handle's stream and a second one, so that
+  // launch s + 1 starts WHILE launch s runs — on the half of the chip a stage launch leaves idle — and does everything that
+  // needs the record only (entry, y, the first GEMM phase) before it waits, on the device, for launch s's arrivals
+  // (lrnde_adjoint.hpp).  Not with cotangent impulses (segments), which keep the one-stream order.
+  const bool ovl_on = opt(OPT_ADJ_OVERLAP) != 0 && impulses.empty() && !opt(OPT_ADJ_ERR_ONE_LAUNCH);
+  if (ovl_on) {
+    if (!c->adj_stream2) {
+      HIPCHK(c, hipStreamCreateWithFlags(&c->adj_stream2, hipStreamNonBlocking));
+      for (int i = 0; i < 2; ++i) {
+        HIPCHK(c, hipEventCreateWithFlags(&c->adj_evA[i], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->adj_evB[i], hipEventDisableTiming));
+      }
+      HIPCHK(c, hipMalloc(&c->adj_sync, sizeof(int) * 32));
+    }
+    HIPCHK(c, hipMemsetAsync(c->adj_sync, 0, sizeof(int) * 32, c->stream));
+    g.sync = c->adj_sync;
+    c->adj_launch_id = 0;
+    c->adj_hstat[11] = 0;   // (the prologue copies sync[1], the timeout word, here)
+  }
+  hipStream_t const sA = c->stream, sB = ovl_on ? c->adj_stream2 : c->stream;
   const size_t N = v.N, n = v.n_lam;
   float* const zb0 = c->adj; float* const K0 = c->adj + 4 * N; float* const K1 = c->adj + 5 * N;
   AdjErrArgs e{};
@@ -4071,6 +4118,7 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
     // written (up to seq0 + j + 1) are retired, so the next solve's first wait cannot be satisfied by a stale report
     auto bail = [&](int code) -> int {
       hipStreamSynchronize(c->stream);
+      if (c->adj_stream2) hipStreamSynchronize(c->adj_stream2);
       c->adj_seq += j + 1;
       c->after_first_attempt = nullptr;
       return code;
@@ -4082,9 +4130,14 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
     bool maybe_last = false;
     int trace_prev = -1, trace_nacc = 0;
     auto enqueue_rest = [&](int jj) -> int {
+      if (ovl_on) HIPCHK(c, hipStreamWaitEvent(sB, c->adj_evA[jj & 1], 0));   // (recorded on the handle's stream ahead of this attempt's stage 2)
       for (int sidx = 3; sidx <= 7; ++sidx) {
-        const int r = adj_enqueue_eval(c, B, g, ADJ_STAGE, sidx, jj, true, ADJ_STAGE, sidx - 1);
+        const int r = adj_enqueue_eval(c, B, g, ADJ_STAGE, sidx, jj, true, ADJ_STAGE, sidx - 1, (sidx & 1) ? sB : sA, ovl_on ? 1 : 0);
         if (r) return r;
+      }
+      if (ovl_on) {   // the end of the attempt needs stage 7 (second stream) and its tiles
+        HIPCHK(c, hipEventRecord(c->adj_evB[jj & 1], sB));
+        HIPCHK(c, hipStreamWaitEvent(sA, c->adj_evB[jj & 1], 0));
       }
       const bool split_off = opt(OPT_ADJ_ERR_ONE_LAUNCH) != 0;  // diagnostic: the error norm in one launch of its own
       if (split_off) {
@@ -4092,7 +4145,7 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
         if (r) return r;
         hipLaunchKernelGGL(k_adj_err_dev, dim3(512), dim3(256), 0, c->stream, e, g, jj, 0);
       } else {
-        PgradArgs pg = pgrad_args(c, B, 0.f, nullptr, nullptr, c->bw_cur ^ 1);
+        PgradArgs pg = pgrad_args(c, B, 0.f, nullptr, nullptr, ovl_on ? (c->bw_cur + 2) % 3 : c->bw_cur ^ 1);
         pg.adj_mode = ADJ_STAGE; pg.adj_stage = 7; pg.adj_j = jj;
         const int nt = pg.ntile1 + pg.ntile2;
         hipLaunchKernelGGL(k_pgrad_adj_err, dim3(nt + 256), dim3(256), 0, c->stream, pg, g, e, nt, jj, fold_mu ? 1 : 0);
@@ -4102,7 +4155,8 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
       return LRNDE_OK;
     };
     while (!done) {
-      if ((rc = adj_enqueue_eval(c, B, g, ADJ_STAGE, 2, j, false, ADJ_STAGE, 1))) return bail(rc);
+      if (ovl_on) { c->bw_cur = 0; HIPCHK(c, hipEventRecord(c->adj_evA[j & 1], sA)); }   // (the second stream starts this attempt's stage 3 from here)
+      if ((rc = adj_enqueue_eval(c, B, g, ADJ_STAGE, 2, j, false, ADJ_STAGE, 1, sA, 0))) return bail(rc);
       const bool rest_ahead = !maybe_last;
       if (rest_ahead && (rc = enqueue_rest(j))) return bail(rc);
       if (c->after_first_attempt) {  // (the handle's stream now holds ~150 us of work: time for the caller's side enqueues)
@@ -4146,6 +4200,7 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
       if (j > maxiters + 16) break;
     }
     c->adj_seq += j;
+    if (ovl_on && hs[11]) return bail(fail(c, LRNDE_HIP_ERROR, "adjoint loop: a wait between overlapped stage launches timed out"));
     if (done) {
       // the report of the last attempt's prologue carries the integrator's final state (adj_hstat_fill): no read-back
       // copy on the stream, no synchronisation here — the caller's own, after its output copies, is the only one
