@@ -219,6 +219,10 @@ __device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
   const int lane = threadIdx.x & 63;
   AdjCtrl c = g.ctl[j & 1];
   const AdjRecLanes rec = adj_rec_load(g);  // (independent of the control block: in flight with it)
+  // so are the error norm's partial sums and the tstops: loaded (and summed) before the control block says whether they
+  // are needed — behind its branches each was one more memory round trip of the launch every other launch waits for
+  const float stop_l = (lane < g.nstops) ? g.stops[lane] : 3.0e38f;
+  const double esum = adj_norm_sum(g.part, g.use_slots, g.nranks, g.P != 0, g.mu_tiles);
   AdjCtrl* cout = g.ctl + ((j + 1) & 1);
   c.do_step = 0;
   if (c.status != ST_RUNNING) {
@@ -258,7 +262,7 @@ __device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
     dt = c.dtpropose;
     c.resume = 0;
   } else {
-    const float eest = (float)sqrt(adj_norm_sum(g.part, g.use_slots, g.nranks, g.P != 0, g.mu_tiles) / ntot);
+    const float eest = (float)sqrt(esum / ntot);
     c.eest_last = eest;
     if (eest != eest) {
       c.status = LRNDE_DT_NAN;
@@ -291,8 +295,17 @@ __device__ __forceinline__ AdjCtrl adj_prologue(const AdjArgs& g, int j) {
     if (!(t < g.s1)) {
       c.status = ST_DONE;
     } else {
-      while (c.istop < g.nstops && g.stops[c.istop] <= t) ++c.istop;
-      const float tstop = (c.istop < g.nstops && g.stops[c.istop] < g.s1) ? g.stops[c.istop] : g.s1;
+      float tstop = g.s1;
+      if (g.nstops <= 64) {   // (ascending: the entries from istop on that t has reached are a prefix)
+        c.istop += __popcll(__ballot(lane >= c.istop && lane < g.nstops && stop_l <= t));
+        if (c.istop < g.nstops) {
+          const float sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, stop_l), c.istop));
+          if (sv < g.s1) tstop = sv;
+        }
+      } else {
+        while (c.istop < g.nstops && g.stops[c.istop] <= t) ++c.istop;
+        if (c.istop < g.nstops && g.stops[c.istop] < g.s1) tstop = g.stops[c.istop];
+      }
       c.iter++;
       dt = fminf_(dtmax, dt);
       dt = fmaxf_(dt, dtmin);

@@ -280,6 +280,53 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, c
   for (int si = 0; si < TS; ++si)
 #pragma unroll
     for (int sj = 0; sj < TS; ++sj) acc[si][sj] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // D fragment: row = ti*16 + lk*4 + r, col = tj*16 + li ; flat weight index = row + M*col
+  float* const gW = a.gp + (first ? (size_t)0 : oW2);
+  float* const gb = a.gp + (first ? ob1 : ob2);
+  auto dst_of = [&](int si, int sj, int r) -> float* {
+    const int c = (tj * TS + sj) * 16 + li, rr = (ti * TS + si) * 16 + lk * 4 + r;
+    if (rr >= M) return nullptr;
+    if (c < N) return gW + (size_t)rr + (size_t)M * c;
+    if (c == N) return a.td ? gW + (size_t)rr + (size_t)M * N : nullptr;
+    if (c == N + 1) return gb + rr;
+    return nullptr;
+  };
+  // fold: K1..K6 and z at the lane's (up to) four entries of a sub-tile.  The four entries are consecutive rows of one column:
+  // one 16-byte load per array when the layout allows it (M % 4 == 0, as for the MNIST field) — as scalar loads a tile touched
+  // 2048 cache lines for 1024 entries and the launch got 14 us longer
+  struct FoldOps { float kv[4][6], zv[4]; };
+  auto fold_load = [&](int si, int sj, FoldOps& o) {
+    float* d0 = dst_of(si, sj, 0);
+    float* d3 = dst_of(si, sj, 3);
+    const bool vec4 = (M & 3) == 0 && d0 && d3 == d0 + 3 && ((d0 - a.gp) & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(fold->z) | reinterpret_cast<uintptr_t>(fold->K[0])) & 15) == 0;
+    if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(vec4 || !d0)) == 64)) {
+      const size_t i = d0 ? (size_t)(d0 - a.gp) : 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(fold->K[q] + i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.kv[r][q] = v[r];
+      }
+      const f32x4 zz = *reinterpret_cast<const f32x4*>(fold->z + i);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o.zv[r] = zz[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* d = dst_of(si, sj, r);
+        const size_t i = d ? (size_t)(d - a.gp) : 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) o.kv[r][q] = fold->K[q][i];
+        o.zv[r] = fold->z[i];
+      }
+    }
+  };
+  // one tile per workgroup: the fold's operands are requested BEFORE the GEMM's (they were written by other launches — nothing
+  // of them is in the L2; behind the GEMM they were a round trip of their own at the end of every tile)
+  FoldOps pre;
+  constexpr bool hoist = TS == 1;
+  if (hoist && fold && wave == 0) fold_load(0, 0, pre);
   constexpr int UN = 8;   // 8 MFMA k-steps (32 samples) per block
   constexpr int GB = TS == 1 ? 4 : 2;   // blocks whose loads are all in flight before the first MFMA (64 independent loads per lane):
                           // at B = 512 and TS = 1 a wave's whole share; block after block the kernel paid one L2 round trip per block
@@ -337,76 +384,43 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, c
       }
     }
   if (wave > 0) return;
-  // D fragment: row = ti*16 + lk*4 + r, col = tj*16 + li ; flat weight index = row + M*col
-  float* gW = a.gp + (first ? (size_t)0 : oW2);
-  float* gb = a.gp + (first ? ob1 : ob2);
   double esum = 0.0;
 #pragma unroll
   for (int si = 0; si < TS; ++si)
 #pragma unroll
-  for (int sj = 0; sj < TS; ++sj) {
-  const f32x4 accv = acc[si][sj];
-  const int c = (tj * TS + sj) * 16 + li;
-  float* dsts[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int rr = (ti * TS + si) * 16 + lk * 4 + r;
-    float* dst = nullptr;
-    if (rr < M) {
-      if (c < N) dst = gW + (size_t)rr + (size_t)M * c;
-      else if (c == N) { if (a.td) dst = gW + (size_t)rr + (size_t)M * N; }
-      else if (c == N + 1) dst = gb + rr;
-    }
-    dsts[r] = dst;
-    if (dst) *dst = a.accumulate ? *dst + accv[r] : accv[r];
-  }
-  if (fold) {
-    // all loads of the lane's (up to) four entries first: K1..K6 and z at the entry's index of the mu part.  The four entries
-    // are consecutive rows of one column: one 16-byte load per array when the layout allows it (M % 4 == 0, as for the MNIST
-    // field) — as scalar loads a tile touched 2048 cache lines for 1024 entries and the launch got 14 us longer
-    float kv[4][6], zv[4];
-    const bool vec4 = (M & 3) == 0 && dsts[0] && dsts[3] == dsts[0] + 3 && ((dsts[0] - a.gp) & 3) == 0 &&
-                      ((reinterpret_cast<uintptr_t>(fold->z) | reinterpret_cast<uintptr_t>(fold->K[0])) & 15) == 0;
-    if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(vec4 || !dsts[0])) == 64)) {
-      const size_t i = dsts[0] ? (size_t)(dsts[0] - a.gp) : 0;
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(fold->K[q] + i);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) kv[r][q] = v[r];
-      }
-      const f32x4 zz = *reinterpret_cast<const f32x4*>(fold->z + i);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) zv[r] = zz[r];
-    } else {
+    for (int sj = 0; sj < TS; ++sj) {
+      const f32x4 accv = acc[si][sj];
+      float* dsts[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const size_t i = dsts[r] ? (size_t)(dsts[r] - a.gp) : 0;
+        float* dst = dst_of(si, sj, r);
+        dsts[r] = dst;
+        if (dst) *dst = a.accumulate ? *dst + accv[r] : accv[r];
+      }
+      if (fold) {
+        FoldOps late;
+        if (!hoist) fold_load(si, sj, late);
+        const FoldOps& o = hoist ? pre : late;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) kv[r][q] = fold->K[q][i];
-        zv[r] = fold->z[i];
+        for (int r = 0; r < 4; ++r) {
+          if (!dsts[r]) continue;
+          const size_t i = (size_t)(dsts[r] - a.gp);
+          float sacc = fold->A7[0] * o.kv[r][0];
+#pragma unroll
+          for (int q = 1; q < 6; ++q) sacc = sacc + fold->A7[q] * o.kv[r][q];
+          const float znv = o.zv[r] + fold->dt * sacc;
+          fold->zn[i] = znv;
+          float sb = fold->BT[0] * o.kv[r][0];
+#pragma unroll
+          for (int q = 1; q < 6; ++q) sb = sb + fold->BT[q] * o.kv[r][q];
+          sb = sb + fold->BT[6] * accv[r];
+          const float ut = 0.f + fold->dt * sb;
+          const float sc = fold->abstol + fmaxf_(__builtin_fabsf(o.zv[r]), __builtin_fabsf(znv)) * fold->reltol;
+          const float rres = ut / sc;
+          esum += (double)(rres * rres);
+        }
       }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (!dsts[r]) continue;
-      const size_t i = (size_t)(dsts[r] - a.gp);
-      float sacc = fold->A7[0] * kv[r][0];
-#pragma unroll
-      for (int q = 1; q < 6; ++q) sacc = sacc + fold->A7[q] * kv[r][q];
-      const float znv = zv[r] + fold->dt * sacc;
-      fold->zn[i] = znv;
-      float sb = fold->BT[0] * kv[r][0];
-#pragma unroll
-      for (int q = 1; q < 6; ++q) sb = sb + fold->BT[q] * kv[r][q];
-      sb = sb + fold->BT[6] * accv[r];
-      const float ut = 0.f + fold->dt * sb;
-      const float sc = fold->abstol + fmaxf_(__builtin_fabsf(zv[r]), __builtin_fabsf(znv)) * fold->reltol;
-      const float rres = ut / sc;
-      esum += (double)(rres * rres);
-    }
-  }
-  }
   if (fold) {
     esum = wave_sum_dpp(esum);
     if (lane == 0) fold->part[tile] = esum;
