@@ -96,6 +96,15 @@ const char* lrnde_version(void);
  * into the MFMA operand layout.  Call again whenever ps changes. */
 int lrnde_set_params(lrnde_ctx* ctx, const float* p, size_t n);
 
+/* The `solver` field of NeuralODE (src/layers/neural_ode.jl:4,51: `solve(prob, n.solver; ...)`) for the choices the
+ * experiments offer (experiments/src/construct.jl:154-164 `_ode_solver`): 0 = Tsit5 (default), 1 = VCAB3, 2 = VCABM3.
+ * It selects the method of the layer's GLOBAL solve in lrnde_solve / lrnde_node_forward* / lrnde_node_backward*; the
+ * local regularisation step stays Tsit5, as in the reference (neural_ode.jl:75,93 build that integrator with Tsit5()).
+ * VCAB3 / VCABM3: restated from the published algorithm, UPSTREAM-RECALL (csrc/lrnde_adams.hpp says what is recalled);
+ * the backward pass of a recorded Adams forward interpolates its Hermite record and integrates the adjoint with Tsit5. */
+enum { LRNDE_ALG_TSIT5 = 0, LRNDE_ALG_VCAB3 = 1, LRNDE_ALG_VCABM3 = 2 };
+int lrnde_set_solver(lrnde_ctx* ctx, int32_t alg);
+
 /* du = dudt(u, p, t)  — src/layers/neural_ode.jl:45-48, src/layers/common.jl:10-40. */
 int lrnde_rhs(lrnde_ctx* ctx, const float* u, float t, int32_t B, float* du);
 

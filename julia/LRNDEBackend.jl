@@ -75,6 +75,9 @@ destroy(ctx) = ccall((:lrnde_destroy, lib), Cint, (Ptr{Cvoid},), ctx)
 set_params!(ctx, ps) = check(ctx, ccall((:lrnde_set_params, lib), Cint, (Ptr{Cvoid}, Ptr{Float32}, Csize_t),
                                         ctx, pointer(ps), length(ps)))
 
+# n.solver of the layer's global solve: 0 Tsit5, 1 VCAB3, 2 VCABM3 (experiments/src/construct.jl:154-164)
+set_solver!(ctx, alg) = check(ctx, ccall((:lrnde_set_solver, lib), Cint, (Ptr{Cvoid}, Int32), ctx, alg))
+
 # dudt(u, p, t) — src/layers/neural_ode.jl:44-48
 function rhs(ctx, u, t)
     du = similar(u)

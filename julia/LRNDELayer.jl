@@ -11,7 +11,7 @@
 #     (`diffeqsol_to_timeseries`, src/utils.jl:42-46); `reg_val`'s gradient goes to `ps` only (neural_ode.jl:40).
 # Everything else (other solvers, other model shapes, CPU arrays) falls through to the reference's own methods.
 #
-# Supported models (solver `Tsit5()`):
+# Supported models (solver `Tsit5()`; the MLP field also with `VCAB3()` / `VCABM3()`):
 #   * `TDChain(Dense(D+1 => H, act), Dense(H+1 => D))` / `Chain(Dense(D => H, act), Dense(H => D))`, act ∈ (identity, tanh,
 #     gelu) — the MNIST-ODE field of experiments/src/construct.jl:180-189;
 #   * the CIFAR10 `node_core` of experiments/src/construct.jl:213-218, `TDChain(Chain(Conv((3,3), 9 => 64; pad=1,
@@ -61,14 +61,20 @@ function lrnde_field_shape(model)
 end
 
 const _lrnde_handles = IdDict{Any, Ptr{Cvoid}}()   # one handle per layer object (one task, one stream: SURVEY.md §8b)
+# n.solver -> lrnde_set_solver's code: the three choices of experiments/src/construct.jl:154-164 (`_ode_solver`)
+_lrnde_alg(solver) = solver isa Tsit5 ? Int32(0) : nameof(typeof(solver)) === :VCAB3 ? Int32(1) :
+                     nameof(typeof(solver)) === :VCABM3 ? Int32(2) : nothing
+
 function lrnde_handle(n::NeuralODE)
     get!(_lrnde_handles, n) do
         D, H, td, act = lrnde_field_shape(n.model)
-        LRNDEBackend.create(D, H, td, act)
+        ctx = LRNDEBackend.create(D, H, td, act)
+        LRNDEBackend.set_solver!(ctx, _lrnde_alg(n.solver))   # the global solve's method; the local step stays Tsit5 (:75, :93)
+        ctx
     end
 end
 
-lrnde_supported(n::NeuralODE, x) = n.solver isa Tsit5 && lrnde_field_shape(n.model) !== nothing &&
+lrnde_supported(n::NeuralODE, x) = _lrnde_alg(n.solver) !== nothing && lrnde_field_shape(n.model) !== nothing &&
                                    nameof(typeof(x)) === :ROCArray && eltype(x) === Float32
 
 _lrnde_opts(n::NeuralODE) = SolveOpts(Float32(get(n.kwargs, :abstol, 1f-6)), Float32(get(n.kwargs, :reltol, 1f-3)),

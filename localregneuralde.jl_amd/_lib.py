@@ -68,6 +68,7 @@ SYMBOLS = [
     ("lrnde_param_count", C.c_size_t, [C.POINTER(ModelDesc)]),
     ("lrnde_version", C.c_char_p, []),
     ("lrnde_set_params", C.c_int, [_vp, _vp, C.c_size_t]),
+    ("lrnde_set_solver", C.c_int, [_vp, _i32]),
     ("lrnde_rhs", C.c_int, [_vp, _vp, _f, _i32, _vp]),
     ("lrnde_init_dt", C.c_int, [_vp, _vp, _i32, _f, _f, _f, _f, _vp, _fp]),
     ("lrnde_perform_step", C.c_int, [_vp, _vp, _vp, _i32, _f, _f, _f, _f, _vp, _vp, _fp, _fp, _fp]),

@@ -1867,6 +1867,7 @@ struct lrnde_ctx {
   const float* adj_init_src = nullptr;  // adj_solve_device: its first launch also sets z = [this; 0] (k_adj_begin)
   std::function<int()> final_hook;
   bool final_hook_fired = false, last_u_end_done = false;
+  int solver_alg = 0;        // lrnde_set_solver: 0 Tsit5 (k_step_q / k_step), 1 VCAB3, 2 VCABM3 (lrnde_adams.hpp)
   bool hung = false;         // a host loop waited LRNDE_SPIN_DEADLINE_S for a report while the queue stayed busy: only lrnde_destroy is safe
   bool reports_off = false;  // lrnde_set_reports(ctx, 0): the solve loop polls by copies (its fall-back when no report arrives)
   // lrnde_set_adjoint_trace: per-attempt (s, dt, EEst, accepted) rows of the next adjoint solves, host memory of the caller
@@ -2205,6 +2206,11 @@ int side_quiesce(lrnde_ctx* c) {
 }
 
 }  // namespace
+namespace {  // (defined in lrnde_adams.hpp, behind the vector helpers)
+int adams_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1, const lrnde_solve_opts* o,
+                const float* saveat_host, int32_t nsave, float* u_saved, float* t_saved_host, int32_t cap_saved,
+                lrnde_stats* st, lrnde_trace_row* trace_host, int32_t cap_trace);
+}
 
 extern "C" {
 
@@ -2333,6 +2339,14 @@ int lrnde_set_params(lrnde_ctx* c, const float* p, size_t n) {
   return LRNDE_OK;
 }
 
+int lrnde_set_solver(lrnde_ctx* c, int32_t alg) {
+  if (!c) return LRNDE_BADARG;
+  if (alg < 0 || alg > 2) return fail(c, LRNDE_BADARG, "solver must be 0 (Tsit5), 1 (VCAB3) or 2 (VCABM3)");
+  c->solver_alg = alg;
+  c->rec_valid = false;
+  return LRNDE_OK;
+}
+
 int lrnde_rhs(lrnde_ctx* c, const float* u, float t, int32_t B, float* du) {
   int rc = check_ready(c, B);
   if (rc) return rc;
@@ -2457,6 +2471,8 @@ int lrnde_solve(lrnde_ctx* c, const float* u0, int32_t B, float t0, float t1,
   if (cap_saved > 0 && !u_saved) return fail(c, LRNDE_BADARG, "null save buffer");
   if ((rc = ensure_workspace(c, B))) return rc;
   if (!c->dense_on) c->rec_valid = false;
+  if (c->solver_alg != 0)   // n.solver = VCAB3() / VCABM3() (experiments/src/construct.jl:154-164)
+    return adams_solve(c, u0, B, t0, t1, o, saveat_host, nsave, u_saved, t_saved_host, cap_saved, st, trace_host, cap_trace);
   const size_t n = (size_t)B * c->desc.state_dim;
   if (nsave > c->saveat_cap) {
     if (c->saveat_dev) HIPCHK(c, hipFree(c->saveat_dev));
@@ -3758,6 +3774,8 @@ int norm_readback(lrnde_ctx* c, size_t n_lam, size_t P, float* out) {
   *out = (float)sqrt(s / ((double)n_lam * (double)nr + (double)P));
   return LRNDE_OK;
 }
+
+#include "lrnde_adams.hpp"
 
 // adjoint RHS in reversed time s = -t: K = [J^T lambda; (df/dp)^T lambda] at y(t) from the dense record
 int adj_rhs(lrnde_ctx* c, const std::vector<float>& dt_, const std::vector<float>& dd_, int B, size_t n,

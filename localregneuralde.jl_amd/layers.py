@@ -97,6 +97,17 @@ def _dev_ptr(t, name, shape_tail=None):
 
 
 # ----- thin object over lrnde_ctx -----
+SOLVERS = {"tsit5": 0, "vcab3": 1, "vcabm3": 2}
+
+
+def _solver_name(solver):
+    """"Tsit5" / "tsit5" / "Tsit5()" ... -> the key of SOLVERS (ArgumentError of `_ode_solver` otherwise)."""
+    name = str(solver).strip().rstrip("()").lower()
+    if name not in SOLVERS:
+        raise ValueError("unknown SolverConfig.")   # experiments/src/construct.jl:163
+    return name
+
+
 class Handle:
     def __init__(self, desc, device=None, stream=None):
         if not torch.cuda.is_available():
@@ -131,6 +142,10 @@ class Handle:
         ps = ps.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous().reshape(-1)
         self._params = ps  # keep alive until packed
         self._chk(L.lib.lrnde_set_params(self._ctx, C.c_void_p(ps.data_ptr()), ps.numel()))
+
+    def set_solver(self, solver):
+        """n.solver of the layer's global solve (experiments/src/construct.jl:154-164): "tsit5" | "vcab3" | "vcabm3"."""
+        self._chk(L.lib.lrnde_set_solver(self._ctx, SOLVERS[_solver_name(solver)]))
 
     def rhs(self, u, t):
         B = u.numel() // self.D
@@ -417,15 +432,15 @@ class NeuralODE:
         regularize, regularize_type = _sym(regularize), _sym(regularize_type)
         _check_valid_regularize(regularize)
         _check_valid_regularize(regularize_type, _VALID_REG_TYPES)
-        if solver not in ("Tsit5", "tsit5"):
-            raise NotImplementedError("only Tsit5() is implemented on the device path")
-        self.model, self.solver, self.sensealg = model, "Tsit5", sensealg
+        self.model, self.solver, self.sensealg = model, _solver_name(solver), sensealg
         self.tspan = (np.float32(tspan[0]), np.float32(tspan[1]))
         self.maxiters, self.kwargs = int(maxiters), dict(kwargs)
         self.regularize, self.regularize_type = regularize, regularize_type
         from .conv import conv_topology
         self._conv = conv_topology(model)  # (C, Hc, act, eps) for the CIFAR node_core, else None
         self.desc = None if self._conv else _mlp_desc(model)
+        if self._conv and self.solver != "tsit5":
+            raise NotImplementedError("VCAB3 / VCABM3 are built for the MLP field's handle (csrc/lrnde_adams.hpp)")
         self._handle = None
         self._bound = False
 
@@ -451,6 +466,7 @@ class NeuralODE:
             return self._handle
         if self._handle is None:
             self._handle = Handle(self.desc)
+            self._handle.set_solver(self.solver)
         return self._handle
 
     def _bind(self, ps, x=None, changed=True):

@@ -529,8 +529,15 @@ int lro_tsit5_step_sums(const lro_field* f, const float* uprev, const float* k1,
 /* initial dt (OrdinaryDiffEq ode_determine_initdt, out-of-place) */
 /* ------------------------------------------------------------------------- */
 
+static int init_dt_order(const lro_field* f, const float* u0, float t0, float tend, float abstol,
+                         float reltol, int B, float* f0_out, float* dt_out, float order);
 int lro_init_dt(const lro_field* f, const float* u0, float t0, float tend, float abstol,
                 float reltol, int B, float* f0_out, float* dt_out) {
+  return init_dt_order(f, u0, t0, tend, abstol, reltol, B, f0_out, dt_out, 5.0f);
+}
+/* (the exponent's divisor is get_current_alg_order(alg): 5 for Tsit5, 3 for the Adams methods below) */
+static int init_dt_order(const lro_field* f, const float* u0, float t0, float tend, float abstol,
+                         float reltol, int B, float* f0_out, float* dt_out, float order) {
   const long n = (long)f->D * B;
   const float dtmax = tend - t0;
   float* f0 = f0_out ? f0_out : (float*)malloc(sizeof(float) * (size_t)n);
@@ -569,7 +576,7 @@ int lro_init_dt(const lro_field* f, const float* u0, float t0, float tend, float
     dt1 = fmaxf(1e-6f, dt0 * 1e-3f);
   } else {
     float l10 = (float)log10((double)maxd);
-    float e = (-(2.0f + l10)) / 5.0f;
+    float e = (-(2.0f + l10)) / order;
     dt1 = (float)pow(10.0, (double)e);
   }
   *dt_out = fminf(fminf(100.0f * dt0, dt1), dtmax);
@@ -687,12 +694,256 @@ void lro_dense_eval(const lro_dense* d, float t, float* out) {
   }
 }
 
+/* one step's record given directly in polynomial form (the Adams methods' Hermite interpolant) */
+static int dense_push_poly(lro_dense* d, float t, float dt, const float* const arr[LRO_REC_ARRAYS]) {
+  if (d->nsteps >= d->cap) {
+    int nc = d->cap ? 2 * d->cap : 64;
+    d->t = (float*)realloc(d->t, sizeof(float) * nc);
+    d->dt = (float*)realloc(d->dt, sizeof(float) * nc);
+    d->data = (float*)realloc(d->data, sizeof(float) * (size_t)nc * LRO_REC_ARRAYS * d->n);
+    if (!d->t || !d->dt || !d->data) return LRO_CAPACITY;
+    d->cap = nc;
+  }
+  float* dst = d->data + (size_t)d->nsteps * LRO_REC_ARRAYS * d->n;
+  for (int m = 0; m < LRO_REC_ARRAYS; ++m) memcpy(dst + (size_t)m * d->n, arr[m], sizeof(float) * d->n);
+  d->t[d->nsteps] = t; d->dt[d->nsteps] = dt;
+  d->nsteps++;
+  return LRO_OK;
+}
+/* y(theta) of a record [y0, k1, P2, P3, P4] (the arithmetic of lro_dense_eval) */
+static void rec_poly_eval(const float* y0, const float* k1, const float* P2, const float* P3, const float* P4, float th,
+                          float ddt, long n, float* out) {
+  const float th2 = th * th;
+  for (long e = 0; e < n; ++e) {
+    float sm = P4[e] * th;
+    sm = sm + P3[e];
+    sm = sm * th;
+    sm = sm + P2[e];
+    sm = sm * th2;
+    sm = sm + th * k1[e];
+    out[e] = y0[e] + ddt * sm;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* VCAB3 / VCABM3: the `solver` choices "vcab3" / "vcabm3" of experiments/src/construct.jl:154-164.
+ * UPSTREAM-RECALL, parity unpinned: OrdinaryDiffEq's adams_bashforth_moulton_perform_step.jl / adams_utils.jl are not in
+ * /root/reference.  Restated from the published algorithm they implement — Hairer, Norsett, Wanner, "Solving ODEs I",
+ * III.5 (variable step size Adams methods in terms of phi_j(n), phi*_j(n), beta_j(n), g_j(n); recurrences (5.9)/(5.10)) —
+ * with what is recalled of the package: order 3, the first two steps by Bogacki-Shampine 3(2) with its own error estimate,
+ * VCAB3 = three-term predictor (PE), error dt*g_3*phi_3(n+1); VCABM3 = two-term predictor, corrector dt*g_2*phi_2(n+1),
+ * second evaluation (PECE), error dt*(g_3 - g_2)*phi_3(n+1) (indices from 0 as in the book; the code below counts from 1);
+ * a rejected step changes nothing but dt; PI controller with the order-3 exponents beta1 = 7/30, beta2 = 2/15; initial dt
+ * by ode_determine_initdt with order 3; dense output / saveat = cubic Hermite on (u_n, f_n, u_{n+1}, f_{n+1}), kept in
+ * the record's polynomial form: with D = (u_{n+1} - u_n)/dt, P2 = 3D - 2 f_n - f_{n+1}, P3 = f_n + f_{n+1} - 2D, P4 = 0.
+ * The arithmetic (operation order) is the product's (csrc/lrnde_adams.hpp). */
+/* ------------------------------------------------------------------------- */
+static int adams_solve(const lro_field* f, const float* u0, int B, float t0, float t1, const lro_opts* o,
+                       const float* saveat, int nsave, float* u_saved, float* t_saved, int cap_saved,
+                       lro_stats* st, lro_trace_row* trace, int cap_trace, lro_dense* dense) {
+  const long n = (long)f->D * B;
+  const float abstol = o->abstol, reltol = o->reltol;
+  const float gamma = 0.9f, qmin = 0.2f, qmax = 10.0f, qoldinit = 1e-4f;
+  const float beta1 = (float)(7.0 / 30.0), beta2 = (float)(2.0 / 15.0);
+  const int moulton = (o->alg == LRO_ALG_VCABM3);
+  memset(st, 0, sizeof(*st));
+  if (!(t1 > t0) || B <= 0) return (st->retcode = LRO_BADARG);
+  for (int i = 1; i < nsave; ++i)
+    if (!(saveat[i] >= saveat[i - 1])) return (st->retcode = LRO_BADARG);
+  float* buf = (float*)malloc(sizeof(float) * (size_t)n * 16);
+  float *uprev = buf, *u = buf + n, *k1 = buf + 2 * n, *kprev = buf + 3 * n, *kend = buf + 4 * n, *du = buf + 5 * n;
+  float *sp2 = buf + 6 * n, *s2 = buf + 7 * n, *s3 = buf + 8 * n, *P2 = buf + 9 * n, *P3 = buf + 10 * n, *P4 = buf + 11 * n;
+  float *tmp = buf + 12 * n, *kb2 = buf + 13 * n, *kb3 = buf + 14 * n, *interp = buf + 15 * n;
+  for (long i = 0; i < n; ++i) P4[i] = 0.0f;
+  int rc = LRO_OK;
+  int nsaved = 0, isave = 0, ntrace = 0;
+#define PUSH_SAVE(tt, uu)                                            \
+  do {                                                               \
+    if (nsaved >= cap_saved) { rc = LRO_CAPACITY; goto done; }       \
+    memcpy(u_saved + (size_t)nsaved * n, (uu), sizeof(float) * n);   \
+    if (t_saved) t_saved[nsaved] = (tt);                             \
+    nsaved++;                                                        \
+  } while (0)
+  memcpy(uprev, u0, sizeof(float) * n);
+  float t = t0;
+  const float dtmax = t1 - t0;
+  const float dtmin = fmaxf(eps_f(t1), eps_f(t0));
+  float dt;
+  init_dt_order(f, uprev, t0, t1, abstol, reltol, B, k1, &dt, 3.0f); /* k1 = f(u0,t0) = fsalfirst */
+  st->nf = 3;
+  st->dt_init = dt;
+  float qold = qoldinit, q11 = 1.0f, dtpropose = dt;
+  float h1 = 0.0f, h2 = 0.0f;   /* the last two accepted step sizes */
+  int accept = 0, iter = 0;
+  if (o->save_start) PUSH_SAVE(t0, u0);
+  while (isave < nsave && saveat[isave] <= t0) isave++;
+  if (dense) dense->n = n;
+  const float a21 = 0.5f, a32 = 0.75f, a41 = (float)(2.0 / 9.0), a42 = (float)(1.0 / 3.0), a43 = (float)(4.0 / 9.0);
+  const float bt1 = (float)(5.0 / 72.0), bt2 = (float)(-1.0 / 12.0), bt3 = (float)(-1.0 / 9.0), bt4 = 0.125f;
+  const float c21 = 0.5f, c22 = (float)(1.0 / 6.0), c23 = (float)(1.0 / 12.0);   /* c_{1,q} = 1/(q(q+1)) */
+
+  while (t < t1) {
+    if (iter > 0) {
+      if (accept) {
+        float* sw = uprev; uprev = u; u = sw;
+        sw = kprev; kprev = k1; k1 = kend; kend = sw;   /* phi*_0(n-1) <- f_n; fsalfirst <- fsallast */
+        sw = sp2; sp2 = s2; s2 = sw;                    /* phi*_1(n-1) */
+        dt = dtpropose;
+      } else {
+        dt = dt / fminf(1.0f / qmin, q11 / gamma);
+      }
+    }
+    iter++;
+    dt = fminf(dtmax, dt);
+    dt = fmaxf(dt, dtmin);
+    dt = fminf(fabsf(dt), fabsf(t1 - t));
+    if (iter > o->maxiters) { rc = LRO_MAXITERS; break; }
+    if (dt != dt) { rc = LRO_DT_NAN; break; }
+    if (fabsf(dt) <= fabsf(dtmin)) { rc = LRO_DT_LESS_THAN_MIN; break; }
+    double acc = 0.0;
+    const int nacc = st->naccept;
+    /* phi*_1(n), phi*_2(n) of this attempt (a start-up step keeps phi*_1 for the next one) */
+    const float b2 = nacc >= 1 ? dt / h1 : 0.0f;
+    const float b3 = nacc >= 2 ? b2 * ((dt + h1) / (h1 + h2)) : 0.0f;
+    if (nacc < 2) {
+      /* Bogacki-Shampine 3(2) */
+      const float c2s = dt * a21;
+      for (long i = 0; i < n; ++i) tmp[i] = uprev[i] + c2s * k1[i];
+      f->fn(f->ctx, tmp, t + 0.5f * dt, B, kb2);
+      const float c3s = dt * a32;
+      for (long i = 0; i < n; ++i) tmp[i] = uprev[i] + c3s * kb2[i];
+      f->fn(f->ctx, tmp, t + 0.75f * dt, B, kb3);
+      for (long i = 0; i < n; ++i) {
+        float sm = a41 * k1[i];
+        sm = sm + a42 * kb2[i];
+        sm = sm + a43 * kb3[i];
+        u[i] = uprev[i] + dt * sm;
+      }
+      f->fn(f->ctx, u, t + dt, B, kend);
+      st->nf += 3;
+      for (long i = 0; i < n; ++i) {
+        float sm = bt1 * k1[i];
+        sm = sm + bt2 * kb2[i];
+        sm = sm + bt3 * kb3[i];
+        sm = sm + bt4 * kend[i];
+        const float ut = 0.0f + dt * sm;
+        const float sc = abstol + fmaxf(fabsf(uprev[i]), fabsf(u[i])) * reltol;
+        const float r = ut / sc;
+        acc += (double)(r * r);
+      }
+      if (nacc == 1)
+        for (long i = 0; i < n; ++i) { const float p2 = k1[i] - kprev[i]; s2[i] = b2 * p2; }
+    } else {
+      const float r1 = dt / (dt + h1);
+      const float g2 = c21;
+      const float g3 = c21 - r1 * c22;
+      const float c32 = c22 - r1 * c23;
+      const float r2 = dt / ((dt + h1) + h2);
+      const float g4 = g3 - r2 * c32;
+      for (long i = 0; i < n; ++i) {
+        const float p2 = k1[i] - kprev[i];
+        const float v2 = b2 * p2;
+        const float p3 = p2 - sp2[i];
+        const float v3 = b3 * p3;
+        s2[i] = v2; s3[i] = v3;
+        float sm = k1[i] + g2 * v2;
+        if (!moulton) sm = sm + g3 * v3;
+        u[i] = uprev[i] + dt * sm;
+      }
+      f->fn(f->ctx, u, t + dt, B, du);
+      st->nf += 1;
+      const float cu = dt * g3, ce = moulton ? dt * (g4 - g3) : dt * g4;
+      for (long i = 0; i < n; ++i) {
+        const float q2 = du[i] - k1[i];
+        const float q3 = q2 - s2[i];
+        const float q4 = q3 - s3[i];
+        if (moulton) u[i] = u[i] + cu * q3;
+        const float ut = ce * q4;
+        const float sc = abstol + fmaxf(fabsf(uprev[i]), fabsf(u[i])) * reltol;
+        const float r = ut / sc;
+        acc += (double)(r * r);
+      }
+      if (moulton) { f->fn(f->ctx, u, t + dt, B, kend); st->nf += 1; }
+      else memcpy(kend, du, sizeof(float) * n);
+    }
+    const float eest = rms_from_sumsq(acc, n);
+    if (eest != eest) { rc = LRO_DT_NAN; st->eest_last = eest; break; }
+    float ttmp = t + dt;
+    float q;
+    if (eest == 0.0f) {
+      q = 1.0f / qmax;
+    } else {
+      if (o->exact_pow) {
+        q11 = (float)pow((double)eest, (double)beta1);
+        q = q11 / (float)pow((double)qold, (double)beta2);
+      } else {
+        q11 = lro_fastpow(eest, beta1);
+        q = q11 / lro_fastpow(qold, beta2);
+      }
+      q = fmaxf(1.0f / qmax, fminf(1.0f / qmin, q / gamma));
+    }
+    accept = (eest <= 1.0f);
+    if (trace && ntrace < cap_trace) {
+      trace[ntrace].t = t; trace[ntrace].dt = dt; trace[ntrace].eest = eest;
+      trace[ntrace].accepted = accept; ntrace++;
+    }
+    st->eest_last = eest;
+    if (accept) {
+      st->naccept++;
+      float dtnew = dt / q;
+      qold = fmaxf(eest, qoldinit);
+      float tprev = t;
+      t = (fabsf(ttmp - t1) < 100.0f * eps_f(fmaxf(fabsf(t), fabsf(t1)))) ? t1 : ttmp;
+      dtpropose = fmaxf(fminf(dtmax, dtnew), fmaxf(eps_f(t), dtmin));
+      h2 = h1; h1 = dt;
+      int need_poly = dense != NULL;
+      for (int i = isave; i < nsave && saveat[i] <= t; ++i) if (saveat[i] != t) need_poly = 1;
+      if (need_poly)
+        for (long i = 0; i < n; ++i) {
+          const float d = (u[i] - uprev[i]) / dt;
+          P2[i] = (3.0f * d - 2.0f * k1[i]) - kend[i];
+          P3[i] = (k1[i] + kend[i]) - 2.0f * d;
+        }
+      if (dense) {
+        const float* arr[LRO_REC_ARRAYS] = {uprev, k1, P2, P3, P4};
+        if ((rc = dense_push_poly(dense, tprev, dt, arr)) != LRO_OK) goto done;
+      }
+      while (isave < nsave && saveat[isave] <= t) {
+        float ts = saveat[isave++];
+        if (ts != t) {
+          rec_poly_eval(uprev, k1, P2, P3, P4, (ts - tprev) / dt, dt, n, interp);
+          PUSH_SAVE(ts, interp);
+        } else {
+          PUSH_SAVE(t, u);
+        }
+      }
+      if (o->save_everystep) PUSH_SAVE(t, u);
+    } else {
+      st->nreject++;
+    }
+  }
+done:
+  st->retcode = rc;
+  st->iters = iter;
+  st->nsaved = nsaved;
+  st->t_final = t;
+  st->dt_final = dt;
+  free(buf);
+  return rc;
+#undef PUSH_SAVE
+}
+
 /* tstops: ascending times strictly inside (t0,t1) the integrator must hit exactly
  * (the discrete cotangent times of the adjoint solve); dense: optional recorder */
 int lro_solve_ex(const lro_field* f, const float* u0, int B, float t0, float t1, const lro_opts* o,
                  const float* saveat, int nsave, float* u_saved, float* t_saved, int cap_saved,
                  lro_stats* st, lro_trace_row* trace, int cap_trace, const float* tstops, int ntstops,
                  lro_dense* dense) {
+  if (o->alg != LRO_ALG_TSIT5) {
+    if (o->alg != LRO_ALG_VCAB3 && o->alg != LRO_ALG_VCABM3) { memset(st, 0, sizeof(*st)); return (st->retcode = LRO_BADARG); }
+    if (ntstops > 0) { memset(st, 0, sizeof(*st)); return (st->retcode = LRO_BADARG); }
+    return adams_solve(f, u0, B, t0, t1, o, saveat, nsave, u_saved, t_saved, cap_saved, st, trace, cap_trace, dense);
+  }
   const long n = (long)f->D * B;
   const float abstol = o->abstol, reltol = o->reltol;
   const float gamma = 0.9f, qmin = 0.2f, qmax = 10.0f, qoldinit = 1e-4f;
@@ -1485,6 +1736,7 @@ static int node_backward_generic(const lro_diff_field* df, const float* x, int B
   float* stops = (float*)malloc(sizeof(float) * (size_t)(ntst > 0 ? ntst : 1));
   for (int i = 0; i < ntst; ++i) stops[i] = -tst[ntst - 1 - i];   /* ascending in s */
   lro_opts ob = *o; ob.save_everystep = 0; ob.save_start = 0;
+  ob.alg = LRO_ALG_TSIT5;   /* the reversed solve is Tsit5 whatever the forward's method was (the product's choice: csrc/lrnde_adams.hpp) */
   float sv[1] = {-t0}; float tsv[2];
   float* zs = (float*)malloc(sizeof(float) * (size_t)N * 2);
   rc = lro_solve_ex(&af, z0, 1, -t2, -t0, &ob, sv, 1, zs, tsv, 2, st_bwd, btrace, cap_btrace, stops, ntst, NULL);

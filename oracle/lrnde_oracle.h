@@ -116,7 +116,9 @@ typedef struct {
   int save_start;     /* push (t0,u0) first */
   int save_everystep; /* saveat empty: push every accepted step */
   int exact_pow;      /* 0: DiffEqBase fastpow (default); 1: pow() in double */
+  int alg;            /* n.solver of the global solve (experiments/src/construct.jl:154-164): 0 Tsit5, 1 VCAB3, 2 VCABM3 */
 } lro_opts;
+enum { LRO_ALG_TSIT5 = 0, LRO_ALG_VCAB3 = 1, LRO_ALG_VCABM3 = 2 };
 
 typedef struct {
   int retcode;

@@ -40,7 +40,10 @@ class Conv(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("abstol", C.c_float), ("reltol", C.c_float), ("maxiters", C.c_int),
-                ("save_start", C.c_int), ("save_everystep", C.c_int), ("exact_pow", C.c_int)]
+                ("save_start", C.c_int), ("save_everystep", C.c_int), ("exact_pow", C.c_int), ("alg", C.c_int)]
+
+
+ALGS = {"tsit5": 0, "vcab3": 1, "vcabm3": 2}
 
 
 class Stats(C.Structure):
@@ -234,9 +237,9 @@ class PyField:
         self.field = Field(self._cb, None, self.D)
 
 
-def make_opts(abstol, reltol, maxiters=1000, save_start=False, save_everystep=False, exact_pow=False):
+def make_opts(abstol, reltol, maxiters=1000, save_start=False, save_everystep=False, exact_pow=False, solver="tsit5"):
     return Opts(float(abstol), float(reltol), int(maxiters), int(save_start), int(save_everystep),
-                int(exact_pow))
+                int(exact_pow), ALGS[solver])
 
 
 def tsit5_step(fld, uprev, k1, t, dt, abstol, reltol, want_stages=False):
@@ -291,7 +294,7 @@ def interp(theta, dt, y0, ks7):
 
 
 def solve(fld, u0, t0, t1, abstol, reltol, saveat=(), maxiters=1000, save_start=False,
-          save_everystep=None, exact_pow=False, cap=None, trace_cap=20000):
+          save_everystep=None, exact_pow=False, cap=None, trace_cap=20000, solver="tsit5"):
     u0 = _f32(u0)
     D = fld.D; B = u0.size // D
     saveat = np.ascontiguousarray(saveat, dtype=np.float32)
@@ -299,7 +302,7 @@ def solve(fld, u0, t0, t1, abstol, reltol, saveat=(), maxiters=1000, save_start=
         save_everystep = saveat.size == 0
     if cap is None:
         cap = saveat.size + 2 + (min(maxiters, 4096) if save_everystep else 0)
-    o = make_opts(abstol, reltol, maxiters, save_start, save_everystep, exact_pow)
+    o = make_opts(abstol, reltol, maxiters, save_start, save_everystep, exact_pow, solver)
     us = np.empty((cap,) + u0.shape, dtype=np.float32)
     ts = np.empty(cap, dtype=np.float32)
     st = Stats()
@@ -314,10 +317,10 @@ def solve(fld, u0, t0, t1, abstol, reltol, saveat=(), maxiters=1000, save_start=
 
 
 def node_forward(fld, x, t0, t2, abstol, reltol, mode="unbiased", reg_type="error_estimate",
-                 t1_or_rand=0.5, maxiters=1000, save_start=False, exact_pow=False):
+                 t1_or_rand=0.5, maxiters=1000, save_start=False, exact_pow=False, solver="tsit5"):
     x = _f32(x)
     B = x.size // fld.D
-    o = make_opts(abstol, reltol, maxiters, save_start, False, exact_pow)
+    o = make_opts(abstol, reltol, maxiters, save_start, False, exact_pow, solver)
     u_end = np.empty_like(x)
     reg = C.c_float(); nfe = C.c_int(); st = Stats(); t1u = C.c_float()
     rc = lib().lro_node_forward(C.byref(fld.field), _fp(x), B, float(t0), float(t2), C.byref(o),
@@ -513,10 +516,10 @@ def step_reg_grad(fld, uprev, k1, t, dt, abstol, reltol, reg_type="error_estimat
 
 
 def node_backward(fld, x, t0, t2, abstol, reltol, du_end, mode="unbiased", reg_type="error_estimate",
-                  t1_or_rand=0.5, w_reg=0.0, maxiters=10000, save_start=False, trace=False):
+                  t1_or_rand=0.5, w_reg=0.0, maxiters=10000, save_start=False, trace=False, solver="tsit5"):
     x = _f32(x); du_end = _f32(du_end)
     B = x.size // fld.D
-    o = make_opts(abstol, reltol, maxiters, save_start, False, False)
+    o = make_opts(abstol, reltol, maxiters, save_start, False, False, solver)
     dx = np.empty_like(x)
     dp = np.zeros(fld.params.size, np.float32)
     sf, sb = Stats(), Stats()
