@@ -188,3 +188,80 @@ def test_layer_object_takes_the_solver_name(gpu_pkg):
     assert not np.array_equal(outs["VCAB3()"][0], outs["Tsit5"][0])
     with pytest.raises(ValueError):
         P.NeuralODE(model, solver="rk4")
+
+
+@pytest.mark.parametrize("solver", ["vcab3", "vcabm3"])
+def test_training_step_with_an_adams_solver(oracle, gpu_pkg, solver):
+    """run_training_step (experiments/src/utils.jl:104-123) with n.solver = VCAB3() / VCABM3(): the fused forward + head
+    call falls back to its two-call form (the Adams solve has no last launch to enqueue the head behind) and the recorded
+    backward runs over the Hermite record; loss and gradients against the oracle with the same t1 draw."""
+    import copy
+    import torch
+    P, O = gpu_pkg, oracle
+    D, H, B, K = 40, 24, 16, 10
+    model = P.TDChain(P.Chain(P.Dense(D + 1, H, "tanh"), P.Dense(H + 1, D)))
+    node = P.NeuralODE(model, solver=solver, regularize="unbiased", abstol=1e-5, reltol=1e-5, save_start=False, maxiters=4000)
+    rng = np.random.default_rng(8)
+    ps = (P.glorot_params(model, seed=2) * np.float32(2.0)).astype(np.float32)
+    pc = (rng.standard_normal(K * (D + 1)) * 0.2).astype(np.float32)
+    x = rng.standard_normal((B, D)).astype(np.float32)
+    lab = rng.integers(0, K, B).astype(np.int32)
+    st = node.initialstates(np.random.default_rng(0))
+    w_reg = 2.5
+    loss, st_, stats, grads, times = P.run_training_step(node, torch.from_numpy(ps).cuda(), torch.from_numpy(pc).cuda(), st,
+                                                         torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda(), w_reg)
+    t1 = np.float32(np.float32(copy.deepcopy(st["rng"]).random(dtype=np.float32)) * 1.0 + 0.0)
+    fld = O.MlpField(D, H, ps, nthreads=4)
+    fo = O.node_forward(fld, x, 0.0, 1.0, 1e-5, 1e-5, mode="unbiased", t1_or_rand=t1, maxiters=4000, solver=solver)
+    lo, lg, du, dpc = O.classifier_ce(fo["u_end"], pc, K, lab)
+    assert st_["nfe"] == fo["nfe"]
+    assert abs(float(loss) - (float(lo) + w_reg * float(fo["reg_val"]))) <= 1e-5 * abs(float(loss))
+    bo = O.node_backward(fld, x, 0.0, 1.0, 1e-5, 1e-5, du, mode="unbiased", t1_or_rand=t1, w_reg=w_reg, maxiters=4000, solver=solver)
+    gp, gx = grads["neural_ode"].cpu().numpy(), grads["x"].cpu().numpy()
+    assert np.abs(gp - bo["dp"]).max() <= 2e-3 * np.abs(bo["dp"]).max()
+    assert np.abs(gx - bo["dx"]).max() <= 2e-3 * np.abs(bo["dx"]).max()
+
+
+def test_time_series_layer_with_an_adams_solver(gpu_pkg):
+    """user saveat (the Latent-ODE caller's shape, experiments/src/construct.jl:244-249) with VCAB3: the series comes from the
+    Hermite interpolant, the pullback takes a cotangent on every saved state; against float64 autograd through a fine RK4"""
+    import torch
+    P = gpu_pkg
+    D, H, B = 6, 12, 5
+    model = P.TDChain(P.Chain(P.Dense(D + 1, H, "tanh"), P.Dense(H + 1, D)))
+    sv = [0.25, 0.5, 0.8, 1.0]
+    node = P.NeuralODE(model, solver="vcab3", regularize="none", abstol=1e-6, reltol=1e-6, saveat=sv, save_start=False, maxiters=100000)
+    p = (P.glorot_params(model, seed=3) * np.float32(2.0)).astype(np.float32)
+    x = np.random.default_rng(1).standard_normal((B, D)).astype(np.float32)
+    st = node.initialstates(np.random.default_rng(0))
+    ps = torch.from_numpy(p).cuda()
+    sol, st2 = node(torch.from_numpy(x).cuda(), ps, st)
+    assert [float(t) for t in sol.t] == [np.float32(t) for t in sv]
+    gs = [np.random.default_rng(10 + i).standard_normal((B, D)).astype(np.float32) for i in range(len(sv))]
+    dx, dp, info = node.pullback(torch.from_numpy(x).cuda(), ps, st, torch.from_numpy(np.stack(gs)).cuda())
+    pt = torch.tensor(p, dtype=torch.float64, requires_grad=True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+
+    def f(y, t):
+        W1 = pt[:H * (D + 1)].reshape(D + 1, H); b1 = pt[H * (D + 1):H * (D + 1) + H]
+        o2 = H * (D + 1) + H
+        W2 = pt[o2:o2 + D * (H + 1)].reshape(H + 1, D); b2 = pt[o2 + D * (H + 1):]
+        tt = torch.full((B, 1), t, dtype=torch.float64)
+        hh = torch.tanh(torch.cat([y, tt], 1) @ W1 + b1)
+        return torch.cat([hh, tt], 1) @ W2 + b2
+    N = 400
+    y, loss, nxt = xt, 0.0, 0
+    for i in range(N):
+        t = i / N; dt = 1.0 / N
+        a = f(y, t); b = f(y + 0.5 * dt * a, t + 0.5 * dt); c = f(y + 0.5 * dt * b, t + 0.5 * dt); d = f(y + dt * c, t + dt)
+        y = y + dt / 6 * (a + 2 * b + 2 * c + d)
+        if nxt < len(sv) and abs((i + 1) / N - sv[nxt]) < 1e-9:
+            err = np.abs(sol.u[nxt].cpu().numpy() - y.detach().numpy()).max()
+            assert err < 5e-5, (nxt, err)
+            loss = loss + (y * torch.tensor(gs[nxt], dtype=torch.float64)).sum(); nxt += 1
+    assert nxt == len(sv)
+    loss.backward()
+    rx = np.linalg.norm(dx.cpu().numpy() - xt.grad.numpy()) / np.linalg.norm(xt.grad.numpy())
+    rp = np.linalg.norm(dp.cpu().numpy() - pt.grad.numpy()) / np.linalg.norm(pt.grad.numpy())
+    print("time series, vcab3: dx %.2e dp %.2e" % (rx, rp))
+    assert rx < 2e-4 and rp < 2e-4
