@@ -96,7 +96,7 @@ def test_sde_solve_and_regulariser_gradients_match_float64_autograd(gpu_pkg):
     pdt.grad = None; pgt.grad = None
     val = _eh_reg64(f, g, torch.tensor(u1.cpu().numpy(), dtype=torch.float64), torch.tensor(w1, dtype=torch.float64), float(dt),
                     0.14, 0.14, 1.0 / 6.0)
-    assert abs(float(val) - float(rg["reg_val"])) < 1e-5 * abs(float(val))
+    assert abs(float(val.detach()) - float(rg["reg_val"])) < 1e-5 * abs(float(val.detach()))
     val.backward()
     for name, got, ref in (("dp_drift", rg["dp_drift"], pdt.grad), ("dp_diff", rg["dp_diff"], pgt.grad)):
         e = _rel(got.cpu().numpy(), ref.numpy())
