@@ -204,8 +204,8 @@ struct PgradArgs {
   const float* h;     // (B,Hp)
   const float* dpre;  // (B,Hp)
   float* gp;          // flat (P)
-  int ntile1, ntile2, nt1c, nt2c;  // tiles of gW1: ceil(H/16ts) x ceil((D+2)/16ts); gW2: ceil(D/16ts) x ceil((H+2)/16ts)
-  int ts;          // a workgroup's output tile is 16ts x 16ts (1 or 2)
+  int ntile1, ntile2, nt1c, nt2c;  // tiles of gW1: ceil(H/em) x ceil((D+2)/en); gW2: ceil(D/em) x ceil((H+2)/en) for an em x en tile
+  int ts;          // shape code of a workgroup's output tile: 1 = 16 x 16, 2 = 32 x 32, 3 = 32 x 64 (pgrad_tile_any)
   // device-resolved form (lrnde_adjoint.hpp): t, lam and gp of the evaluation come from the control block
   int adj_mode, adj_stage, adj_j;
   int accumulate;  // 1: gp += result (the regulariser's reverse sweep sums six evaluations' cotangents), 0: overwrite
@@ -242,10 +242,11 @@ __device__ __forceinline__ bool pgrad_resolve(PgradArgs& a, const AdjArgs& g) {
 // forms z_new's and the residual's entry on the spot (K1..K6 and z at the same index; the arithmetic of k_adj_err) and the
 // tile leaves ONE fp64 partial — no launch of its own for the mu part of the error norm
 struct AdjMuFold { const float* K[6]; const float* z; float* zn; float A7[6], BT[7]; float dt, abstol, reltol; double* part; };
-// TS x TS MFMA tiles of 16 x 16 per workgroup (a.ts: 1 or 2).  A wave's loads per k-step are TS A values + TS B values for
-// TS*TS MFMAs: at TS = 1 the GEMM re-read its operands 45 MB per launch at B = 512 through the L2 (700 workgroups, two loads
-// per MFMA), at TS = 2 half of that with 200 workgroups.  The sums are the same chains in the same order either way.
-template <bool CC = false, int TS = 1>
+// TSM x TSN MFMA tiles of 16 x 16 per workgroup (the launch's shape code a.ts: 1 = 1 x 1, 2 = 2 x 2, 3 = 2 x 4).  A wave's loads
+// per k-step are TSM A values + TSN B values for TSM*TSN MFMAs: at 1 x 1 the GEMM re-read its operands 45 MB per launch at
+// B = 512 through the L2 (700 workgroups, two loads per MFMA), at 2 x 2 half of that with 200 workgroups, at 2 x 4 (32 x 64
+// outputs) 102 workgroups.  The sums are the same chains in the same order in every shape.
+template <bool CC = false, int TSM = 1, int TSN = 1>
 __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, const AdjMuFold* fold = nullptr) {  // one output tile per workgroup, the batch (K) split over its 4 waves
   __shared__ f32x4 red[3][64];
   const int lane = threadIdx.x & 63;
@@ -263,28 +264,33 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, c
   const float* Bm = first ? a.y : a.h;
   const int lda = first ? a.Hp : a.D, ldb = first ? a.D : a.Hp;
   const int M = first ? a.H : a.D, N = first ? a.D : a.H;
-  bool rok[TS], cok[TS];
-  float cconst[TS];
-  const float* Ap[TS];
-  const float* Bp[TS];
+  bool rok[TSM], cok[TSN];
+  float cconst[TSN];
+  const float* Ap[TSM];
+  const float* Bp[TSN];
 #pragma unroll
-  for (int s = 0; s < TS; ++s) {
-    const int row = (ti * TS + s) * 16 + li, col = (tj * TS + s) * 16 + li;
-    rok[s] = row < M; cok[s] = col < N;
-    cconst[s] = (col == N) ? a.t : ((col == N + 1) ? 1.0f : 0.0f);
+  for (int s = 0; s < TSM; ++s) {
+    const int row = (ti * TSM + s) * 16 + li;
+    rok[s] = row < M;
     Ap[s] = A + (rok[s] ? row : 0);
+  }
+#pragma unroll
+  for (int s = 0; s < TSN; ++s) {
+    const int col = (tj * TSN + s) * 16 + li;
+    cok[s] = col < N;
+    cconst[s] = (col == N) ? a.t : ((col == N + 1) ? 1.0f : 0.0f);
     Bp[s] = Bm + (cok[s] ? col : 0);
   }
-  f32x4 acc[TS][TS];
+  f32x4 acc[TSM][TSN];
 #pragma unroll
-  for (int si = 0; si < TS; ++si)
+  for (int si = 0; si < TSM; ++si)
 #pragma unroll
-    for (int sj = 0; sj < TS; ++sj) acc[si][sj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sj = 0; sj < TSN; ++sj) acc[si][sj] = f32x4{0.f, 0.f, 0.f, 0.f};
   // D fragment: row = ti*16 + lk*4 + r, col = tj*16 + li ; flat weight index = row + M*col
   float* const gW = a.gp + (first ? (size_t)0 : oW2);
   float* const gb = a.gp + (first ? ob1 : ob2);
   auto dst_of = [&](int si, int sj, int r) -> float* {
-    const int c = (tj * TS + sj) * 16 + li, rr = (ti * TS + si) * 16 + lk * 4 + r;
+    const int c = (tj * TSN + sj) * 16 + li, rr = (ti * TSM + si) * 16 + lk * 4 + r;
     if (rr >= M) return nullptr;
     if (c < N) return gW + (size_t)rr + (size_t)M * c;
     if (c == N) return a.td ? gW + (size_t)rr + (size_t)M * N : nullptr;
@@ -325,15 +331,15 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, c
   // one tile per workgroup: the fold's operands are requested BEFORE the GEMM's (they were written by other launches — nothing
   // of them is in the L2; behind the GEMM they were a round trip of their own at the end of every tile)
   FoldOps pre;
-  constexpr bool hoist = TS == 1;
+  constexpr bool hoist = TSM * TSN == 1;
   if (hoist && fold && wave == 0) fold_load(0, 0, pre);
   constexpr int UN = 8;   // 8 MFMA k-steps (32 samples) per block
-  constexpr int GB = TS == 1 ? 4 : 2;   // blocks whose loads are all in flight before the first MFMA (64 independent loads per lane):
-                          // at B = 512 and TS = 1 a wave's whole share; block after block the kernel paid one L2 round trip per block
+  constexpr int GB = TSM + TSN == 2 ? 4 : 2;   // (2 x 4 with all four blocks in flight: 256 registers and spills, a tile 14.6 -> 16.4 us)   // blocks whose loads are all in flight before the first MFMA (64 independent loads per lane):
+                          // at B = 512 and 1 x 1 a wave's whole share; block after block the kernel paid one L2 round trip per block
   // blocks of 32 samples go round-robin to the 4 waves (fixed, so the summation order is fixed)
   const int nblk = (a.B + 4 * UN - 1) / (4 * UN);
   for (int blk0 = wave < 4 ? wave : nblk; blk0 < nblk; blk0 += 4 * GB) {  // waves beyond the fourth (512-thread launch) only join the barrier
-    float av[GB][UN][TS], bv[GB][UN][TS];
+    float av[GB][UN][TSM], bv[GB][UN][TSN];
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
       const int b0 = (blk0 + 4 * g) * 4 * UN;
@@ -342,9 +348,14 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, c
         for (int u = 0; u < UN; ++u) {
           const size_t b = (size_t)(b0 + 4 * u + lk);
 #pragma unroll
-          for (int s = 0; s < TS; ++s) {
-            if constexpr (CC) { av[g][u][s] = rok[s] ? ldcc(Ap[s] + b * lda) : 0.f; bv[g][u][s] = cok[s] ? ldcc(Bp[s] + b * ldb) : cconst[s]; }
-            else { av[g][u][s] = rok[s] ? Ap[s][b * lda] : 0.f; bv[g][u][s] = cok[s] ? Bp[s][b * ldb] : cconst[s]; }
+          for (int s = 0; s < TSM; ++s) {
+            if constexpr (CC) av[g][u][s] = rok[s] ? ldcc(Ap[s] + b * lda) : 0.f;
+            else av[g][u][s] = rok[s] ? Ap[s][b * lda] : 0.f;
+          }
+#pragma unroll
+          for (int s = 0; s < TSN; ++s) {
+            if constexpr (CC) bv[g][u][s] = cok[s] ? ldcc(Bp[s] + b * ldb) : cconst[s];
+            else bv[g][u][s] = cok[s] ? Bp[s][b * ldb] : cconst[s];
           }
         }
       } else {  // the ragged last block, or no block at all (zeros add nothing)
@@ -353,9 +364,14 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, c
           const int b = b0 + 4 * u + lk;
           const bool bok = b < a.B;
 #pragma unroll
-          for (int s = 0; s < TS; ++s) {
-            if constexpr (CC) { av[g][u][s] = (rok[s] && bok) ? ldcc(Ap[s] + (size_t)b * lda) : 0.f; bv[g][u][s] = bok ? (cok[s] ? ldcc(Bp[s] + (size_t)b * ldb) : cconst[s]) : 0.f; }
-            else { av[g][u][s] = (rok[s] && bok) ? Ap[s][(size_t)b * lda] : 0.f; bv[g][u][s] = bok ? (cok[s] ? Bp[s][(size_t)b * ldb] : cconst[s]) : 0.f; }
+          for (int s = 0; s < TSM; ++s) {
+            if constexpr (CC) av[g][u][s] = (rok[s] && bok) ? ldcc(Ap[s] + (size_t)b * lda) : 0.f;
+            else av[g][u][s] = (rok[s] && bok) ? Ap[s][(size_t)b * lda] : 0.f;
+          }
+#pragma unroll
+          for (int s = 0; s < TSN; ++s) {
+            if constexpr (CC) bv[g][u][s] = bok ? (cok[s] ? ldcc(Bp[s] + (size_t)b * ldb) : cconst[s]) : 0.f;
+            else bv[g][u][s] = bok ? (cok[s] ? Bp[s][(size_t)b * ldb] : cconst[s]) : 0.f;
           }
         }
       }
@@ -365,16 +381,16 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, c
 #pragma unroll
       for (int u = 0; u < UN; ++u)
 #pragma unroll
-        for (int si = 0; si < TS; ++si)
+        for (int si = 0; si < TSM; ++si)
 #pragma unroll
-          for (int sj = 0; sj < TS; ++sj) acc[si][sj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][u][si], bv[g][u][sj], acc[si][sj], 0, 0, 0);
+          for (int sj = 0; sj < TSN; ++sj) acc[si][sj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][u][si], bv[g][u][sj], acc[si][sj], 0, 0, 0);
   }
   // chains 1..3 join chain 0 in wave 0, sub-tile by sub-tile through the one staging array
 #pragma unroll
-  for (int si = 0; si < TS; ++si)
+  for (int si = 0; si < TSM; ++si)
 #pragma unroll
-    for (int sj = 0; sj < TS; ++sj) {
-      if (TS > 1 && (si | sj)) __syncthreads();
+    for (int sj = 0; sj < TSN; ++sj) {
+      if (TSM * TSN > 1 && (si | sj)) __syncthreads();
       if (wave > 0 && wave < 4) red[wave - 1][lane] = acc[si][sj];
       __syncthreads();
       if (wave == 0) {
@@ -386,9 +402,9 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, c
   if (wave > 0) return;
   double esum = 0.0;
 #pragma unroll
-  for (int si = 0; si < TS; ++si)
+  for (int si = 0; si < TSM; ++si)
 #pragma unroll
-    for (int sj = 0; sj < TS; ++sj) {
+    for (int sj = 0; sj < TSN; ++sj) {
       const f32x4 accv = acc[si][sj];
       float* dsts[4];
 #pragma unroll
@@ -427,10 +443,13 @@ __device__ __forceinline__ void pgrad_tile(const PgradArgs& a, const int tile, c
   }
 }
 // the tile shape is the launch's (PgradArgs::ts, set with the tile counts by pgrad_args)
-template <bool CC = false>
+// (WIDE: the 32 x 64 shape exists in this kernel — the VJP launch that carries the tiles; it holds 192 operand registers per
+//  lane in flight, which a kernel of tiles alone would pay for in occupancy)
+template <bool CC = false, bool WIDE = false>
 __device__ __forceinline__ void pgrad_tile_any(const PgradArgs& a, const int tile, const AdjMuFold* fold = nullptr) {
-  if (a.ts == 2) pgrad_tile<CC, 2>(a, tile, fold);
-  else pgrad_tile<CC, 1>(a, tile, fold);
+  if constexpr (WIDE) { if (a.ts == 3) { pgrad_tile<CC, 2, 4>(a, tile, fold); return; } }
+  if (a.ts == 2) pgrad_tile<CC, 2, 2>(a, tile, fold);
+  else pgrad_tile<CC, 1, 1>(a, tile, fold);
 }
 
 __global__ __launch_bounds__(256) void k_pgrad(PgradArgs a) { pgrad_tile_any(a, blockIdx.x); }
@@ -744,6 +763,9 @@ struct VjpQArgs {
   // launch started while its producer (id - 1) was still running — it forms y, h and act' first, then waits for the
   // producer's arrivals before it touches lambda and the newest K
   int sync_id, ovl;
+  // act'(pre) of this evaluation, (B, Hp) like hsc: written when dact_out != NULL (stage 6 of an adjoint attempt), read by the
+  // REUSE variant (stage 7: same time t + dt, same record step, same theta -> the same y, h and act' bit for bit)
+  float* dact_out; const float* dact_in;
 };
 
 constexpr int VQB = 3 * QSB1;  // stream blocks of one VJP (QSB2 == QSB1)
@@ -964,15 +986,21 @@ __device__ __forceinline__ bool vjp_q_resolve(VjpQArgs& a, const AdjEarly& early
   return true;
 }
 
+#ifndef LRNDE_STAMP_STAGE
+#define LRNDE_STAMP_STAGE 5
+#endif
 #ifdef LRNDE_STAMPS
 __device__ unsigned long long g_vstamps[16];  // tools/vjp_probe: phases of a stage-5 launch of the adjoint loop (workgroup 0)
 #define VSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && vst_on) g_vstamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define VSTAMP(i) do { } while (0)
 #endif
-template <int KT, bool SYNC = false> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
+// REUSE (stage 7 of an adjoint attempt, one-stream loop): the evaluation point is stage 6's (c6 = c7 = 1), so y, h and act' are
+// stage 6's — its scratch set still holds y and h for the parameter-gradient GEMM and its act' comes from dact_in.  The launch
+// skips the record's five arrays, the y tile and all of phase 1 (a third of the weight stream); same results, bit for bit.
+template <int KT, bool SYNC = false, bool REUSE = false> __device__ __forceinline__ void vjp_q_body(VjpQArgs a) {
 #ifdef LRNDE_STAMPS
-  const bool vst_on = a.adj_mode == ADJ_STAGE && a.adj_stage == 5;
+  const bool vst_on = a.adj_mode == ADJ_STAGE && a.adj_stage == LRNDE_STAMP_STAGE;
 #endif
   VSTAMP(0);
   // SYNC: a stage launch of the overlapped adjoint loop (compile-time: a run-time flag around every store and in the operand
@@ -1012,8 +1040,13 @@ template <int KT, bool SYNC = false> __device__ __forceinline__ void vjp_q_body(
       st.s2[c] = (g < m.RG2 ? g : 0) * m.KQ2p * 1024;
     }
     st.kq2_real = (m.H + 3) / 4;
-    vq_stream_load<0, 0>(st);
-    vq_stream_load<1, 1>(st);
+    if constexpr (REUSE) {   // the stream starts at phase 2's first block
+      vq_stream_load<QSB1, QSB1 % VRING>(st);
+      vq_stream_load<QSB1 + 1, (QSB1 + 1) % VRING>(st);
+    } else {
+      vq_stream_load<0, 0>(st);
+      vq_stream_load<1, 1>(st);
+    }
   }
   smem_zero_q(m, s);
   for (int i = threadIdx.x; i < (m.KQ1p - KQ1) * 4; i += QNT) ll[KQ1 * 4 + i] = zero4;
@@ -1041,7 +1074,10 @@ template <int KT, bool SYNC = false> __device__ __forceinline__ void vjp_q_body(
       const size_t g = gg[r];
       bs[r] = ld4(a.lbase + g);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) kv[r][j] = (j < a.lnk) ? (j == a.lnk - 1 ? ld4cc(a.lk[j] + g) : ld4(a.lk[j] + g)) : zero4;
+      for (int j = 0; j < 6; ++j) {
+        if constexpr (wt) kv[r][j] = (j < a.lnk) ? (j == a.lnk - 1 ? ld4cc(a.lk[j] + g) : ld4(a.lk[j] + g)) : zero4;
+        else kv[r][j] = (j < a.lnk) ? ld4(a.lk[j] + g) : zero4;
+      }
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -1063,11 +1099,14 @@ template <int KT, bool SYNC = false> __device__ __forceinline__ void vjp_q_body(
 #pragma unroll
           for (int h = 0; h < 4; ++h) lv[h] = bs[r][h] + a.ldt * sacc[h];
         }
-        st4wt(a.lam_out + gg[r], lv);
+        if constexpr (wt) st4wt(a.lam_out + gg[r], lv); else st4(a.lam_out + gg[r], lv);
       }
       ll[li[r]] = lv;
     }
   };
+  if constexpr (REUSE) {
+    lambda_tile();
+  } else
   if (ovl) {   // y tile alone: record -> y -> LDS x tile and scratch
     const size_t nst = (size_t)a.B * m.D;
 #pragma unroll
@@ -1162,6 +1201,15 @@ template <int KT, bool SYNC = false> __device__ __forceinline__ void vjp_q_body(
   float* hlf = reinterpret_cast<float*>(s.hl);
   const int ne = m.RG1 * 256;
   const int nseg1 = q_nseg1(m);
+  if constexpr (REUSE) {
+    // act' of the evaluation at the same point (stage 6), in the epilogue's element order
+    for (int e = threadIdx.x; e < ne; e += QNT) {
+      const int r = e & 3, l = (e >> 2) & 63, rg = e >> 8;
+      const int o = rg * 64 + (l >> 2) * 4 + r, sx = l & 3;
+      if ((o >> 2) >= m.KQ2p) continue;
+      dact[e] = (sx < nvalid && o < m.Hp) ? a.dact_in[(size_t)(b0 + sx) * m.Hp + o] : 0.f;
+    }
+  } else {
   // ---- phase 1: pre = W1 [y;t] + b1 ; h, act' ----
   vq_phase_ksplit<0, KT>(m, s, st, s.xl);
   q_barrier();
@@ -1174,8 +1222,13 @@ template <int KT, bool SYNC = false> __device__ __forceinline__ void vjp_q_body(
     float pre = m.td ? fma_(w1t[o], a.t, v) : v;
     pre = pre + b1[o];
     const float h = act_apply(m.act, pre);
-    dact[e] = act_deriv_c(m.act, pre, h);
-    if (sx < nvalid && o < m.Hp) { float* hp_ = a.hsc + (size_t)(b0 + sx) * m.Hp + o; if constexpr (wt) stwt(hp_, h); else *hp_ = h; }
+    const float da = act_deriv_c(m.act, pre, h);
+    dact[e] = da;
+    if (sx < nvalid && o < m.Hp) {
+      float* hp_ = a.hsc + (size_t)(b0 + sx) * m.Hp + o; if constexpr (wt) stwt(hp_, h); else *hp_ = h;
+      if (a.dact_out) a.dact_out[(size_t)(b0 + sx) * m.Hp + o] = da;
+    }
+  }
   }
   if (ovl) {
     // everything above needed the record only.  Now the producer (launch id - 1: the previous stage) must have stored its
@@ -1232,7 +1285,18 @@ template <int KT, bool SYNC = false> __global__ __launch_bounds__(QNT) void k_vj
 // The VJP of one adjoint RHS evaluation and, on the CUs it leaves idle (it has B/4 workgroups: 128 at B = 512), the
 // parameter-gradient GEMM of the PREVIOUS evaluation (its tiles are workgroups nvjp, nvjp+1, ...).  The two touch
 // disjoint buffers: the scratch (y, h, dpre) and the stage lambda are double buffered by the host (launch_vjp).
-template <int KT, bool SYNC = false> __global__ __launch_bounds__(QNT) void k_vjp_q_pg(VjpQArgs a, PgradArgs pg, int nvjp) {
+#ifdef LRNDE_STAMPS
+__device__ unsigned long long g_wgstamps[1024][2];   // tools/vjp_probe: start / end (100-MHz clock) of every workgroup of the stamped stage launch
+struct WgStamp {
+  bool on; unsigned long long t0;
+  __device__ WgStamp(bool o) : on(o && threadIdx.x == 0 && blockIdx.x < 1024), t0(__builtin_amdgcn_s_memrealtime()) {}
+  __device__ ~WgStamp() { if (on) { g_wgstamps[blockIdx.x][0] = t0; g_wgstamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime(); } }
+};
+#endif
+template <int KT, bool SYNC = false, bool REUSE = false> __global__ __launch_bounds__(QNT) void k_vjp_q_pg(VjpQArgs a, PgradArgs pg, int nvjp) {
+#ifdef LRNDE_STAMPS
+  WgStamp wgs(a.adj_mode == ADJ_STAGE && a.adj_stage == LRNDE_STAMP_STAGE);
+#endif
   if ((int)blockIdx.x >= nvjp) {
     constexpr bool synced = SYNC;
     if (synced) {   // the attempt's control block may not be published yet (its stage-2 launch runs beside this one)
@@ -1244,11 +1308,11 @@ template <int KT, bool SYNC = false> __global__ __launch_bounds__(QNT) void k_vj
       // the scratch set and lambda these tiles read belong to launch id - 1, which may still be running elsewhere on the chip
       if (threadIdx.x == 0) adj_spin(a.adj.sync + 8 + ((a.sync_id - 1) & 7), nvjp, a.adj.sync + 1);
       __syncthreads();
-      pgrad_tile_any<LRNDE_OVL_TILE_CC>(pg, (int)blockIdx.x - nvjp);
+      pgrad_tile_any<LRNDE_OVL_TILE_CC, true>(pg, (int)blockIdx.x - nvjp);
       return;
     }
-    pgrad_tile_any(pg, (int)blockIdx.x - nvjp);
+    pgrad_tile_any<false, true>(pg, (int)blockIdx.x - nvjp);
     return;
   }
-  vjp_q_body<KT, SYNC>(a);
+  vjp_q_body<KT, SYNC, REUSE>(a);
 }

@@ -1780,7 +1780,7 @@ struct lrnde_ctx {
   float *W1q = nullptr, *W2q = nullptr;
   float *V1p = nullptr, *U2p = nullptr;          // transposed weights for the backward pass
   float *V1q = nullptr, *U2q = nullptr;          // the same in the 4-column layouts
-  float *bw_y = nullptr, *bw_h = nullptr, *bw_dp = nullptr;  // VJP scratch (B*D, B*Hp, B*Hp), two sets each
+  float *bw_y = nullptr, *bw_h = nullptr, *bw_dp = nullptr, *bw_da = nullptr;  // VJP scratch (B*D, B*Hp, B*Hp, B*Hp), three sets each
   // deferred parameter-gradient GEMM (adjoint Tsit5 loop): the GEMM of RHS evaluation e rides in the launch of the VJP
   // of evaluation e+1 (k_vjp_q_pg); scratch set bw_cur is the one the next VJP writes
   bool pg_defer = false, pg_pending = false; int bw_cur = 0; PgradArgs pg_args;
@@ -1867,6 +1867,7 @@ struct lrnde_ctx {
   const float* adj_init_src = nullptr;  // adj_solve_device: its first launch also sets z = [this; 0] (k_adj_begin)
   std::function<int()> final_hook;
   bool final_hook_fired = false, last_u_end_done = false;
+  bool adj_stage7_reused = false;   // the last stage-7 launch of the adjoint loop took y / h from stage 6's scratch set (its GEMM must too)
   int solver_alg = 0;        // lrnde_set_solver: 0 Tsit5 (k_step_q / k_step), 1 VCAB3, 2 VCABM3 (lrnde_adams.hpp)
   bool hung = false;         // a host loop waited LRNDE_SPIN_DEADLINE_S for a report while the queue stayed busy: only lrnde_destroy is safe
   bool reports_off = false;  // lrnde_set_reports(ctx, 0): the solve loop polls by copies (its fall-back when no report arrives)
@@ -1883,13 +1884,13 @@ namespace {
 // path in the same process as the default one and holds the two to the same bits.
 enum {
   OPT_NO_QTILE, OPT_QTILE_MAX_B, OPT_NO_FUSE, OPT_DENSE_COPY, OPT_NO_OVERLAP, OPT_NO_SDE_FAST, OPT_SDE_HOST_LOOP, OPT_NO_QVJP,
-  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_OVERLAP, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_PGRAD_TS, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
+  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_OVERLAP, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_PGRAD_TS, OPT_ADJ_NO_REUSE, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
 };
 struct OptDef { const char* name; int dflt; bool flag; };   // flag: present in the environment = 1
 const OptDef g_optdef[N_OPT] = {
     {"LRNDE_NO_QTILE", 0, true}, {"LRNDE_QTILE_MAX_B", 2048, false}, {"LRNDE_NO_FUSE", 0, true}, {"LRNDE_DENSE_COPY", 0, true},
     {"LRNDE_NO_OVERLAP", 0, true}, {"LRNDE_NO_SDE_FAST", 0, true}, {"LRNDE_SDE_HOST_LOOP", 0, true}, {"LRNDE_NO_QVJP", 0, true},
-    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_OVERLAP", 0, false}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_PGRAD_TS", 0, false}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
+    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_OVERLAP", 0, false}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_PGRAD_TS", 0, false}, {"LRNDE_ADJ_NO_REUSE", 0, true}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
     {"LRNDE_FEED_M", 2, false}, {"LRNDE_GATHER_TILES", 0, true}, {"LRNDE_FORCE_COMM", 0, true}};
 int g_opt[N_OPT];
 bool g_opt_set[N_OPT];     // set by the hook: the environment no longer counts
@@ -2290,7 +2291,7 @@ int lrnde_destroy(lrnde_ctx* c) {
   }
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->adj_part_host) hipHostFree(c->adj_part_host);
-  void* ptrs[] = {c->dense, c->dense_t, c->dense_dt, c->adj, c->adj_part, c->V1p, c->U2p, c->V1q, c->U2q, c->bw_y, c->bw_h, c->bw_dp, c->W1q, c->W2q, c->W1p, c->W2p, c->w1t, c->b1, c->w2t, c->b2, c->state, c->ctrl, c->part,
+  void* ptrs[] = {c->dense, c->dense_t, c->dense_dt, c->adj, c->adj_part, c->V1p, c->U2p, c->V1q, c->U2q, c->bw_y, c->bw_h, c->bw_dp, c->bw_da, c->W1q, c->W2q, c->W1p, c->W2p, c->w1t, c->b1, c->w2t, c->b2, c->state, c->ctrl, c->part,
                   c->part_rx, c->pinit, c->pinit_rx, c->arrive, c->tile_part, c->tile_pinit, c->rec_gr, c->saveat_dev, c->trace_dev,
                   c->usave};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -3566,19 +3567,33 @@ static int ensure_bw(lrnde_ctx* c, int B) {
   if (c->bw_y) HIPCHK(c, hipFree(c->bw_y));
   if (c->bw_h) HIPCHK(c, hipFree(c->bw_h));
   if (c->bw_dp) HIPCHK(c, hipFree(c->bw_dp));
-  c->bw_y = c->bw_h = c->bw_dp = nullptr;
+  if (c->bw_da) HIPCHK(c, hipFree(c->bw_da));
+  c->bw_y = c->bw_h = c->bw_dp = c->bw_da = nullptr;
   // (three sets: two alternate between consecutive evaluations; overlapped stage launches rotate through all three)
   HIPCHK(c, hipMalloc(&c->bw_y, sizeof(float) * 3 * (size_t)B * c->desc.state_dim));
   HIPCHK(c, hipMalloc(&c->bw_h, sizeof(float) * 3 * (size_t)B * c->m.Hp));
   HIPCHK(c, hipMalloc(&c->bw_dp, sizeof(float) * 3 * (size_t)B * c->m.Hp));
+  HIPCHK(c, hipMalloc(&c->bw_da, sizeof(float) * 3 * (size_t)B * c->m.Hp));   // act'(pre) of a stage-6 evaluation, for stage 7
   c->bwB = B;
   return LRNDE_OK;
 }
 
 // (df/dp)^T lam from the scratch left by the last VJP launch (y, h, dpre); gp may be NULL
-// riding: the tiles share a VJP launch's grid (k_vjp_q_pg) — 32 x 32 tiles there (half the operand traffic beside the VJP's weight
-// stream: the stage launch went 22.5 -> 18.9 us at B = 512), 16 x 16 in a launch of their own (700 workgroups instead of 200
-// hide the loads' latency better: 9.5 vs 11.2 us).  LRNDE_PGRAD_TS = 1 | 2 forces one shape everywhere.
+// riding: the tiles share a VJP launch's grid (k_vjp_q_pg).  Every workgroup of that launch reserves the VJP's ~127 KB of
+// dynamic LDS, so a CU holds ONE of them: at B = 512 the 128 VJP workgroups leave 128 CUs, and tiles beyond 128 run in a
+// second round after the first (workgroup stamps of tools/vjp_probe: 200 tiles of 32 x 32 started at 0 and at ~9.5 us and the
+// launch ended with them, not with the VJP).  32 x 64 tiles are 102 workgroups at the MNIST shape: one round.  In a launch of
+// their own 16 x 16 tiles (700 workgroups at 6 KB of LDS, several per CU) hide the loads' latency best (9.5 us vs 11.2 for
+// 32 x 32).  LRNDE_PGRAD_TS = 1 | 2 | 3 forces one shape everywhere.
+static void pgrad_shape(PgradArgs& g, bool riding) {
+  const int ots = opt(OPT_PGRAD_TS);
+  g.ts = (ots >= 1 && ots <= 3) ? ots : (riding ? 3 : 1);
+  if (!riding && g.ts == 3) g.ts = 2;   // the 32 x 64 shape exists in the VJP launch only (pgrad_tile_any<CC, WIDE>)
+  const int em = g.ts == 1 ? 16 : 32, en = g.ts == 1 ? 16 : (g.ts == 2 ? 32 : 64);
+  const int th = (g.H + em - 1) / em, td16 = (g.D + em - 1) / em;
+  g.nt1c = (g.D + 2 + en - 1) / en; g.nt2c = (g.H + 2 + en - 1) / en;
+  g.ntile1 = th * g.nt1c; g.ntile2 = td16 * g.nt2c;
+}
 static PgradArgs pgrad_args(const lrnde_ctx* c, int B, float t, const float* lam, float* gp, int set, bool riding = false) {
   PgradArgs g{};
   memset(&g, 0, sizeof(g));  // adj_mode = ADJ_HOST: t / lam / gp as given here
@@ -3587,15 +3602,12 @@ static PgradArgs pgrad_args(const lrnde_ctx* c, int B, float t, const float* lam
   g.lam = lam; g.gp = gp;
   g.y = c->bw_y + (size_t)set * B * c->desc.state_dim; g.h = c->bw_h + (size_t)set * B * c->m.Hp; g.dpre = c->bw_dp + (size_t)set * B * c->m.Hp;
   // output tiles incl. the two virtual columns (time column, bias): gW1 is H x (D+2), gW2 is D x (H+2)
-  const int ots = opt(OPT_PGRAD_TS);
-  g.ts = (ots == 1 || ots == 2) ? ots : (riding ? 2 : 1);
-  const int e = 16 * g.ts;
-  const int th = (g.H + e - 1) / e, td16 = (g.D + e - 1) / e;
-  g.nt1c = (g.D + 2 + e - 1) / e; g.nt2c = (g.H + 2 + e - 1) / e;
-  g.ntile1 = th * g.nt1c; g.ntile2 = td16 * g.nt2c;
+  pgrad_shape(g, riding);
   return g;
 }
-static int launch_pgrad_args(lrnde_ctx* c, const PgradArgs& g) {
+static int launch_pgrad_args(lrnde_ctx* c, const PgradArgs& g0) {
+  PgradArgs g = g0;
+  pgrad_shape(g, false);   // (a deferred GEMM that no VJP launch came to carry: the shape of a launch of its own)
   hipLaunchKernelGGL(k_pgrad, dim3(g.ntile1 + g.ntile2), dim3(256), 0, c->stream, g);
   HIPCHK(c, hipGetLastError());
   // batch-sharded run: the parameter cotangent is a sum over all samples (SURVEY.md §8e caveat 1)
@@ -3958,6 +3970,12 @@ int adj_enqueue_eval(lrnde_ctx* c, int B, const AdjArgs& g, int mode, int stage,
   const int set = c->bw_cur, prev_set = rot3 ? (set + 2) % 3 : set ^ 1;
   a.ysc = c->bw_y + (size_t)set * B * c->desc.state_dim; a.hsc = c->bw_h + (size_t)set * B * c->m.Hp; a.dpsc = c->bw_dp + (size_t)set * B * c->m.Hp;
   if (rot3) { a.sync_id = c->adj_launch_id++; a.ovl = ovl; }
+  // stages 6 and 7 of an attempt are evaluations at the same point (c6 = c7 = 1): stage 7 takes y, h and act' from stage 6
+  const bool reuse_on = !rot3 && opt(OPT_ADJ_NO_REUSE) == 0 && mode == ADJ_STAGE && with_prev_pgrad && prev_mode == ADJ_STAGE;
+  const bool reuse7 = reuse_on && stage == 7 && prev_stage == 6;
+  if (reuse_on && stage == 6) a.dact_out = c->bw_da + (size_t)set * B * c->m.Hp;
+  if (reuse7) a.dact_in = c->bw_da + (size_t)prev_set * B * c->m.Hp;
+  c->adj_stage7_reused = reuse7;
   const size_t smq = smem_bytes_vq(c->m.KQ1p, c->m.KQ2p, c->m.RG1, c->m.RG2);
   const int qcv = vjp_qcols(B); a.qcols = qcv;
   const int nvjp = (B + qcv - 1) / qcv;
@@ -3969,6 +3987,9 @@ int adj_enqueue_eval(lrnde_ctx* c, int B, const AdjArgs& g, int mode, int stage,
     if (rot3) {
       if (kt1) hipLaunchKernelGGL((k_vjp_q_pg<1, true>), grid, dim3(QNT), smq, st, a, pg, nvjp);
       else hipLaunchKernelGGL((k_vjp_q_pg<4, true>), grid, dim3(QNT), smq, st, a, pg, nvjp);
+    } else if (reuse7) {
+      if (kt1) hipLaunchKernelGGL((k_vjp_q_pg<1, false, true>), grid, dim3(QNT), smq, st, a, pg, nvjp);
+      else hipLaunchKernelGGL((k_vjp_q_pg<4, false, true>), grid, dim3(QNT), smq, st, a, pg, nvjp);
     } else {
       if (kt1) hipLaunchKernelGGL(k_vjp_q_pg<1>, grid, dim3(QNT), smq, st, a, pg, nvjp);
       else hipLaunchKernelGGL(k_vjp_q_pg<4>, grid, dim3(QNT), smq, st, a, pg, nvjp);
@@ -3985,11 +4006,19 @@ int adj_enqueue_eval(lrnde_ctx* c, int B, const AdjArgs& g, int mode, int stage,
   return LRNDE_OK;
 }
 
+// stage 7's GEMM after a REUSE launch: y and h are stage 6's (the set written before the last one), dpre and lambda its own
+void pgrad_stage7_operands(const lrnde_ctx* c, int B, PgradArgs& pg) {
+  if (!c->adj_stage7_reused) return;
+  const int s6 = c->bw_cur;   // (bw_cur has moved on: bw_cur ^ 1 is stage 7's set, bw_cur stage 6's)
+  pg.y = c->bw_y + (size_t)s6 * B * c->desc.state_dim; pg.h = c->bw_h + (size_t)s6 * B * c->m.Hp;
+}
+
 // the parameter-gradient GEMM of the evaluation whose scratch was written by the LAST VJP launch, by itself; on a
 // sharded handle followed by the all-reduce of mu's slot (every rank's sum over its own columns -> the batch sum)
 int adj_enqueue_pgrad(lrnde_ctx* c, int B, const AdjArgs& g, int mode, int stage, int j) {
   PgradArgs pg = pgrad_args(c, B, 0.f, nullptr, nullptr, c->bw_cur ^ 1);
   pg.adj_mode = mode; pg.adj_stage = stage; pg.adj_j = j;
+  if (mode == ADJ_STAGE && stage == 7) pgrad_stage7_operands(c, B, pg);
   hipLaunchKernelGGL(k_pgrad_adj, dim3(pg.ntile1 + pg.ntile2), dim3(256), 0, c->stream, pg, g);
   HIPCHK(c, hipGetLastError());
   return LRNDE_OK;
@@ -4165,6 +4194,7 @@ int adj_solve_device(lrnde_ctx* c, AdjVec& v, int B, float s0, float s1, float a
       } else {
         PgradArgs pg = pgrad_args(c, B, 0.f, nullptr, nullptr, ovl_on ? (c->bw_cur + 2) % 3 : c->bw_cur ^ 1);
         pg.adj_mode = ADJ_STAGE; pg.adj_stage = 7; pg.adj_j = jj;
+        if (!ovl_on) pgrad_stage7_operands(c, B, pg);
         const int nt = pg.ntile1 + pg.ntile2;
         hipLaunchKernelGGL(k_pgrad_adj_err, dim3(nt + 256), dim3(256), 0, c->stream, pg, g, e, nt, jj, fold_mu ? 1 : 0);
         if (!fold_mu) hipLaunchKernelGGL(k_adj_err_dev, dim3(256), dim3(256), 0, c->stream, e, g, jj, 1);

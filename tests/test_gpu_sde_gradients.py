@@ -223,7 +223,7 @@ def test_sde_gradients_soak_against_float64_autograd(gpu_pkg, seed):
     rg = h.euler_heun_reg_grad(u1, torch.from_numpy(w1).cuda(), 0.3, dt, 0.14, 0.14, 1.0 / 6.0)
     pdt.grad = None; pgt.grad = None
     val = _eh_reg64(f, g, torch.tensor(u1.cpu().numpy(), dtype=torch.float64), torch.tensor(w1, dtype=torch.float64), float(dt), 0.14, 0.14, 1.0 / 6.0)
-    assert abs(float(val) - float(rg["reg_val"])) < 2e-5 * abs(float(val)), what
+    assert abs(float(val.detach()) - float(rg["reg_val"])) < 2e-5 * abs(float(val.detach())), what
     val.backward()
     for name, got, ref in (("dp_drift", rg["dp_drift"], pdt.grad), ("dp_diff", rg["dp_diff"], pgt.grad)):
         assert _rel(got.cpu().numpy(), ref.numpy()) < 5e-5, (what, "reg " + name, _rel(got.cpu().numpy(), ref.numpy()))

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"LRNDE_NO_QTILE": 0, "LRNDE_QTILE_MAX_B": 2048, "LRNDE_NO_FUSE": 0, "LRNDE_DENSE_COPY": 0, "LRNDE_NO_OVERLAP": 0,
             "LRNDE_NO_SDE_FAST": 0, "LRNDE_SDE_HOST_LOOP": 0, "LRNDE_NO_QVJP": 0, "LRNDE_ADJ_ERR_ONE_LAUNCH": 0, "LRNDE_ADJ_MU_FOLD": 0,
-            "LRNDE_ADJ_HOST": 0, "LRNDE_VJP_QCOLS": 4, "LRNDE_ADJ_OVERLAP": 0, "LRNDE_PGRAD_TS": 0,
+            "LRNDE_ADJ_HOST": 0, "LRNDE_VJP_QCOLS": 4, "LRNDE_ADJ_OVERLAP": 0, "LRNDE_PGRAD_TS": 0, "LRNDE_ADJ_NO_REUSE": 0,
             "LRNDE_FEED_T": 3, "LRNDE_FEED_E": 1, "LRNDE_FEED_M": 2}
 
 
@@ -65,7 +65,7 @@ def baseline(gpu_pkg):
 
 @pytest.mark.parametrize("switch", [{"LRNDE_NO_QTILE": 1}, {"LRNDE_QTILE_MAX_B": 16}, {"LRNDE_NO_QTILE": 1, "LRNDE_NO_FUSE": 1},
                                     {"LRNDE_DENSE_COPY": 1}, {"LRNDE_NO_OVERLAP": 1}, {"LRNDE_NO_QVJP": 1},
-                                    {"LRNDE_ADJ_ERR_ONE_LAUNCH": 1}, {"LRNDE_ADJ_MU_FOLD": 1}, {"LRNDE_ADJ_HOST": 1}, {"LRNDE_VJP_QCOLS": 2}, {"LRNDE_ADJ_OVERLAP": 1}, {"LRNDE_PGRAD_TS": 1}, {"LRNDE_PGRAD_TS": 2},
+                                    {"LRNDE_ADJ_ERR_ONE_LAUNCH": 1}, {"LRNDE_ADJ_MU_FOLD": 1}, {"LRNDE_ADJ_HOST": 1}, {"LRNDE_VJP_QCOLS": 2}, {"LRNDE_ADJ_OVERLAP": 1}, {"LRNDE_PGRAD_TS": 1}, {"LRNDE_PGRAD_TS": 2}, {"LRNDE_PGRAD_TS": 3}, {"LRNDE_ADJ_NO_REUSE": 1},
                                     {"LRNDE_PGRAD_TS": 2, "LRNDE_ADJ_MU_FOLD": 1},
                                     {"LRNDE_FEED_T": 100, "LRNDE_FEED_E": 1, "LRNDE_FEED_M": 2}, {"LRNDE_FEED_T": 0, "LRNDE_FEED_E": 0, "LRNDE_FEED_M": 1}],
                          ids=lambda d: "+".join(f"{k[6:]}={v}" for k, v in d.items()))

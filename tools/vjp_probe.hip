@@ -31,8 +31,27 @@ int main(int argc, char** argv) {
   const char* nm[] = {"entry -> LDS init, stream start", "resolve (control block, barrier)", "operand tiles (record interp, stage lambda)",
                       "phase 1 GEMM (W1 y)", "epilogue 1 (tanh, act')", "phase 2 GEMM (W2^T lam)", "epilogue 2 (dpre)", "phase 3 GEMM (W1^T dpre) + store"};
   printf("forward: %d accepted; adjoint: %d accepted + %d rejected, nf %d\n", sf.naccept, sb.naccept, sb.nreject, sb.nf);
-  printf("stage-5 launch of the adjoint loop, workgroup 0 (cycles):\n");
+  printf("stage-%d launch of the adjoint loop, workgroup 0 (cycles):\n", LRNDE_STAMP_STAGE);
   for (int i = 0; i < 8; ++i) printf("  %-46s %8llu\n", nm[i], v[i + 1] - v[i]);
   printf("  total %llu cycles\n", v[8] - v[0]);
+  // every workgroup of that launch on the 100-MHz clock: the VJP workgroups (B/4) and the parameter-gradient tiles behind them
+  static unsigned long long w[1024][2];
+  hipMemcpyFromSymbol(w, HIP_SYMBOL(g_wgstamps), sizeof(w));
+  const int nv = (B + 3) / 4;
+  unsigned long long t0 = ~0ull;
+  int nw = 0;
+  for (int i = 0; i < 1024; ++i) if (w[i][1]) { if (w[i][0] < t0) t0 = w[i][0]; nw = i + 1; }
+  auto stat = [&](int lo, int hi, const char* what) {
+    if (hi <= lo) return;
+    double s0 = 1e30, s1 = 0, e0 = 1e30, e1 = 0, dsum = 0;
+    for (int i = lo; i < hi; ++i) {
+      const double st = (w[i][0] - t0) / 100.0, en = (w[i][1] - t0) / 100.0;
+      s0 = st < s0 ? st : s0; s1 = st > s1 ? st : s1; e0 = en < e0 ? en : e0; e1 = en > e1 ? en : e1; dsum += en - st;
+    }
+    printf("  %-22s %4d workgroups: start %.2f .. %.2f us, end %.2f .. %.2f us, mean duration %.2f us\n", what, hi - lo, s0, s1, e0, e1, dsum / (hi - lo));
+  };
+  printf("workgroups of the stamped launch (stage %d):\n", LRNDE_STAMP_STAGE);
+  stat(0, nv < nw ? nv : nw, "VJP");
+  stat(nv, nw, "parameter-gradient tiles");
   return 0;
 }
