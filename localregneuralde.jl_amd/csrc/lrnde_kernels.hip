@@ -1884,13 +1884,13 @@ namespace {
 // path in the same process as the default one and holds the two to the same bits.
 enum {
   OPT_NO_QTILE, OPT_QTILE_MAX_B, OPT_NO_FUSE, OPT_DENSE_COPY, OPT_NO_OVERLAP, OPT_NO_SDE_FAST, OPT_SDE_HOST_LOOP, OPT_NO_QVJP,
-  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_OVERLAP, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_PGRAD_TS, OPT_ADJ_NO_REUSE, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
+  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_OVERLAP, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_PGRAD_TS, OPT_ADJ_NO_REUSE, OPT_NO_SDE_BWD_FUSED, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
 };
 struct OptDef { const char* name; int dflt; bool flag; };   // flag: present in the environment = 1
 const OptDef g_optdef[N_OPT] = {
     {"LRNDE_NO_QTILE", 0, true}, {"LRNDE_QTILE_MAX_B", 2048, false}, {"LRNDE_NO_FUSE", 0, true}, {"LRNDE_DENSE_COPY", 0, true},
     {"LRNDE_NO_OVERLAP", 0, true}, {"LRNDE_NO_SDE_FAST", 0, true}, {"LRNDE_SDE_HOST_LOOP", 0, true}, {"LRNDE_NO_QVJP", 0, true},
-    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_OVERLAP", 0, false}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_PGRAD_TS", 0, false}, {"LRNDE_ADJ_NO_REUSE", 0, true}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
+    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_OVERLAP", 0, false}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_PGRAD_TS", 0, false}, {"LRNDE_ADJ_NO_REUSE", 0, true}, {"LRNDE_NO_SDE_BWD_FUSED", 0, true}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
     {"LRNDE_FEED_M", 2, false}, {"LRNDE_GATHER_TILES", 0, true}, {"LRNDE_FORCE_COMM", 0, true}};
 int g_opt[N_OPT];
 bool g_opt_set[N_OPT];     // set by the hook: the environment no longer counts
@@ -3064,6 +3064,9 @@ struct lrnde_sde {
   Ctrl *traj_host = nullptr, *traj_dev = nullptr; int traj_cap = 0;  // per-step records of lrnde_sde_solve_fixed (pinned / device)
   float* sri_ws = nullptr; size_t sri_n = 0; double *sri_part = nullptr, *sri_part_host = nullptr;  // lrnde_sde_sri_step scratch
   float* bwd_ws = nullptr; size_t bwd_n = 0;  // lrnde_sde_*_backward / _reg_grad scratch
+  // the one-launch reverse sweep (lrnde_sde_bwd_fused.hpp): raw drift parameters as the caller gave them, the workgroups'
+  // parameter-cotangent partials, the recorded steps and the series table on the device
+  float* pdr = nullptr; float* bwf_part = nullptr; size_t bwf_part_n = 0; int* bwf_meta = nullptr; size_t bwf_meta_n = 0;
   int* arrive = nullptr;                      // arrival counter of the one-launch step's footer (lrnde_sde_fast.hpp)
   float* ad_ws = nullptr; size_t ad_n = 0;    // lrnde_sde_solve_adaptive: two states + the current increment
   SdeCtl* ad_ctl = nullptr; SdeCtl* ad_ctl_host = nullptr;             // device-controlled adaptive loop: control block (device / pinned)
@@ -3100,6 +3103,9 @@ int lrnde_sde_destroy(lrnde_sde* s) {
   if (s->traj_dev) hipFree(s->traj_dev);
   if (s->sri_ws) hipFree(s->sri_ws);
   if (s->bwd_ws) hipFree(s->bwd_ws);
+  if (s->pdr) hipFree(s->pdr);
+  if (s->bwf_part) hipFree(s->bwf_part);
+  if (s->bwf_meta) hipFree(s->bwf_meta);
   if (s->ad_ctl) hipFree(s->ad_ctl);
   if (s->ad_ctl_host) hipHostFree(s->ad_ctl_host);
   if (s->ad_prog) hipHostFree(s->ad_prog);
@@ -3121,6 +3127,8 @@ int lrnde_sde_set_params(lrnde_sde* s, const float* p_drift, size_t n_drift, con
     return fail(s->drift, LRNDE_BADARG, "diffusion parameter count %zu != %zu", n_diff, (size_t)D * D + (s->diff_bias ? D : 0));
   int rc = lrnde_set_params(s->drift, p_drift, n_drift);
   if (rc) return rc;
+  if (!s->pdr) HIPCHK(s->drift, hipMalloc(&s->pdr, sizeof(float) * n_drift));
+  HIPCHK(s->drift, hipMemcpyAsync(s->pdr, p_drift, sizeof(float) * n_drift, hipMemcpyDeviceToDevice, s->drift->stream));
   hipLaunchKernelGGL(k_diff_expand, dim3(64), dim3(256), 0, s->diff->stream, p_diff, D, s->diff_bias, s->p2);
   return lrnde_set_params(s->diff, s->p2, lrnde_param_count(&s->diff->desc));
 }
@@ -3705,6 +3713,7 @@ int lrnde_vjp(lrnde_ctx* c, const float* y, float t, const float* lam, int32_t B
 
 }  // extern "C"
 #include "lrnde_sde_bwd.hpp"
+#include "lrnde_sde_bwd_fused.hpp"
 #include "lrnde_sde_node.hpp"
 extern "C" {
 // ---- backward drivers -----------------------------------------------------------------------

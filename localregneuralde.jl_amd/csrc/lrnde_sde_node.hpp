@@ -298,6 +298,60 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
   return LRNDE_OK;
 }
 
+}  // extern "C"
+namespace {
+// the reverse sweep over the recorded steps as one launch + the fixed-order sum of the workgroups' partials
+// (lrnde_sde_bwd_fused.hpp); what remains for the caller is the regulariser's part
+int sde_node_sweep_fused(lrnde_sde* s, SdeNodeRecord& r, int B, const float* du_series, int nseries, float* dx, float* dp_drift,
+                         float* dp_diff) {
+  lrnde_ctx* c = s->drift;
+  const int D = c->desc.state_dim, H = c->desc.hidden_dim;
+  const int Pf = (int)lrnde_param_count(&c->desc), Pg = D * D + (s->diff_bias ? D : 0), Ptot = Pf + D * D + D;
+  const int nwg = (B + SBF_NS - 1) / SBF_NS;
+  const size_t need = (size_t)nwg * Ptot;
+  if (s->bwf_part_n < need) {
+    if (s->bwf_part) HIPCHK(c, hipFree(s->bwf_part));
+    s->bwf_part = nullptr; s->bwf_part_n = 0;
+    HIPCHK(c, hipMalloc(&s->bwf_part, sizeof(float) * need));
+    s->bwf_part_n = need;
+  }
+  const size_t meta = (size_t)2 * SBF_MAXSER + 2 * (size_t)(r.K > 0 ? r.K : 1);
+  if (s->bwf_meta_n < meta) {
+    if (s->bwf_meta) HIPCHK(c, hipFree(s->bwf_meta));
+    s->bwf_meta = nullptr; s->bwf_meta_n = 0;
+    HIPCHK(c, hipMalloc(&s->bwf_meta, sizeof(int) * meta));
+    s->bwf_meta_n = meta;
+  }
+  // [series k (MAXSER ints)][series theta (MAXSER floats)][(i, m) of the K steps]
+  std::vector<int> hm(meta, 0);
+  for (int j = 0; j < nseries; ++j) { hm[j] = r.series[j].k; hm[SBF_MAXSER + j] = __builtin_bit_cast(int, r.series[j].theta); }
+  for (int k = 0; k < r.K; ++k) { hm[2 * SBF_MAXSER + 2 * k] = r.im[k].x; hm[2 * SBF_MAXSER + 2 * k + 1] = r.im[k].y; }
+  HIPCHK(c, hipMemcpyAsync(s->bwf_meta, hm.data(), sizeof(int) * meta, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // (hm leaves scope; the copy is a few hundred bytes)
+  SdeBwdFusedArgs a{};
+  a.pdr = s->pdr; a.Wg = s->p2 + (size_t)D * D + D; a.bg = a.Wg + (size_t)D * D;
+  a.D = D; a.H = H; a.act = c->m.act; a.B = B; a.K = r.K;
+  a.x = r.x; a.rec_u = r.rec_u; a.im = reinterpret_cast<const int2*>(s->bwf_meta + 2 * SBF_MAXSER); a.W = r.W; a.h = r.h;
+  a.du_series = du_series; a.nseries = nseries; a.ser_k = s->bwf_meta; a.ser_theta = reinterpret_cast<const float*>(s->bwf_meta + SBF_MAXSER);
+  a.dx = dx; a.part = s->bwf_part; a.Pf = Pf; a.Ptot = Ptot;
+  const size_t sm = sbf_smem_bytes(D, H);
+  // (the kernel also has 4 KB of static LDS: the limit asked for is what this launch needs, not the CU's 160 KB)
+  if (sm > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_bwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+  hipLaunchKernelGGL(k_sde_eh_bwd_fused, dim3(nwg), dim3(SBF_NT), sm, c->stream, a);
+  hipLaunchKernelGGL(k_sde_bwd_reduce, dim3((Ptot + 255) / 256), dim3(256), 0, c->stream, (const float*)s->bwf_part, nwg, Ptot, Pf, Pg, dp_drift, dp_diff);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRNDE_OK;
+}
+bool sde_bwd_fused_ok(const lrnde_sde* s, int nseries) {
+  const lrnde_ctx* c = s->drift;
+  const int D = c->desc.state_dim, H = c->desc.hidden_dim;
+  return !opt(OPT_NO_SDE_BWD_FUSED) && sde_uses_fast(s) && s->pdr && nseries <= SBF_MAXSER &&
+         sbf_smem_bytes(D, H) + 8 * SBF_MAXSER + 1024 <= 160 * 1024;   // (64 x 128 does not fit: weights 98 KB + cotangent 83 KB)
+}
+}  // namespace
+extern "C" {
+
 int lrnde_sde_node_backward_recorded(lrnde_sde* s, int32_t B, const float* du_series, int32_t nseries, float w_reg, float* dx,
                                      float* dp_drift, float* dp_diff) {
   if (!s) return LRNDE_BADARG;
@@ -318,6 +372,9 @@ int lrnde_sde_node_backward_recorded(lrnde_sde* s, int32_t B, const float* du_se
   float *du1 = v[0], *L = v[1], *tmp = v[2], *fb2 = v[3], *gb2 = v[4], *dtf = v[5], *dtg = v[6], *du1b = v[7], *Lb = v[8],
         *up = v[9], *duf = v[10], *dug = v[11], *w = v[12];
   const int nb = sde_nb(n);
+  const bool fused = sde_bwd_fused_ok(s, nseries);
+  if (fused) { if ((rc = sde_node_sweep_fused(s, r, B, du_series, nseries, dx, dp_drift, dp_diff))) return rc; }
+  else {
   HIPCHK(c, hipMemsetAsync(dx, 0, sizeof(float) * n, c->stream));   // dx doubles as ub, the cotangent of the current step's end state
   HIPCHK(c, hipMemsetAsync(dp_drift, 0, sizeof(float) * Pf, c->stream));
   HIPCHK(c, hipMemsetAsync(dp_diff, 0, sizeof(float) * Pg, c->stream));
@@ -351,6 +408,7 @@ int lrnde_sde_node_backward_recorded(lrnde_sde* s, int32_t B, const float* du_se
     if (r.series[j].k < 0) hipLaunchKernelGGL(k_sde_axpy, dim3(nb), dim3(256), 0, c->stream, n, dx, du_series + (size_t)j * n, 1.0f);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   // the regulariser (w.r.t. the parameters only: the local step's integrator is a constant of the tape, neural_sde.jl:42)
   if (r.mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
     float rv = 0.f;

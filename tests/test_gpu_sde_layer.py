@@ -221,3 +221,30 @@ def test_adaptive_layer_soak_bit_exact(oracle, gpu_pkg, seed):
         return
     got = h.node_forward_record(torch.from_numpy(x).cuda(), torch.from_numpy(W).cuda(), 0.0, 1.0, tol, tol, z_local=torch.from_numpy(z).cuda(), **kw)
     _check_forward(got, ref, what)
+
+
+@pytest.mark.parametrize("D,H,B,tol,nfine,mode,saveat", [(32, 64, 512, 0.14, 128, "unbiased", ()), (20, 48, 33, 0.05, 64, "biased", ()),
+                                                         (64, 128, 17, 0.1, 64, "unbiased", (0.3, 0.7, 1.0)), (2, 4, 1, 0.05, 64, "none", (0.0, 0.5, 1.0)),
+                                                         (33, 100, 9, 0.1, 32, "unbiased", ())])
+def test_one_launch_reverse_sweep_agrees_with_the_generic_path(oracle, gpu_pkg, D, H, B, tol, nfine, mode, saveat):
+    """lrnde_sde_bwd_fused.hpp: the whole reverse sweep in one launch (a workgroup carries four samples through every recorded
+    step) against the launch-per-piece path it replaces (LRNDE_NO_SDE_BWD_FUSED=1).  Different summation orders (plain fma chains
+    and per-workgroup partials here, MFMA chains and the four-chain batch sum there): agreement to fp32 rounding of the sums."""
+    h, drift, diff, pd, pg, x, W, z = _setup(gpu_pkg, oracle, D, H, B, nfine, seed=31, scale=1.5)
+    xd, Wd, zd = torch.from_numpy(x).cuda(), torch.from_numpy(W).cuda(), torch.from_numpy(z).cuda()
+    kw = dict(mode=mode, t1_or_rand=0.37, saveat=saveat, save_start=-1)
+    outs = []
+    for flag in (0, 1):
+        gpu_pkg.set_option("LRNDE_NO_SDE_BWD_FUSED", flag)
+        try:
+            got = h.node_forward_record(xd, Wd, 0.0, 1.0, tol, tol, z_local=zd, **kw)
+            ns = got["u"].shape[0]
+            du = np.random.default_rng(5).standard_normal((ns, B, D)).astype(f32)
+            bw = h.node_backward_recorded(torch.from_numpy(du).cuda(), w_reg=2.0 if mode != "none" else 0.0)
+        finally:
+            gpu_pkg.set_option("LRNDE_NO_SDE_BWD_FUSED", 0)
+        outs.append({k: bw[k].cpu().numpy() for k in ("dx", "dp_drift", "dp_diff")})
+    for k in ("dx", "dp_drift", "dp_diff"):
+        e = _rel(outs[0][k], outs[1][k])
+        print(f"D={D} H={H} B={B} {mode}: fused vs generic {k} {e:.2e}")
+        assert e < 2e-6, (k, e)
