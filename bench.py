@@ -548,6 +548,29 @@ def sde_main(args):
                      "kernel": "k_sde_eh_fast: ONE launch per step (weights resident in registers, the step's footer by the last workgroup to arrive); 15.7 MFLOP: latency bound by construction",
                      "us_per_launch": el / nst * 1e6, "flop_per_launch": flop},
     }
+    # the NeuralDSDE LAYER as the reference runs it (src/layers/neural_sde.jl:50-123): adaptive solve on a Brownian path drawn
+    # up front, local step at (sol(t1), t1), and the pullback through the recorded accepted steps - config 5's fwd + adjoint
+    nfine = 256
+    hh = np.float32(1.0 / nfine)
+    Wp = np.concatenate([np.zeros((1, B, D), np.float32),
+                         np.cumsum((rng.standard_normal((nfine, B, D)) * np.sqrt(hh)).astype(np.float32), axis=0, dtype=np.float32)], axis=0)
+    Wd, zd = torch.from_numpy(Wp).cuda(), torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)).cuda()
+    du1 = torch.from_numpy(rng.standard_normal((1, B, D)).astype(np.float32)).cuda()
+    tf, tb, att = [], [], 0
+    for i in range(14):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        fw = h.node_forward_record(ud, Wd, 0.0, 1.0, 0.14, 0.14, z_local=zd, mode="unbiased", t1_or_rand=0.3 + 0.03 * i, saveat=(), save_start=-1)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        bw = h.node_backward_recorded(du1.expand(fw["u"].shape[0], B, D).contiguous(), w_reg=2.0)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        if i >= 2:
+            tf.append((t1 - t0) * 1e3); tb.append((t2 - t1) * 1e3)
+        att = fw["stats"]["naccept"] + fw["stats"]["nreject"]
+    out["config"]["layer"] = {
+        "what": "NeuralDSDE layer, :unbiased, adaptive Euler-Heun on a 256-interval Brownian path (lrnde_sde_node_forward_record) and "
+                "the pullback through the recorded steps incl. the regulariser's local step (lrnde_sde_node_backward_recorded); medians of 12",
+        "attempted_steps": att, "fwd_ms": float(np.median(tf)), "pullback_ms": float(np.median(tb)),
+        "fwd_plus_adjoint_ms_per_batch": float(np.median(np.array(tf) + np.array(tb)))}
     if not args.no_cpu_baseline:
         import oracle as O
         cores = int(os.environ.get("LRNDE_CPU_CORES", min(len(os.sched_getaffinity(0)), 16)))
