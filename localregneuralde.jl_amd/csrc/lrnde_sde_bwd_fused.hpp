@@ -19,6 +19,11 @@
 // increasing order; the forward values are RECOMPUTED here in that order (the forward kernel's canonical MFMA chains differ
 // in the last bits), which is inside the gradient's bar — tests/test_gpu_sde_layer.py holds the result to 5e-6 of float64
 // autograd over the recorded grid, and to the generic path (LRNDE_NO_SDE_BWD_FUSED=1).
+//
+// The regulariser's part — d(EEst*dt)/dp of the ONE local Euler-Heun step at (sol(t1), t1), src/perform_step.jl:193-205 with
+// uprev, dW, dt constant (neural_sde.jl:42) — is a second kernel of the same construction (k_sde_eh_reg_fused): three
+// evaluation points per sample (K and utilde, tmp, uprev), EEst taken from the forward's record (the norm is the one thing
+// that couples the batch, and the forward has it).
 
 namespace {
 
@@ -37,46 +42,57 @@ struct SdeBwdFusedArgs {
   float* dx;                        // (B, D): cotangent of the input
   float* part;                      // [gridDim.x][Ptot] parameter-cotangent partials of the workgroups
   int Pf, Ptot;                     // drift parameters; drift + diffusion (D*D + D)
+  // the regulariser's kernel: the local step's start state, increment and end state, its dt, EEst and tolerances
+  const float *u1, *dW1, *un1; float dt1, eest, abstol, reltol, delta;
 };
 
-// offsets inside a sample's vector block of one evaluation point: x (D), the constant 1, dpre (H), h (H), lam (D), lam_g (D);
-// every vector padded to whole quads (the pads stay zero) so that a product's input is read four elements at a time
-struct SbfOff { int Dq, Hq, X, ONE, DPRE, HV, LAM, LAMG, VS; };
-__host__ __device__ inline SbfOff sbf_off(int D, int H) {
+// offsets inside a sample's vector block of one evaluation point: x (D), the constant 1, dpre (H), h (H), lam (D), lam_g (D)
+// [, x_g (D): the diffusion's input where it is not the drift's]; every vector padded to whole quads (the pads stay zero) so
+// that a product's input is read four elements at a time
+struct SbfOff { int Dq, Hq, X, ONE, DPRE, HV, LAM, LAMG, XG, VS; };
+__host__ __device__ inline SbfOff sbf_off(int D, int H, bool own_xg) {
   SbfOff o; o.Dq = (D + 3) & ~3; o.Hq = (H + 3) & ~3;
   o.X = 0; o.ONE = o.Dq; o.DPRE = o.Dq + 4; o.HV = o.DPRE + o.Hq; o.LAM = o.HV + o.Hq; o.LAMG = o.LAM + o.Dq; o.VS = o.LAMG + o.Dq;
+  o.XG = o.X;
+  if (own_xg) { o.XG = o.VS; o.VS += o.Dq; }
   return o;
 }
 __host__ __device__ inline int sbf_up4(int n) { return (n + 3) & ~3; }
-inline size_t sbf_smem_bytes(int D, int H) {
-  const SbfOff o = sbf_off(D, H);
+// nev evaluation points per sample: 2 in the sweep, 3 (with their own x_g) in the regulariser's kernel
+inline size_t sbf_smem_bytes(int D, int H, int nev) {
+  const SbfOff o = sbf_off(D, H, nev == 3);
   return sizeof(float) * ((size_t)sbf_up4((H + 1) * o.Dq + 4) + sbf_up4((D + 1) * o.Hq + 4) + sbf_up4((D + 1) * o.Dq + 4) + o.Hq + 2 * o.Dq   // weights, biases
-                          + (size_t)SBF_NS * 2 * o.VS                                                  // two evaluation points per sample
+                          + (size_t)SBF_NS * nev * o.VS                                                // the evaluation points' vectors
                           + (size_t)((size_t)D * H * 2 + H + D + (size_t)D * D + D));                  // the workgroup's parameter cotangent
 }
 
-__global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_fused(SdeBwdFusedArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int D = a.D, H = a.H;
-  const SbfOff o = sbf_off(D, H);
-  const int Dq = o.Dq, Hq = o.Hq;
-  const int ld1 = H + 1, ld2 = D + 1;          // leading dimensions of W1 (H x D) and of W2 (D x H) / Wg (D x D)
-  float* W1s = sm;                             // W1[h + ld1 * d], d < Dq (zero columns beyond D)
-  float* W2s = W1s + sbf_up4(ld1 * Dq + 4);    // W2[d + ld2 * h], h < Hq
-  float* Wgs = W2s + sbf_up4(ld2 * Hq + 4);    // Wg[i + ld2 * j], j < Dq
-  float* b1s = Wgs + sbf_up4(ld2 * Dq + 4);
-  float* b2s = b1s + Hq;
-  float* bgs = b2s + Dq;
-  float* V = bgs + Dq;                         // [NS][2][VS]: evaluation point 0 = tmp, 1 = u
-  float* accL = V + (size_t)SBF_NS * 2 * o.VS; // [Ptot] parameter cotangent of this workgroup's samples, summed over the steps
-  __shared__ int sk[SBF_MAXSER];
-  __shared__ float sth[SBF_MAXSER];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's sample of the workgroup
-  const int b = blockIdx.x * SBF_NS + sw;
-  const bool valid = b < a.B;
-  // ---- weights into LDS (pads zero), vector blocks zeroed (a sample beyond the batch stays all zero: it adds nothing) ----
-  {
+// what both kernels share: the LDS image of the weights, this wave's sample, the products
+struct SbfDev {
+  int D, H, Dq, Hq, ld1, ld2, act, Pf, Ptot, nev;
+  SbfOff o;
+  float *W1s, *W2s, *Wgs, *b1s, *b2s, *bgs, *V, *accL;
+  int tid, lane, sw, b;
+  bool valid, row, k0, k1, twoH;
+  int lh0, lh1, ld_;
+  size_t nst, g;
+
+  __device__ __forceinline__ void setup(const SdeBwdFusedArgs& a, float* sm, int nev_) {
+    D = a.D; H = a.H; act = a.act; Pf = a.Pf; Ptot = a.Ptot; nev = nev_;
+    o = sbf_off(D, H, nev == 3);
+    Dq = o.Dq; Hq = o.Hq; ld1 = H + 1; ld2 = D + 1;   // leading dimensions of W1 (H x D) and of W2 (D x H) / Wg (D x D)
+    W1s = sm;                                  // W1[h + ld1 * d], d < Dq (zero columns beyond D)
+    W2s = W1s + sbf_up4(ld1 * Dq + 4);         // W2[d + ld2 * h], h < Hq
+    Wgs = W2s + sbf_up4(ld2 * Hq + 4);         // Wg[i + ld2 * j], j < Dq
+    b1s = Wgs + sbf_up4(ld2 * Dq + 4);
+    b2s = b1s + Hq;
+    bgs = b2s + Dq;
+    V = bgs + Dq;                              // [NS][nev][VS]
+    accL = V + (size_t)SBF_NS * nev * o.VS;    // [Ptot] parameter cotangent of this workgroup's samples
+    tid = threadIdx.x; lane = tid & 63;
+    sw = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's sample of the workgroup
+    b = blockIdx.x * SBF_NS + sw;
+    valid = b < a.B;
+    // weights into LDS (pads zero), vector blocks zeroed (a sample beyond the batch stays all zero: it adds nothing)
     const float* W1 = a.pdr; const float* b1 = W1 + (size_t)H * D; const float* W2 = b1 + H; const float* b2 = W2 + (size_t)D * H;
     for (int e = tid; e < (int)(V - sm); e += SBF_NT) sm[e] = 0.f;
     __syncthreads();
@@ -85,36 +101,24 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_fused(SdeBwdFusedArgs a) 
     for (int e = tid; e < D * D; e += SBF_NT) { const int i = e % D, j = e / D; Wgs[i + ld2 * j] = a.Wg[e]; }
     for (int e = tid; e < H; e += SBF_NT) b1s[e] = b1[e];
     for (int e = tid; e < D; e += SBF_NT) { b2s[e] = b2[e]; bgs[e] = a.bg[e]; }
-    for (int e = tid; e < SBF_NS * 2 * o.VS; e += SBF_NT) V[e] = 0.f;
-    for (int e = tid; e < a.Ptot; e += SBF_NT) accL[e] = 0.f;
-    for (int e = tid; e < a.nseries; e += SBF_NT) { sk[e] = a.ser_k[e]; sth[e] = a.ser_theta[e]; }
+    for (int e = tid; e < SBF_NS * nev * o.VS; e += SBF_NT) V[e] = 0.f;
+    for (int e = tid; e < Ptot; e += SBF_NT) accL[e] = 0.f;
+    row = lane < D;                       // this lane owns row `lane` of every D-vector
+    k0 = lane < H; k1 = lane + 64 < H;    // ... and rows lane, lane + 64 of every H-vector
+    twoH = H > 64;
+    lh0 = k0 ? lane : 0; lh1 = k1 ? lane + 64 : 0; ld_ = row ? lane : 0;   // (lanes without a row compute row 0's value and drop it)
+    nst = (size_t)a.B * D;
+    g = valid ? (size_t)b * D + (row ? lane : 0) : 0;
   }
-  // which two vectors of a sample's block the parameter entry e multiplies (flat layout: W1, b1, W2, b2, Wg, bg);
-  // q / n by a float reciprocal (exact for the q < 2^15 that occur here)
-  const float rH = 1.0f / (float)H, rD = 1.0f / (float)D;
-  auto decode = [&](int e, int& ao, int& bo) {
-    const int n1 = H * D, n2 = n1 + H, n3 = n2 + D * H, n4 = a.Pf, n5 = n4 + D * D;
-    if (e < n1) { const int d = (int)(((float)e + 0.5f) * rH); ao = o.DPRE + (e - d * H); bo = o.X + d; }
-    else if (e < n2) { ao = o.DPRE + (e - n1); bo = o.ONE; }
-    else if (e < n3) { const int q = e - n2; const int hh = (int)(((float)q + 0.5f) * rD); ao = o.LAM + (q - hh * D); bo = o.HV + hh; }
-    else if (e < n4) { ao = o.LAM + (e - n3); bo = o.ONE; }
-    else if (e < n5) { const int q = e - n4; const int jj = (int)(((float)q + 0.5f) * rD); ao = o.LAMG + (q - jj * D); bo = o.X + jj; }
-    else { ao = o.LAMG + (e - n5); bo = o.ONE; }
-  };
-  __syncthreads();
-  float* V0 = V + (size_t)(sw * 2 + 0) * o.VS;   // evaluation point tmp
-  float* V1 = V + (size_t)(sw * 2 + 1) * o.VS;   // evaluation point u
-  if (valid && lane == 0) { V0[o.ONE] = 1.0f; V1[o.ONE] = 1.0f; }
-  const bool row = lane < D;                      // this lane owns row `lane` of every D-vector
-  const bool k0 = lane < H, k1 = lane + 64 < H;   // ... and rows lane, lane + 64 of every H-vector
-  const size_t nst = (size_t)a.B * D;
-  const size_t g = valid ? (size_t)b * D + (row ? lane : 0) : 0;
-  // Matrix-vector products of this wave's sample: the input is a vector of the sample's block in LDS (written by this wave
+  __device__ __forceinline__ float* block(int ev) const { return V + (size_t)(sw * nev + ev) * o.VS; }
+  __device__ __forceinline__ void ones() const { if (valid && lane == 0) for (int ev = 0; ev < nev; ++ev) block(ev)[o.ONE] = 1.0f; }
+
+  // Matrix-vector product of this wave's sample: the input is a vector of the sample's block in LDS (written by this wave
   // just before: a wave's LDS operations execute in order), read four elements at a time; the weight element of lane l and
-  // input index k is W[l + ld k] (W x) or W[k + ld l] (W^T x) — consecutive lanes hit consecutive banks either way, the
-  // leading dimensions being odd.  One fma chain per output over the input index in increasing order (the pads add 0 * w).
-  // S = 1: rows `lane`; S = 2: rows `lane` and `lane + 64`.
-  auto mv = [&](const float* Wm, int ld, const float* in, int nq, int base0, int base1, int kstride, bool two, float& r0, float& r1) {
+  // input index k is W[l + ld k] (W x: kstride = ld) or W[k + ld l] (W^T x: kstride = 1) — consecutive lanes hit consecutive
+  // banks either way, the leading dimensions being odd.  One fma chain per output over the input index in increasing order
+  // (the pads add 0 * w).  two: rows `lane` and `lane + 64`.
+  __device__ __forceinline__ void mv(const float* Wm, const float* in, int nq, int base0, int base1, int kstride, bool two, float& r0, float& r1) const {
     float s0 = 0.f, s1 = 0.f;
     for (int k = 0; k < nq; k += 4) {
       const f32x4 xv = *reinterpret_cast<const f32x4*>(in + k);
@@ -128,32 +132,76 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_fused(SdeBwdFusedArgs a) 
       }
     }
     r0 = s0; r1 = s1;
-    (void)ld;
-  };
-  const bool twoH = H > 64;
-  const int lh0 = k0 ? lane : 0, lh1 = k1 ? lane + 64 : 0, ld_ = row ? lane : 0;   // (lanes without a row compute row 0's value and drop it)
+  }
   // hidden layer at the point whose x is in Vp[X]: h to Vp[HV], act' in registers
-  auto hidden = [&](float* Vp, float& a0, float& a1) {
+  __device__ __forceinline__ void hidden(float* Vp, float& a0, float& a1) const {
     float p0, p1;
-    mv(W1s, ld1, Vp + o.X, Dq, lh0, lh1, ld1, twoH, p0, p1);                    // W1 x: element (h, d) at h + ld1 d
+    mv(W1s, Vp + o.X, Dq, lh0, lh1, ld1, twoH, p0, p1);                        // W1 x: element (h, d) at h + ld1 d
     a0 = a1 = 0.f;
-    if (k0) { const float pre = p0 + b1s[lane]; const float hv = act_apply(a.act, pre); a0 = act_deriv_c(a.act, pre, hv); if (valid) Vp[o.HV + lane] = hv; }
-    if (k1) { const float pre = p1 + b1s[lane + 64]; const float hv = act_apply(a.act, pre); a1 = act_deriv_c(a.act, pre, hv); if (valid) Vp[o.HV + lane + 64] = hv; }
-  };
-  auto w2_h = [&](const float* Vp) { float r0, r1; mv(W2s, ld2, Vp + o.HV, Hq, ld_, 0, ld2, false, r0, r1); return row ? r0 : 0.f; };      // (W2 h)[d]
-  auto wg_x = [&](const float* in) { float r0, r1; mv(Wgs, ld2, in, Dq, ld_, 0, ld2, false, r0, r1); return row ? r0 : 0.f; };             // (Wg x)[i]
-  auto wgt_x = [&](const float* in) { float r0, r1; mv(Wgs, ld2, in, Dq, ld2 * ld_, 0, 1, false, r0, r1); return row ? r0 : 0.f; };        // (Wg^T x)[j]
+    if (k0) { const float pre = p0 + b1s[lane]; const float hv = act_apply(act, pre); a0 = act_deriv_c(act, pre, hv); if (valid) Vp[o.HV + lane] = hv; }
+    if (k1) { const float pre = p1 + b1s[lane + 64]; const float hv = act_apply(act, pre); a1 = act_deriv_c(act, pre, hv); if (valid) Vp[o.HV + lane + 64] = hv; }
+  }
+  __device__ __forceinline__ float f_out(const float* Vp) const {   // (W2 h + b2)[d] from Vp[HV]
+    float r0, r1; mv(W2s, Vp + o.HV, Hq, ld_, 0, ld2, false, r0, r1); return row ? r0 + b2s[lane] : 0.f;
+  }
+  __device__ __forceinline__ float g_out(const float* in) const {   // (Wg x + bg)[i]
+    float r0, r1; mv(Wgs, in, Dq, ld_, 0, ld2, false, r0, r1); return row ? r0 + bgs[lane] : 0.f;
+  }
+  __device__ __forceinline__ float wgt_x(const float* in) const {   // (Wg^T x)[j]
+    float r0, r1; mv(Wgs, in, Dq, ld2 * ld_, 0, 1, false, r0, r1); return row ? r0 : 0.f;
+  }
   // J_f^T lam at the point of block Vp (lam in Vp[LAM], act' in registers): dpre to Vp[DPRE], returns row `lane`
-  auto drift_vjp = [&](float* Vp, float a0, float a1) {
+  __device__ __forceinline__ float drift_vjp(float* Vp, float a0, float a1) const {
     float d0, d1;
-    mv(W2s, ld2, Vp + o.LAM, Dq, ld2 * lh0, ld2 * lh1, 1, twoH, d0, d1);         // (W2^T lam)[h]: element (d, h) at d + ld2 h
+    mv(W2s, Vp + o.LAM, Dq, ld2 * lh0, ld2 * lh1, 1, twoH, d0, d1);            // (W2^T lam)[h]: element (d, h) at d + ld2 h
     if (valid && k0) Vp[o.DPRE + lane] = d0 * a0;
     if (valid && k1) Vp[o.DPRE + lane + 64] = d1 * a1;
     float r0, r1;
-    mv(W1s, ld1, Vp + o.DPRE, Hq, ld1 * ld_, 0, 1, false, r0, r1);               // (W1^T dpre)[d]: element (h, d) at h + ld1 d
+    mv(W1s, Vp + o.DPRE, Hq, ld1 * ld_, 0, 1, false, r0, r1);                  // (W1^T dpre)[d]: element (h, d) at h + ld1 d
     return row ? r0 : 0.f;
-  };
+  }
+  // The parameter cotangent of the vectors now in LDS: entry e of the flat layout (W1, b1, W2, b2, Wg, bg) is a product of two
+  // vectors of a block, summed over the workgroup's samples and evaluation points.  q / n by a float reciprocal (exact for
+  // the q < 2^15 that occur here).  Call between two barriers.
+  __device__ __forceinline__ void accumulate() const {
+    const float rH = 1.0f / (float)H, rD = 1.0f / (float)D;
+    const int n1 = H * D, n2 = n1 + H, n3 = n2 + D * H, n4 = Pf, n5 = n4 + D * D;
+    const int nb = SBF_NS * nev;
+#pragma unroll 1
+    for (int e = tid; e < Ptot; e += SBF_NT) {
+      int ao, bo;
+      if (e < n1) { const int d = (int)(((float)e + 0.5f) * rH); ao = o.DPRE + (e - d * H); bo = o.X + d; }
+      else if (e < n2) { ao = o.DPRE + (e - n1); bo = o.ONE; }
+      else if (e < n3) { const int q = e - n2; const int hh = (int)(((float)q + 0.5f) * rD); ao = o.LAM + (q - hh * D); bo = o.HV + hh; }
+      else if (e < n4) { ao = o.LAM + (e - n3); bo = o.ONE; }
+      else if (e < n5) { const int q = e - n4; const int jj = (int)(((float)q + 0.5f) * rD); ao = o.LAMG + (q - jj * D); bo = o.XG + jj; }
+      else { ao = o.LAMG + (e - n5); bo = o.ONE; }
+      float s = accL[e];
+      for (int q = 0; q < nb; ++q) s = fma_(V[q * o.VS + ao], V[q * o.VS + bo], s);
+      accL[e] = s;
+    }
+  }
+  __device__ __forceinline__ void store_partial(float* part) const {
+    float* pp = part + (size_t)blockIdx.x * Ptot;
+    for (int e = tid; e < Ptot; e += SBF_NT) pp[e] = accL[e];   // (each entry is its owner thread's: no barrier needed)
+  }
+};
 
+__global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_fused(SdeBwdFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ int sk[SBF_MAXSER];
+  __shared__ float sth[SBF_MAXSER];
+  SbfDev c;
+  c.setup(a, sm, 2);
+  for (int e = c.tid; e < a.nseries; e += SBF_NT) { sk[e] = a.ser_k[e]; sth[e] = a.ser_theta[e]; }
+  __syncthreads();
+  c.ones();
+  const SbfOff o = c.o;
+  const int lane = c.lane;
+  const bool live = c.valid && c.row;
+  const size_t nst = c.nst, g = c.g;
+  float* V0 = c.block(0);   // evaluation point tmp
+  float* V1 = c.block(1);   // evaluation point u
   float ub = 0.f;   // cotangent of the state at the end of the step being undone (row `lane` of this wave's sample)
   // the step's data: start state, the two path values, its length; the next (older) step's are requested while this one is worked on
   auto step_src = [&](int k, float& u, float& wlo, float& whi, int& m) {
@@ -165,67 +213,123 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_fused(SdeBwdFusedArgs a) 
   int m_n = 0;
   if (a.K > 0) step_src(a.K - 1, u_n, wlo_n, whi_n, m_n);
   for (int k = a.K - 1; k >= 0; --k) {
-    const float u = (valid && row) ? u_n : 0.f;
-    const float dW = (valid && row) ? whi_n - wlo_n : 0.f;
+    const float u = live ? u_n : 0.f;
+    const float dW = live ? whi_n - wlo_n : 0.f;
     const float dt = (float)m_n * a.h;
     if (k > 0) step_src(k - 1, u_n, wlo_n, whi_n, m_n);
     // cotangents of the series values taken inside step k: theta of each onto the step's end state ...
     for (int j = 0; j < a.nseries; ++j)
-      if (sk[j] == k) { const float th = sth[j]; if (th != 0.f && valid && row) ub = ub + th * a.du_series[(size_t)j * nst + g]; }
+      if (sk[j] == k) { const float th = sth[j]; if (th != 0.f && live) ub = ub + th * a.du_series[(size_t)j * nst + g]; }
     const float hdt = dt / 2.0f;
     // ---- forward pieces (src/perform_step.jl:175,179,183): du1 = f(u), L = g(u), tmp = (u + dt du1) + L dW ----
-    if (valid && row) V1[o.X + lane] = u;
+    if (live) V1[o.X + lane] = u;
     float a1a, a1b, a2a, a2b;
-    hidden(V1, a1a, a1b);
-    const float du1 = w2_h(V1) + (row ? b2s[lane] : 0.f);
-    const float L = wg_x(V1 + o.X) + (row ? bgs[lane] : 0.f);
-    const float tmp = (valid && row) ? (u + dt * du1) + L * dW : 0.f;
+    c.hidden(V1, a1a, a1b);
+    const float du1 = c.f_out(V1);
+    const float L = c.g_out(V1 + o.X);
+    const float tmp = live ? (u + dt * du1) + L * dW : 0.f;
     const float fb2 = hdt * ub, gb2 = (0.5f * dW) * ub;
-    if (valid && row) { V0[o.X + lane] = tmp; V0[o.LAM + lane] = fb2; V0[o.LAMG + lane] = gb2; }
-    hidden(V0, a2a, a2b);   // h(tmp), act'(tmp); f(tmp) itself is not needed
+    if (live) { V0[o.X + lane] = tmp; V0[o.LAM + lane] = fb2; V0[o.LAMG + lane] = gb2; }
+    c.hidden(V0, a2a, a2b);   // h(tmp), act'(tmp); f(tmp) itself is not needed
     // ---- second half backwards: cotangent of tmp ----
-    const float dtf = drift_vjp(V0, a2a, a2b);
-    const float dtg = wgt_x(V0 + o.LAMG);
+    const float dtf = c.drift_vjp(V0, a2a, a2b);
+    const float dtg = c.wgt_x(V0 + o.LAMG);
     const float tb = dtf + dtg;
     const float du1b = hdt * ub + dt * tb;
     const float Lb = (0.5f * dW) * ub + dW * tb;
     const float up_ = ub + tb;
-    if (valid && row) { V1[o.LAM + lane] = du1b; V1[o.LAMG + lane] = Lb; }
-    const float duf = drift_vjp(V1, a1a, a1b);
-    const float dug = wgt_x(V1 + o.LAMG);
-    ub = (valid && row) ? (up_ + duf) + dug : 0.f;
+    if (live) { V1[o.LAM + lane] = du1b; V1[o.LAMG + lane] = Lb; }
+    const float duf = c.drift_vjp(V1, a1a, a1b);
+    const float dug = c.wgt_x(V1 + o.LAMG);
+    ub = live ? (up_ + duf) + dug : 0.f;
     __syncthreads();
-    // ---- the step's parameter cotangent: every entry is a product of two of the vectors now in LDS, summed over the
-    //      workgroup's samples and the step's two evaluation points ----
-#pragma unroll 1
-    for (int e = tid; e < a.Ptot; e += SBF_NT) {
-      int ao, bo;
-      decode(e, ao, bo);
-      float s = accL[e];
-#pragma unroll
-      for (int q = 0; q < SBF_NS * 2; ++q) s = fma_(V[q * o.VS + ao], V[q * o.VS + bo], s);
-      accL[e] = s;
-    }
+    c.accumulate();
     // ... and 1 - theta of the series values onto its start state
     for (int j = 0; j < a.nseries; ++j)
-      if (sk[j] == k) { const float th = sth[j]; if (th != 1.0f && valid && row) ub = ub + (1.0f - th) * a.du_series[(size_t)j * nst + g]; }
+      if (sk[j] == k) { const float th = sth[j]; if (th != 1.0f && live) ub = ub + (1.0f - th) * a.du_series[(size_t)j * nst + g]; }
     __syncthreads();
   }
   for (int j = 0; j < a.nseries; ++j)   // a saved start value is the input itself
-    if (sk[j] < 0 && valid && row) ub = ub + a.du_series[(size_t)j * nst + g];
-  if (valid && row) a.dx[g] = ub;
-  float* pp = a.part + (size_t)blockIdx.x * a.Ptot;
-  for (int e = tid; e < a.Ptot; e += SBF_NT) pp[e] = accL[e];   // (each entry is its owner thread's: no barrier needed)
+    if (sk[j] < 0 && live) ub = ub + a.du_series[(size_t)j * nst + g];
+  if (live) a.dx[g] = ub;
+  c.store_partial(a.part);
 }
 
-// dp = sum over the workgroups' partials, in workgroup order; the diffusion part is [vec(Wg); bg] with bg present or not
-__global__ void k_sde_bwd_reduce(const float* part, int nwg, int Ptot, int Pf, int Pg, float* dp_drift, float* dp_diff) {
+// d(EEst*dt)/dp of the local step (the arithmetic of k_sder_seed / k_sdeb_seed / k_sder_join and of the six products of
+// lrnde_sde_euler_heun_reg_grad), one launch.  Evaluation points: 0 = (K for the drift, utilde for the diffusion), 1 = tmp,
+// 2 = uprev.  uprev, dW, dt and the step's end state are constants of the tape.
+__global__ __launch_bounds__(SBF_NT) void k_sde_eh_reg_fused(SdeBwdFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  SbfDev c;
+  c.setup(a, sm, 3);
+  __syncthreads();
+  c.ones();
+  const SbfOff o = c.o;
+  const int lane = c.lane;
+  const bool live = c.valid && c.row;
+  const size_t g = c.g;
+  float* V0 = c.block(0); float* V1 = c.block(1); float* V2 = c.block(2);
+  const float u = live ? a.u1[g] : 0.f, dW = live ? a.dW1[g] : 0.f, un = live ? a.un1[g] : 0.f;
+  const float dt = a.dt1, sqdt = sqrtf(dt), hdt = dt / 2.0f, nf = (float)((size_t)a.B * a.D);
+  if (live) { V2[o.X + lane] = u; V2[o.XG + lane] = u; }
+  float aua, aub, aka, akb, ata, atb;
+  c.hidden(V2, aua, aub);
+  const float du1 = c.f_out(V2);
+  const float L = c.g_out(V2 + o.XG);
+  const float ut = live ? u + L * sqdt : 0.f;            // :196
+  const float K = live ? u + dt * du1 : 0.f;             // :175
+  const float tmp = live ? K + L * dW : 0.f;
+  if (live) { V0[o.X + lane] = K; V0[o.XG + lane] = ut; }
+  c.hidden(V0, aka, akb);
+  const float du2 = c.f_out(V0);
+  const float g3 = c.g_out(V0 + o.XG);
+  // seeds (k_sder_seed)
+  float du2b = 0.f, du1b0 = 0.f, g3b = 0.f, Lb0 = 0.f, unb = 0.f;
+  if (live) {
+    const float Ed = (dt * (du2 - du1)) / 2.0f;
+    const float ggp = (g3 - L) / sqdt;
+    const float w2 = dW * dW;
+    const float En = (ggp * w2) / 2.0f;
+    const float sc = a.abstol + fmaxf_(__builtin_fabsf(u), __builtin_fabsf(un)) * a.reltol;
+    const float num = a.delta * Ed + En;
+    const float r = num / sc;
+    const float rb = (a.eest > 0.f) ? dt * r / (nf * a.eest) : 0.f;   // reg = dt * sqrt(mean r^2)
+    const float numb = rb / sc;
+    const float scb = -rb * num / (sc * sc);
+    unb = (__builtin_fabsf(un) > __builtin_fabsf(u)) ? scb * a.reltol * (un >= 0.f ? 1.f : -1.f) : 0.f;
+    const float Edb = a.delta * numb, ggpb = numb * w2 * 0.5f;
+    du2b = hdt * Edb; du1b0 = -hdt * Edb;
+    g3b = ggpb / sqdt; Lb0 = -ggpb / sqdt;
+  }
+  // f at K with du2b, g at utilde with g3b
+  if (live) { V0[o.LAM + lane] = du2b; V0[o.LAMG + lane] = g3b; }
+  const float Kb = c.drift_vjp(V0, aka, akb);
+  const float utb = c.wgt_x(V0 + o.LAMG);
+  // u_new's cotangent through f, g at tmp
+  const float fb2 = hdt * unb, gb2 = (0.5f * dW) * unb;
+  if (live) { V1[o.X + lane] = tmp; V1[o.XG + lane] = tmp; V1[o.LAM + lane] = fb2; V1[o.LAMG + lane] = gb2; }
+  c.hidden(V1, ata, atb);
+  const float dtf = c.drift_vjp(V1, ata, atb);
+  const float dtg = c.wgt_x(V1 + o.LAMG);
+  const float tb = dtf + dtg;
+  const float du1b = ((du1b0 + dt * Kb) + hdt * unb) + dt * tb;
+  const float Lb = ((Lb0 + sqdt * utb) + (0.5f * dW) * unb) + dW * tb;
+  // f, g at uprev: only their parameter cotangents count
+  if (live) { V2[o.LAM + lane] = du1b; V2[o.LAMG + lane] = Lb; }
+  (void)c.drift_vjp(V2, aua, aub);
+  __syncthreads();
+  c.accumulate();
+  c.store_partial(a.part);
+}
+
+// dp (+)= scale * sum over the workgroups' partials, in workgroup order; the diffusion part is [vec(Wg); bg] with bg present or not
+__global__ void k_sde_bwd_reduce(const float* part, int nwg, int Ptot, int Pf, int Pg, float* dp_drift, float* dp_diff, float scale, int add) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= Ptot) return;
   float s = 0.f;
   for (int w = 0; w < nwg; ++w) s = s + part[(size_t)w * Ptot + e];
-  if (e < Pf) dp_drift[e] = s;
-  else if (e - Pf < Pg) dp_diff[e - Pf] = s;
+  float* dst = e < Pf ? dp_drift + e : (e - Pf < Pg ? dp_diff + (e - Pf) : nullptr);
+  if (dst) *dst = add ? *dst + scale * s : scale * s;
 }
 
 }  // namespace

@@ -27,7 +27,7 @@ struct SdeNodeRecord {
   std::vector<int2> im;            // (i, m) of every accepted step
   std::vector<SdeSeriesEntry> series;  // the caller's view of the solution (after the _CorrectedDESolution filter)
   float* u1 = nullptr; float* dWloc = nullptr; float* tmp = nullptr; size_t n_alloc = 0;
-  float t1 = 0.f, dt_loc = 0.f;
+  float t1 = 0.f, dt_loc = 0.f, ee_loc = 0.f;   // the local step: its time, dt and EEst (u_new stays in tmp)
   float* gdr = nullptr; float* gdf = nullptr; size_t pf = 0, pg = 0;
 };
 
@@ -277,6 +277,7 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
     float ee = 0.f, rv = 0.f;
     if ((rc = sde_step_impl(s, 0, r.u1, r.dWloc, B, t1, dtl, o->abstol, o->reltol, o->delta, r.tmp, &ee, &rv))) return rc;
     *reg_val_host = rv;
+    r.ee_loc = ee;
     nfe_f += 3; nfe_g += 3;
     r.dt_loc = dtl;
   }
@@ -334,11 +335,30 @@ int sde_node_sweep_fused(lrnde_sde* s, SdeNodeRecord& r, int B, const float* du_
   a.x = r.x; a.rec_u = r.rec_u; a.im = reinterpret_cast<const int2*>(s->bwf_meta + 2 * SBF_MAXSER); a.W = r.W; a.h = r.h;
   a.du_series = du_series; a.nseries = nseries; a.ser_k = s->bwf_meta; a.ser_theta = reinterpret_cast<const float*>(s->bwf_meta + SBF_MAXSER);
   a.dx = dx; a.part = s->bwf_part; a.Pf = Pf; a.Ptot = Ptot;
-  const size_t sm = sbf_smem_bytes(D, H);
+  const size_t sm = sbf_smem_bytes(D, H, 2);
   // (the kernel also has 4 KB of static LDS: the limit asked for is what this launch needs, not the CU's 160 KB)
   if (sm > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_bwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
   hipLaunchKernelGGL(k_sde_eh_bwd_fused, dim3(nwg), dim3(SBF_NT), sm, c->stream, a);
-  hipLaunchKernelGGL(k_sde_bwd_reduce, dim3((Ptot + 255) / 256), dim3(256), 0, c->stream, (const float*)s->bwf_part, nwg, Ptot, Pf, Pg, dp_drift, dp_diff);
+  hipLaunchKernelGGL(k_sde_bwd_reduce, dim3((Ptot + 255) / 256), dim3(256), 0, c->stream, (const float*)s->bwf_part, nwg, Ptot, Pf, Pg, dp_drift, dp_diff, 1.0f, 0);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return LRNDE_OK;
+}
+// the regulariser's parameter cotangent, w_reg * d(EEst*dt)/dp of the recorded local step, ADDED to dp_drift / dp_diff
+int sde_node_reg_fused(lrnde_sde* s, SdeNodeRecord& r, int B, float w_reg, float* dp_drift, float* dp_diff) {
+  lrnde_ctx* c = s->drift;
+  const int D = c->desc.state_dim, H = c->desc.hidden_dim;
+  const int Pf = (int)lrnde_param_count(&c->desc), Pg = D * D + (s->diff_bias ? D : 0), Ptot = Pf + D * D + D;
+  const int nwg = (B + SBF_NS - 1) / SBF_NS;   // (bwf_part was sized by the sweep: same grid)
+  SdeBwdFusedArgs a{};
+  a.pdr = s->pdr; a.Wg = s->p2 + (size_t)D * D + D; a.bg = a.Wg + (size_t)D * D;
+  a.D = D; a.H = H; a.act = c->m.act; a.B = B; a.part = s->bwf_part; a.Pf = Pf; a.Ptot = Ptot;
+  a.u1 = r.u1; a.dW1 = r.dWloc; a.un1 = r.tmp; a.dt1 = r.dt_loc; a.eest = r.ee_loc;
+  a.abstol = r.o.abstol; a.reltol = r.o.reltol; a.delta = r.o.delta;
+  const size_t sm = sbf_smem_bytes(D, H, 3);
+  if (sm > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_reg_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+  hipLaunchKernelGGL(k_sde_eh_reg_fused, dim3(nwg), dim3(SBF_NT), sm, c->stream, a);
+  hipLaunchKernelGGL(k_sde_bwd_reduce, dim3((Ptot + 255) / 256), dim3(256), 0, c->stream, (const float*)s->bwf_part, nwg, Ptot, Pf, Pg, dp_drift, dp_diff, w_reg, 1);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRNDE_OK;
@@ -347,7 +367,7 @@ bool sde_bwd_fused_ok(const lrnde_sde* s, int nseries) {
   const lrnde_ctx* c = s->drift;
   const int D = c->desc.state_dim, H = c->desc.hidden_dim;
   return !opt(OPT_NO_SDE_BWD_FUSED) && sde_uses_fast(s) && s->pdr && nseries <= SBF_MAXSER &&
-         sbf_smem_bytes(D, H) + 8 * SBF_MAXSER + 1024 <= 160 * 1024;   // (64 x 128 does not fit: weights 98 KB + cotangent 83 KB)
+         sbf_smem_bytes(D, H, 2) + 8 * SBF_MAXSER + 1024 <= 160 * 1024;   // (64 x 128 does not fit: weights 98 KB + cotangent 83 KB)
 }
 }  // namespace
 extern "C" {
@@ -410,7 +430,9 @@ int lrnde_sde_node_backward_recorded(lrnde_sde* s, int32_t B, const float* du_se
   HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   // the regulariser (w.r.t. the parameters only: the local step's integrator is a constant of the tape, neural_sde.jl:42)
-  if (r.mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
+  if (r.mode != LRNDE_MODE_NONE && w_reg != 0.0f && fused && sbf_smem_bytes(D, c->desc.hidden_dim, 3) + 1024 <= 160 * 1024) {
+    if ((rc = sde_node_reg_fused(s, r, B, w_reg, dp_drift, dp_diff))) return rc;
+  } else if (r.mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
     float rv = 0.f;
     if ((rc = lrnde_sde_euler_heun_reg_grad(s, r.u1, r.dWloc, B, r.t1, r.dt_loc, r.o.abstol, r.o.reltol, r.o.delta, r.gdr, r.gdf, &rv))) return rc;
     hipLaunchKernelGGL(k_sde_axpy, dim3(sde_nb(Pf)), dim3(256), 0, c->stream, Pf, dp_drift, (const float*)r.gdr, w_reg);
