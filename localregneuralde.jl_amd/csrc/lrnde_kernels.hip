@@ -1884,13 +1884,13 @@ namespace {
 // path in the same process as the default one and holds the two to the same bits.
 enum {
   OPT_NO_QTILE, OPT_QTILE_MAX_B, OPT_NO_FUSE, OPT_DENSE_COPY, OPT_NO_OVERLAP, OPT_NO_SDE_FAST, OPT_SDE_HOST_LOOP, OPT_NO_QVJP,
-  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_OVERLAP, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_PGRAD_TS, OPT_ADJ_NO_REUSE, OPT_NO_SDE_BWD_FUSED, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
+  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_OVERLAP, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_PGRAD_TS, OPT_ADJ_NO_REUSE, OPT_NO_SDE_BWD_FUSED, OPT_SDE_NO_PERSIST, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
 };
 struct OptDef { const char* name; int dflt; bool flag; };   // flag: present in the environment = 1
 const OptDef g_optdef[N_OPT] = {
     {"LRNDE_NO_QTILE", 0, true}, {"LRNDE_QTILE_MAX_B", 2048, false}, {"LRNDE_NO_FUSE", 0, true}, {"LRNDE_DENSE_COPY", 0, true},
     {"LRNDE_NO_OVERLAP", 0, true}, {"LRNDE_NO_SDE_FAST", 0, true}, {"LRNDE_SDE_HOST_LOOP", 0, true}, {"LRNDE_NO_QVJP", 0, true},
-    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_OVERLAP", 0, false}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_PGRAD_TS", 0, false}, {"LRNDE_ADJ_NO_REUSE", 0, true}, {"LRNDE_NO_SDE_BWD_FUSED", 0, true}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
+    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_OVERLAP", 0, false}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_PGRAD_TS", 0, false}, {"LRNDE_ADJ_NO_REUSE", 0, true}, {"LRNDE_NO_SDE_BWD_FUSED", 0, true}, {"LRNDE_SDE_NO_PERSIST", 0, true}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
     {"LRNDE_FEED_M", 2, false}, {"LRNDE_GATHER_TILES", 0, true}, {"LRNDE_FORCE_COMM", 0, true}};
 int g_opt[N_OPT];
 bool g_opt_set[N_OPT];     // set by the hook: the environment no longer counts
@@ -3068,6 +3068,7 @@ struct lrnde_sde {
   // parameter-cotangent partials, the recorded steps and the series table on the device
   float* pdr = nullptr; float* bwf_part = nullptr; size_t bwf_part_n = 0; int* bwf_meta = nullptr; size_t bwf_meta_n = 0;
   int* arrive = nullptr;                      // arrival counter of the one-launch step's footer (lrnde_sde_fast.hpp)
+  int* bar = nullptr;                         // grid-barrier counter of the persistent solve kernel
   float* ad_ws = nullptr; size_t ad_n = 0;    // lrnde_sde_solve_adaptive: two states + the current increment
   SdeCtl* ad_ctl = nullptr; SdeCtl* ad_ctl_host = nullptr;             // device-controlled adaptive loop: control block (device / pinned)
   unsigned long long* ad_prog = nullptr; unsigned long long* ad_prog_dev = nullptr;  // its pinned progress word
@@ -3111,6 +3112,7 @@ int lrnde_sde_destroy(lrnde_sde* s) {
   if (s->ad_prog) hipHostFree(s->ad_prog);
   if (s->ad_trace) hipFree(s->ad_trace);
   if (s->arrive) hipFree(s->arrive);
+  if (s->bar) hipFree(s->bar);
   if (s->ad_ws) hipFree(s->ad_ws);
   if (s->sri_part) hipFree(s->sri_part);
   if (s->sri_part_host) hipHostFree(s->sri_part_host);
@@ -3323,10 +3325,23 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
   f.trace = trace_host ? s->ad_trace : nullptr; f.cap_trace = trace_host ? cap_trace : 0;
   f.prog = s->ad_prog_dev;
   const int nwg = (B + NB - 1) / NB;
+  // The whole solve as ONE cooperative launch (k_sde_eh_fast<DT, HT, true>: state and weights stay in registers, a grid barrier
+  // per step) when every workgroup fits on the chip at once; LRNDE_SDE_NO_PERSIST=1, a launch the runtime refuses or more than
+  // 256 workgroups: the launch-per-step loop below.  Same arithmetic, same controller: same bits.
+  bool persisted = false;
+  if (!opt(OPT_SDE_NO_PERSIST) && nwg <= 256) {
+    if (!s->bar) HIPCHK(c, hipMalloc(&s->bar, sizeof(int)));
+    HIPCHK(c, hipMemsetAsync(s->bar, 0, sizeof(int), c->stream));
+    f.bar = s->bar; f.part2 = c->part;
+    f.jlaunch = 0;
+    const hipError_t le = sde_persist_launch(f.D, c->desc.hidden_dim, nwg, c->stream, f);
+    if (le == hipSuccess) persisted = true;
+    else (void)hipGetLastError();   // (not resident / not supported: fall through to the loop)
+  }
   // launches are enqueued eight at a time, the next eight when four of them have reported; launches that find the solve
   // finished return at once (at most eight of them)
   int j = 0;
-  bool done = false;
+  bool done = persisted;
   const long cap = (long)o->maxiters + 16;
   while (!done && j <= cap) {
     for (int k = 0; k < 8; ++k, ++j) {

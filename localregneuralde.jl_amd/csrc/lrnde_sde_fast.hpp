@@ -52,6 +52,9 @@ struct SdeFastArgs {
   // the layer's recorded forward: end state of accepted step k -> rec_u[k] (slot = accepted steps so far; a rejected
   // attempt's slot is rewritten by the retry), its (i, m) -> rec_im[k]
   float* rec_u; int2* rec_im; int rec_cap;
+  // persistent form (k_sde_eh_fast<DT, HT, true>, cooperative launch): the workgroups' arrival counter of the per-step grid
+  // barrier (zero at launch) and the base of the TWO partial-sum blocks the steps alternate between
+  int* bar; double* part2;
 };
 // dtc: the controller's step proposal as a REAL number; the step taken is its floor on the path's grid (m intervals, at least
 // one).  Growth accumulates in dtc — with qmax = 1.125 a proposal quantised after every step could never leave m = 1.
@@ -73,20 +76,71 @@ __device__ __forceinline__ f32x4 sf_chain(const f32x4 (&frag)[NKG], const f32x4*
   return acc;
 }
 
-template <int DT, int HT>
+// The controller of lrnde_sde_solve_adaptive's host loop, expression for expression, on a copy of the control block: PI
+// step factor from EEst, the proposal kept as a real number, position on the caller's grid, buffer flip.  `writer` (one
+// thread of the whole grid) also leaves the trace row and the accepted step's (start, length).
+__device__ __forceinline__ void sde_ctl_update(SdeCtl& c, float eest, float dt, const SdeFastArgs& a, bool writer) {
+  const float qoldinit = 1e-4f;
+  c.nf += 3; c.eest_last = eest;
+  if (eest != eest) { c.status = LRNDE_DT_NAN; return; }
+  float q;
+  if (eest == 0.0f) q = 1.0f / a.qmax;
+  else {
+    const float q11 = fastpow(eest, a.beta1);
+    q = q11 / fastpow(c.qold, a.beta2);
+    q = fmaxf_(1.0f / a.qmax, fminf_(1.0f / a.qmin, q / a.gamma));
+  }
+  const int accepted = eest <= 1.0f;
+  const int ntr = c.naccept + c.nreject;
+  if (writer && a.trace && ntr < a.cap_trace) {
+    lrnde_trace_row r; r.t = a.t0 + (float)c.i * a.h; r.dt = dt; r.eest = eest; r.accepted = accepted;
+    a.trace[ntr] = r;
+  }
+  c.dtc = (accepted ? fmaxf_(c.dtc, dt) : dt) / q;
+  int mnew = (int)(c.dtc / a.h);
+  if (mnew < 1) mnew = 1;
+  if (accepted) {
+    if (a.rec_im) {
+      if (c.naccept < a.rec_cap) { if (writer) a.rec_im[c.naccept] = make_int2(c.i, c.m); }
+      else c.status = LRNDE_CAPACITY;
+    }
+    c.naccept++;
+    c.qold = fmaxf_(eest, qoldinit);
+    c.i += c.m;
+    c.cur ^= 1;
+    c.m = mnew;
+    if (c.i >= a.nfine && c.status == ST_RUNNING) c.status = ST_DONE;
+  } else {
+    c.nreject++;
+    if (c.m == 1) c.status = LRNDE_DT_LESS_THAN_MIN;  // the path's grid cannot be refined further
+    else c.m = mnew < c.m ? mnew : c.m - 1;
+  }
+  if (c.status == ST_RUNNING) {
+    if (c.m > a.nfine - c.i) c.m = a.nfine - c.i;
+    if (++c.iters > a.maxiters) c.status = LRNDE_MAXITERS;
+  }
+}
+
+// PERSIST: the whole adaptive solve in ONE cooperative launch.  The workgroups stay resident with their weight fragments and
+// their columns' state in registers; a step ends in a grid barrier (arrival counter + bounded spin) after which EVERY
+// workgroup reduces the partial sums in the same fixed order and runs the same controller on its own copy of the control
+// block — the same decisions everywhere, no broadcast, and the arithmetic of a step is the code of the one-launch form.
+template <int DT, int HT, bool PERSIST = false>
 __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
   static_assert(DT >= 1 && DT <= 4 && HT >= 1 && HT <= 8, "D <= 64, H <= 128");
   constexpr int NJ = (HT + 3) / 4;   // hidden tiles per wave
   const bool adapt = a.ctl != nullptr;
   int ad_i = 0, ad_m = 0, ad_slot = 0;
+  SdeCtl cc{};
   if (adapt) {
-    const SdeCtl cc = *a.ctl;   // written by the previous launch's last workgroup (kernel boundary in between)
+    cc = *a.ctl;   // written by the previous launch's last workgroup (kernel boundary in between) / by k_sde_ctl_init
     if (cc.status != ST_RUNNING) return;
     ad_i = cc.i; ad_m = cc.m; ad_slot = cc.naccept;
     a.dt = (float)ad_m * a.h;
     a.u = cc.cur ? a.ub : a.ua;
     a.un = cc.cur ? a.ua : a.ub;
   }
+  __shared__ SdeCtl sh_cc;
   // LDS: three x tiles in B-operand layout (16 DT rows x 16 columns each: [kg][64 lanes] float4), the h tile, the
   // diffusion results in C-fragment order, the reduction scratch
   __shared__ f32x4 xA[DT * 64], xB[DT * 64], xC[DT * 64], hl[HT * 64], gl[DT * 64];
@@ -142,8 +196,9 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
     }
   };
   f32x4 u4 = zero4, w4 = zero4;
+  if (live) u4 = ld4s(a.u);
+  for (int it = 0;; ++it) {   // (one trip unless PERSIST)
   if (live) {
-    u4 = ld4s(a.u);
     if (adapt) {  // dW = W[i + m] - W[i], the path's own increment (the expression of k_sde_dw)
       const f32x4 lo = ld4s(a.Wpath + (size_t)ad_i * nn);
       const f32x4 hi = ld4s(a.Wpath + (size_t)(ad_i + ad_m) * nn);
@@ -223,7 +278,7 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
       un[r] = (u4[r] + hdt * (du1[r] + f2[r])) + noise2;   // :191
     }
     if (live) {
-      st4s(a.un, un);
+      if (!PERSIST) st4s(a.un, un);   // (PERSIST: the state lives in registers until the solve ends)
       if (a.rec_u && ad_slot < a.rec_cap) st4s(a.rec_u + (size_t)ad_slot * nn, un);
     }
     put(xA, Kv);   // xA is free: every wave has read it (barrier above)
@@ -254,6 +309,58 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
     if (lane == 0) red[wave] = acc;
   }
   __syncthreads();
+  if constexpr (PERSIST) {
+    const int nwg = (int)gridDim.x;
+    double* blk = a.part2 + (size_t)(it & 1) * nwg * PSTRIDE;   // (two blocks: a fast workgroup's next step must not overwrite what a slow one still reads)
+    if (threadIdx.x < 64) {
+      double tot = red[0];
+#pragma unroll
+      for (int w = 1; w < DT; ++w) tot += red[w];
+      if (lane == 0) {
+        double* p = blk + (size_t)blockIdx.x * PSTRIDE;
+        __hip_atomic_store(p + 0, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 1, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 2, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(a.bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // grid barrier: every workgroup of the (cooperative) launch arrives once per step; bounded — 50 ms on the 100-MHz
+        // clock — so that a lost workgroup ends the solve with an error instead of hanging the queue
+        const int want = (it + 1) * nwg;
+        const unsigned long long t0c = __builtin_amdgcn_s_memrealtime();
+        bool ok = true;
+        while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
+          __builtin_amdgcn_s_sleep(2);
+          if (__builtin_amdgcn_s_memrealtime() - t0c > 5000000ull) { ok = false; break; }
+        }
+        red[0] = ok ? 1.0 : 0.0;
+      }
+      const bool ok = __shfl(red[0], 0, 64) != 0.0;   // (same wave: lane 0 has written it)
+      SdeCtl c2 = cc;
+      if (!ok) c2.status = LRNDE_HIP_ERROR;
+      else {
+        const Sum3 s3 = reduce_partials3(blk, nwg);
+        const float eest = rms_from(s3.a, a.n_norm);
+        sde_ctl_update(c2, eest, dt, a, blockIdx.x == 0 && lane == 0);
+      }
+      if (lane == 0) sh_cc = c2;
+    }
+    __syncthreads();
+    const int nacc0 = cc.naccept;
+    cc = sh_cc;
+    if (cc.naccept != nacc0) u4 = un;   // accepted: the end state is the next step's start state (rows of the Dense-2 waves)
+    if (cc.status != ST_RUNNING) {
+      if (live) st4s(cc.cur ? a.ub : a.ua, u4);
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *a.ctl = cc;
+        __hip_atomic_store(a.prog, (unsigned long long)(unsigned)(it + 1) | ((unsigned long long)(unsigned)cc.status << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+    ad_i = cc.i; ad_m = cc.m; ad_slot = cc.naccept;
+    a.dt = (float)ad_m * a.h;
+    continue;
+  } else {
   if (threadIdx.x < 64) {
     double tot = red[0];
 #pragma unroll
@@ -281,50 +388,8 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
         a.rec->reg_error = eest * dt;
         a.rec->status = ST_DONE;
       } else {
-        // the controller of lrnde_sde_solve_adaptive's host loop, expression for expression
         SdeCtl c = *a.ctl;
-        const float qoldinit = 1e-4f;
-        c.nf += 3; c.eest_last = eest;
-        if (eest != eest) {
-          c.status = LRNDE_DT_NAN;
-        } else {
-          float q;
-          if (eest == 0.0f) q = 1.0f / a.qmax;
-          else {
-            const float q11 = fastpow(eest, a.beta1);
-            q = q11 / fastpow(c.qold, a.beta2);
-            q = fmaxf_(1.0f / a.qmax, fminf_(1.0f / a.qmin, q / a.gamma));
-          }
-          const int accepted = eest <= 1.0f;
-          const int ntr = c.naccept + c.nreject;
-          if (a.trace && ntr < a.cap_trace) {
-            lrnde_trace_row r; r.t = a.t0 + (float)c.i * a.h; r.dt = dt; r.eest = eest; r.accepted = accepted;
-            a.trace[ntr] = r;
-          }
-          c.dtc = (accepted ? fmaxf_(c.dtc, dt) : dt) / q;
-          int mnew = (int)(c.dtc / a.h);
-          if (mnew < 1) mnew = 1;
-          if (accepted) {
-            if (a.rec_im) {
-              if (c.naccept < a.rec_cap) a.rec_im[c.naccept] = make_int2(c.i, c.m);
-              else c.status = LRNDE_CAPACITY;
-            }
-            c.naccept++;
-            c.qold = fmaxf_(eest, qoldinit);
-            c.i += c.m;
-            c.cur ^= 1;
-            c.m = mnew;
-            if (c.i >= a.nfine && c.status == ST_RUNNING) c.status = ST_DONE;
-          } else {
-            c.nreject++;
-            if (c.m == 1) c.status = LRNDE_DT_LESS_THAN_MIN;  // the path's grid cannot be refined further
-            else c.m = mnew < c.m ? mnew : c.m - 1;
-          }
-          if (c.status == ST_RUNNING) {
-            if (c.m > a.nfine - c.i) c.m = a.nfine - c.i;
-            if (++c.iters > a.maxiters) c.status = LRNDE_MAXITERS;
-          }
-        }
+        sde_ctl_update(c, eest, dt, a, true);
         *a.ctl = c;
         __hip_atomic_store(a.prog, (unsigned long long)(unsigned)(a.jlaunch + 1) | ((unsigned long long)(unsigned)c.status << 32),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -332,6 +397,9 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
       __hip_atomic_store(a.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  return;
+  }
+  }   // for (it)
 }
 
 // launch by shape: DT = ceil(D / 16) in 1..4, HT = ceil(H / 16) in 1..8
@@ -355,5 +423,33 @@ inline void sde_fast_launch(int D, int H, int nwg, hipStream_t st, const SdeFast
     case 2: sde_fast_launch_h<2>(HT, nwg, st, f); break;
     case 3: sde_fast_launch_h<3>(HT, nwg, st, f); break;
     default: sde_fast_launch_h<4>(HT, nwg, st, f); break;
+  }
+}
+
+// the persistent form: a cooperative launch (all workgroups resident, or the call fails and the caller takes the launch-per-step
+// loop).  Returns the launch's hipError_t.
+template <int DT, int HT> inline hipError_t sde_persist_launch_1(int nwg, hipStream_t st, SdeFastArgs& f) {
+  void* args[] = {&f};
+  return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_sde_eh_fast<DT, HT, true>), dim3(nwg), dim3(SF_NT), args, 0, st);
+}
+template <int DT> inline hipError_t sde_persist_launch_h(int HT, int nwg, hipStream_t st, SdeFastArgs& f) {
+  switch (HT) {
+    case 1: return sde_persist_launch_1<DT, 1>(nwg, st, f);
+    case 2: return sde_persist_launch_1<DT, 2>(nwg, st, f);
+    case 3: return sde_persist_launch_1<DT, 3>(nwg, st, f);
+    case 4: return sde_persist_launch_1<DT, 4>(nwg, st, f);
+    case 5: return sde_persist_launch_1<DT, 5>(nwg, st, f);
+    case 6: return sde_persist_launch_1<DT, 6>(nwg, st, f);
+    case 7: return sde_persist_launch_1<DT, 7>(nwg, st, f);
+    default: return sde_persist_launch_1<DT, 8>(nwg, st, f);
+  }
+}
+inline hipError_t sde_persist_launch(int D, int H, int nwg, hipStream_t st, SdeFastArgs& f) {
+  const int DT = (D + 15) / 16, HT = (H + 15) / 16;
+  switch (DT) {
+    case 1: return sde_persist_launch_h<1>(HT, nwg, st, f);
+    case 2: return sde_persist_launch_h<2>(HT, nwg, st, f);
+    case 3: return sde_persist_launch_h<3>(HT, nwg, st, f);
+    default: return sde_persist_launch_h<4>(HT, nwg, st, f);
   }
 }
