@@ -9,6 +9,16 @@
 
 namespace {
 
+// the one-launch reverse sweep (lrnde_sde_bwd_fused.hpp; launcher in lrnde_sde_node.hpp): what it walks — K steps given as
+// (start index, length) on a grid of interval h, the state at each step's start, and either the Brownian PATH (dW formed as a
+// difference) or the array of increments itself (dw_direct: the fixed-grid solve)
+struct SdeSweepSrc {
+  int K; const int2* im; float h; const float* x; const float* rec_u; const float* W; int dw_direct;
+  int nseries; const int* ser_k; const float* ser_theta;   // host arrays: which step a cotangent's state was taken in, and where
+};
+int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float* du_series, float* dx, float* dp_drift, float* dp_diff);
+bool sde_bwd_fused_ok(const lrnde_sde* s, int nseries);
+
 // forward pieces of a step recomputed for the backward sweep (src/perform_step.jl:175,179,183) and the cotangent seeds
 // of its second half:  tmp = (u + dt*du1) + L*dW ;  fb2 = (dt/2) ub ;  gb2 = (dW/2) ub     (ub = cotangent of u_{n+1})
 __global__ void k_sdeb_seed(size_t n, const float* u, const float* du1, const float* L, const float* dW, const float* ub, float dt,
@@ -160,6 +170,15 @@ int lrnde_sde_solve_fixed_backward(lrnde_sde* s, const float* u0, const float* u
   const int D = c->desc.state_dim;
   const size_t n = (size_t)B * D, Pf = lrnde_param_count(&c->desc), Pg2 = lrnde_param_count(&cg->desc);
   const size_t Pg = (size_t)D * D + (s->diff_bias ? D : 0), goff = (size_t)D * D + D;  // [vec(I); 0] precede [vec(Wg); bg] in the expanded form
+  if (sde_bwd_fused_ok(s, 1)) {
+    // the whole sweep in one launch: step k = (k, 1) on a grid of interval dt, increments given directly, one cotangent on the
+    // end state of the last step
+    std::vector<int2> im(nsteps);
+    for (int k = 0; k < nsteps; ++k) im[k] = make_int2(k, 1);
+    const int sk = nsteps - 1; const float sth = 1.0f;
+    SdeSweepSrc src{nsteps, im.data(), dt, u0, u_traj, dW, 1, 1, &sk, &sth};
+    return sde_sweep_fused_core(s, src, B, du_end, dx, dp_drift, dp_diff);
+  }
   float* v[12]; float* gpf[2]; float* gpg[2];
   if ((rc = sde_bwd_ws(s, n, Pf, Pg2, v, 12, gpf, gpg))) return rc;
   float *du1 = v[0], *L = v[1], *tmp = v[2], *fb2 = v[3], *gb2 = v[4], *dtf = v[5], *dtg = v[6], *du1b = v[7], *Lb = v[8],

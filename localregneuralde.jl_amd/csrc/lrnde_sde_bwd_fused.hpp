@@ -38,6 +38,7 @@ struct SdeBwdFusedArgs {
   const int2* im;                   // (start index, length) of step k on the path's grid
   const float* W;                   // the caller's Brownian path ((nfine + 1), B, D)
   float h;                          // grid interval
+  int dw_direct;                    // 1: W is the array of INCREMENTS, one (B, D) block per step (fixed-grid solve): dW = W[im.x]
   const float* du_series; int nseries; const int* ser_k; const float* ser_theta;   // cotangents of the caller's series
   float* dx;                        // (B, D): cotangent of the input
   float* part;                      // [gridDim.x][Ptot] parameter-cotangent partials of the workgroups
@@ -207,7 +208,9 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_fused(SdeBwdFusedArgs a) 
   auto step_src = [&](int k, float& u, float& wlo, float& whi, int& m) {
     const int2 im = a.im[k];
     const float* up = (k == 0) ? a.x : a.rec_u + (size_t)(k - 1) * nst;
-    u = up[g]; wlo = a.W[(size_t)im.x * nst + g]; whi = a.W[(size_t)(im.x + im.y) * nst + g]; m = im.y;
+    u = up[g]; m = im.y;
+    if (a.dw_direct) { wlo = 0.f; whi = a.W[(size_t)im.x * nst + g]; }
+    else { wlo = a.W[(size_t)im.x * nst + g]; whi = a.W[(size_t)(im.x + im.y) * nst + g]; }
   };
   float u_n = 0.f, wlo_n = 0.f, whi_n = 0.f;
   int m_n = 0;

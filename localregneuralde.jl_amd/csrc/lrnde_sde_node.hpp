@@ -303,8 +303,8 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
 namespace {
 // the reverse sweep over the recorded steps as one launch + the fixed-order sum of the workgroups' partials
 // (lrnde_sde_bwd_fused.hpp); what remains for the caller is the regulariser's part
-int sde_node_sweep_fused(lrnde_sde* s, SdeNodeRecord& r, int B, const float* du_series, int nseries, float* dx, float* dp_drift,
-                         float* dp_diff) {
+int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float* du_series, float* dx, float* dp_drift, float* dp_diff) {
+  const int nseries = r.nseries;
   lrnde_ctx* c = s->drift;
   const int D = c->desc.state_dim, H = c->desc.hidden_dim;
   const int Pf = (int)lrnde_param_count(&c->desc), Pg = D * D + (s->diff_bias ? D : 0), Ptot = Pf + D * D + D;
@@ -325,14 +325,14 @@ int sde_node_sweep_fused(lrnde_sde* s, SdeNodeRecord& r, int B, const float* du_
   }
   // [series k (MAXSER ints)][series theta (MAXSER floats)][(i, m) of the K steps]
   std::vector<int> hm(meta, 0);
-  for (int j = 0; j < nseries; ++j) { hm[j] = r.series[j].k; hm[SBF_MAXSER + j] = __builtin_bit_cast(int, r.series[j].theta); }
+  for (int j = 0; j < nseries; ++j) { hm[j] = r.ser_k[j]; hm[SBF_MAXSER + j] = __builtin_bit_cast(int, r.ser_theta[j]); }
   for (int k = 0; k < r.K; ++k) { hm[2 * SBF_MAXSER + 2 * k] = r.im[k].x; hm[2 * SBF_MAXSER + 2 * k + 1] = r.im[k].y; }
   HIPCHK(c, hipMemcpyAsync(s->bwf_meta, hm.data(), sizeof(int) * meta, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // (hm leaves scope; the copy is a few hundred bytes)
   SdeBwdFusedArgs a{};
   a.pdr = s->pdr; a.Wg = s->p2 + (size_t)D * D + D; a.bg = a.Wg + (size_t)D * D;
   a.D = D; a.H = H; a.act = c->m.act; a.B = B; a.K = r.K;
-  a.x = r.x; a.rec_u = r.rec_u; a.im = reinterpret_cast<const int2*>(s->bwf_meta + 2 * SBF_MAXSER); a.W = r.W; a.h = r.h;
+  a.x = r.x; a.rec_u = r.rec_u; a.im = reinterpret_cast<const int2*>(s->bwf_meta + 2 * SBF_MAXSER); a.W = r.W; a.h = r.h; a.dw_direct = r.dw_direct;
   a.du_series = du_series; a.nseries = nseries; a.ser_k = s->bwf_meta; a.ser_theta = reinterpret_cast<const float*>(s->bwf_meta + SBF_MAXSER);
   a.dx = dx; a.part = s->bwf_part; a.Pf = Pf; a.Ptot = Ptot;
   const size_t sm = sbf_smem_bytes(D, H, 2);
@@ -343,6 +343,13 @@ int sde_node_sweep_fused(lrnde_sde* s, SdeNodeRecord& r, int B, const float* du_
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRNDE_OK;
+}
+int sde_node_sweep_fused(lrnde_sde* s, SdeNodeRecord& r, int B, const float* du_series, int nseries, float* dx, float* dp_drift,
+                         float* dp_diff) {
+  std::vector<int> sk(nseries); std::vector<float> sth(nseries);
+  for (int j = 0; j < nseries; ++j) { sk[j] = r.series[j].k; sth[j] = r.series[j].theta; }
+  SdeSweepSrc src{r.K, r.im.data(), r.h, r.x, r.rec_u, r.W, 0, nseries, sk.data(), sth.data()};
+  return sde_sweep_fused_core(s, src, B, du_series, dx, dp_drift, dp_diff);
 }
 // the regulariser's parameter cotangent, w_reg * d(EEst*dt)/dp of the recorded local step, ADDED to dp_drift / dp_diff
 int sde_node_reg_fused(lrnde_sde* s, SdeNodeRecord& r, int B, float w_reg, float* dp_drift, float* dp_diff) {
