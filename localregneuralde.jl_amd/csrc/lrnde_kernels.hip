@@ -3068,7 +3068,6 @@ struct lrnde_sde {
   // parameter-cotangent partials, the recorded steps and the series table on the device
   float* pdr = nullptr; float* bwf_part = nullptr; size_t bwf_part_n = 0; int* bwf_meta = nullptr; size_t bwf_meta_n = 0;
   int* arrive = nullptr;                      // arrival counter of the one-launch step's footer (lrnde_sde_fast.hpp)
-  int* bar = nullptr;                         // grid-barrier counter of the persistent solve kernel
   float* ad_ws = nullptr; size_t ad_n = 0;    // lrnde_sde_solve_adaptive: two states + the current increment
   SdeCtl* ad_ctl = nullptr; SdeCtl* ad_ctl_host = nullptr;             // device-controlled adaptive loop: control block (device / pinned)
   unsigned long long* ad_prog = nullptr; unsigned long long* ad_prog_dev = nullptr;  // its pinned progress word
@@ -3112,7 +3111,6 @@ int lrnde_sde_destroy(lrnde_sde* s) {
   if (s->ad_prog) hipHostFree(s->ad_prog);
   if (s->ad_trace) hipFree(s->ad_trace);
   if (s->arrive) hipFree(s->arrive);
-  if (s->bar) hipFree(s->bar);
   if (s->ad_ws) hipFree(s->ad_ws);
   if (s->sri_part) hipFree(s->sri_part);
   if (s->sri_part_host) hipHostFree(s->sri_part_host);
@@ -3330,9 +3328,8 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
   // 256 workgroups: the launch-per-step loop below.  Same arithmetic, same controller: same bits.
   bool persisted = false;
   if (!opt(OPT_SDE_NO_PERSIST) && nwg <= 256) {
-    if (!s->bar) HIPCHK(c, hipMalloc(&s->bar, sizeof(int)));
-    HIPCHK(c, hipMemsetAsync(s->bar, 0, sizeof(int), c->stream));
-    f.bar = s->bar; f.part2 = c->part;
+    f.part2 = c->part;
+    HIPCHK(c, hipMemsetAsync(c->part, 0, sizeof(double) * 2 * (size_t)nwg * PSTRIDE, c->stream));   // (tags of an earlier solve)
     f.jlaunch = 0;
     const hipError_t le = sde_persist_launch(f.D, c->desc.hidden_dim, nwg, c->stream, f);
     if (le == hipSuccess) persisted = true;

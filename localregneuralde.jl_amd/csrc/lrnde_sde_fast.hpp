@@ -52,9 +52,9 @@ struct SdeFastArgs {
   // the layer's recorded forward: end state of accepted step k -> rec_u[k] (slot = accepted steps so far; a rejected
   // attempt's slot is rewritten by the retry), its (i, m) -> rec_im[k]
   float* rec_u; int2* rec_im; int rec_cap;
-  // persistent form (k_sde_eh_fast<DT, HT, true>, cooperative launch): the workgroups' arrival counter of the per-step grid
-  // barrier (zero at launch) and the base of the TWO partial-sum blocks the steps alternate between
-  int* bar; double* part2;
+  // persistent form (k_sde_eh_fast<DT, HT, true>, cooperative launch): the base of the TWO blocks of {partial sum, tag} slots the
+  // steps alternate between (zero at launch: no slot carries a step's tag yet)
+  double* part2;
 };
 // dtc: the controller's step proposal as a REAL number; the step taken is its floor on the path's grid (m intervals, at least
 // one).  Growth accumulates in dtc — with qmax = 1.125 a proposal quantised after every step could never leave m = 1.
@@ -122,8 +122,8 @@ __device__ __forceinline__ void sde_ctl_update(SdeCtl& c, float eest, float dt, 
 }
 
 // PERSIST: the whole adaptive solve in ONE cooperative launch.  The workgroups stay resident with their weight fragments and
-// their columns' state in registers; a step ends in a grid barrier (arrival counter + bounded spin) after which EVERY
-// workgroup reduces the partial sums in the same fixed order and runs the same controller on its own copy of the control
+// their columns' state in registers; a step ends in a grid barrier (tagged partial-sum slots + bounded polling) after which EVERY
+// workgroup adds the partial sums in the same fixed order and runs the same controller on its own copy of the control
 // block — the same decisions everywhere, no broadcast, and the arithmetic of a step is the code of the one-launch form.
 template <int DT, int HT, bool PERSIST = false>
 __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
@@ -316,29 +316,47 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
       double tot = red[0];
 #pragma unroll
       for (int w = 1; w < DT; ++w) tot += red[w];
+      // The step's grid barrier IS the exchange of the partial sums: a workgroup publishes {sum, tag} as ONE 16-byte agent-scope
+      // store — tag = step number and a checksum of the sum's bits, so that a reader can tell a slot of this step from a stale
+      // or (should a 16-byte access ever be split) a torn one — and every workgroup polls all slots with 16-byte loads until
+      // each carries this step's tag.  Two trips past the L2 per step (publish, poll) instead of four (store, arrive, poll,
+      // read).  Bounded: 50 ms on the 100-MHz clock, then the solve ends with an error instead of hanging the queue.
+      typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+      const unsigned step_tag = (unsigned)(it + 1);
       if (lane == 0) {
+        const unsigned long long vb = __builtin_bit_cast(unsigned long long, tot);
+        const u32x4_ w = {(unsigned)vb, (unsigned)(vb >> 32), (unsigned)(vb >> 32) ^ (unsigned)vb, step_tag};
         double* p = blk + (size_t)blockIdx.x * PSTRIDE;
-        __hip_atomic_store(p + 0, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(p + 1, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(p + 2, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(a.bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // grid barrier: every workgroup of the (cooperative) launch arrives once per step; bounded — 50 ms on the 100-MHz
-        // clock — so that a lost workgroup ends the solve with an error instead of hanging the queue
-        const int want = (it + 1) * nwg;
-        const unsigned long long t0c = __builtin_amdgcn_s_memrealtime();
-        bool ok = true;
-        while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0) {
-          __builtin_amdgcn_s_sleep(2);
-          if (__builtin_amdgcn_s_memrealtime() - t0c > 5000000ull) { ok = false; break; }
-        }
-        red[0] = ok ? 1.0 : 0.0;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
       }
-      const bool ok = __shfl(red[0], 0, 64) != 0.0;   // (same wave: lane 0 has written it)
+      PartLoads L;
+      const unsigned long long t0c = __builtin_amdgcn_s_memrealtime();
+      bool ok = true;
+      for (;;) {
+        u32x4_ v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = lane + 64 * u;
+          const double* p = blk + (size_t)(i < nwg ? i : 0) * PSTRIDE;
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[u]) : "v"(p) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bool good = true;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          asm volatile("" : "+v"(v[u]));
+          const bool mine = lane + 64 * u < nwg;
+          good = good && (!mine || (v[u].w == step_tag && v[u].z == (v[u].x ^ v[u].y)));
+          L.va[u] = __builtin_bit_cast(double, (unsigned long long)v[u].x | ((unsigned long long)v[u].y << 32));
+        }
+        if (__ballot(good) == ~0ull) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0c > 5000000ull) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
       SdeCtl c2 = cc;
       if (!ok) c2.status = LRNDE_HIP_ERROR;
       else {
-        const Sum3 s3 = reduce_partials3(blk, nwg);
+        const Sum3 s3 = part_finish<false>(L, blk, nwg);   // (the fixed order of every reduction of these partials)
         const float eest = rms_from(s3.a, a.n_norm);
         sde_ctl_update(c2, eest, dt, a, blockIdx.x == 0 && lane == 0);
       }
