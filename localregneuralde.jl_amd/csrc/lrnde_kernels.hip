@@ -3327,7 +3327,10 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
   // per step) when every workgroup fits on the chip at once; LRNDE_SDE_NO_PERSIST=1, a launch the runtime refuses or more than
   // 256 workgroups: the launch-per-step loop below.  Same arithmetic, same controller: same bits.
   bool persisted = false;
-  if (!opt(OPT_SDE_NO_PERSIST) && nwg <= 256) {
+  // (under rocprofv3 a process that made a cooperative launch dies in the tool's exit handler after the trace is written —
+  //  observed with ROCm 7.2; the profiler preloads its tool library, and profiled runs take the launch-per-step loop)
+  static const bool profiled = [] { const char* p = getenv("LD_PRELOAD"); return p && strstr(p, "rocprofiler") != nullptr; }();
+  if (!opt(OPT_SDE_NO_PERSIST) && !profiled && nwg <= 256) {
     f.part2 = c->part;
     HIPCHK(c, hipMemsetAsync(c->part, 0, sizeof(double) * 2 * (size_t)nwg * PSTRIDE, c->stream));   // (tags of an earlier solve)
     f.jlaunch = 0;
