@@ -265,3 +265,24 @@ def test_time_series_layer_with_an_adams_solver(gpu_pkg):
     rp = np.linalg.norm(dp.cpu().numpy() - pt.grad.numpy()) / np.linalg.norm(pt.grad.numpy())
     print("time series, vcab3: dx %.2e dp %.2e" % (rx, rp))
     assert rx < 2e-4 and rp < 2e-4
+
+
+def test_solver_code_is_validated_and_the_conv_field_keeps_tsit5(gpu_pkg):
+    """lrnde_set_solver rejects anything but 0 / 1 / 2 (LRNDE_BADARG, the handle stays usable); the conv field's handle has no
+    Adams solve (csrc/lrnde_adams.hpp is built on the MLP handle's vector helpers): the layer object says so when it is made."""
+    import ctypes as C
+    import torch
+    from localregneuralde_jl_amd import _lib as L
+    from localregneuralde_jl_amd.layers import Handle, _mlp_desc
+    P = gpu_pkg
+    model = P.TDChain(P.Chain(P.Dense(5, 8, "tanh"), P.Dense(9, 4)))
+    h = Handle(_mlp_desc(model))
+    assert L.lib.lrnde_set_solver(h._ctx, 3) == 4 and L.lib.lrnde_set_solver(h._ctx, -1) == 4
+    h.set_solver("vcab3"); h.set_solver("Tsit5()")
+    h.set_params(torch.from_numpy(P.glorot_params(model, seed=1)))
+    assert h.rhs(torch.rand(3, 4, device="cuda"), 0.2).shape == (3, 4)
+    conv = P.TDChain(P.Chain(P.Chain(P.Conv((3, 3), 9, 64), P.BatchNorm(64, "gelu")), P.Chain(P.Conv((3, 3), 65, 64), P.BatchNorm(64, "gelu")),
+                             P.Conv((3, 3), 65, 8)))
+    P.NeuralODE(conv, solver="Tsit5")
+    with pytest.raises(NotImplementedError):
+        P.NeuralODE(conv, solver="vcab3")
