@@ -248,3 +248,31 @@ def test_one_launch_reverse_sweep_agrees_with_the_generic_path(oracle, gpu_pkg, 
         e = _rel(outs[0][k], outs[1][k])
         print(f"D={D} H={H} B={B} {mode}: fused vs generic {k} {e:.2e}")
         assert e < 2e-6, (k, e)
+
+
+def test_diffusion_without_a_bias_through_both_reverse_sweeps(gpu_pkg):
+    """Dense(D => D, use_bias=false) as the diffusion: the parameter vector is vec(Wg) alone; the one-launch sweep and the generic
+    one agree and leave D*D cotangents"""
+    from localregneuralde_jl_amd.layers import _mlp_desc
+    D, H, B, nfine = 12, 20, 9, 32
+    rng = np.random.default_rng(3)
+    pd = (rng.standard_normal(D * H + H + H * D + D) * 0.3).astype(f32)
+    pg = (rng.standard_normal(D * D) * 0.1).astype(f32)
+    h = gpu_pkg.SdeHandle(_mlp_desc(gpu_pkg.Chain(gpu_pkg.Dense(D, H, "tanh"), gpu_pkg.Dense(H, D))), diffusion_bias=False)
+    h.set_params(pd, pg)
+    x = torch.from_numpy(rng.standard_normal((B, D)).astype(f32)).cuda()
+    W = torch.from_numpy(_path(rng, nfine, B, D)).cuda()
+    z = torch.from_numpy(rng.standard_normal((B, D)).astype(f32)).cuda()
+    outs = []
+    for flag in (0, 1):
+        gpu_pkg.set_option("LRNDE_NO_SDE_BWD_FUSED", flag)
+        try:
+            fw = h.node_forward_record(x, W, 0.0, 1.0, 0.05, 0.05, z_local=z, mode="unbiased", t1_or_rand=0.4, saveat=(), save_start=-1)
+            du = torch.from_numpy(np.random.default_rng(5).standard_normal((fw["u"].shape[0], B, D)).astype(f32)).cuda()
+            bw = h.node_backward_recorded(du, w_reg=1.5)
+        finally:
+            gpu_pkg.set_option("LRNDE_NO_SDE_BWD_FUSED", 0)
+        outs.append({k: bw[k].cpu().numpy() for k in ("dx", "dp_drift", "dp_diff")})
+    assert outs[0]["dp_diff"].shape == (D * D,)
+    for k in ("dx", "dp_drift", "dp_diff"):
+        assert np.isfinite(outs[0][k]).all() and _rel(outs[0][k], outs[1][k]) < 2e-6, (k, _rel(outs[0][k], outs[1][k]))
