@@ -221,4 +221,32 @@ comm_unique_id() = (id = zeros(UInt8, 128); ccall((:lrnde_comm_unique_id, lib), 
 comm_init!(ctx, id::Vector{UInt8}, rank, nranks) = check(ctx, ccall((:lrnde_comm_init, lib), Cint,
     (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), ctx, id, rank, nranks))
 
+# the same for the Milstein step (solver = RKMilCommute(), src/perform_step.jl:108-170): pullback of the fixed-grid solve and
+# d(EEst*dt)/dp of one local step
+function sde_solve_fixed_backward_rkmil(h, u0, utraj, dW, t0, dt, nsteps, du_end, npd, npg)
+    dx = similar(u0); dpd = similar(u0, npd); dpg = similar(u0, npg)
+    sde_check(h, ccall((:lrnde_sde_solve_fixed_backward_rkmil, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int32, Float32, Float32, Int32, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+        h, pointer(u0), pointer(utraj), pointer(dW), nbatch(u0), t0, dt, Int32(nsteps), pointer(du_end), pointer(dx), pointer(dpd), pointer(dpg)))
+    return dx, dpd, dpg
+end
+function sde_rkmil_reg_grad(h, uprev, dW, t, dt, abstol, reltol, npd, npg)
+    dpd = similar(uprev, npd); dpg = similar(uprev, npg); rv = Ref{Float32}()
+    sde_check(h, ccall((:lrnde_sde_rkmil_reg_grad, lib), Cint,
+        (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int32, Float32, Float32, Float32, Float32, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+        h, pointer(uprev), pointer(dW), nbatch(uprev), t, dt, abstol, reltol, pointer(dpd), pointer(dpg), rv))
+    return dpd, dpg, rv[]
+end
+# reverse sweep of ONE four-stage SRI step (src/perform_step.jl:49-106; SOSRI's coefficients are the caller's, as for sde_sri_step):
+# loss = <du_new, u'> + w_reg * EEst*dt; dp_drift / dp_diff are ADDED to (zero them first)
+function sde_sri_step_backward!(h, tab::SriTableau, uprev, dW, dZ, t, dt, abstol, reltol, delta, du_new, w_reg, dpd, dpg)
+    dx = similar(uprev); rv = Ref{Float32}()
+    sde_check(h, ccall((:lrnde_sde_sri_step_backward, lib), Cint,
+        (Ptr{Cvoid}, Ref{SriTableau}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Int32, Float32, Float32, Float32, Float32, Float32,
+         Ptr{Float32}, Float32, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
+        h, tab, pointer(uprev), pointer(dW), pointer(dZ), nbatch(uprev), t, dt, abstol, reltol, delta,
+        pointer(du_new), w_reg, pointer(dx), pointer(dpd), pointer(dpg), rv))
+    return dx, rv[]
+end
+
 end # module
