@@ -341,6 +341,8 @@ def main():
         # reference's tolerance 1e-4 the bf16 field's rounding noise drives the controller (NFE counts below)
         out["config"]["cifar_conv_bf16_b256"] = conv_measure(args, "cifar_conv_bf16", brief=True)
         out["config"]["cifar_conv_f32_b256"] = conv_measure(args, "cifar_conv_f32", brief=True)
+        # BASELINE.json configs[4] (MNIST-SDE, B=512): the NeuralDSDE layer's forward and pullback; `--workload mnist_sde` gives its line
+        out["config"]["mnist_sde_layer_b512"] = sde_layer_side_measurement(512)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the GPU box gives one GPU's share of the host: 16 cores (os.cpu_count() reports the whole host)
         cores = int(os.environ.get("LRNDE_CPU_CORES", min(len(os.sched_getaffinity(0)), 16)))
@@ -497,6 +499,48 @@ def conv_measure(args, workload, brief=False):
     return out
 
 
+def sde_layer_leg(h, ud, rng, B, D):
+    """The NeuralDSDE LAYER as the reference runs it (src/layers/neural_sde.jl:50-123): adaptive solve on a Brownian path drawn up
+    front, local step at (sol(t1), t1), and the pullback through the recorded accepted steps - BASELINE config 5's fwd + adjoint."""
+    nfine = 256
+    hh = np.float32(1.0 / nfine)
+    Wp = np.concatenate([np.zeros((1, B, D), np.float32),
+                         np.cumsum((rng.standard_normal((nfine, B, D)) * np.sqrt(hh)).astype(np.float32), axis=0, dtype=np.float32)], axis=0)
+    Wd, zd = torch.from_numpy(Wp).cuda(), torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)).cuda()
+    du1 = torch.from_numpy(rng.standard_normal((1, B, D)).astype(np.float32)).cuda()
+    tf, tb, att = [], [], 0
+    for i in range(14):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        fw = h.node_forward_record(ud, Wd, 0.0, 1.0, 0.14, 0.14, z_local=zd, mode="unbiased", t1_or_rand=0.3 + 0.03 * i, saveat=(), save_start=-1)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        h.node_backward_recorded(du1.expand(fw["u"].shape[0], B, D).contiguous(), w_reg=2.0)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        if i >= 2:
+            tf.append((t1 - t0) * 1e3); tb.append((t2 - t1) * 1e3)
+        att = fw["stats"]["naccept"] + fw["stats"]["nreject"]
+    return {"what": "NeuralDSDE layer (state 32, hidden 64, abstol = reltol = 0.14), :unbiased, adaptive Euler-Heun on a 256-interval Brownian "
+                    "path (lrnde_sde_node_forward_record: one cooperative launch for the whole solve) and the pullback through the recorded steps "
+                    "incl. the regulariser's local step (lrnde_sde_node_backward_recorded: one launch for the whole sweep); medians of 12",
+            "attempted_steps": att, "fwd_ms": float(np.median(tf)), "pullback_ms": float(np.median(tb)),
+            "fwd_plus_adjoint_ms_per_batch": float(np.median(np.array(tf) + np.array(tb)))}
+
+
+def sde_layer_side_measurement(B):
+    """the same leg for the default bench line (BASELINE config 5 next to the headline, like the conv configs)"""
+    import lrnde_amd as P
+    from localregneuralde_jl_amd.layers import _mlp_desc
+    D, H = 32, 64
+    rng = np.random.default_rng(0)
+    lim1, lim2 = np.sqrt(6.0 / (D + H)), np.sqrt(6.0 / (H + D))
+    pd = np.concatenate([(rng.random(H * D, dtype=np.float32) * 2 - 1) * np.float32(lim1), np.zeros(H, np.float32),
+                         (rng.random(D * H, dtype=np.float32) * 2 - 1) * np.float32(lim2), np.zeros(D, np.float32)]).astype(np.float32)
+    pg = np.concatenate([(rng.random(D * D, dtype=np.float32) * 2 - 1) * np.float32(np.sqrt(6.0 / (2 * D))), np.zeros(D, np.float32)]).astype(np.float32)
+    h = P.SdeHandle(_mlp_desc(P.Chain(P.Dense(D, H, "tanh"), P.Dense(H, D))))
+    h.set_params(pd, pg)
+    ud = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)).cuda()
+    return sde_layer_leg(h, ud, rng, B, D)
+
+
 # ---- MNIST-SDE (BASELINE.json config 5): Euler-Heun steps with the local-regularisation residual, B=512 ----
 def sde_main(args):
     """state 32, drift Dense(32=>64,tanh)->Dense(64=>32), diagonal diffusion Dense(32=>32), dW supplied.
@@ -548,29 +592,7 @@ def sde_main(args):
                      "kernel": "k_sde_eh_fast: ONE launch per step (weights resident in registers, the step's footer by the last workgroup to arrive); 15.7 MFLOP: latency bound by construction",
                      "us_per_launch": el / nst * 1e6, "flop_per_launch": flop},
     }
-    # the NeuralDSDE LAYER as the reference runs it (src/layers/neural_sde.jl:50-123): adaptive solve on a Brownian path drawn
-    # up front, local step at (sol(t1), t1), and the pullback through the recorded accepted steps - config 5's fwd + adjoint
-    nfine = 256
-    hh = np.float32(1.0 / nfine)
-    Wp = np.concatenate([np.zeros((1, B, D), np.float32),
-                         np.cumsum((rng.standard_normal((nfine, B, D)) * np.sqrt(hh)).astype(np.float32), axis=0, dtype=np.float32)], axis=0)
-    Wd, zd = torch.from_numpy(Wp).cuda(), torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)).cuda()
-    du1 = torch.from_numpy(rng.standard_normal((1, B, D)).astype(np.float32)).cuda()
-    tf, tb, att = [], [], 0
-    for i in range(14):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        fw = h.node_forward_record(ud, Wd, 0.0, 1.0, 0.14, 0.14, z_local=zd, mode="unbiased", t1_or_rand=0.3 + 0.03 * i, saveat=(), save_start=-1)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        bw = h.node_backward_recorded(du1.expand(fw["u"].shape[0], B, D).contiguous(), w_reg=2.0)
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        if i >= 2:
-            tf.append((t1 - t0) * 1e3); tb.append((t2 - t1) * 1e3)
-        att = fw["stats"]["naccept"] + fw["stats"]["nreject"]
-    out["config"]["layer"] = {
-        "what": "NeuralDSDE layer, :unbiased, adaptive Euler-Heun on a 256-interval Brownian path (lrnde_sde_node_forward_record) and "
-                "the pullback through the recorded steps incl. the regulariser's local step (lrnde_sde_node_backward_recorded); medians of 12",
-        "attempted_steps": att, "fwd_ms": float(np.median(tf)), "pullback_ms": float(np.median(tb)),
-        "fwd_plus_adjoint_ms_per_batch": float(np.median(np.array(tf) + np.array(tb)))}
+    out["config"]["layer"] = sde_layer_leg(h, ud, rng, B, D)
     if not args.no_cpu_baseline:
         import oracle as O
         cores = int(os.environ.get("LRNDE_CPU_CORES", min(len(os.sched_getaffinity(0)), 16)))
