@@ -1884,13 +1884,13 @@ namespace {
 // path in the same process as the default one and holds the two to the same bits.
 enum {
   OPT_NO_QTILE, OPT_QTILE_MAX_B, OPT_NO_FUSE, OPT_DENSE_COPY, OPT_NO_OVERLAP, OPT_NO_SDE_FAST, OPT_SDE_HOST_LOOP, OPT_NO_QVJP,
-  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_OVERLAP, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_PGRAD_TS, OPT_ADJ_NO_REUSE, OPT_NO_SDE_BWD_FUSED, OPT_SDE_NO_PERSIST, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
+  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_OVERLAP, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_PGRAD_TS, OPT_ADJ_NO_REUSE, OPT_NO_SDE_BWD_FUSED, OPT_SDE_NO_PERSIST, OPT_SDE_HOST_INITDT, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
 };
 struct OptDef { const char* name; int dflt; bool flag; };   // flag: present in the environment = 1
 const OptDef g_optdef[N_OPT] = {
     {"LRNDE_NO_QTILE", 0, true}, {"LRNDE_QTILE_MAX_B", 2048, false}, {"LRNDE_NO_FUSE", 0, true}, {"LRNDE_DENSE_COPY", 0, true},
     {"LRNDE_NO_OVERLAP", 0, true}, {"LRNDE_NO_SDE_FAST", 0, true}, {"LRNDE_SDE_HOST_LOOP", 0, true}, {"LRNDE_NO_QVJP", 0, true},
-    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_OVERLAP", 0, false}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_PGRAD_TS", 0, false}, {"LRNDE_ADJ_NO_REUSE", 0, true}, {"LRNDE_NO_SDE_BWD_FUSED", 0, true}, {"LRNDE_SDE_NO_PERSIST", 0, true}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
+    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_OVERLAP", 0, false}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_PGRAD_TS", 0, false}, {"LRNDE_ADJ_NO_REUSE", 0, true}, {"LRNDE_NO_SDE_BWD_FUSED", 0, true}, {"LRNDE_SDE_NO_PERSIST", 0, true}, {"LRNDE_SDE_HOST_INITDT", 0, true}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
     {"LRNDE_FEED_M", 2, false}, {"LRNDE_GATHER_TILES", 0, true}, {"LRNDE_FORCE_COMM", 0, true}};
 int g_opt[N_OPT];
 bool g_opt_set[N_OPT];     // set by the hook: the environment no longer counts
@@ -3057,6 +3057,9 @@ namespace { struct SdeNodeRecord; }   // the layer's forward record (lrnde_sde_n
 struct lrnde_sde {
   SdeNodeRecord* node = nullptr;
   double *idt_part = nullptr, *idt_part_host = nullptr;   // sde_init_dt's norm partials (device / pinned)
+  double* idt_pp = nullptr; int idt_pp_nwg = 0;           // sde_init_dt_dev's per-workgroup partial sums (two phases)
+  float *idt_scal = nullptr, *idt_scal_host = nullptr;    // sde_init_dt_dev's results: {dt0, d1, dt} of the solve, then of the local step
+  int2* rec_im_pin = nullptr; int rec_im_pin_cap = 0;     // pinned landing buffer of the record's (start, length) pairs
   lrnde_ctx* drift = nullptr;
   lrnde_ctx* diff = nullptr;
   float* p2 = nullptr;  // expanded diffusion parameters
@@ -3096,6 +3099,10 @@ int lrnde_sde_destroy(lrnde_sde* s) {
   sde_node_release(s);
   if (s->idt_part) hipFree(s->idt_part);
   if (s->idt_part_host) hipHostFree(s->idt_part_host);
+  if (s->idt_pp) hipFree(s->idt_pp);
+  if (s->idt_scal) hipFree(s->idt_scal);
+  if (s->idt_scal_host) hipHostFree(s->idt_scal_host);
+  if (s->rec_im_pin) hipHostFree(s->rec_im_pin);
   lrnde_destroy(s->drift);
   lrnde_destroy(s->diff);
   if (s->p2) hipFree(s->p2);
@@ -3161,7 +3168,8 @@ int lrnde_sde_rkmil_step(lrnde_sde* s, const float* uprev, const float* dW, int3
 // one step on the stream; its record goes to `rec` (pinned host: integrator-state footer k_finalize + async copy) or to
 // the device slot `rec_dev` (k_sde_record: two launches per step, no copy)
 static int sde_step_enqueue(lrnde_sde* s, int which, const float* uprev, const float* dW, int32_t B, float t, float dt,
-                            float abstol, float reltol, float delta, float* u, Ctrl* rec, Ctrl* rec_dev = nullptr) {
+                            float abstol, float reltol, float delta, float* u, Ctrl* rec, Ctrl* rec_dev = nullptr,
+                            const float* dt_dev = nullptr) {
   lrnde_ctx* c = s->drift;
   int rc;
   StepArgs a{};
@@ -3184,7 +3192,8 @@ static int sde_step_enqueue(lrnde_sde* s, int which, const float* uprev, const f
       HIPCHK(c, hipGetLastError());
       return LRNDE_OK;
     }
-    hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t, dt, 0, 0);
+    if (dt_dev) f.dt_dev = dt_dev;  // (the layer's local step with a device-computed dt: k_sde_initdt_fin has initialised c->ctrl)
+    else hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t, dt, 0, 0);
     sde_fast_launch(f.D, c->desc.hidden_dim, nwg, c->stream, f);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, a, 1);
     HIPCHK(c, hipGetLastError());
@@ -3278,22 +3287,34 @@ __global__ void k_sde_ctl_init(SdeCtl* ctl, int m0, float dtc0) {
   *ctl = c;
 }
 
+// the end state of a device-controlled solve (the control block says which of the two buffers holds it) -> out
+__global__ void k_sde_pick_end(size_t n, const SdeCtl* ctl, const float* ua, const float* ub, float* out) {
+  const float* src = ctl->cur ? ub : ua;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = src[i];
+}
+
 // lrnde_sde_solve_adaptive on the one-launch kernel's shape: the controller runs in the step kernel's footer (SdeCtl,
 // lrnde_sde_fast.hpp), the host only keeps launches enqueued and watches a pinned progress word — one launch per attempted
 // step, no synchronisation inside the solve (the host-controlled loop below paid one per step: ~45 us for a 10-us step).
 // rec_u / rec_im / rec_cap: the layer's dense record of the accepted steps (device; NULL / 0 for a plain solve)
-static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
-                               const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
-                               int32_t cap_trace, float* ua, float* ub, float* rec_u = nullptr, int2* rec_im = nullptr,
-                               int rec_cap = 0) {
+static int sde_adaptive_prepare(lrnde_sde* s) {   // the device-controlled loop's control block and progress word
   lrnde_ctx* c = s->drift;
-  const size_t n = (size_t)B * c->desc.state_dim;
   if (!s->ad_ctl) {
     HIPCHK(c, hipMalloc(&s->ad_ctl, sizeof(SdeCtl)));
     HIPCHK(c, hipHostMalloc(&s->ad_ctl_host, sizeof(SdeCtl)));
     HIPCHK(c, hipHostMalloc(&s->ad_prog, 64, hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void**)&s->ad_prog_dev, s->ad_prog, 0));
   }
+  return LRNDE_OK;
+}
+static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
+                               const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
+                               int32_t cap_trace, float* ua, float* ub, float* rec_u = nullptr, int2* rec_im = nullptr,
+                               int rec_cap = 0, int2* rec_im_host = nullptr, const float* dt0_dev = nullptr) {
+  lrnde_ctx* c = s->drift;
+  const size_t n = (size_t)B * c->desc.state_dim;
+  int rc0 = sde_adaptive_prepare(s);
+  if (rc0) return rc0;
   if (trace_host && cap_trace > s->ad_trace_cap) {
     if (s->ad_trace) HIPCHK(c, hipFree(s->ad_trace));
     s->ad_trace = nullptr; s->ad_trace_cap = 0;
@@ -3306,7 +3327,8 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
   if (m0 > nfine) m0 = nfine;
   if (1 > o->maxiters) { st->iters = 1; st->retcode = LRNDE_MAXITERS; return fail(c, LRNDE_MAXITERS, "adaptive SDE solve stopped with retcode %d at t=%g", LRNDE_MAXITERS, (double)t0); }
   HIPCHK(c, hipMemcpyAsync(ua, u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(k_sde_ctl_init, dim3(1), dim3(1), 0, c->stream, s->ad_ctl, m0, o->dt0);
+  if (!dt0_dev)   // (dt0_dev: sde_init_dt_dev's closing launch has initialised the control block from its dt)
+    hipLaunchKernelGGL(k_sde_ctl_init, dim3(1), dim3(1), 0, c->stream, s->ad_ctl, m0, o->dt0);
   volatile unsigned long long* pw = s->ad_prog;
   *pw = 0ull;
   StepArgs a{};
@@ -3363,9 +3385,27 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
       }
     }
   }
+  // one synchronisation ends the solve: the control block, the end state (picked on the device) and the record's
+  // (start, length) pairs are all enqueued before it
   HIPCHK(c, hipMemcpyAsync(s->ad_ctl_host, s->ad_ctl, sizeof(SdeCtl), hipMemcpyDeviceToHost, c->stream));
+  {
+    int nb = (int)((n + 255) / 256); if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_sde_pick_end, dim3(nb), dim3(256), 0, c->stream, n, (const SdeCtl*)s->ad_ctl, (const float*)ua, (const float*)ub, u_end);
+    HIPCHK(c, hipGetLastError());
+  }
+  if (rec_im_host && rec_im && rec_cap > 0) {
+    if (s->rec_im_pin_cap < rec_cap) {
+      if (s->rec_im_pin) HIPCHK(c, hipHostFree(s->rec_im_pin));
+      s->rec_im_pin = nullptr; s->rec_im_pin_cap = 0;
+      HIPCHK(c, hipHostMalloc(&s->rec_im_pin, sizeof(int2) * (size_t)rec_cap));
+      s->rec_im_pin_cap = rec_cap;
+    }
+    HIPCHK(c, hipMemcpyAsync(s->rec_im_pin, rec_im, sizeof(int2) * (size_t)rec_cap, hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const SdeCtl fin = *s->ad_ctl_host;
+  if (rec_im_host && rec_im && rec_cap > 0 && fin.naccept > 0)
+    memcpy(rec_im_host, s->rec_im_pin, sizeof(int2) * (size_t)(fin.naccept < rec_cap ? fin.naccept : rec_cap));
   st->naccept = fin.naccept; st->nreject = fin.nreject; st->iters = fin.iters; st->nf = fin.nf; st->eest_last = fin.eest_last;
   st->t_final = t0 + (float)fin.i * h; st->dt_final = (float)fin.m * h;
   st->retcode = (fin.status == ST_DONE) ? LRNDE_OK : (fin.status == ST_RUNNING ? LRNDE_MAXITERS : fin.status);
@@ -3374,8 +3414,6 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
     if (nt > cap_trace) nt = cap_trace;
     if (nt > 0) HIPCHK(c, hipMemcpy(trace_host, s->ad_trace, sizeof(lrnde_trace_row) * nt, hipMemcpyDeviceToHost));
   }
-  HIPCHK(c, hipMemcpyAsync(u_end, fin.cur ? ub : ua, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   if (st->retcode != LRNDE_OK) return fail(c, st->retcode, "adaptive SDE solve stopped with retcode %d at t=%g", st->retcode, (double)st->t_final);
   return LRNDE_OK;
 }
@@ -3384,7 +3422,8 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
 // end state, (start index, length) on the path's grid — for the layer's recorded forward; all NULL for a plain solve
 static int sde_solve_adaptive_impl(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
                                    const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
-                                   int32_t cap_trace, float* rec_u, int2* rec_im_dev, int2* rec_im_host, int rec_cap);
+                                   int32_t cap_trace, float* rec_u, int2* rec_im_dev, int2* rec_im_host, int rec_cap,
+                                   const float* dt0_dev = nullptr);
 int lrnde_sde_solve_adaptive(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
                              const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
                              int32_t cap_trace) {
@@ -3392,7 +3431,8 @@ int lrnde_sde_solve_adaptive(lrnde_sde* s, const float* u0, const float* W, int3
 }
 static int sde_solve_adaptive_impl(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
                                    const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
-                                   int32_t cap_trace, float* rec_u, int2* rec_im_dev, int2* rec_im_host, int rec_cap) {
+                                   int32_t cap_trace, float* rec_u, int2* rec_im_dev, int2* rec_im_host, int rec_cap,
+                                   const float* dt0_dev) {
   int rc = sde_check(s, u0, W, u_end, B, 1.0f);
   if (rc) return rc;
   lrnde_ctx* c = s->drift;
@@ -3409,10 +3449,8 @@ static int sde_solve_adaptive_impl(lrnde_sde* s, const float* u0, const float* W
   {
     const bool host_loop = opt(OPT_SDE_HOST_LOOP) != 0;  // diagnostic: the host-controlled loop below
     if (sde_uses_fast(s) && !host_loop) {
-      rc = sde_adaptive_device(s, u0, W, nfine, B, t0, t1, o, u_end, st, trace_host, cap_trace, ua, ub, rec_u, rec_im_dev, rec_cap);
-      if (!rc && rec_im_host && st->naccept > 0)
-        HIPCHK(c, hipMemcpy(rec_im_host, rec_im_dev, sizeof(int2) * (size_t)(st->naccept < rec_cap ? st->naccept : rec_cap), hipMemcpyDeviceToHost));
-      return rc;
+      return sde_adaptive_device(s, u0, W, nfine, B, t0, t1, o, u_end, st, trace_host, cap_trace, ua, ub, rec_u, rec_im_dev, rec_cap,
+                                 rec_im_host, dt0_dev);
     }
   }
   HIPCHK(c, hipMemcpyAsync(ua, u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));

@@ -37,6 +37,10 @@ struct SdeFastArgs {
   const float* u; const float* dW; float* un;   // (B, D)
   int B;
   float dt, abstol, reltol, delta;
+  const float* dt_dev;   // non-NULL: the single step's dt is read from here (a dt an earlier launch on the stream computed)
+  // sde_determine_initdt on this kernel's tiles (idt_phase 1 / 2, lrnde_sde_node.hpp: sde_init_dt_dev): per-workgroup fp64
+  // sums of the norms into idt_part (phase 1: d0, d1) / idt_part2 (phase 2: d2); phase 2 leaves {dt0, d1} in idt_scal
+  int idt_phase; double* idt_part; double* idt_part2; float* idt_scal; float idt_dtmax;
   double* part;      // per-workgroup fp64 sums of the squared residual (PSTRIDE doubles each)
   int* arrive;       // fixed-grid solve: arrival counter of the step's footer, or NULL
   Ctrl* rec;         //   ... and the record slot the last workgroup fills (EEst, EEst*dt)
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
     a.dt = (float)ad_m * a.h;
     a.u = cc.cur ? a.ub : a.ua;
     a.un = cc.cur ? a.ua : a.ub;
-  }
+  } else if (a.dt_dev) a.dt = *a.dt_dev;
   __shared__ SdeCtl sh_cc;
   // LDS: three x tiles in B-operand layout (16 DT rows x 16 columns each: [kg][64 lanes] float4), the h tile, the
   // diffusion results in C-fragment order, the reduction scratch
@@ -245,6 +249,87 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
     return acc;
   };
 
+  if constexpr (!PERSIST) {
+    if (a.idt_phase) {
+      // StochasticDiffEq.sde_determine_initdt's evaluations and norms (UPSTREAM-RECALL; the expressions of k_sde_initdt):
+      // phase 1: f0 = f(u), g0 = g(u) -> sums of (u / sk)^2 and (max(|f0 + 3 g0|, |f0 - 3 g0|) / sk)^2;
+      // phase 2: dt0 from phase 1's sums (every workgroup adds them in the same fixed order), u1 = u + dt0 f0, f1, g1 ->
+      //          sum of (max(|df + dg|, |df - dg|) / sk)^2.  The launch ends here.
+      __shared__ double red2[4];
+      __shared__ float sh_dt0;
+      dense1(xA);
+      diffusion(xA);
+      __syncthreads();
+      f32x4 f0 = zero4, g0 = zero4;
+      if (has_d2) { f0 = dense2(); g0 = gl[t * 64 + lane]; }
+      double a0 = 0.0, a1 = 0.0;
+      if (a.idt_phase == 1) {
+        if (live) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (row0 + r >= D) continue;
+            const float sk = a.abstol + __builtin_fabsf(u4[r]) * a.reltol;
+            const float G0 = 3.0f * g0[r];
+            const float r0 = u4[r] / sk;
+            const float r1 = fmaxf_(__builtin_fabsf(f0[r] + G0), __builtin_fabsf(f0[r] - G0)) / sk;
+            a0 += (double)(r0 * r0); a1 += (double)(r1 * r1);
+          }
+        }
+      } else {
+        if (threadIdx.x < 64) {
+          const Sum3 s = reduce_partials3(a.idt_part, (int)gridDim.x);
+          if (lane == 0) {
+            const float d0 = (float)sqrt(s.a / a.n_norm), d1 = (float)sqrt(s.b / a.n_norm);
+            float dt0 = ((double)d0 < 1e-5 || (double)d1 < 1e-5) ? 1e-6f : (d0 / d1) / 100.0f;
+            dt0 = fminf_(dt0, a.idt_dtmax);
+            sh_dt0 = dt0;
+            if (blockIdx.x == 0) { a.idt_scal[0] = dt0; a.idt_scal[1] = d1; }
+          }
+        }
+        __syncthreads();
+        const float dt0 = sh_dt0;
+        if (has_d2) {
+          f32x4 u1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u1[r] = u4[r] + dt0 * f0[r];
+          put(xB, u1);
+        }
+        __syncthreads();
+        dense1(xB);
+        diffusion(xB);
+        __syncthreads();
+        if (has_d2) {
+          const f32x4 f1 = dense2();
+          const f32x4 g1 = gl[t * 64 + lane];
+          if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (row0 + r >= D) continue;
+              const float sk = a.abstol + __builtin_fabsf(u4[r]) * a.reltol;
+              const float G0 = 3.0f * g0[r], G1 = 3.0f * g1[r];
+              const float dg = fmaxf_(__builtin_fabsf(G0 - G1), __builtin_fabsf(G0 + G1));
+              const float df = f1[r] - f0[r];
+              const float r2 = fmaxf_(__builtin_fabsf(df + dg), __builtin_fabsf(df - dg)) / sk;
+              a0 += (double)(r2 * r2);
+            }
+          }
+        }
+      }
+      if (has_d2) {
+        a0 = wave_sum_dpp(a0); a1 = wave_sum_dpp(a1);
+        if (lane == 0) { red[wave] = a0; red2[wave] = a1; }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double t0s = red[0], t1s = red2[0];
+#pragma unroll
+        for (int w = 1; w < DT; ++w) { t0s += red[w]; t1s += red2[w]; }
+        double* pp = (a.idt_phase == 1 ? a.idt_part : a.idt_part2) + (size_t)blockIdx.x * PSTRIDE;
+        pp[0] = t0s; pp[1] = t1s; pp[2] = 0.0;
+      }
+      return;
+    }
+  }
   // ---- round 1: du1 = f(u), L = g(u) (:174-176) ----
   dense1(xA);
   diffusion(xA);

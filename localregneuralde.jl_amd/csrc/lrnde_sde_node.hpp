@@ -122,6 +122,77 @@ int sde_init_dt(lrnde_sde* s, const float* u, int B, float t, float tend, float 
   return LRNDE_OK;
 }
 
+// sde_init_dt without the two host synchronisations and in three launches instead of nine, for the one-launch step's shape
+// (no time input: the evaluations at t + dt0 do not need dt0 on the host).  The four evaluations and the three norms run on
+// k_sde_eh_fast's tiles (its idt_phase 1 / 2: lrnde_sde_fast.hpp), the scalar tail in k_sde_initdt_fin — the expressions of
+// the host code above, fp64 sums in the partial-vector order every reduction here uses — and the result stays on the
+// device: scal[0] = dt0, scal[1] = d1, scal[2] = the initial dt.  The tail also starts what consumes the dt: the adaptive
+// solve's control block (ctl) or the single step's (ctrl).
+__global__ void k_sde_initdt_fin(const double* part2, int nwg, double n, float dtmax, float order, float* scal, SdeCtl* ctl, float h,
+                                 int nfine, Ctrl* ctrl, float t0) {
+  if (threadIdx.x >= 64 || blockIdx.x != 0) return;
+  const Sum3 s = reduce_partials3(part2, nwg);
+  if (threadIdx.x != 0) return;
+  const float dt0 = scal[0], d1 = scal[1];
+  const float d2 = (float)sqrt(s.a / n) / dt0;
+  const float maxd = fmaxf_(d1, d2);
+  float dt1;
+  if ((double)maxd <= 1e-15) dt1 = fmaxf_(1e-6f, dt0 * 1e-3f);
+  else {
+    const float l10 = (float)log10((double)maxd);
+    const float e = (-(2.0f + l10)) / (order + 0.5f);
+    dt1 = (float)pow(10.0, (double)e);
+  }
+  const float dt = fminf_(fminf_(100.0f * dt0, dt1), dtmax);
+  scal[2] = dt;
+  if (ctl) {      // k_sde_ctl_init with the host's quantisation of dt to the path's grid
+    int m0 = (int)(dt / h); if (m0 < 1) m0 = 1;
+    if (m0 > nfine) m0 = nfine;
+    SdeCtl c;
+    c.status = ST_RUNNING; c.i = 0; c.m = m0; c.cur = 0; c.naccept = 0; c.nreject = 0; c.iters = 1; c.nf = 0;
+    c.qold = 1e-4f; c.eest_last = 0.f; c.dtc = dt;
+    *ctl = c;
+  }
+  if (ctrl) {     // k_ctrl_init
+    Ctrl c;
+    memset(&c, 0, sizeof(c));
+    c.status = ST_RUNNING; c.first = 1;
+    c.t = t0; c.dt = dt; c.qold = 1e-4f; c.q11 = 1.0f; c.dtpropose = dt;
+    ctrl[0] = c;
+    ctrl[1] = c;
+  }
+}
+// dW = sqrt(dt[0]) * z
+__global__ void k_sde_scale_dtdev(size_t n, const float* z, const float* dt, float* out) {
+  const float c = __builtin_sqrtf(dt[0]);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = c * z[i];
+}
+int sde_init_dt_dev(lrnde_sde* s, const float* u, int B, float t, float tend, float abstol, float reltol, float order, float* scal,
+                    SdeCtl* ctl, float h, int nfine, Ctrl* ctrl) {
+  lrnde_ctx* c = s->drift;
+  const int nwg = (B + NB - 1) / NB;
+  if (s->idt_pp_nwg < nwg) {
+    if (s->idt_pp) HIPCHK(c, hipFree(s->idt_pp));
+    s->idt_pp = nullptr; s->idt_pp_nwg = 0;
+    HIPCHK(c, hipMalloc(&s->idt_pp, sizeof(double) * 2 * (size_t)nwg * PSTRIDE));
+    s->idt_pp_nwg = nwg;
+  }
+  SdeFastArgs f{};
+  sde_fast_args(s, f);
+  f.u = u; f.B = B; f.abstol = abstol; f.reltol = reltol;
+  f.n_norm = (double)((size_t)B * c->desc.state_dim);
+  f.idt_part = s->idt_pp; f.idt_part2 = s->idt_pp + (size_t)nwg * PSTRIDE; f.idt_scal = scal; f.idt_dtmax = tend - t;
+  f.dW = u; f.un = nullptr; f.dt = 1.0f;   // (not used by these phases; dW is loaded before the phase branch)
+  f.idt_phase = 1;
+  sde_fast_launch(f.D, c->desc.hidden_dim, nwg, c->stream, f);
+  f.idt_phase = 2;
+  sde_fast_launch(f.D, c->desc.hidden_dim, nwg, c->stream, f);
+  hipLaunchKernelGGL(k_sde_initdt_fin, dim3(1), dim3(64), 0, c->stream, (const double*)f.idt_part2, nwg, f.n_norm, tend - t, order, scal, ctl, h,
+                     nfine, ctrl, t);
+  HIPCHK(c, hipGetLastError());
+  return LRNDE_OK;
+}
+
 int sde_node_alloc(lrnde_sde* s, SdeNodeRecord& r, int B, int nfine) {
   lrnde_ctx* c = s->drift;
   const size_t n = (size_t)B * c->desc.state_dim;
@@ -194,14 +265,27 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
   int nfe_f = 0, nfe_g = 0;
   HIPCHK(c, hipMemcpyAsync(r.x, x, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   // the main solve (src/layers/neural_sde.jl:50-72): dt0 <= 0 -> automatic initial dt
+  // (the one-launch step's shape keeps both automatic initial dts on the device: two host synchronisations per call — the
+  //  end of the solve and the end of this function — instead of nine; LRNDE_SDE_HOST_INITDT=1: the host form)
+  const bool devdt = sde_uses_fast(s) && !opt(OPT_SDE_HOST_LOOP) && !opt(OPT_SDE_HOST_INITDT);
+  if (devdt && !s->idt_scal) {
+    HIPCHK(c, hipMalloc(&s->idt_scal, sizeof(float) * 8));
+    HIPCHK(c, hipHostMalloc(&s->idt_scal_host, sizeof(float) * 8));
+  }
   lrnde_sde_adapt_opts oo = *o;
+  const float* dt0_dev = nullptr;
   if (!(oo.dt0 > 0.f)) {
-    if ((rc = sde_init_dt(s, r.x, B, t0, t2, oo.abstol, oo.reltol, 0.5f, r.tmp, &oo.dt0))) return rc;
+    if (devdt) {
+      if ((rc = sde_adaptive_prepare(s))) return rc;
+      if ((rc = sde_init_dt_dev(s, r.x, B, t0, t2, oo.abstol, oo.reltol, 0.5f, s->idt_scal, s->ad_ctl, h, nfine, nullptr))) return rc;
+      dt0_dev = s->idt_scal + 2;
+      oo.dt0 = t2 - t0;   // (placeholder for the argument checks; the control block is initialised from the device value)
+    } else if ((rc = sde_init_dt(s, r.x, B, t0, t2, oo.abstol, oo.reltol, 0.5f, r.tmp, &oo.dt0))) return rc;
     nfe_f += 2; nfe_g += 2;
   }
   r.im.assign((size_t)nfine, make_int2(0, 0));
   float* u_end = r.tmp;  // (scratch: the end state is also the record's last slot)
-  rc = sde_solve_adaptive_impl(s, r.x, W, nfine, B, t0, t2, &oo, u_end, st, nullptr, 0, r.rec_u, r.rec_im_dev, r.im.data(), r.rec_cap);
+  rc = sde_solve_adaptive_impl(s, r.x, W, nfine, B, t0, t2, &oo, u_end, st, nullptr, 0, r.rec_u, r.rec_im_dev, r.im.data(), r.rec_cap, dt0_dev);
   if (rc) return rc;
   const int K = st->naccept;
   nfe_f += 3 * (st->naccept + st->nreject); nfe_g += 3 * (st->naccept + st->nreject);
@@ -264,22 +348,35 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
   // step with a fresh increment sqrt(dt) z
   *reg_val_host = 0.f;
   r.t1 = t1; r.dt_loc = 0.f;
+  bool local_pending = false;   // the local step's record is still in flight (device-side initial dt)
   if (mode != LRNDE_MODE_NONE) {
     if (!(t1 < t2)) return fail(c, LRNDE_BADARG, "t1 must lie before the end of tspan");
     if ((rc = value_of(e1, r.u1))) return rc;
     float dtl = o->dt0;
-    if (!(dtl > 0.f)) {
-      if ((rc = sde_init_dt(s, r.u1, B, t1, t2, o->abstol, o->reltol, 0.5f, r.tmp, &dtl))) return rc;
+    if (!(dtl > 0.f) && devdt) {
+      // dt, sqrt(dt) z and the step itself from the device value (sde_init_dt_dev clamps to t2 - t1 as the line below does);
+      // EEst, EEst * dt and dt come back with this function's closing synchronisation
+      float* scal = s->idt_scal + 4;
+      if ((rc = sde_init_dt_dev(s, r.u1, B, t1, t2, o->abstol, o->reltol, 0.5f, scal, nullptr, 0.f, 0, c->ctrl))) return rc;
       nfe_f += 2; nfe_g += 2;
+      hipLaunchKernelGGL(k_sde_scale_dtdev, dim3(sde_nb(n)), dim3(256), 0, c->stream, n, z_local, (const float*)(scal + 2), r.dWloc);
+      if ((rc = sde_step_enqueue(s, 0, r.u1, r.dWloc, B, t1, t2 - t1, o->abstol, o->reltol, o->delta, r.tmp, c->ctrl_host, nullptr, scal + 2))) return rc;
+      HIPCHK(c, hipMemcpyAsync(s->idt_scal_host, s->idt_scal, sizeof(float) * 8, hipMemcpyDeviceToHost, c->stream));
+      local_pending = true;
+    } else {
+      if (!(dtl > 0.f)) {
+        if ((rc = sde_init_dt(s, r.u1, B, t1, t2, o->abstol, o->reltol, 0.5f, r.tmp, &dtl))) return rc;
+        nfe_f += 2; nfe_g += 2;
+      }
+      dtl = fminf(dtl, t2 - t1);
+      hipLaunchKernelGGL(k_sde_scale, dim3(sde_nb(n)), dim3(256), 0, c->stream, n, z_local, sqrtf(dtl), r.dWloc);
+      float ee = 0.f, rv = 0.f;
+      if ((rc = sde_step_impl(s, 0, r.u1, r.dWloc, B, t1, dtl, o->abstol, o->reltol, o->delta, r.tmp, &ee, &rv))) return rc;
+      *reg_val_host = rv;
+      r.ee_loc = ee;
+      r.dt_loc = dtl;
     }
-    dtl = fminf(dtl, t2 - t1);
-    hipLaunchKernelGGL(k_sde_scale, dim3(sde_nb(n)), dim3(256), 0, c->stream, n, z_local, sqrtf(dtl), r.dWloc);
-    float ee = 0.f, rv = 0.f;
-    if ((rc = sde_step_impl(s, 0, r.u1, r.dWloc, B, t1, dtl, o->abstol, o->reltol, o->delta, r.tmp, &ee, &rv))) return rc;
-    *reg_val_host = rv;
-    r.ee_loc = ee;
     nfe_f += 3; nfe_g += 3;
-    r.dt_loc = dtl;
   }
   // the caller's view: _CorrectedDESolution drops the entries at t1 (src/utils.jl:31-33: `sol.u[t1 .!= sol.t]`)
   r.series.clear();
@@ -292,6 +389,11 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
     t_series_host[i] = r.series[i].t;
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (local_pending) {
+    *reg_val_host = c->ctrl_host[0].reg_error;   // EEst * dt (src/perform_step.jl:205)
+    r.ee_loc = c->ctrl_host[0].eest_last;
+    r.dt_loc = s->idt_scal_host[6];
+  }
   if (nfe_drift_host) *nfe_drift_host = nfe_f;
   if (nfe_diffusion_host) *nfe_diffusion_host = nfe_g;
   if (t1_used_host) *t1_used_host = t1;

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"LRNDE_NO_QTILE": 0, "LRNDE_QTILE_MAX_B": 2048, "LRNDE_NO_FUSE": 0, "LRNDE_DENSE_COPY": 0, "LRNDE_NO_OVERLAP": 0,
             "LRNDE_NO_SDE_FAST": 0, "LRNDE_SDE_HOST_LOOP": 0, "LRNDE_NO_QVJP": 0, "LRNDE_ADJ_ERR_ONE_LAUNCH": 0, "LRNDE_ADJ_MU_FOLD": 0,
-            "LRNDE_ADJ_HOST": 0, "LRNDE_VJP_QCOLS": 4, "LRNDE_ADJ_OVERLAP": 0, "LRNDE_PGRAD_TS": 0, "LRNDE_ADJ_NO_REUSE": 0, "LRNDE_SDE_NO_PERSIST": 0, "LRNDE_NO_SDE_BWD_FUSED": 0,
+            "LRNDE_ADJ_HOST": 0, "LRNDE_VJP_QCOLS": 4, "LRNDE_ADJ_OVERLAP": 0, "LRNDE_PGRAD_TS": 0, "LRNDE_ADJ_NO_REUSE": 0, "LRNDE_SDE_NO_PERSIST": 0, "LRNDE_SDE_HOST_INITDT": 0, "LRNDE_NO_SDE_BWD_FUSED": 0,
             "LRNDE_FEED_T": 3, "LRNDE_FEED_E": 1, "LRNDE_FEED_M": 2}
 
 
@@ -108,6 +108,50 @@ def test_sde_switch_gives_the_default_bits(gpu_pkg, options, switch):
         options(k, v)
     got = _sde_pass(gpu_pkg)
     _same(base, got, switch)
+
+
+def _sde_layer_pass(P, mode):
+    """the NeuralDSDE layer's recorded forward + pullback at the one-launch step's shape, automatic initial dts"""
+    import torch
+    from localregneuralde_jl_amd.layers import _mlp_desc
+    D, H, B, nfine = 32, 64, 48, 64
+    rng = np.random.default_rng(3)
+    pd = (rng.standard_normal(H * D + H + D * H + D) * 0.25).astype(np.float32)
+    pg = (rng.standard_normal(D * D + D) * 0.08).astype(np.float32)
+    x = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)).cuda()
+    hh = np.float32(1.0 / nfine)
+    dW = (rng.standard_normal((nfine, B, D)) * np.sqrt(hh)).astype(np.float32)
+    W = torch.from_numpy(np.concatenate([np.zeros((1, B, D), np.float32), np.cumsum(dW, axis=0, dtype=np.float32)])).cuda()
+    z = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)).cuda()
+    h = P.SdeHandle(_mlp_desc(P.Chain(P.Dense(D, H, "tanh"), P.Dense(H, D))))
+    h.set_params(pd, pg)
+    fw = h.node_forward_record(x, W, 0.0, 1.0, 0.1, 0.1, z_local=z, mode=mode, t1_or_rand=0.37, saveat=(), save_start=-1)
+    ns = fw["u"].shape[0]
+    du = torch.from_numpy(rng.standard_normal((ns, B, D)).astype(np.float32)).cuda()
+    bw = h.node_backward_recorded(du, w_reg=2.0 if mode != "none" else 0.0)
+    out = dict(u=fw["u"].cpu().numpy(), t=fw["t"], reg=fw["reg_val"], st=fw["stats"], nf=fw["nfe_drift"], ng=fw["nfe_diffusion"], t1=fw["t1"])
+    for k, v in bw.items():
+        if hasattr(v, "cpu"):
+            out["bw_" + k] = v.cpu().numpy()
+    return out
+
+
+@pytest.mark.parametrize("switch", [{"LRNDE_SDE_HOST_INITDT": 1}, {"LRNDE_SDE_NO_PERSIST": 1}, {"LRNDE_SDE_HOST_LOOP": 1}, {"LRNDE_NO_SDE_FAST": 1}],
+                         ids=lambda d: "+".join(k[6:] for k in d))
+@pytest.mark.parametrize("mode", ["unbiased", "biased", "none"])
+def test_sde_layer_switch_gives_the_default_bits(gpu_pkg, options, switch, mode):
+    for k, v in DEFAULTS.items():
+        gpu_pkg.set_option(k, v)
+    base = _sde_layer_pass(gpu_pkg, mode)
+    assert base["st"]["naccept"] > 1
+    for k, v in switch.items():
+        options(k, v)
+    got = _sde_layer_pass(gpu_pkg, mode)
+    if "LRNDE_NO_SDE_FAST" in switch:   # the generic pullback adds the parameter gradients in another order (DESIGN.md 4.3)
+        for k in ("bw_dx", "bw_dp_drift", "bw_dp_diff"):
+            x, y = base.pop(k), got.pop(k)
+            assert np.allclose(x, y, rtol=2e-5, atol=2e-5 * float(np.abs(x).max())), (switch, mode, k)
+    _same(base, got, (switch, mode))
 
 
 def test_unknown_option_is_rejected(gpu_pkg):
