@@ -16,7 +16,8 @@ struct SdeSweepSrc {
   int K; const int2* im; float h; const float* x; const float* rec_u; const float* W; int dw_direct;
   int nseries; const int* ser_k; const float* ser_theta;   // host arrays: which step a cotangent's state was taken in, and where
 };
-int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float* du_series, float* dx, float* dp_drift, float* dp_diff);
+int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float* du_series, float* dx, float* dp_drift, float* dp_diff,
+                         bool sync_after = true);
 bool sde_bwd_fused_ok(const lrnde_sde* s, int nseries);
 
 // forward pieces of a step recomputed for the backward sweep (src/perform_step.jl:175,179,183) and the cotangent seeds

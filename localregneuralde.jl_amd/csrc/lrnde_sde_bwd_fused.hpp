@@ -20,6 +20,10 @@
 // in the last bits), which is inside the gradient's bar — tests/test_gpu_sde_layer.py holds the result to 5e-6 of float64
 // autograd over the recorded grid, and to the generic path (LRNDE_NO_SDE_BWD_FUSED=1).
 //
+// At the MNIST-SDE shape class (D <= 32, H <= 64) both kernels run in the compile-time form further down (SbfR: per-product
+// weight images read 16 bytes at a time, the parameter cotangent in registers, no barrier inside the sweep); the kernels
+// right below are the general form (LRNDE_SDE_BWD_LDSACC=1 forces it).
+//
 // The regulariser's part — d(EEst*dt)/dp of the ONE local Euler-Heun step at (sol(t1), t1), src/perform_step.jl:193-205 with
 // uprev, dW, dt constant (neural_sde.jl:42) — is a second kernel of the same construction (k_sde_eh_reg_fused): three
 // evaluation points per sample (K and utilde, tmp, uprev), EEst taken from the forward's record (the norm is the one thing
@@ -258,6 +262,283 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_fused(SdeBwdFusedArgs a) 
   c.store_partial(a.part);
 }
 
+// The two kernels for D <= DM, H <= HM = 64 with every size a compile-time constant (vectors and weight images padded to
+// DM / HM, pads zero): the products unroll completely — a product's LDS reads are all in flight before its fma chain starts —
+// and the parameter cotangent of a wave's sample lives in the wave's REGISTERS for the whole kernel (lane h: row h of dW1 and
+// column h of dW2, DM values each; lane j: column j of dWg; one bias entry per lane), so a step of the sweep has no workgroup
+// barrier at all: the four waves run their samples independently.  At the end the waves add their registers into the
+// workgroup's LDS vector one after the other (wave order: fixed) and the partial goes out as in the kernels above.  Same
+// expressions as k_sde_eh_bwd_fused / k_sde_eh_reg_fused; the sums over samples and steps associate differently (per sample
+// over its steps first).
+template <int DM, int HM> struct SbfR {
+  static_assert(DM % 4 == 0 && DM <= 64 && HM == 64, "one row per lane; the h vector is written by all 64 lanes");
+  // Every product reads ITS OWN image of the matrix, one row of the product per lane, contiguous: lane l's row at l * LD with
+  // LD = K + 4 — 16-byte reads, and LD mod 32 = 4 spreads eight lanes' quads over all 32 banks.  Six images (W1, W1^T, W2,
+  // W2^T, Wg, Wg^T): 45 KB at 32 / 64; the workgroup's parameter cotangent reuses that space after the last step.
+  static constexpr int LDD = DM + 4, LDH = HM + 4;                 // leading dimensions of images whose rows run over D / over H
+  static_assert(LDD % 32 == 4 && LDH % 32 == 4, "conflict-free 16-byte reads");
+  static constexpr int X = 0, DPRE = DM, HV = DM + HM, LAM = DM + 2 * HM, LAMG = LAM + DM, XG = LAMG + DM, VS = XG + DM;
+  static constexpr int NIMG = 2 * HM * LDD + 2 * DM * LDH + 2 * DM * LDD;
+  static size_t smem_bytes(int nev, int Ptot) {
+    const size_t img = (size_t)NIMG + HM + 2 * DM;
+    return sizeof(float) * ((img > (size_t)Ptot ? img : (size_t)Ptot) + (size_t)SBF_NS * nev * VS);
+  }
+  float *A1, *A1T, *A2, *A2T, *AG, *AGT, *V, *accL;
+  int D, H, Ptot, Pf, act, nev, tid, lane, sw, b, lh, ld;
+  bool valid, row, k0;
+  float b1l, b2l, bgl;
+  float g1[DM], g2[DM], gg[DM], gb1, gb2, gbg;
+  size_t nst, g;
+
+  __device__ __forceinline__ void setup(const SdeBwdFusedArgs& a, float* sm, int nev_) {
+    D = a.D; H = a.H; Ptot = a.Ptot; Pf = a.Pf; act = a.act; nev = nev_;
+    const int nimg = NIMG + HM + 2 * DM;
+    A1 = sm;                     // W1[h][d] at h LDD + d       (W1 x)
+    A1T = A1 + HM * LDD;         // W1[h][d] at d LDH + h       (W1^T dpre)
+    A2 = A1T + DM * LDH;         // W2[d][h] at d LDH + h       (W2 h)
+    A2T = A2 + DM * LDH;         // W2[d][h] at h LDD + d       (W2^T lam)
+    AG = A2T + HM * LDD;         // Wg[i][j] at i LDD + j       (Wg x)
+    AGT = AG + DM * LDD;         // Wg[i][j] at j LDD + i       (Wg^T lam_g)
+    float* b1s = AGT + DM * LDD;
+    float* b2s = b1s + HM;
+    float* bgs = b2s + DM;
+    accL = sm;                   // [Ptot], after the last step (finish)
+    V = sm + (nimg > Ptot ? nimg : Ptot);   // [NS][nev][VS]
+    tid = threadIdx.x; lane = tid & 63;
+    sw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    b = blockIdx.x * SBF_NS + sw;
+    valid = b < a.B;
+    const float* W1 = a.pdr; const float* b1 = W1 + (size_t)H * D; const float* W2 = b1 + H; const float* b2 = W2 + (size_t)D * H;
+    const int nz = (int)(V - sm) + SBF_NS * nev * VS;
+    for (int e = tid; e < nz; e += SBF_NT) sm[e] = 0.f;
+    __syncthreads();
+    for (int e = tid; e < H * D; e += SBF_NT) { const int hh = e % H, d = e / H; const float w = W1[e]; A1[hh * LDD + d] = w; A1T[d * LDH + hh] = w; }
+    for (int e = tid; e < D * H; e += SBF_NT) { const int d = e % D, hh = e / D; const float w = W2[e]; A2[d * LDH + hh] = w; A2T[hh * LDD + d] = w; }
+    for (int e = tid; e < D * D; e += SBF_NT) { const int i = e % D, jj = e / D; const float w = a.Wg[e]; AG[i * LDD + jj] = w; AGT[jj * LDD + i] = w; }
+    for (int e = tid; e < H; e += SBF_NT) b1s[e] = b1[e];
+    for (int e = tid; e < D; e += SBF_NT) { b2s[e] = b2[e]; bgs[e] = a.bg[e]; }
+    __syncthreads();
+    row = lane < D; k0 = lane < H;
+    lh = k0 ? lane : 0; ld = row ? lane : 0;   // (lanes without a row compute row 0's value and drop it)
+    b1l = b1s[lh]; b2l = b2s[ld]; bgl = bgs[ld];
+    nst = (size_t)a.B * D;
+    g = valid ? (size_t)b * D + ld : 0;
+#pragma unroll
+    for (int d = 0; d < DM; ++d) { g1[d] = 0.f; g2[d] = 0.f; gg[d] = 0.f; }
+    gb1 = gb2 = gbg = 0.f;
+  }
+  __device__ __forceinline__ float* block(int ev) const { return V + (size_t)(sw * nev + ev) * VS; }
+  // sum over k < N of rowp[k] * in[k]: one fma chain in increasing k, row and input read four elements at a time (four
+  // interleaved chains measured the same: a step is bound by the lone wave's LDS round trips, not by the chain's depth)
+  template <int N> __device__ __forceinline__ float mv(const float* rowp, const float* in) const {
+    f32x4 wv[N / 4];
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) wv[q] = *reinterpret_cast<const f32x4*>(rowp + 4 * q);
+    float sacc = 0.f;
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(in + 4 * q);
+      sacc = fma_(wv[q].x, xv.x, sacc); sacc = fma_(wv[q].y, xv.y, sacc); sacc = fma_(wv[q].z, xv.z, sacc); sacc = fma_(wv[q].w, xv.w, sacc);
+    }
+    return sacc;
+  }
+  __device__ __forceinline__ void put(float* Vp, int off, float v) const { if (lane < DM) Vp[off + lane] = v; }   // a D-vector's row `lane` (0 beyond D)
+  // hidden layer at the point whose x is in Vp[X]: h to Vp[HV] and returned, act' returned
+  __device__ __forceinline__ void hidden(float* Vp, float& hv, float& da) const {
+    const float pre = mv<DM>(A1 + lh * LDD, Vp + X) + b1l;
+    hv = act_apply(act, pre); da = act_deriv_c(act, pre, hv);
+    if (!k0) { hv = 0.f; da = 0.f; }
+    Vp[HV + lane] = hv;
+  }
+  __device__ __forceinline__ float f_out(const float* Vp) const { return row ? mv<HM>(A2 + ld * LDH, Vp + HV) + b2l : 0.f; }   // (W2 h + b2)[d]
+  __device__ __forceinline__ float g_out(const float* in) const { return row ? mv<DM>(AG + ld * LDD, in) + bgl : 0.f; }       // (Wg x + bg)[i]
+  __device__ __forceinline__ float wgt_x(const float* in) const { return row ? mv<DM>(AGT + ld * LDD, in) : 0.f; }            // (Wg^T x)[j]
+  // J_f^T lam at the point of block Vp (lam in Vp[LAM]): dpre to Vp[DPRE] and returned, row `lane` of W1^T dpre returned
+  __device__ __forceinline__ float drift_vjp(float* Vp, float da, float& dpre) const {
+    dpre = mv<DM>(A2T + lh * LDD, Vp + LAM) * da;          // (W2^T lam)[h] act'
+    if (!k0) dpre = 0.f;
+    Vp[DPRE + lane] = dpre;
+    const float r = mv<HM>(A1T + ld * LDH, Vp + DPRE);     // (W1^T dpre)[d]
+    return row ? r : 0.f;
+  }
+  // the parameter cotangent of one evaluation point: outer products of the vectors in LDS (x, lam, lam_g) with this lane's
+  // entries (dpre[h], h[h]; the diffusion's input x_g[j]; lam[d], lam_g[d] for the biases)
+  __device__ __forceinline__ void accumulate(const float* Vp, float dpre, float hv, float xgl, float laml, float lamgl) {
+#pragma unroll
+    for (int d = 0; d < DM; d += 4) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(Vp + X + d);
+      const f32x4 lv = *reinterpret_cast<const f32x4*>(Vp + LAM + d);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(Vp + LAMG + d);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        g1[d + r] = fma_(dpre, xv[r], g1[d + r]);      // dW1[h][d] += dpre[h] x[d]
+        g2[d + r] = fma_(hv, lv[r], g2[d + r]);        // dW2[d][h] += lam[d] h[h]
+        gg[d + r] = fma_(xgl, gv[r], gg[d + r]);       // dWg[i][j] += lam_g[i] x_g[j]     (lane j, register i)
+      }
+    }
+    gb1 = gb1 + dpre; gb2 = gb2 + laml; gbg = gbg + lamgl;
+  }
+  // the waves' registers into the workgroup's vector, wave after wave, and out; flat layout (W1, b1, W2, b2, Wg, bg), column-major
+  __device__ __forceinline__ void finish(float* part) {
+    const int n1 = H * D, n2 = n1 + H, n3 = n2 + D * H, n4 = Pf, n5 = n4 + D * D;
+    __syncthreads();   // every wave is past its last product: the images' space becomes the cotangent vector
+    for (int e = tid; e < Ptot; e += SBF_NT) accL[e] = 0.f;
+    __syncthreads();
+    for (int w = 0; w < SBF_NS; ++w) {
+      if (sw == w && valid) {
+#pragma unroll
+        for (int d = 0; d < DM; ++d) {
+          if (d < D) {
+            if (k0) { accL[lane + H * d] += g1[d]; accL[n2 + d + D * lane] += g2[d]; }
+            if (row) accL[n4 + d + D * lane] += gg[d];
+          }
+        }
+        if (k0) accL[n1 + lane] += gb1;
+        if (row) { accL[n3 + lane] += gb2; accL[n5 + lane] += gbg; }
+      }
+      __syncthreads();
+    }
+    float* pp = part + (size_t)blockIdx.x * Ptot;
+    for (int e = tid; e < Ptot; e += SBF_NT) pp[e] = accL[e];
+  }
+};
+
+template <int DM, int HM>
+__global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_fused_r(SdeBwdFusedArgs a) {
+  using R = SbfR<DM, HM>;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ int sk[SBF_MAXSER];
+  __shared__ float sth[SBF_MAXSER];
+  for (int e = threadIdx.x; e < a.nseries; e += SBF_NT) { sk[e] = a.ser_k[e]; sth[e] = a.ser_theta[e]; }
+  R c;
+  c.setup(a, sm, 2);   // (its barriers cover sk / sth)
+  const bool row = c.row;
+  const size_t nst = c.nst, g = c.g;
+  float* V0 = c.block(0);   // evaluation point tmp
+  float* V1 = c.block(1);   // evaluation point u
+  float ub = 0.f;
+  if (c.valid) {
+    auto step_src = [&](int k, float& u, float& wlo, float& whi, int& m) {
+      const int2 im = a.im[k];
+      const float* up = (k == 0) ? a.x : a.rec_u + (size_t)(k - 1) * nst;
+      u = up[g]; m = im.y;
+      if (a.dw_direct) { wlo = 0.f; whi = a.W[(size_t)im.x * nst + g]; }
+      else { wlo = a.W[(size_t)im.x * nst + g]; whi = a.W[(size_t)(im.x + im.y) * nst + g]; }
+    };
+    float u_n = 0.f, wlo_n = 0.f, whi_n = 0.f;
+    int m_n = 0;
+    if (a.K > 0) step_src(a.K - 1, u_n, wlo_n, whi_n, m_n);
+    for (int k = a.K - 1; k >= 0; --k) {
+      const float u = row ? u_n : 0.f;
+      const float dW = row ? whi_n - wlo_n : 0.f;
+      const float dt = (float)m_n * a.h;
+      if (k > 0) step_src(k - 1, u_n, wlo_n, whi_n, m_n);
+      // cotangents of the series values taken inside step k: theta of each onto the step's end state ...
+      for (int j = 0; j < a.nseries; ++j)
+        if (sk[j] == k) { const float th = sth[j]; if (th != 0.f && row) ub = ub + th * a.du_series[(size_t)j * nst + g]; }
+      const float hdt = dt / 2.0f;
+      // ---- forward pieces (src/perform_step.jl:175,179,183): du1 = f(u), L = g(u), tmp = (u + dt du1) + L dW ----
+      c.put(V1, R::X, u);
+      float hv1, da1, hv0, da0;
+      c.hidden(V1, hv1, da1);
+      const float du1 = c.f_out(V1);
+      const float L = c.g_out(V1 + R::X);
+      const float tmp = row ? (u + dt * du1) + L * dW : 0.f;
+      const float fb2 = hdt * ub, gb2v = (0.5f * dW) * ub;
+      c.put(V0, R::X, tmp); c.put(V0, R::LAM, fb2); c.put(V0, R::LAMG, gb2v);
+      c.hidden(V0, hv0, da0);   // h(tmp), act'(tmp); f(tmp) itself is not needed
+      // ---- second half backwards: cotangent of tmp ----
+      float dpre0, dpre1;
+      const float dtf = c.drift_vjp(V0, da0, dpre0);
+      const float dtg = c.wgt_x(V0 + R::LAMG);
+      const float tb = dtf + dtg;
+      const float du1b = hdt * ub + dt * tb;
+      const float Lb = (0.5f * dW) * ub + dW * tb;
+      const float up_ = ub + tb;
+      c.put(V1, R::LAM, du1b); c.put(V1, R::LAMG, Lb);
+      const float duf = c.drift_vjp(V1, da1, dpre1);
+      const float dug = c.wgt_x(V1 + R::LAMG);
+      ub = row ? (up_ + duf) + dug : 0.f;
+      c.accumulate(V0, dpre0, hv0, tmp, fb2, gb2v);
+      c.accumulate(V1, dpre1, hv1, u, du1b, Lb);
+      // ... and 1 - theta of the series values onto its start state
+      for (int j = 0; j < a.nseries; ++j)
+        if (sk[j] == k) { const float th = sth[j]; if (th != 1.0f && row) ub = ub + (1.0f - th) * a.du_series[(size_t)j * nst + g]; }
+    }
+    for (int j = 0; j < a.nseries; ++j)   // a saved start value is the input itself
+      if (sk[j] < 0 && row) ub = ub + a.du_series[(size_t)j * nst + g];
+    if (row) a.dx[g] = ub;
+  }
+  c.finish(a.part);
+}
+
+// k_sde_eh_reg_fused in that form.  Evaluation points: 0 = (K for the drift, utilde for the diffusion), 1 = tmp, 2 = uprev.
+template <int DM, int HM>
+__global__ __launch_bounds__(SBF_NT) void k_sde_eh_reg_fused_r(SdeBwdFusedArgs a) {
+  using R = SbfR<DM, HM>;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  R c;
+  c.setup(a, sm, 3);
+  const bool row = c.row;
+  const size_t g = c.g;
+  float* V0 = c.block(0); float* V1 = c.block(1); float* V2 = c.block(2);
+  if (c.valid) {
+    const float u = row ? a.u1[g] : 0.f, dW = row ? a.dW1[g] : 0.f, un = row ? a.un1[g] : 0.f;
+    const float dt = a.dt1, sqdt = sqrtf(dt), hdt = dt / 2.0f, nf = (float)((size_t)a.B * a.D);
+    c.put(V2, R::X, u);
+    float hvu, dau, hvk, dak, hvt, dat;
+    c.hidden(V2, hvu, dau);
+    const float du1 = c.f_out(V2);
+    const float L = c.g_out(V2 + R::X);
+    const float ut = row ? u + L * sqdt : 0.f;            // :196
+    const float K = row ? u + dt * du1 : 0.f;             // :175
+    const float tmp = row ? K + L * dW : 0.f;
+    c.put(V0, R::X, K); c.put(V0, R::XG, ut);
+    c.hidden(V0, hvk, dak);
+    const float du2 = c.f_out(V0);
+    const float g3 = c.g_out(V0 + R::XG);
+    // seeds (k_sder_seed)
+    float du2b = 0.f, du1b0 = 0.f, g3b = 0.f, Lb0 = 0.f, unb = 0.f;
+    if (row) {
+      const float Ed = (dt * (du2 - du1)) / 2.0f;
+      const float ggp = (g3 - L) / sqdt;
+      const float w2 = dW * dW;
+      const float En = (ggp * w2) / 2.0f;
+      const float sc = a.abstol + fmaxf_(__builtin_fabsf(u), __builtin_fabsf(un)) * a.reltol;
+      const float num = a.delta * Ed + En;
+      const float r = num / sc;
+      const float rb = (a.eest > 0.f) ? dt * r / (nf * a.eest) : 0.f;   // reg = dt * sqrt(mean r^2)
+      const float numb = rb / sc;
+      const float scb = -rb * num / (sc * sc);
+      unb = (__builtin_fabsf(un) > __builtin_fabsf(u)) ? scb * a.reltol * (un >= 0.f ? 1.f : -1.f) : 0.f;
+      const float Edb = a.delta * numb, ggpb = numb * w2 * 0.5f;
+      du2b = hdt * Edb; du1b0 = -hdt * Edb;
+      g3b = ggpb / sqdt; Lb0 = -ggpb / sqdt;
+    }
+    // f at K with du2b, g at utilde with g3b
+    c.put(V0, R::LAM, du2b); c.put(V0, R::LAMG, g3b);
+    float dprek, dpret, dpreu;
+    const float Kb = c.drift_vjp(V0, dak, dprek);
+    const float utb = c.wgt_x(V0 + R::LAMG);
+    // u_new's cotangent through f, g at tmp
+    const float fb2 = hdt * unb, gb2v = (0.5f * dW) * unb;
+    c.put(V1, R::X, tmp); c.put(V1, R::LAM, fb2); c.put(V1, R::LAMG, gb2v);
+    c.hidden(V1, hvt, dat);
+    const float dtf = c.drift_vjp(V1, dat, dpret);
+    const float dtg = c.wgt_x(V1 + R::LAMG);
+    const float tb = dtf + dtg;
+    const float du1b = ((du1b0 + dt * Kb) + hdt * unb) + dt * tb;
+    const float Lb = ((Lb0 + sqdt * utb) + (0.5f * dW) * unb) + dW * tb;
+    // f, g at uprev: only their parameter cotangents count
+    c.put(V2, R::LAM, du1b); c.put(V2, R::LAMG, Lb);
+    (void)c.drift_vjp(V2, dau, dpreu);
+    c.accumulate(V0, dprek, hvk, ut, du2b, g3b);
+    c.accumulate(V1, dpret, hvt, tmp, fb2, gb2v);
+    c.accumulate(V2, dpreu, hvu, u, du1b, Lb);
+  }
+  c.finish(a.part);
+}
+
 // d(EEst*dt)/dp of the local step (the arithmetic of k_sder_seed / k_sdeb_seed / k_sder_join and of the six products of
 // lrnde_sde_euler_heun_reg_grad), one launch.  Evaluation points: 0 = (K for the drift, utilde for the diffusion), 1 = tmp,
 // 2 = uprev.  uprev, dW, dt and the step's end state are constants of the tape.
@@ -325,14 +606,35 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_reg_fused(SdeBwdFusedArgs a) 
   c.store_partial(a.part);
 }
 
-// dp (+)= scale * sum over the workgroups' partials, in workgroup order; the diffusion part is [vec(Wg); bg] with bg present or not
-__global__ void k_sde_bwd_reduce(const float* part, int nwg, int Ptot, int Pf, int Pg, float* dp_drift, float* dp_diff, float scale, int add) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= Ptot) return;
+// dp (+)= scale * sum over the workgroups' partials; the diffusion part is [vec(Wg); bg] with bg present or not.  A block takes
+// 32 entries, eight threads per entry add an eighth of the workgroups each (in workgroup order, loads unrolled), and the
+// eight sums are added in slice order: the association is fixed by nwg alone, never by scheduling.
+__global__ __launch_bounds__(256) void k_sde_bwd_reduce(const float* part, int nwg, int Ptot, int Pf, int Pg, float* dp_drift, float* dp_diff, float scale, int add) {
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
+  const int cnt = (nwg + 7) >> 3;
+  const int w0 = sl * cnt, w1 = min(nwg, w0 + cnt);
   float s = 0.f;
-  for (int w = 0; w < nwg; ++w) s = s + part[(size_t)w * Ptot + e];
+  if (e < Ptot) {
+    int w = w0;
+    for (; w + 8 <= w1; w += 8) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(w + q) * Ptot + e];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s = s + v[q];
+    }
+    for (; w < w1; ++w) s = s + part[(size_t)w * Ptot + e];
+  }
+  red[sl][el] = s;
+  __syncthreads();
+  if (sl != 0 || e >= Ptot) return;
+  float t = red[0][el];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) t = t + red[q][el];
   float* dst = e < Pf ? dp_drift + e : (e - Pf < Pg ? dp_diff + (e - Pf) : nullptr);
-  if (dst) *dst = add ? *dst + scale * s : scale * s;
+  if (dst) *dst = add ? *dst + scale * t : scale * t;
 }
 
 }  // namespace

@@ -405,7 +405,8 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
 namespace {
 // the reverse sweep over the recorded steps as one launch + the fixed-order sum of the workgroups' partials
 // (lrnde_sde_bwd_fused.hpp); what remains for the caller is the regulariser's part
-int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float* du_series, float* dx, float* dp_drift, float* dp_diff) {
+int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float* du_series, float* dx, float* dp_drift, float* dp_diff,
+                         bool sync_after) {
   const int nseries = r.nseries;
   lrnde_ctx* c = s->drift;
   const int D = c->desc.state_dim, H = c->desc.hidden_dim;
@@ -423,35 +424,44 @@ int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float*
     if (s->bwf_meta) HIPCHK(c, hipFree(s->bwf_meta));
     s->bwf_meta = nullptr; s->bwf_meta_n = 0;
     HIPCHK(c, hipMalloc(&s->bwf_meta, sizeof(int) * meta));
+    if (s->bwf_meta_pin) HIPCHK(c, hipHostFree(s->bwf_meta_pin));
+    s->bwf_meta_pin = nullptr;
+    HIPCHK(c, hipHostMalloc(&s->bwf_meta_pin, sizeof(int) * meta));
     s->bwf_meta_n = meta;
   }
-  // [series k (MAXSER ints)][series theta (MAXSER floats)][(i, m) of the K steps]
-  std::vector<int> hm(meta, 0);
+  // [series k (MAXSER ints)][series theta (MAXSER floats)][(i, m) of the K steps], staged in pinned memory: the copy needs no
+  // wait (every call that uses the buffer ends in a synchronisation of this stream before the next one fills it)
+  int* hm = s->bwf_meta_pin;
   for (int j = 0; j < nseries; ++j) { hm[j] = r.ser_k[j]; hm[SBF_MAXSER + j] = __builtin_bit_cast(int, r.ser_theta[j]); }
   for (int k = 0; k < r.K; ++k) { hm[2 * SBF_MAXSER + 2 * k] = r.im[k].x; hm[2 * SBF_MAXSER + 2 * k + 1] = r.im[k].y; }
-  HIPCHK(c, hipMemcpyAsync(s->bwf_meta, hm.data(), sizeof(int) * meta, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));   // (hm leaves scope; the copy is a few hundred bytes)
+  HIPCHK(c, hipMemcpyAsync(s->bwf_meta, hm, sizeof(int) * ((size_t)2 * SBF_MAXSER + 2 * (size_t)r.K), hipMemcpyHostToDevice, c->stream));
   SdeBwdFusedArgs a{};
   a.pdr = s->pdr; a.Wg = s->p2 + (size_t)D * D + D; a.bg = a.Wg + (size_t)D * D;
   a.D = D; a.H = H; a.act = c->m.act; a.B = B; a.K = r.K;
   a.x = r.x; a.rec_u = r.rec_u; a.im = reinterpret_cast<const int2*>(s->bwf_meta + 2 * SBF_MAXSER); a.W = r.W; a.h = r.h; a.dw_direct = r.dw_direct;
   a.du_series = du_series; a.nseries = nseries; a.ser_k = s->bwf_meta; a.ser_theta = reinterpret_cast<const float*>(s->bwf_meta + SBF_MAXSER);
   a.dx = dx; a.part = s->bwf_part; a.Pf = Pf; a.Ptot = Ptot;
-  const size_t sm = sbf_smem_bytes(D, H, 2);
-  // (the kernel also has 4 KB of static LDS: the limit asked for is what this launch needs, not the CU's 160 KB)
-  if (sm > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_bwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-  hipLaunchKernelGGL(k_sde_eh_bwd_fused, dim3(nwg), dim3(SBF_NT), sm, c->stream, a);
-  hipLaunchKernelGGL(k_sde_bwd_reduce, dim3((Ptot + 255) / 256), dim3(256), 0, c->stream, (const float*)s->bwf_part, nwg, Ptot, Pf, Pg, dp_drift, dp_diff, 1.0f, 0);
+  if (D <= 32 && H <= 64 && !opt(OPT_SDE_BWD_LDSACC)) {
+    // the MNIST-SDE shape class: compile-time sizes, the parameter cotangent in registers, no barrier inside the sweep
+    const size_t smr = SbfR<32, 64>::smem_bytes(2, Ptot);
+    hipLaunchKernelGGL((k_sde_eh_bwd_fused_r<32, 64>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
+  } else {
+    const size_t sm = sbf_smem_bytes(D, H, 2);
+    // (the kernel also has 4 KB of static LDS: the limit asked for is what this launch needs, not the CU's 160 KB)
+    if (sm > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_bwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    hipLaunchKernelGGL(k_sde_eh_bwd_fused, dim3(nwg), dim3(SBF_NT), sm, c->stream, a);
+  }
+  hipLaunchKernelGGL(k_sde_bwd_reduce, dim3((Ptot + 31) / 32), dim3(256), 0, c->stream, (const float*)s->bwf_part, nwg, Ptot, Pf, Pg, dp_drift, dp_diff, 1.0f, 0);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (sync_after) HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRNDE_OK;
 }
 int sde_node_sweep_fused(lrnde_sde* s, SdeNodeRecord& r, int B, const float* du_series, int nseries, float* dx, float* dp_drift,
-                         float* dp_diff) {
+                         float* dp_diff, bool sync_after) {
   std::vector<int> sk(nseries); std::vector<float> sth(nseries);
   for (int j = 0; j < nseries; ++j) { sk[j] = r.series[j].k; sth[j] = r.series[j].theta; }
   SdeSweepSrc src{r.K, r.im.data(), r.h, r.x, r.rec_u, r.W, 0, nseries, sk.data(), sth.data()};
-  return sde_sweep_fused_core(s, src, B, du_series, dx, dp_drift, dp_diff);
+  return sde_sweep_fused_core(s, src, B, du_series, dx, dp_drift, dp_diff, sync_after);
 }
 // the regulariser's parameter cotangent, w_reg * d(EEst*dt)/dp of the recorded local step, ADDED to dp_drift / dp_diff
 int sde_node_reg_fused(lrnde_sde* s, SdeNodeRecord& r, int B, float w_reg, float* dp_drift, float* dp_diff) {
@@ -464,10 +474,15 @@ int sde_node_reg_fused(lrnde_sde* s, SdeNodeRecord& r, int B, float w_reg, float
   a.D = D; a.H = H; a.act = c->m.act; a.B = B; a.part = s->bwf_part; a.Pf = Pf; a.Ptot = Ptot;
   a.u1 = r.u1; a.dW1 = r.dWloc; a.un1 = r.tmp; a.dt1 = r.dt_loc; a.eest = r.ee_loc;
   a.abstol = r.o.abstol; a.reltol = r.o.reltol; a.delta = r.o.delta;
-  const size_t sm = sbf_smem_bytes(D, H, 3);
-  if (sm > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_reg_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-  hipLaunchKernelGGL(k_sde_eh_reg_fused, dim3(nwg), dim3(SBF_NT), sm, c->stream, a);
-  hipLaunchKernelGGL(k_sde_bwd_reduce, dim3((Ptot + 255) / 256), dim3(256), 0, c->stream, (const float*)s->bwf_part, nwg, Ptot, Pf, Pg, dp_drift, dp_diff, w_reg, 1);
+  if (D <= 32 && H <= 64 && !opt(OPT_SDE_BWD_LDSACC)) {
+    const size_t smr = SbfR<32, 64>::smem_bytes(3, Ptot);
+    hipLaunchKernelGGL((k_sde_eh_reg_fused_r<32, 64>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
+  } else {
+    const size_t sm = sbf_smem_bytes(D, H, 3);
+    if (sm > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_reg_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    hipLaunchKernelGGL(k_sde_eh_reg_fused, dim3(nwg), dim3(SBF_NT), sm, c->stream, a);
+  }
+  hipLaunchKernelGGL(k_sde_bwd_reduce, dim3((Ptot + 31) / 32), dim3(256), 0, c->stream, (const float*)s->bwf_part, nwg, Ptot, Pf, Pg, dp_drift, dp_diff, w_reg, 1);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRNDE_OK;
@@ -502,7 +517,9 @@ int lrnde_sde_node_backward_recorded(lrnde_sde* s, int32_t B, const float* du_se
         *up = v[9], *duf = v[10], *dug = v[11], *w = v[12];
   const int nb = sde_nb(n);
   const bool fused = sde_bwd_fused_ok(s, nseries);
-  if (fused) { if ((rc = sde_node_sweep_fused(s, r, B, du_series, nseries, dx, dp_drift, dp_diff))) return rc; }
+  // (the regulariser's one-launch kernel follows on the stream and ends in the call's one synchronisation)
+  const bool reg_fused = r.mode != LRNDE_MODE_NONE && w_reg != 0.0f && fused && sbf_smem_bytes(D, c->desc.hidden_dim, 3) + 1024 <= 160 * 1024;
+  if (fused) { if ((rc = sde_node_sweep_fused(s, r, B, du_series, nseries, dx, dp_drift, dp_diff, !reg_fused))) return rc; }
   else {
   HIPCHK(c, hipMemsetAsync(dx, 0, sizeof(float) * n, c->stream));   // dx doubles as ub, the cotangent of the current step's end state
   HIPCHK(c, hipMemsetAsync(dp_drift, 0, sizeof(float) * Pf, c->stream));
@@ -539,7 +556,7 @@ int lrnde_sde_node_backward_recorded(lrnde_sde* s, int32_t B, const float* du_se
   HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   // the regulariser (w.r.t. the parameters only: the local step's integrator is a constant of the tape, neural_sde.jl:42)
-  if (r.mode != LRNDE_MODE_NONE && w_reg != 0.0f && fused && sbf_smem_bytes(D, c->desc.hidden_dim, 3) + 1024 <= 160 * 1024) {
+  if (reg_fused) {
     if ((rc = sde_node_reg_fused(s, r, B, w_reg, dp_drift, dp_diff))) return rc;
   } else if (r.mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
     float rv = 0.f;
