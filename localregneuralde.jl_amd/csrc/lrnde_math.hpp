@@ -65,6 +65,46 @@ LRNDE_HD float tanhf_c(float x) {
   return __builtin_copysignf(r, x);
 }
 
+// tanhf_c without control flow: both pieces evaluated, the result selected — the same operations on the same inputs for the
+// piece that counts, so the same bits.  For code that applies the activation to several independent elements per lane: the
+// branches of tanhf_c keep the compiler from interleaving the elements' dependent chains (lrnde_sde_fast.hpp: 1.9k of a
+// round's 3.5k cycles were four serial tanh).
+LRNDE_HD float tanhf_sel(float x) {
+  const float ax = __builtin_fabsf(x);
+  const float s = x * x;
+  float q = -0x1.c4070cp-11f;
+  q = fma_(q, s, 0x1.b159b6p-9f);
+  q = fma_(q, s, -0x1.201022p-7f);
+  q = fma_(q, s, 0x1.662708p-6f);
+  q = fma_(q, s, -0x1.ba1a58p-5f);
+  q = fma_(q, s, 0x1.111110p-3f);
+  q = fma_(q, s, -0x1.555556p-2f);
+  const float xs = x * s;
+  const float small = fma_(xs, q, x);
+  // expf_c(2 ax), its clamps and its NaN exit as selects
+  float y = 2.0f * ax;
+  y = y > 87.0f ? 87.0f : y;
+  const float n = __builtin_rintf(y * 0x1.715476p+0f);
+  float r = fma_(n, -0x1.63p-1f, y);
+  r = fma_(n, 0x1.bd0106p-13f, r);
+  float p = 0x1.a124f2p-13f;
+  p = fma_(p, r, 0x1.6d4324p-10f);
+  p = fma_(p, r, 0x1.1110e0p-7f);
+  p = fma_(p, r, 0x1.5554eap-5f);
+  p = fma_(p, r, 0x1.555556p-3f);
+  p = fma_(p, r, 0x1.000000p-1f);
+  const float r2 = r * r;
+  float e = fma_(p, r2, r);
+  e = e + 1.0f;
+  const int32_t ni = (int32_t)n;
+  const float es = u2f(f2u(e) + ((uint32_t)ni << 23));
+  const float ex = (e != e) ? e : es;
+  const float big = __builtin_copysignf(1.0f - 2.0f / (ex + 1.0f), x);
+  const float sat = __builtin_copysignf(1.0f, x);
+  return ax < 0.625f ? small : (ax >= 9.0f ? sat : big);
+}
+LRNDE_HD float act_apply_sel(int act, float v);
+
 LRNDE_HD float geluf_c(float x) {
   const float two_lambda = 1.5957691216057308f;
   const float x2 = x * x;
@@ -75,6 +115,11 @@ LRNDE_HD float geluf_c(float x) {
 
 LRNDE_HD float act_apply(int act, float v) {
   if (act == 1) return tanhf_c(v);
+  if (act == 2) return geluf_c(v);
+  return v;
+}
+LRNDE_HD float act_apply_sel(int act, float v) {
+  if (act == 1) return tanhf_sel(v);
   if (act == 2) return geluf_c(v);
   return v;
 }

@@ -26,6 +26,13 @@
 // reverse sweep of lrnde_sde_node_backward_recorded walks.
 
 constexpr int SF_NT = 256;
+// -DLRNDE_SDE_STAMPS (tools/sde_persist_probe.hip): s_memtime of workgroup 0 at the phase boundaries of its first 32 steps
+#ifdef LRNDE_SDE_STAMPS
+__device__ unsigned long long g_sde_stamps[32][16];
+#define SDE_STAMP(i) do { if (PERSIST && blockIdx.x == 0 && threadIdx.x == 0 && it < 32) g_sde_stamps[it][(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SDE_STAMP(i) do { } while (0)
+#endif
 constexpr int SF_MAXD = 64, SF_MAXH = 128;
 
 struct SdeFastArgs {
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
   f32x4 u4 = zero4, w4 = zero4;
   if (live) u4 = ld4s(a.u);
   for (int it = 0;; ++it) {   // (one trip unless PERSIST)
+  SDE_STAMP(0);
   if (live) {
     if (adapt) {  // dW = W[i + m] - W[i], the path's own increment (the expression of k_sde_dw)
       const f32x4 lo = ld4s(a.Wpath + (size_t)ad_i * nn);
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
         const f32x4 acc = sf_chain<DT>(w1[j], xs, lane);
         float* p = reinterpret_cast<float*>(hl) + ((ht * 64 + n) << 2) + rq;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[r * 64] = act_apply(a.act, acc[r] + b1v[j][r]);
+        for (int r = 0; r < 4; ++r) p[r * 64] = act_apply_sel(a.act, acc[r] + b1v[j][r]);   // (four independent elements: the select form interleaves them)
       }
     }
   };
@@ -330,13 +338,18 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
       return;
     }
   }
+  SDE_STAMP(1);
   // ---- round 1: du1 = f(u), L = g(u) (:174-176) ----
   dense1(xA);
+  SDE_STAMP(8);
   diffusion(xA);
+  SDE_STAMP(9);
   __syncthreads();
+  SDE_STAMP(10);
   f32x4 du1 = zero4, L = zero4, Kv = zero4;
   if (has_d2) {
     du1 = dense2();
+    SDE_STAMP(11);
     L = gl[t * 64 + lane];
     f32x4 tmp, ut;
 #pragma unroll
@@ -347,7 +360,9 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
     }
     put(xB, tmp); put(xC, ut);
   }
+  SDE_STAMP(12);
   __syncthreads();
+  SDE_STAMP(2);
   // ---- round 2: g(tmp), f(tmp) at t + dt (:184, :191) ----
   dense1(xB);
   diffusion(xB);
@@ -369,6 +384,7 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
     put(xA, Kv);   // xA is free: every wave has read it (barrier above)
   }
   __syncthreads();
+  SDE_STAMP(3);
   // ---- round 3: du2 = f(K, t + dt) (:193), g(utilde, t) (:197) ----
   dense1(xA);
   diffusion(xC);
@@ -394,6 +410,7 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
     if (lane == 0) red[wave] = acc;
   }
   __syncthreads();
+  SDE_STAMP(4);
   if constexpr (PERSIST) {
     const int nwg = (int)gridDim.x;
     double* blk = a.part2 + (size_t)(it & 1) * nwg * PSTRIDE;   // (two blocks: a fast workgroup's next step must not overwrite what a slow one still reads)
@@ -438,6 +455,7 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
         if (__builtin_amdgcn_s_memrealtime() - t0c > 5000000ull) { ok = false; break; }
         __builtin_amdgcn_s_sleep(1);
       }
+      SDE_STAMP(5);
       SdeCtl c2 = cc;
       if (!ok) c2.status = LRNDE_HIP_ERROR;
       else {
@@ -448,6 +466,7 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
       if (lane == 0) sh_cc = c2;
     }
     __syncthreads();
+    SDE_STAMP(6);
     const int nacc0 = cc.naccept;
     cc = sh_cc;
     if (cc.naccept != nacc0) u4 = un;   // accepted: the end state is the next step's start state (rows of the Dense-2 waves)
