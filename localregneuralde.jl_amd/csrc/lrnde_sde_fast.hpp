@@ -90,7 +90,9 @@ __device__ __forceinline__ f32x4 sf_chain(const f32x4 (&frag)[NKG], const f32x4*
 // The controller of lrnde_sde_solve_adaptive's host loop, expression for expression, on a copy of the control block: PI
 // step factor from EEst, the proposal kept as a real number, position on the caller's grid, buffer flip.  `writer` (one
 // thread of the whole grid) also leaves the trace row and the accepted step's (start, length).
-__device__ __forceinline__ void sde_ctl_update(SdeCtl& c, float eest, float dt, const SdeFastArgs& a, bool writer) {
+// qpow = fastpow(c.qold, a.beta2): does not depend on this step's EEst — the cooperative form computes it while the partial
+// sums are still in flight.
+__device__ __forceinline__ void sde_ctl_update(SdeCtl& c, float eest, float dt, const SdeFastArgs& a, bool writer, float qpow) {
   const float qoldinit = 1e-4f;
   c.nf += 3; c.eest_last = eest;
   if (eest != eest) { c.status = LRNDE_DT_NAN; return; }
@@ -98,7 +100,7 @@ __device__ __forceinline__ void sde_ctl_update(SdeCtl& c, float eest, float dt, 
   if (eest == 0.0f) q = 1.0f / a.qmax;
   else {
     const float q11 = fastpow(eest, a.beta1);
-    q = q11 / fastpow(c.qold, a.beta2);
+    q = q11 / qpow;
     q = fmaxf_(1.0f / a.qmax, fminf_(1.0f / a.qmin, q / a.gamma));
   }
   const int accepted = eest <= 1.0f;
@@ -431,6 +433,8 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
         double* p = blk + (size_t)blockIdx.x * PSTRIDE;
         asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
       }
+      float qpow = fastpow(cc.qold, a.beta2);   // (ahead of the wait: see sde_ctl_update)
+      asm volatile("" : "+v"(qpow));              // (pinned here: the value is only used after the polling loop)
       PartLoads L;
       const unsigned long long t0c = __builtin_amdgcn_s_memrealtime();
       bool ok = true;
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
       else {
         const Sum3 s3 = part_finish<false>(L, blk, nwg);   // (the fixed order of every reduction of these partials)
         const float eest = rms_from(s3.a, a.n_norm);
-        sde_ctl_update(c2, eest, dt, a, blockIdx.x == 0 && lane == 0);
+        sde_ctl_update(c2, eest, dt, a, blockIdx.x == 0 && lane == 0, qpow);
       }
       if (lane == 0) sh_cc = c2;
     }
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
         a.rec->status = ST_DONE;
       } else {
         SdeCtl c = *a.ctl;
-        sde_ctl_update(c, eest, dt, a, true);
+        sde_ctl_update(c, eest, dt, a, true, fastpow(c.qold, a.beta2));
         *a.ctl = c;
         __hip_atomic_store(a.prog, (unsigned long long)(unsigned)(a.jlaunch + 1) | ((unsigned long long)(unsigned)c.status << 32),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
