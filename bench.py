@@ -564,7 +564,7 @@ def sde_main(args):
     h.set_params(pd, pg)
     ud, dWd = torch.from_numpy(u0).cuda(), torch.from_numpy(dW).cuda()
 
-    def one_pass():  # lrnde_sde_solve_fixed: the steps of the grid enqueued back to back, one host sync per solve
+    def one_pass():  # lrnde_sde_solve_fixed: the grid's steps in one launch + one for their records, one host sync per solve
         tr = h.solve_fixed(ud, dWd, 0.0, dt, 0.14, 0.14, 1.0 / 6.0)  # abstol=reltol=0.14 (mnist_sde/mlp.yml)
         return dict(eest=tr["eest"][-1], reg_val=tr["reg_val"][-1])
 
@@ -584,13 +584,15 @@ def sde_main(args):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"mnist_sde: NeuralDSDE drift Dense(32=>64,tanh)->Dense(64=>32), diffusion Dense(32=>32), Euler-Heun "
                                f"(src/perform_step.jl:172-206) on a fixed grid of {nsteps} steps with supplied dW, abstol=reltol=0.14, B={B}; "
-                               "one pass = one solve (lrnde_sde_solve_fixed); every step's error estimate and residual are returned to the host after it",
+                               "one pass = one solve (lrnde_sde_solve_fixed: ONE launch marches the grid's steps, a second forms their records); every step's "
+                               "state, error estimate and residual are returned with the solve",
                    "global_batch": B, "parallelism": "single GPU", "us_per_sde_step": el / nst * 1e6, "flop_per_step": flop,
                    "last_eest": float(r["eest"]), "last_reg_val": float(r["reg_val"])},
         "roofline": {"bound": "mfma", "achieved": flop / (el / nst) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": flop / (el / nst) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                     "kernel": "k_sde_eh_fast: ONE launch per step (weights resident in registers, the step's footer by the last workgroup to arrive); 15.7 MFLOP: latency bound by construction",
-                     "us_per_launch": el / nst * 1e6, "flop_per_launch": flop},
+                     "kernel": f"k_sde_eh_fast, march mode: the {nsteps} steps of the solve in ONE launch (weights resident in registers, no step waits for another "
+                               "workgroup; k_sde_march_records forms the records); 15.7 MFLOP per step: latency bound by construction; wall clock per solve incl. the host's part",
+                     "us_per_launch": el / args.steps * 1e6, "flop_per_launch": flop * nsteps},
     }
     out["config"]["layer"] = sde_layer_leg(h, ud, rng, B, D)
     if not args.no_cpu_baseline:

@@ -1885,13 +1885,13 @@ namespace {
 // path in the same process as the default one and holds the two to the same bits.
 enum {
   OPT_NO_QTILE, OPT_QTILE_MAX_B, OPT_NO_FUSE, OPT_DENSE_COPY, OPT_NO_OVERLAP, OPT_NO_SDE_FAST, OPT_SDE_HOST_LOOP, OPT_NO_QVJP,
-  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_OVERLAP, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_PGRAD_TS, OPT_ADJ_NO_REUSE, OPT_NO_SDE_BWD_FUSED, OPT_SDE_NO_PERSIST, OPT_SDE_HOST_INITDT, OPT_SDE_BWD_LDSACC, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
+  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_OVERLAP, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_PGRAD_TS, OPT_ADJ_NO_REUSE, OPT_NO_SDE_BWD_FUSED, OPT_SDE_NO_PERSIST, OPT_SDE_HOST_INITDT, OPT_SDE_BWD_LDSACC, OPT_SDE_NO_MARCH, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
 };
 struct OptDef { const char* name; int dflt; bool flag; };   // flag: present in the environment = 1
 const OptDef g_optdef[N_OPT] = {
     {"LRNDE_NO_QTILE", 0, true}, {"LRNDE_QTILE_MAX_B", 2048, false}, {"LRNDE_NO_FUSE", 0, true}, {"LRNDE_DENSE_COPY", 0, true},
     {"LRNDE_NO_OVERLAP", 0, true}, {"LRNDE_NO_SDE_FAST", 0, true}, {"LRNDE_SDE_HOST_LOOP", 0, true}, {"LRNDE_NO_QVJP", 0, true},
-    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_OVERLAP", 0, false}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_PGRAD_TS", 0, false}, {"LRNDE_ADJ_NO_REUSE", 0, true}, {"LRNDE_NO_SDE_BWD_FUSED", 0, true}, {"LRNDE_SDE_NO_PERSIST", 0, true}, {"LRNDE_SDE_HOST_INITDT", 0, true}, {"LRNDE_SDE_BWD_LDSACC", 0, true}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
+    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_OVERLAP", 0, false}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_PGRAD_TS", 0, false}, {"LRNDE_ADJ_NO_REUSE", 0, true}, {"LRNDE_NO_SDE_BWD_FUSED", 0, true}, {"LRNDE_SDE_NO_PERSIST", 0, true}, {"LRNDE_SDE_HOST_INITDT", 0, true}, {"LRNDE_SDE_BWD_LDSACC", 0, true}, {"LRNDE_SDE_NO_MARCH", 0, true}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
     {"LRNDE_FEED_M", 2, false}, {"LRNDE_GATHER_TILES", 0, true}, {"LRNDE_FORCE_COMM", 0, true}};
 int g_opt[N_OPT];
 bool g_opt_set[N_OPT];     // set by the hook: the environment no longer counts
@@ -3058,6 +3058,7 @@ namespace { struct SdeNodeRecord; }   // the layer's forward record (lrnde_sde_n
 struct lrnde_sde {
   SdeNodeRecord* node = nullptr;
   double *idt_part = nullptr, *idt_part_host = nullptr;   // sde_init_dt's norm partials (device / pinned)
+  double* march_part = nullptr; size_t march_part_n = 0;   // marched fixed-grid solve: [step][workgroup] partial sums
   double* idt_pp = nullptr; int idt_pp_nwg = 0;           // sde_init_dt_dev's per-workgroup partial sums (two phases)
   float *idt_scal = nullptr, *idt_scal_host = nullptr;    // sde_init_dt_dev's results: {dt0, d1, dt} of the solve, then of the local step
   int2* rec_im_pin = nullptr; int rec_im_pin_cap = 0;     // pinned landing buffer of the record's (start, length) pairs
@@ -3101,6 +3102,7 @@ int lrnde_sde_destroy(lrnde_sde* s) {
   if (s->idt_part) hipFree(s->idt_part);
   if (s->idt_part_host) hipHostFree(s->idt_part_host);
   if (s->idt_pp) hipFree(s->idt_pp);
+  if (s->march_part) hipFree(s->march_part);
   if (s->idt_scal) hipFree(s->idt_scal);
   if (s->idt_scal_host) hipHostFree(s->idt_scal_host);
   if (s->rec_im_pin) hipHostFree(s->rec_im_pin);
@@ -3245,6 +3247,19 @@ static int sde_step_impl(lrnde_sde* s, int which, const float* uprev, const floa
 // NeuralDSDE forward runs (src/layers/neural_sde.jl with a fixed-step solver), enqueued without a host round trip
 // per step.  u_traj (device, nsteps x B x D) receives every step's u; eest_host / reg_val_host (host, nsteps, may
 // be NULL) every step's EEst and EEst*dt.  which: 0 Euler-Heun (delta used), 1 Milstein.
+// every step's record of a marched fixed-grid solve: EEst and EEst*dt from the workgroups' partial sums (one wave per step)
+__global__ void k_sde_march_records(const double* part, int nwg, double n_norm, float dt, Ctrl* rec) {
+  if (threadIdx.x >= 64) return;
+  const Sum3 s = reduce_partials3(part + (size_t)blockIdx.x * nwg * PSTRIDE, nwg);
+  if (threadIdx.x == 0) {
+    const float eest = rms_from(s.a, n_norm);
+    Ctrl* r = rec + blockIdx.x;
+    r->eest_last = eest;
+    r->reg_error = eest * dt;
+    r->status = ST_DONE;
+  }
+}
+
 int lrnde_sde_solve_fixed(lrnde_sde* s, int32_t which, const float* u0, const float* dW, int32_t B, float t0, float dt,
                           int32_t nsteps, float abstol, float reltol, float delta, float* u_traj, float* eest_host,
                           float* reg_val_host) {
@@ -3262,6 +3277,26 @@ int lrnde_sde_solve_fixed(lrnde_sde* s, int32_t which, const float* u0, const fl
     s->traj_cap = nsteps;
   }
   const size_t n = (size_t)B * c->desc.state_dim;
+  if (which == 0 && sde_uses_fast(s) && !opt(OPT_SDE_NO_MARCH)) {
+    // the one-launch step's shape: the whole grid in ONE launch, no step waiting for another workgroup (lrnde_sde_fast.hpp,
+    // march_n), then one launch for the nsteps records.  LRNDE_SDE_NO_MARCH=1: a launch per step (same bits)
+    const int nwg = (B + NB - 1) / NB;
+    const size_t need = (size_t)nsteps * nwg * PSTRIDE;
+    if (s->march_part_n < need) {
+      if (s->march_part) HIPCHK(c, hipFree(s->march_part));
+      s->march_part = nullptr; s->march_part_n = 0;
+      HIPCHK(c, hipMalloc(&s->march_part, sizeof(double) * need));
+      s->march_part_n = need;
+    }
+    SdeFastArgs f{};
+    sde_fast_args(s, f);
+    f.u = u0; f.dW = dW; f.un = u_traj; f.B = B; f.dt = dt; f.abstol = abstol; f.reltol = reltol; f.delta = delta;
+    f.n_norm = (double)n;
+    f.march_n = nsteps; f.march_part = s->march_part;
+    sde_fast_launch(f.D, c->desc.hidden_dim, nwg, c->stream, f);
+    hipLaunchKernelGGL(k_sde_march_records, dim3(nsteps), dim3(64), 0, c->stream, (const double*)s->march_part, nwg, (double)n, dt, s->traj_dev);
+    HIPCHK(c, hipGetLastError());
+  } else
   for (int i = 0; i < nsteps; ++i) {
     const float t = t0 + (float)i * dt;
     if ((rc = sde_step_enqueue(s, which, i == 0 ? u0 : u_traj + (size_t)(i - 1) * n, dW + (size_t)i * n, B, t, dt, abstol, reltol,

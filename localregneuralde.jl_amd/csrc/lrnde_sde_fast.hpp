@@ -48,6 +48,11 @@ struct SdeFastArgs {
   // sde_determine_initdt on this kernel's tiles (idt_phase 1 / 2, lrnde_sde_node.hpp: sde_init_dt_dev): per-workgroup fp64
   // sums of the norms into idt_part (phase 1: d0, d1) / idt_part2 (phase 2: d2); phase 2 leaves {dt0, d1} in idt_scal
   int idt_phase; double* idt_part; double* idt_part2; float* idt_scal; float idt_dtmax;
+  // fixed-grid solve as ONE launch (lrnde_sde_solve_fixed): march_n > 0 — the workgroup takes its columns through march_n steps,
+  // step i with the increments dW + i * B * D, end state to un + i * B * D, and leaves its partial sum of step i in
+  // march_part[(i * gridDim.x + workgroup) * PSTRIDE]: no step waits for another workgroup (nothing consumes EEst inside
+  // the solve; k_sde_march_records forms every step's record afterwards, in the partial-vector order)
+  int march_n; double* march_part;
   double* part;      // per-workgroup fp64 sums of the squared residual (PSTRIDE doubles each)
   int* arrive;       // fixed-grid solve: arrival counter of the step's footer, or NULL
   Ctrl* rec;         //   ... and the record slot the last workgroup fills (EEst, EEst*dt)
@@ -487,6 +492,20 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
     a.dt = (float)ad_m * a.h;
     continue;
   } else {
+  if (a.march_n > 0) {
+    if (threadIdx.x == 0) {
+      double tot = red[0];
+#pragma unroll
+      for (int w = 1; w < DT; ++w) tot += red[w];
+      double* p = a.march_part + ((size_t)it * gridDim.x + blockIdx.x) * PSTRIDE;
+      p[0] = tot; p[1] = 0.0; p[2] = 0.0;
+    }
+    if (it + 1 == a.march_n) return;
+    u4 = un;                       // the end state is the next step's start state (rows of the Dense-2 waves)
+    a.dW += nn; a.un += nn;
+    __syncthreads();               // red and the tiles are rewritten by the next step
+    continue;
+  }
   if (threadIdx.x < 64) {
     double tot = red[0];
 #pragma unroll
