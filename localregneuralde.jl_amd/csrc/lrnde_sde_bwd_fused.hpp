@@ -49,6 +49,9 @@ struct SdeBwdFusedArgs {
   int Pf, Ptot;                     // drift parameters; drift + diffusion (D*D + D)
   // the regulariser's kernel: the local step's start state, increment and end state, its dt, EEst and tolerances
   const float *u1, *dW1, *un1; float dt1, eest, abstol, reltol, delta;
+  // the deferred form of the sweep (k_sde_eh_bwd_fused_r<.., true> + k_sde_bwd_hist_gemm): one record of SbfR::HREC floats per
+  // (step, sample, evaluation point) — x, dpre, h, lam, lam_g — from which the parameter cotangent is formed after the sweep
+  float* hist; int nrec;
 };
 
 // offsets inside a sample's vector block of one evaluation point: x (D), the constant 1, dpre (H), h (H), lam (D), lam_g (D)
@@ -270,6 +273,67 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_fused(SdeBwdFusedArgs a) 
 // workgroup's LDS vector one after the other (wave order: fixed) and the partial goes out as in the kernels above.  Same
 // expressions as k_sde_eh_bwd_fused / k_sde_eh_reg_fused; the sums over samples and steps associate differently (per sample
 // over its steps first).
+#ifdef LRNDE_SBF_STAMPS
+__device__ unsigned long long g_sbf_stamps[4][8];
+#define SBF_STAMP(k, i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sbf_stamps[(k)][(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SBF_STAMP(k, i) do { } while (0)
+#endif
+// The waves' register accumulators (lane h: g1[d] = dW1[h][d], g2[d] = dW2[d][h]; lane j: gg[i] = dWg[i][j]; one bias entry per
+// lane) to part[workgroup][flat layout (W1, b1, W2, b2, Wg, bg), column-major], the four waves added in wave order.  Every wave
+// writes its values into its OWN copy of a padded LDS vector (no read-modify-write, no wave waiting for another), one barrier,
+// then every thread adds the four copies of its output entries.  Inside LDS the W2 and Wg parts have leading dimension D + 1:
+// lane l writes at d + (D + 1) l — with the flat leading dimension D = 32 all 64 lanes of a store hit ONE bank.  (The first form
+// — one LDS vector, `acc[i] += g` wave after wave — took 23 us of a 36-us launch.)
+template <int DM>
+__device__ __forceinline__ void sbf_sum_out(float* acc, const float (&g1)[DM], const float (&g2)[DM], const float (&gg)[DM], float gb1, float gb2,
+                                            float gbg, int D, int H, int Pf, int Ptot, float* part) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool row = lane < D, k0 = lane < H;
+  const int LP = D + 1;
+  const int m1 = H * D, m2 = m1 + H, m3 = m2 + LP * H, m4 = m3 + D, m5 = m4 + LP * D, mtot = (m5 + D + 3) & ~3;   // padded layout
+  __syncthreads();   // (the caller's LDS use is over: acc may alias it)
+  float* mine = acc + (size_t)sw * mtot;
+#pragma unroll
+  for (int d = 0; d < DM; ++d) {
+    if (d < D) {
+      if (k0) { mine[lane + H * d] = g1[d]; mine[m2 + d + LP * lane] = g2[d]; }
+      if (row) mine[m4 + d + LP * lane] = gg[d];
+    }
+  }
+  if (k0) mine[m1 + lane] = gb1;
+  if (row) { mine[m3 + lane] = gb2; mine[m5 + lane] = gbg; }
+  __syncthreads();
+  const int n1 = H * D, n2 = n1 + H, n3 = n2 + D * H, n4 = Pf, n5 = n4 + D * D;
+  const float rD = 1.0f / (float)D;
+  float* pp = part + (size_t)blockIdx.x * Ptot;
+  auto src_of = [&](int e) {
+    if (e < n2) return e;                                                                                    // W1, b1: as they are
+    if (e < n3) { const int q = e - n2; const int hh = (int)(((float)q + 0.5f) * rD); return m2 + (q - hh * D) + LP * hh; }
+    if (e < n4) return m3 + (e - n3);
+    if (e < n5) { const int q = e - n4; const int jj = (int)(((float)q + 0.5f) * rD); return m4 + (q - jj * D) + LP * jj; }
+    return m5 + (e - n5);
+  };
+  for (int e0 = tid; e0 < Ptot; e0 += SBF_NT * 4) {   // four entries per trip: sixteen LDS reads in flight
+    float v[4][SBF_NS];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + q * SBF_NT;
+      const int sidx = e < Ptot ? src_of(e) : 0;
+#pragma unroll
+      for (int w = 0; w < SBF_NS; ++w) v[q][w] = acc[(size_t)w * mtot + sidx];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + q * SBF_NT;
+      if (e < Ptot) pp[e] = ((v[q][0] + v[q][1]) + v[q][2]) + v[q][3];
+    }
+  }
+}
+static_assert(SBF_NS == 4, "sbf_sum_out adds four waves");
+inline size_t sbf_acc_floats(int D, int H) { return (size_t)SBF_NS * ((((size_t)H * D + H + (size_t)(D + 1) * H + D + (size_t)(D + 1) * D + D) + 3) & ~(size_t)3); }
+
 template <int DM, int HM> struct SbfR {
   static_assert(DM % 4 == 0 && DM <= 64 && HM == 64, "one row per lane; the h vector is written by all 64 lanes");
   // Every product reads ITS OWN image of the matrix, one row of the product per lane, contiguous: lane l's row at l * LD with
@@ -279,9 +343,10 @@ template <int DM, int HM> struct SbfR {
   static_assert(LDD % 32 == 4 && LDH % 32 == 4, "conflict-free 16-byte reads");
   static constexpr int X = 0, DPRE = DM, HV = DM + HM, LAM = DM + 2 * HM, LAMG = LAM + DM, XG = LAMG + DM, VS = XG + DM;
   static constexpr int NIMG = 2 * HM * LDD + 2 * DM * LDH + 2 * DM * LDD;
-  static size_t smem_bytes(int nev, int Ptot) {
-    const size_t img = (size_t)NIMG + HM + 2 * DM;
-    return sizeof(float) * ((img > (size_t)Ptot ? img : (size_t)Ptot) + (size_t)SBF_NS * nev * VS);
+  static constexpr int HREC = XG;   // a history record = the block's first five vectors (x, dpre, h, lam, lam_g), in that order
+  static size_t smem_bytes(int nev, int D, int H) {   // (the four waves' padded cotangent vectors reuse the space at the end)
+    const size_t work = (size_t)NIMG + HM + 2 * DM + (size_t)SBF_NS * nev * VS, fin = sbf_acc_floats(D, H);
+    return sizeof(float) * (work > fin ? work : fin);
   }
   float *A1, *A1T, *A2, *A2T, *AG, *AGT, *V, *accL;
   int D, H, Ptot, Pf, act, nev, tid, lane, sw, b, lh, ld;
@@ -302,8 +367,8 @@ template <int DM, int HM> struct SbfR {
     float* b1s = AGT + DM * LDD;
     float* b2s = b1s + HM;
     float* bgs = b2s + DM;
-    accL = sm;                   // [Ptot], after the last step (finish)
-    V = sm + (nimg > Ptot ? nimg : Ptot);   // [NS][nev][VS]
+    accL = sm;                   // the padded cotangent vector, after the last step (finish)
+    V = sm + nimg;               // [NS][nev][VS]
     tid = threadIdx.x; lane = tid & 63;
     sw = __builtin_amdgcn_readfirstlane(tid >> 6);
     b = blockIdx.x * SBF_NS + sw;
@@ -312,11 +377,22 @@ template <int DM, int HM> struct SbfR {
     const int nz = (int)(V - sm) + SBF_NS * nev * VS;
     for (int e = tid; e < nz; e += SBF_NT) sm[e] = 0.f;
     __syncthreads();
-    for (int e = tid; e < H * D; e += SBF_NT) { const int hh = e % H, d = e / H; const float w = W1[e]; A1[hh * LDD + d] = w; A1T[d * LDH + hh] = w; }
-    for (int e = tid; e < D * H; e += SBF_NT) { const int d = e % D, hh = e / D; const float w = W2[e]; A2[d * LDH + hh] = w; A2T[hh * LDD + d] = w; }
-    for (int e = tid; e < D * D; e += SBF_NT) { const int i = e % D, jj = e / D; const float w = a.Wg[e]; AG[i * LDD + jj] = w; AGT[jj * LDD + i] = w; }
-    for (int e = tid; e < H; e += SBF_NT) b1s[e] = b1[e];
-    for (int e = tid; e < D; e += SBF_NT) { b2s[e] = b2[e]; bgs[e] = a.bg[e]; }
+    // (eight loads in flight per thread before the first store: a load per loop trip made the launch's start 20 global round trips long)
+    auto fill = [&](const float* src, int n, auto&& put) {
+      for (int e0 = tid; e0 < n; e0 += SBF_NT * 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int e = e0 + q * SBF_NT; v[q] = e < n ? src[e] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int e = e0 + q * SBF_NT; if (e < n) put(e, v[q]); }
+      }
+    };
+    fill(W1, H * D, [&](int e, float w) { const int hh = e % H, d = e / H; A1[hh * LDD + d] = w; A1T[d * LDH + hh] = w; });
+    fill(W2, D * H, [&](int e, float w) { const int d = e % D, hh = e / D; A2[d * LDH + hh] = w; A2T[hh * LDD + d] = w; });
+    fill(a.Wg, D * D, [&](int e, float w) { const int i = e % D, jj = e / D; AG[i * LDD + jj] = w; AGT[jj * LDD + i] = w; });
+    fill(b1, H, [&](int e, float w) { b1s[e] = w; });
+    fill(b2, D, [&](int e, float w) { b2s[e] = w; });
+    fill(a.bg, D, [&](int e, float w) { bgs[e] = w; });
     __syncthreads();
     row = lane < D; k0 = lane < H;
     lh = k0 ? lane : 0; ld = row ? lane : 0;   // (lanes without a row compute row 0's value and drop it)
@@ -378,40 +454,24 @@ template <int DM, int HM> struct SbfR {
     }
     gb1 = gb1 + dpre; gb2 = gb2 + laml; gbg = gbg + lamgl;
   }
-  // the waves' registers into the workgroup's vector, wave after wave, and out; flat layout (W1, b1, W2, b2, Wg, bg), column-major
-  __device__ __forceinline__ void finish(float* part) {
-    const int n1 = H * D, n2 = n1 + H, n3 = n2 + D * H, n4 = Pf, n5 = n4 + D * D;
-    __syncthreads();   // every wave is past its last product: the images' space becomes the cotangent vector
-    for (int e = tid; e < Ptot; e += SBF_NT) accL[e] = 0.f;
-    __syncthreads();
-    for (int w = 0; w < SBF_NS; ++w) {
-      if (sw == w && valid) {
-#pragma unroll
-        for (int d = 0; d < DM; ++d) {
-          if (d < D) {
-            if (k0) { accL[lane + H * d] += g1[d]; accL[n2 + d + D * lane] += g2[d]; }
-            if (row) accL[n4 + d + D * lane] += gg[d];
-          }
-        }
-        if (k0) accL[n1 + lane] += gb1;
-        if (row) { accL[n3 + lane] += gb2; accL[n5 + lane] += gbg; }
-      }
-      __syncthreads();
-    }
-    float* pp = part + (size_t)blockIdx.x * Ptot;
-    for (int e = tid; e < Ptot; e += SBF_NT) pp[e] = accL[e];
+  // the block's record to the history buffer: 16 bytes per lane, one contiguous HREC-float row
+  __device__ __forceinline__ void store_hist(float* dst, const float* Vp) const {
+    if (lane < HREC / 4) *reinterpret_cast<f32x4*>(dst + 4 * lane) = *reinterpret_cast<const f32x4*>(Vp + 4 * lane);
   }
+  __device__ __forceinline__ void finish(float* part) { sbf_sum_out<DM>(accL, g1, g2, gg, gb1, gb2, gbg, D, H, Pf, Ptot, part); }
 };
 
-template <int DM, int HM>
+template <int DM, int HM, bool DEFER = false>
 __global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_fused_r(SdeBwdFusedArgs a) {
   using R = SbfR<DM, HM>;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ int sk[SBF_MAXSER];
   __shared__ float sth[SBF_MAXSER];
   for (int e = threadIdx.x; e < a.nseries; e += SBF_NT) { sk[e] = a.ser_k[e]; sth[e] = a.ser_theta[e]; }
+  SBF_STAMP(2, 0);
   R c;
   c.setup(a, sm, 2);   // (its barriers cover sk / sth)
+  SBF_STAMP(2, 1);
   const bool row = c.row;
   const size_t nst = c.nst, g = c.g;
   float* V0 = c.block(0);   // evaluation point tmp
@@ -459,8 +519,14 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_fused_r(SdeBwdFusedArgs a
       const float duf = c.drift_vjp(V1, da1, dpre1);
       const float dug = c.wgt_x(V1 + R::LAMG);
       ub = row ? (up_ + duf) + dug : 0.f;
-      c.accumulate(V0, dpre0, hv0, tmp, fb2, gb2v);
-      c.accumulate(V1, dpre1, hv1, u, du1b, Lb);
+      if constexpr (DEFER) {   // the step's two records out; k_sde_bwd_hist_gemm forms the parameter cotangent from them
+        float* hr = a.hist + ((size_t)k * a.B + c.b) * 2 * R::HREC;
+        c.store_hist(hr, V0);
+        c.store_hist(hr + R::HREC, V1);
+      } else {
+        c.accumulate(V0, dpre0, hv0, tmp, fb2, gb2v);
+        c.accumulate(V1, dpre1, hv1, u, du1b, Lb);
+      }
       // ... and 1 - theta of the series values onto its start state
       for (int j = 0; j < a.nseries; ++j)
         if (sk[j] == k) { const float th = sth[j]; if (th != 1.0f && row) ub = ub + (1.0f - th) * a.du_series[(size_t)j * nst + g]; }
@@ -469,7 +535,72 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_fused_r(SdeBwdFusedArgs a
       if (sk[j] < 0 && row) ub = ub + a.du_series[(size_t)j * nst + g];
     if (row) a.dx[g] = ub;
   }
-  c.finish(a.part);
+  SBF_STAMP(2, 2);
+  if constexpr (!DEFER) c.finish(a.part);
+  SBF_STAMP(2, 3);
+}
+
+// The parameter cotangent from the sweep's history: record r = {x (DM), dpre (HM), h (HM), lam (DM), lam_g (DM)} of one
+// (step, sample, evaluation point); dW1 += dpre x^T, dW2 += lam h^T, dWg += lam_g x^T, the biases += dpre, lam, lam_g.  A wave
+// takes records gw, gw + (waves of the grid), ... in that order with the accumulators of SbfR::accumulate (lane h: row h of
+// dW1, column h of dW2; lane j: column j of dWg), the row vectors through wave-uniform loads; waves -> workgroup vector in
+// wave order -> one partial per workgroup -> k_sde_bwd_reduce.  Full occupancy: this is where the sweep's 96 accumulators
+// per lane went.
+template <int DM, int HM>
+__global__ __launch_bounds__(SBF_NT) void k_sde_bwd_hist_gemm(SdeBwdFusedArgs a) {
+  using R = SbfR<DM, HM>;
+  constexpr int NBATCH = 32, Q = R::HREC / 4;   // records per batch; 16-byte quads per record
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [Ptot] the workgroup's vector, then [NBATCH][HREC] the batch
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = a.D, H = a.H, Ptot = a.Ptot;
+  SBF_STAMP(1, 0);
+  float* bat = sm;   // [NBATCH][HREC] the batch; the workgroup's padded vector reuses the space at the end
+  float g1[DM], g2[DM], gg[DM], gb1 = 0.f, gb2 = 0.f, gbg = 0.f;
+#pragma unroll
+  for (int d = 0; d < DM; ++d) { g1[d] = 0.f; g2[d] = 0.f; gg[d] = 0.f; }
+  // this workgroup's records: a contiguous chunk, batches of NBATCH staged through LDS (all threads load, 16 bytes each, several
+  // in flight), wave w takes records w, w + 4, ... of the batch
+  const int per = (a.nrec + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int r0 = (int)blockIdx.x * per, r1 = min(a.nrec, r0 + per);
+  const int lx = lane < DM ? lane : 0;
+  for (int b0 = r0; b0 < r1; b0 += NBATCH) {
+    const int nb = min(NBATCH, r1 - b0);
+    __syncthreads();
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.hist + (size_t)b0 * R::HREC);
+    f32x4* dst = reinterpret_cast<f32x4*>(bat);
+    for (int i0 = tid; i0 < nb * Q; i0 += SBF_NT * 4) {
+      f32x4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int i = i0 + q * SBF_NT; if (i < nb * Q) v[q] = src[i]; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int i = i0 + q * SBF_NT; if (i < nb * Q) dst[i] = v[q]; }
+    }
+    __syncthreads();
+    for (int j = sw; j < nb; j += SBF_NS) {
+      const float* rec = bat + j * R::HREC;
+      const float dpre = rec[R::DPRE + lane], hv = rec[R::HV + lane];
+      float xl = rec[R::X + lx], laml = rec[R::LAM + lx], lamgl = rec[R::LAMG + lx];
+      if (lane >= DM) { xl = 0.f; laml = 0.f; lamgl = 0.f; }
+#pragma unroll
+      for (int d = 0; d < DM; d += 4) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(rec + R::X + d);
+        const f32x4 lv = *reinterpret_cast<const f32x4*>(rec + R::LAM + d);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(rec + R::LAMG + d);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          g1[d + q] = fma_(dpre, xv[q], g1[d + q]);
+          g2[d + q] = fma_(hv, lv[q], g2[d + q]);
+          gg[d + q] = fma_(xl, gv[q], gg[d + q]);
+        }
+      }
+      gb1 = gb1 + dpre; gb2 = gb2 + laml; gbg = gbg + lamgl;
+    }
+  }
+  SBF_STAMP(1, 1);
+  sbf_sum_out<DM>(sm, g1, g2, gg, gb1, gb2, gbg, D, H, a.Pf, Ptot, a.part);
+  SBF_STAMP(1, 2);
+  SBF_STAMP(1, 3);
 }
 
 // k_sde_eh_reg_fused in that form.  Evaluation points: 0 = (K for the drift, utilde for the diffusion), 1 = tmp, 2 = uprev.
@@ -477,8 +608,10 @@ template <int DM, int HM>
 __global__ __launch_bounds__(SBF_NT) void k_sde_eh_reg_fused_r(SdeBwdFusedArgs a) {
   using R = SbfR<DM, HM>;
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  SBF_STAMP(0, 0);
   R c;
   c.setup(a, sm, 3);
+  SBF_STAMP(0, 1);
   const bool row = c.row;
   const size_t g = c.g;
   float* V0 = c.block(0); float* V1 = c.block(1); float* V2 = c.block(2);
@@ -536,7 +669,9 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_reg_fused_r(SdeBwdFusedArgs a
     c.accumulate(V1, dpret, hvt, tmp, fb2, gb2v);
     c.accumulate(V2, dpreu, hvu, u, du1b, Lb);
   }
+  SBF_STAMP(0, 2);
   c.finish(a.part);
+  SBF_STAMP(0, 3);
 }
 
 // d(EEst*dt)/dp of the local step (the arithmetic of k_sder_seed / k_sdeb_seed / k_sder_join and of the six products of

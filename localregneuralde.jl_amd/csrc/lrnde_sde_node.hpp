@@ -441,9 +441,36 @@ int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float*
   a.x = r.x; a.rec_u = r.rec_u; a.im = reinterpret_cast<const int2*>(s->bwf_meta + 2 * SBF_MAXSER); a.W = r.W; a.h = r.h; a.dw_direct = r.dw_direct;
   a.du_series = du_series; a.nseries = nseries; a.ser_k = s->bwf_meta; a.ser_theta = reinterpret_cast<const float*>(s->bwf_meta + SBF_MAXSER);
   a.dx = dx; a.part = s->bwf_part; a.Pf = Pf; a.Ptot = Ptot;
-  if (D <= 32 && H <= 64 && !opt(OPT_SDE_BWD_LDSACC)) {
-    // the MNIST-SDE shape class: compile-time sizes, the parameter cotangent in registers, no barrier inside the sweep
-    const size_t smr = SbfR<32, 64>::smem_bytes(2, Ptot);
+  int nwg_red = nwg;   // partial vectors k_sde_bwd_reduce adds
+  if (D <= 32 && H <= 64 && !opt(OPT_SDE_BWD_LDSACC) && !opt(OPT_SDE_BWD_NO_DEFER) && r.K > 0) {
+    // the MNIST-SDE shape class, deferred form: the sweep leaves a record per (step, sample, evaluation point) and the parameter
+    // cotangent is formed from the records afterwards at full occupancy (LRNDE_SDE_BWD_NO_DEFER=1: accumulators in the sweep)
+    const size_t nrec = (size_t)r.K * B * 2, nh = nrec * SbfR<32, 64>::HREC;
+    if (s->bwf_hist_n < nh) {
+      if (s->bwf_hist) HIPCHK(c, hipFree(s->bwf_hist));
+      s->bwf_hist = nullptr; s->bwf_hist_n = 0;
+      HIPCHK(c, hipMalloc(&s->bwf_hist, sizeof(float) * nh));
+      s->bwf_hist_n = nh;
+    }
+    const int ngw = 256;
+    if (s->bwf_part_n < (size_t)ngw * Ptot) {
+      HIPCHK(c, hipFree(s->bwf_part));
+      s->bwf_part = nullptr; s->bwf_part_n = 0;
+      HIPCHK(c, hipMalloc(&s->bwf_part, sizeof(float) * (size_t)ngw * Ptot));
+      s->bwf_part_n = (size_t)ngw * Ptot;
+      a.part = s->bwf_part;
+    }
+    a.hist = s->bwf_hist; a.nrec = (int)nrec;
+    const size_t smr = SbfR<32, 64>::smem_bytes(2, 1, 1);   // (no cotangent vector in this kernel)
+    hipLaunchKernelGGL((k_sde_eh_bwd_fused_r<32, 64, true>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
+    const size_t smg = sizeof(float) * std::max((size_t)32 * SbfR<32, 64>::HREC, sbf_acc_floats(D, H));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_bwd_hist_gemm<32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smg));
+    hipLaunchKernelGGL((k_sde_bwd_hist_gemm<32, 64>), dim3(ngw), dim3(SBF_NT), smg, c->stream, a);
+    nwg_red = ngw;
+  } else if (D <= 32 && H <= 64 && !opt(OPT_SDE_BWD_LDSACC)) {
+    // compile-time sizes, the parameter cotangent in registers, no barrier inside the sweep
+    const size_t smr = SbfR<32, 64>::smem_bytes(2, D, H);
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_bwd_fused_r<32, 64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr));
     hipLaunchKernelGGL((k_sde_eh_bwd_fused_r<32, 64>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
   } else {
     const size_t sm = sbf_smem_bytes(D, H, 2);
@@ -451,7 +478,7 @@ int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float*
     if (sm > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_bwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     hipLaunchKernelGGL(k_sde_eh_bwd_fused, dim3(nwg), dim3(SBF_NT), sm, c->stream, a);
   }
-  hipLaunchKernelGGL(k_sde_bwd_reduce, dim3((Ptot + 31) / 32), dim3(256), 0, c->stream, (const float*)s->bwf_part, nwg, Ptot, Pf, Pg, dp_drift, dp_diff, 1.0f, 0);
+  hipLaunchKernelGGL(k_sde_bwd_reduce, dim3((Ptot + 31) / 32), dim3(256), 0, c->stream, (const float*)s->bwf_part, nwg_red, Ptot, Pf, Pg, dp_drift, dp_diff, 1.0f, 0);
   HIPCHK(c, hipGetLastError());
   if (sync_after) HIPCHK(c, hipStreamSynchronize(c->stream));
   return LRNDE_OK;
@@ -475,7 +502,8 @@ int sde_node_reg_fused(lrnde_sde* s, SdeNodeRecord& r, int B, float w_reg, float
   a.u1 = r.u1; a.dW1 = r.dWloc; a.un1 = r.tmp; a.dt1 = r.dt_loc; a.eest = r.ee_loc;
   a.abstol = r.o.abstol; a.reltol = r.o.reltol; a.delta = r.o.delta;
   if (D <= 32 && H <= 64 && !opt(OPT_SDE_BWD_LDSACC)) {
-    const size_t smr = SbfR<32, 64>::smem_bytes(3, Ptot);
+    const size_t smr = SbfR<32, 64>::smem_bytes(3, D, H);
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_reg_fused_r<32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr));
     hipLaunchKernelGGL((k_sde_eh_reg_fused_r<32, 64>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
   } else {
     const size_t sm = sbf_smem_bytes(D, H, 3);
