@@ -540,6 +540,139 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_fused_r(SdeBwdFusedArgs a
   SBF_STAMP(2, 3);
 }
 
+// The deferred sweep with the weights in REGISTERS (DM = 32, HM = 64).  Without the cotangent's 96 accumulators a lane has room
+// for its rows of all six products for the whole sweep: lane h keeps row h of W1 and column h of W2 (the products with H
+// outputs); the products with D <= 32 outputs run on BOTH half-waves — lane d and lane d + 32 each keep one half of row d's
+// input range (32 of W2's and W1^T's 64, 16 of Wg's and Wg^T's 32) and the halves meet in one cross-half add — 160 registers.
+// A step then reads only its input vectors from LDS (68 16-byte reads instead of 208) and issues 272 fma instead of 416.  The
+// D-output sums associate as (first half) + (second half): dx differs from the kernels above in the last bits.
+template <int DM, int HM>
+__global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_sweep_res(SdeBwdFusedArgs a) {
+  static_assert(DM == 32 && HM == 64, "half-wave split of the D-output products");
+  using R = SbfR<DM, HM>;
+  constexpr int HH = HM / 2, DH = DM / 2;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ int sk[SBF_MAXSER];
+  __shared__ float sth[SBF_MAXSER];
+  for (int e = threadIdx.x; e < a.nseries; e += SBF_NT) { sk[e] = a.ser_k[e]; sth[e] = a.ser_theta[e]; }
+  SBF_STAMP(2, 0);
+  R c;
+  c.setup(a, sm, 2);   // (the LDS images are the source of the register copies; its barriers cover sk / sth)
+  const int lane = c.lane, half = lane >> 5, dl = lane & 31;
+  const bool rowd = dl < c.D;               // this lane's D-row (both half-waves hold every D-vector's row dl)
+  const int ldl = rowd ? dl : 0;
+  float rw1[DM], rw2t[DM], rw2[HH], rw1t[HH], rwg[DH], rwgt[DH];
+#pragma unroll
+  for (int k = 0; k < DM; k += 4) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(c.A1 + c.lh * R::LDD + k), q = *reinterpret_cast<const f32x4*>(c.A2T + c.lh * R::LDD + k);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { rw1[k + r] = p[r]; rw2t[k + r] = q[r]; }
+  }
+#pragma unroll
+  for (int k = 0; k < HH; k += 4) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(c.A2 + ldl * R::LDH + HH * half + k), q = *reinterpret_cast<const f32x4*>(c.A1T + ldl * R::LDH + HH * half + k);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { rw2[k + r] = p[r]; rw1t[k + r] = q[r]; }
+  }
+#pragma unroll
+  for (int k = 0; k < DH; k += 4) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(c.AG + ldl * R::LDD + DH * half + k), q = *reinterpret_cast<const f32x4*>(c.AGT + ldl * R::LDD + DH * half + k);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { rwg[k + r] = p[r]; rwgt[k + r] = q[r]; }
+  }
+  const float b1l = c.b1l;
+  const float b2l = __shfl(c.b2l, ldl, 64), bgl = __shfl(c.bgl, ldl, 64);   // (setup left them in lane d; lane d + 32 needs them too)
+  SBF_STAMP(2, 1);
+  // sum over k < N of w[k] * in[k], the input read four elements at a time
+  auto dotr = [&](auto nk, const float* w, const float* in) {
+    constexpr int N = decltype(nk)::value;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four chains (k mod 4), added pairwise: the step is a chain of seven such sums
+#pragma unroll
+    for (int k = 0; k < N; k += 4) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(in + k);
+      s0 = fma_(w[k], xv.x, s0); s1 = fma_(w[k + 1], xv.y, s1); s2 = fma_(w[k + 2], xv.z, s2); s3 = fma_(w[k + 3], xv.w, s3);
+    }
+    return (s0 + s1) + (s2 + s3);
+  };
+  using IC_D = std::integral_constant<int, DM>; using IC_HH = std::integral_constant<int, HH>; using IC_DH = std::integral_constant<int, DH>;
+  // the two half-waves' sums: the same value on both (v_permlane32_swap instead of the cross-lane read gave wrong sums here — not pursued)
+  auto both = [&](float part) { return part + __shfl_xor(part, 32, 64); };
+  auto hidden = [&](float* Vp, float& hv, float& da) {
+    const float pre = dotr(IC_D{}, rw1, Vp + R::X) + b1l;
+    hv = act_apply(c.act, pre); da = act_deriv_c(c.act, pre, hv);
+    if (!c.k0) { hv = 0.f; da = 0.f; }
+    Vp[R::HV + lane] = hv;
+  };
+  auto f_out = [&](const float* Vp) { const float t = both(dotr(IC_HH{}, rw2, Vp + R::HV + HH * half)); return rowd ? t + b2l : 0.f; };
+  auto g_out = [&](const float* in) { const float t = both(dotr(IC_DH{}, rwg, in + DH * half)); return rowd ? t + bgl : 0.f; };
+  auto wgt_x = [&](const float* in) { const float t = both(dotr(IC_DH{}, rwgt, in + DH * half)); return rowd ? t : 0.f; };
+  auto drift_vjp = [&](float* Vp, float da) {
+    float dpre = dotr(IC_D{}, rw2t, Vp + R::LAM) * da;
+    if (!c.k0) dpre = 0.f;
+    Vp[R::DPRE + lane] = dpre;
+    const float t = both(dotr(IC_HH{}, rw1t, Vp + R::DPRE + HH * half));
+    return rowd ? t : 0.f;
+  };
+  auto put = [&](float* Vp, int off, float v) { if (lane < DM) Vp[off + lane] = v; };
+  const size_t nst = c.nst;
+  const size_t g = c.valid ? (size_t)c.b * c.D + ldl : 0;
+  float* V0 = c.block(0);   // evaluation point tmp
+  float* V1 = c.block(1);   // evaluation point u
+  float ub = 0.f;
+  if (c.valid) {
+    auto step_src = [&](int k, float& u, float& wlo, float& whi, int& m) {
+      const int2 im = a.im[k];
+      const float* up = (k == 0) ? a.x : a.rec_u + (size_t)(k - 1) * nst;
+      u = up[g]; m = im.y;
+      if (a.dw_direct) { wlo = 0.f; whi = a.W[(size_t)im.x * nst + g]; }
+      else { wlo = a.W[(size_t)im.x * nst + g]; whi = a.W[(size_t)(im.x + im.y) * nst + g]; }
+    };
+    float u_n = 0.f, wlo_n = 0.f, whi_n = 0.f;
+    int m_n = 0;
+    if (a.K > 0) step_src(a.K - 1, u_n, wlo_n, whi_n, m_n);
+    for (int k = a.K - 1; k >= 0; --k) {
+      const float u = rowd ? u_n : 0.f;
+      const float dW = rowd ? whi_n - wlo_n : 0.f;
+      const float dt = (float)m_n * a.h;
+      if (k > 0) step_src(k - 1, u_n, wlo_n, whi_n, m_n);
+      for (int j = 0; j < a.nseries; ++j)
+        if (sk[j] == k) { const float th = sth[j]; if (th != 0.f && rowd) ub = ub + th * a.du_series[(size_t)j * nst + g]; }
+      const float hdt = dt / 2.0f;
+      // ---- forward pieces (src/perform_step.jl:175,179,183) ----
+      put(V1, R::X, u);
+      float hv1, da1, hv0, da0;
+      hidden(V1, hv1, da1);
+      const float du1 = f_out(V1);
+      const float L = g_out(V1 + R::X);
+      const float tmp = rowd ? (u + dt * du1) + L * dW : 0.f;
+      const float fb2 = hdt * ub, gb2v = (0.5f * dW) * ub;
+      put(V0, R::X, tmp); put(V0, R::LAM, fb2); put(V0, R::LAMG, gb2v);
+      hidden(V0, hv0, da0);
+      // ---- second half backwards: cotangent of tmp ----
+      const float dtf = drift_vjp(V0, da0);
+      const float dtg = wgt_x(V0 + R::LAMG);
+      const float tb = dtf + dtg;
+      const float du1b = hdt * ub + dt * tb;
+      const float Lb = (0.5f * dW) * ub + dW * tb;
+      const float up_ = ub + tb;
+      put(V1, R::LAM, du1b); put(V1, R::LAMG, Lb);
+      const float duf = drift_vjp(V1, da1);
+      const float dug = wgt_x(V1 + R::LAMG);
+      ub = rowd ? (up_ + duf) + dug : 0.f;
+      float* hr = a.hist + ((size_t)k * a.B + c.b) * 2 * R::HREC;
+      c.store_hist(hr, V0);
+      c.store_hist(hr + R::HREC, V1);
+      for (int j = 0; j < a.nseries; ++j)
+        if (sk[j] == k) { const float th = sth[j]; if (th != 1.0f && rowd) ub = ub + (1.0f - th) * a.du_series[(size_t)j * nst + g]; }
+    }
+    for (int j = 0; j < a.nseries; ++j)   // a saved start value is the input itself
+      if (sk[j] < 0 && rowd) ub = ub + a.du_series[(size_t)j * nst + g];
+    if (lane < c.D) a.dx[g] = ub;
+  }
+  SBF_STAMP(2, 2);
+  SBF_STAMP(2, 3);
+}
+
 // The parameter cotangent from the sweep's history: record r = {x (DM), dpre (HM), h (HM), lam (DM), lam_g (DM)} of one
 // (step, sample, evaluation point); dW1 += dpre x^T, dW2 += lam h^T, dWg += lam_g x^T, the biases += dpre, lam, lam_g.  A wave
 // takes records gw, gw + (waves of the grid), ... in that order with the accumulators of SbfR::accumulate (lane h: row h of

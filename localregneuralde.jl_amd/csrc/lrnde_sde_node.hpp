@@ -462,7 +462,8 @@ int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float*
     }
     a.hist = s->bwf_hist; a.nrec = (int)nrec;
     const size_t smr = SbfR<32, 64>::smem_bytes(2, 1, 1);   // (no cotangent vector in this kernel)
-    hipLaunchKernelGGL((k_sde_eh_bwd_fused_r<32, 64, true>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
+    if (opt(OPT_SDE_BWD_NO_RESIDENT)) hipLaunchKernelGGL((k_sde_eh_bwd_fused_r<32, 64, true>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
+    else hipLaunchKernelGGL((k_sde_eh_bwd_sweep_res<32, 64>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
     const size_t smg = sizeof(float) * std::max((size_t)32 * SbfR<32, 64>::HREC, sbf_acc_floats(D, H));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_bwd_hist_gemm<32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smg));
     hipLaunchKernelGGL((k_sde_bwd_hist_gemm<32, 64>), dim3(ngw), dim3(SBF_NT), smg, c->stream, a);

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"LRNDE_NO_QTILE": 0, "LRNDE_QTILE_MAX_B": 2048, "LRNDE_NO_FUSE": 0, "LRNDE_DENSE_COPY": 0, "LRNDE_NO_OVERLAP": 0,
             "LRNDE_NO_SDE_FAST": 0, "LRNDE_SDE_HOST_LOOP": 0, "LRNDE_NO_QVJP": 0, "LRNDE_ADJ_ERR_ONE_LAUNCH": 0, "LRNDE_ADJ_MU_FOLD": 0,
-            "LRNDE_ADJ_HOST": 0, "LRNDE_VJP_QCOLS": 4, "LRNDE_ADJ_OVERLAP": 0, "LRNDE_PGRAD_TS": 0, "LRNDE_ADJ_NO_REUSE": 0, "LRNDE_SDE_NO_PERSIST": 0, "LRNDE_SDE_HOST_INITDT": 0, "LRNDE_SDE_BWD_LDSACC": 0, "LRNDE_SDE_BWD_NO_DEFER": 0, "LRNDE_SDE_NO_MARCH": 0, "LRNDE_NO_SDE_BWD_FUSED": 0,
+            "LRNDE_ADJ_HOST": 0, "LRNDE_VJP_QCOLS": 4, "LRNDE_ADJ_OVERLAP": 0, "LRNDE_PGRAD_TS": 0, "LRNDE_ADJ_NO_REUSE": 0, "LRNDE_SDE_NO_PERSIST": 0, "LRNDE_SDE_HOST_INITDT": 0, "LRNDE_SDE_BWD_LDSACC": 0, "LRNDE_SDE_BWD_NO_DEFER": 0, "LRNDE_SDE_BWD_NO_RESIDENT": 0, "LRNDE_SDE_NO_MARCH": 0, "LRNDE_NO_SDE_BWD_FUSED": 0,
             "LRNDE_FEED_T": 3, "LRNDE_FEED_E": 1, "LRNDE_FEED_M": 2}
 
 
@@ -137,7 +137,7 @@ def _sde_layer_pass(P, mode):
 
 
 @pytest.mark.parametrize("switch", [{"LRNDE_SDE_HOST_INITDT": 1}, {"LRNDE_SDE_NO_PERSIST": 1}, {"LRNDE_SDE_HOST_LOOP": 1}, {"LRNDE_NO_SDE_FAST": 1},
-                                    {"LRNDE_SDE_BWD_LDSACC": 1}, {"LRNDE_SDE_BWD_NO_DEFER": 1}],
+                                    {"LRNDE_SDE_BWD_LDSACC": 1}, {"LRNDE_SDE_BWD_NO_DEFER": 1}, {"LRNDE_SDE_BWD_NO_RESIDENT": 1}],
                          ids=lambda d: "+".join(k[6:] for k in d))
 @pytest.mark.parametrize("mode", ["unbiased", "biased", "none"])
 def test_sde_layer_switch_gives_the_default_bits(gpu_pkg, options, switch, mode):
@@ -148,7 +148,7 @@ def test_sde_layer_switch_gives_the_default_bits(gpu_pkg, options, switch, mode)
     for k, v in switch.items():
         options(k, v)
     got = _sde_layer_pass(gpu_pkg, mode)
-    if "LRNDE_NO_SDE_FAST" in switch or "LRNDE_SDE_BWD_LDSACC" in switch or "LRNDE_SDE_BWD_NO_DEFER" in switch:   # the other pullbacks add the parameter gradients in another order
+    if "LRNDE_NO_SDE_FAST" in switch or "LRNDE_SDE_BWD_LDSACC" in switch or "LRNDE_SDE_BWD_NO_DEFER" in switch or "LRNDE_SDE_BWD_NO_RESIDENT" in switch:   # the other pullbacks add the parameter gradients in another order
         for k in ("bw_dx", "bw_dp_drift", "bw_dp_diff"):
             x, y = base.pop(k), got.pop(k)
             assert np.allclose(x, y, rtol=2e-5, atol=2e-5 * float(np.abs(x).max())), (switch, mode, k)
