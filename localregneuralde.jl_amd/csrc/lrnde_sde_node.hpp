@@ -405,6 +405,15 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
 namespace {
 // the reverse sweep over the recorded steps as one launch + the fixed-order sum of the workgroups' partials
 // (lrnde_sde_bwd_fused.hpp); what remains for the caller is the regulariser's part
+// a kernel's dynamic-LDS limit, raised only when it has to grow (the call is a few microseconds of host time: not per launch)
+#define SDE_LDS_LIMIT(c, kern, bytes)                                                                                        \
+  do {                                                                                                                       \
+    static size_t lim_ = 64 * 1024;                                                                                          \
+    if ((size_t)(bytes) > lim_) {                                                                                            \
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+      lim_ = (size_t)(bytes);                                                                                                \
+    }                                                                                                                        \
+  } while (0)
 int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float* du_series, float* dx, float* dp_drift, float* dp_diff,
                          bool sync_after) {
   const int nseries = r.nseries;
@@ -465,18 +474,18 @@ int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float*
     if (opt(OPT_SDE_BWD_NO_RESIDENT)) hipLaunchKernelGGL((k_sde_eh_bwd_fused_r<32, 64, true>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
     else hipLaunchKernelGGL((k_sde_eh_bwd_sweep_res<32, 64>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
     const size_t smg = sizeof(float) * std::max((size_t)32 * SbfR<32, 64>::HREC, sbf_acc_floats(D, H));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_bwd_hist_gemm<32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smg));
+    SDE_LDS_LIMIT(c, (k_sde_bwd_hist_gemm<32, 64>), smg);
     hipLaunchKernelGGL((k_sde_bwd_hist_gemm<32, 64>), dim3(ngw), dim3(SBF_NT), smg, c->stream, a);
     nwg_red = ngw;
   } else if (D <= 32 && H <= 64 && !opt(OPT_SDE_BWD_LDSACC)) {
     // compile-time sizes, the parameter cotangent in registers, no barrier inside the sweep
     const size_t smr = SbfR<32, 64>::smem_bytes(2, D, H);
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_bwd_fused_r<32, 64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr));
+    SDE_LDS_LIMIT(c, (k_sde_eh_bwd_fused_r<32, 64, false>), smr);
     hipLaunchKernelGGL((k_sde_eh_bwd_fused_r<32, 64>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
   } else {
     const size_t sm = sbf_smem_bytes(D, H, 2);
     // (the kernel also has 4 KB of static LDS: the limit asked for is what this launch needs, not the CU's 160 KB)
-    if (sm > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_bwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    SDE_LDS_LIMIT(c, k_sde_eh_bwd_fused, sm);
     hipLaunchKernelGGL(k_sde_eh_bwd_fused, dim3(nwg), dim3(SBF_NT), sm, c->stream, a);
   }
   hipLaunchKernelGGL(k_sde_bwd_reduce, dim3((Ptot + 31) / 32), dim3(256), 0, c->stream, (const float*)s->bwf_part, nwg_red, Ptot, Pf, Pg, dp_drift, dp_diff, 1.0f, 0);
@@ -504,11 +513,11 @@ int sde_node_reg_fused(lrnde_sde* s, SdeNodeRecord& r, int B, float w_reg, float
   a.abstol = r.o.abstol; a.reltol = r.o.reltol; a.delta = r.o.delta;
   if (D <= 32 && H <= 64 && !opt(OPT_SDE_BWD_LDSACC)) {
     const size_t smr = SbfR<32, 64>::smem_bytes(3, D, H);
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_reg_fused_r<32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr));
+    SDE_LDS_LIMIT(c, (k_sde_eh_reg_fused_r<32, 64>), smr);
     hipLaunchKernelGGL((k_sde_eh_reg_fused_r<32, 64>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
   } else {
     const size_t sm = sbf_smem_bytes(D, H, 3);
-    if (sm > 64 * 1024) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sde_eh_reg_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    SDE_LDS_LIMIT(c, k_sde_eh_reg_fused, sm);
     hipLaunchKernelGGL(k_sde_eh_reg_fused, dim3(nwg), dim3(SBF_NT), sm, c->stream, a);
   }
   hipLaunchKernelGGL(k_sde_bwd_reduce, dim3((Ptot + 31) / 32), dim3(256), 0, c->stream, (const float*)s->bwf_part, nwg, Ptot, Pf, Pg, dp_drift, dp_diff, w_reg, 1);
