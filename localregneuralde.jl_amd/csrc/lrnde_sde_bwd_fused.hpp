@@ -674,64 +674,100 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_bwd_sweep_res(SdeBwdFusedArgs
 }
 
 // The parameter cotangent from the sweep's history: record r = {x (DM), dpre (HM), h (HM), lam (DM), lam_g (DM)} of one
-// (step, sample, evaluation point); dW1 += dpre x^T, dW2 += lam h^T, dWg += lam_g x^T, the biases += dpre, lam, lam_g.  A wave
-// takes records gw, gw + (waves of the grid), ... in that order with the accumulators of SbfR::accumulate (lane h: row h of
-// dW1, column h of dW2; lane j: column j of dWg), the row vectors through wave-uniform loads; waves -> workgroup vector in
-// wave order -> one partial per workgroup -> k_sde_bwd_reduce.  Full occupancy: this is where the sweep's 96 accumulators
-// per lane went.
+// (step, sample, evaluation point); dW1 = sum dpre x^T (H x D), dW2 = sum lam h^T (D x H), dWg = sum lam_g x^T (D x D), the
+// biases = sum dpre, lam, lam_g — three GEMMs whose inner dimension is the record index: v_mfma_f32_16x16x4_f32, four records
+// per instruction (A[i][k] = left vector of record k, B[k][j] = right vector).  A workgroup takes a contiguous chunk of the
+// records in batches of 32 through LDS (record stride 232 floats: the four k-groups of a fragment read land on different bank
+// octets), the next batch's quads in registers while this one is worked on; the 20 output tiles (8 + 8 + 4) go five to a wave,
+// every tile owned by ONE wave — no cross-wave sum — and leave as the workgroup's partial straight from the C fragments
+// (k_sde_bwd_reduce adds the partials).  The biases: waves 0..2 add one vector each over the batch.  Sums: the MFMA's k-ordered
+// chain over the records of the chunk, in order.  (The VALU form this replaces: 21 us for 31 744 records; the stamps showed it
+// issue-bound with one wave per SIMD.)
+constexpr int SBF_GEMM_BATCH = 32, SBF_GEMM_RS = 232;
 template <int DM, int HM>
 __global__ __launch_bounds__(SBF_NT) void k_sde_bwd_hist_gemm(SdeBwdFusedArgs a) {
+  static_assert(DM == 32 && HM == 64, "tile assignment");
   using R = SbfR<DM, HM>;
-  constexpr int NBATCH = 32, Q = R::HREC / 4;   // records per batch; 16-byte quads per record
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [Ptot] the workgroup's vector, then [NBATCH][HREC] the batch
+  constexpr int NBATCH = SBF_GEMM_BATCH, Q = R::HREC / 4, RS = SBF_GEMM_RS;   // records per batch; 16-byte quads per record; LDS stride of a record
+  extern __shared__ __attribute__((aligned(16))) float bat[];   // [NBATCH][RS]
   const int tid = threadIdx.x, lane = tid & 63;
   const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = a.D, H = a.H, Ptot = a.Ptot;
   SBF_STAMP(1, 0);
-  float* bat = sm;   // [NBATCH][HREC] the batch; the workgroup's padded vector reuses the space at the end
-  float g1[DM], g2[DM], gg[DM], gb1 = 0.f, gb2 = 0.f, gbg = 0.f;
+  // tiles: job t < 8: dW1 tile (mt = t >> 1 of H, nt = t & 1 of D); 8 <= t < 16: dW2 tile (mt = (t - 8) >> 2 of D, nt = (t - 8) & 3 of H);
+  // 16 <= t < 20: dWg tile (mt, nt of D).  Wave w owns jobs w, w + 4, ..., w + 16: two of dW1, two of dW2, one of dWg.
+  int offA[5], offB[5];
 #pragma unroll
-  for (int d = 0; d < DM; ++d) { g1[d] = 0.f; g2[d] = 0.f; gg[d] = 0.f; }
-  // this workgroup's records: a contiguous chunk, batches of NBATCH staged through LDS (all threads load, 16 bytes each, several
-  // in flight), wave w takes records w, w + 4, ... of the batch
+  for (int q = 0; q < 5; ++q) {
+    const int t = sw + 4 * q;
+    if (t < 8) { offA[q] = R::DPRE + 16 * (t >> 1); offB[q] = R::X + 16 * (t & 1); }
+    else if (t < 16) { offA[q] = R::LAM + 16 * ((t - 8) >> 2); offB[q] = R::HV + 16 * ((t - 8) & 3); }
+    else { offA[q] = R::LAMG + 16 * ((t - 16) >> 1); offB[q] = R::X + 16 * ((t - 16) & 1); }
+  }
+  f32x4 acc[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bs0 = 0.f;   // waves 0..2: this lane's entry of b1 (lane h) / b2 / bg (lane d < 32)
   const int per = (a.nrec + (int)gridDim.x - 1) / (int)gridDim.x;
   const int r0 = (int)blockIdx.x * per, r1 = min(a.nrec, r0 + per);
-  const int lx = lane < DM ? lane : 0;
-  for (int b0 = r0; b0 < r1; b0 += NBATCH) {
+  constexpr int NQ = (NBATCH * Q + SBF_NT - 1) / SBF_NT;
+  f32x4 pre[NQ];
+  auto fetch = [&](int b0) {
     const int nb = min(NBATCH, r1 - b0);
-    __syncthreads();
     const f32x4* src = reinterpret_cast<const f32x4*>(a.hist + (size_t)b0 * R::HREC);
-    f32x4* dst = reinterpret_cast<f32x4*>(bat);
-    for (int i0 = tid; i0 < nb * Q; i0 += SBF_NT * 4) {
-      f32x4 v[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const int i = i0 + q * SBF_NT; if (i < nb * Q) v[q] = src[i]; }
+    for (int q = 0; q < NQ; ++q) { const int i = tid + q * SBF_NT; pre[q] = i < nb * Q ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
+  };
+  if (r0 < r1) fetch(r0);
+  const int kl = lane >> 4, il = lane & 15;   // this lane's record of a k-step and its row / column of a fragment
+  const int ld = lane < DM ? lane : 0;
+  for (int b0 = r0; b0 < r1; b0 += NBATCH) {
+    __syncthreads();
+    // quad i of the batch = record i / Q, quad i % Q; records beyond nb are written as zeros (they add nothing)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const int i = i0 + q * SBF_NT; if (i < nb * Q) dst[i] = v[q]; }
+    for (int q = 0; q < NQ; ++q) {
+      const int i = tid + q * SBF_NT;
+      if (i < NBATCH * Q) { const int rr = i / Q, qq = i - rr * Q; *reinterpret_cast<f32x4*>(bat + rr * RS + 4 * qq) = pre[q]; }
     }
     __syncthreads();
-    for (int j = sw; j < nb; j += SBF_NS) {
-      const float* rec = bat + j * R::HREC;
-      const float dpre = rec[R::DPRE + lane], hv = rec[R::HV + lane];
-      float xl = rec[R::X + lx], laml = rec[R::LAM + lx], lamgl = rec[R::LAMG + lx];
-      if (lane >= DM) { xl = 0.f; laml = 0.f; lamgl = 0.f; }
+    if (b0 + NBATCH < r1) fetch(b0 + NBATCH);
+#pragma unroll 2
+    for (int k0 = 0; k0 < NBATCH; k0 += 4) {
+      const float* rec = bat + (k0 + kl) * RS + il;
 #pragma unroll
-      for (int d = 0; d < DM; d += 4) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(rec + R::X + d);
-        const f32x4 lv = *reinterpret_cast<const f32x4*>(rec + R::LAM + d);
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(rec + R::LAMG + d);
+      for (int q = 0; q < 5; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(rec[offA[q]], rec[offB[q]], acc[q], 0, 0, 0);
+    }
+    if (sw < 3) {   // the biases: wave 0 adds dpre (b1), wave 1 lam (b2), wave 2 lam_g (bg) over the batch, eight reads in flight
+      const float* col = bat + (sw == 0 ? R::DPRE + lane : (sw == 1 ? R::LAM + ld : R::LAMG + ld));
+      for (int j = 0; j < NBATCH; j += 8) {   // (records beyond nb are zeros)
+        float v[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          g1[d + q] = fma_(dpre, xv[q], g1[d + q]);
-          g2[d + q] = fma_(hv, lv[q], g2[d + q]);
-          gg[d + q] = fma_(xl, gv[q], gg[d + q]);
-        }
+        for (int q = 0; q < 8; ++q) v[q] = col[(j + q) * RS];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bs0 = bs0 + v[q];
       }
-      gb1 = gb1 + dpre; gb2 = gb2 + laml; gbg = gbg + lamgl;
     }
   }
   SBF_STAMP(1, 1);
-  sbf_sum_out<DM>(sm, g1, g2, gg, gb1, gb2, gbg, D, H, a.Pf, Ptot, a.part);
+  // C fragment of a tile: rows 16 mt + 4 (lane >> 4) + r, column 16 nt + (lane & 15); flat layouts are column-major
+  float* pp = a.part + (size_t)blockIdx.x * Ptot;
+  const int n1 = H * D, n2 = n1 + H, n3 = n2 + D * H, n4 = a.Pf, n5 = n4 + D * D;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int t = sw + 4 * q;
+    int base, ldm, nrow, ncol, mt, nt;
+    if (t < 8) { base = 0; ldm = H; nrow = H; ncol = D; mt = t >> 1; nt = t & 1; }
+    else if (t < 16) { base = n2; ldm = D; nrow = D; ncol = H; mt = (t - 8) >> 2; nt = (t - 8) & 3; }
+    else { base = n4; ldm = D; nrow = D; ncol = D; mt = (t - 16) >> 1; nt = (t - 16) & 1; }
+    const int col = 16 * nt + il, row0 = 16 * mt + 4 * kl;
+    if (col < ncol) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (row0 + r < nrow) pp[base + (row0 + r) + ldm * col] = acc[q][r];
+    }
+  }
+  if (sw == 0 && lane < H) pp[n1 + lane] = bs0;
+  if (sw == 1 && lane < D) pp[n3 + lane] = bs0;
+  if (sw == 2 && lane < D) pp[n5 + lane] = bs0;
   SBF_STAMP(1, 2);
   SBF_STAMP(1, 3);
 }

@@ -461,7 +461,7 @@ int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float*
       HIPCHK(c, hipMalloc(&s->bwf_hist, sizeof(float) * nh));
       s->bwf_hist_n = nh;
     }
-    const int ngw = 256;
+    const int ngw = 512;   // (two resident workgroups per CU take turns waiting for their batches)
     if (s->bwf_part_n < (size_t)ngw * Ptot) {
       HIPCHK(c, hipFree(s->bwf_part));
       s->bwf_part = nullptr; s->bwf_part_n = 0;
@@ -473,7 +473,7 @@ int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float*
     const size_t smr = SbfR<32, 64>::smem_bytes(2, 1, 1);   // (no cotangent vector in this kernel)
     if (opt(OPT_SDE_BWD_NO_RESIDENT)) hipLaunchKernelGGL((k_sde_eh_bwd_fused_r<32, 64, true>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
     else hipLaunchKernelGGL((k_sde_eh_bwd_sweep_res<32, 64>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
-    const size_t smg = sizeof(float) * std::max((size_t)32 * SbfR<32, 64>::HREC, sbf_acc_floats(D, H));
+    const size_t smg = sizeof(float) * (size_t)SBF_GEMM_BATCH * SBF_GEMM_RS;
     SDE_LDS_LIMIT(c, (k_sde_bwd_hist_gemm<32, 64>), smg);
     hipLaunchKernelGGL((k_sde_bwd_hist_gemm<32, 64>), dim3(ngw), dim3(SBF_NT), smg, c->stream, a);
     nwg_red = ngw;
