@@ -17,7 +17,7 @@ struct SdeSweepSrc {
   int nseries; const int* ser_k; const float* ser_theta;   // host arrays: which step a cotangent's state was taken in, and where
 };
 int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float* du_series, float* dx, float* dp_drift, float* dp_diff,
-                         bool sync_after = true);
+                         bool sync_after = true, struct SdeNodeRecord* reg = nullptr, float w_reg = 0.f, bool* reg_done = nullptr);
 bool sde_bwd_fused_ok(const lrnde_sde* s, int nseries);
 
 // forward pieces of a step recomputed for the backward sweep (src/perform_step.jl:175,179,183) and the cotangent seeds

@@ -52,6 +52,7 @@ struct SdeBwdFusedArgs {
   // the deferred form of the sweep (k_sde_eh_bwd_fused_r<.., true> + k_sde_bwd_hist_gemm): one record of SbfR::HREC floats per
   // (step, sample, evaluation point) — x, dpre, h, lam, lam_g — from which the parameter cotangent is formed after the sweep
   float* hist; int nrec;
+  int rec0; float w_reg;   // the regulariser's kernel in the deferred form: its first record, the weight its seeds carry
 };
 
 // offsets inside a sample's vector block of one evaluation point: x (D), the constant 1, dpre (H), h (H), lam (D), lam_g (D)
@@ -773,13 +774,16 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_bwd_hist_gemm(SdeBwdFusedArgs a)
 }
 
 // k_sde_eh_reg_fused in that form.  Evaluation points: 0 = (K for the drift, utilde for the diffusion), 1 = tmp, 2 = uprev.
-template <int DM, int HM>
+// DEFER: the step's cotangents are seeded with w_reg and its records join the sweep's history (four per sample: evaluation point 0
+// leaves two, one for the drift at K and one for the diffusion at utilde — a record has ONE x), so that the sweep's GEMM and
+// reduction cover the regulariser too: no closing sum here, no second reduction.
+template <int DM, int HM, bool DEFER = false>
 __global__ __launch_bounds__(SBF_NT) void k_sde_eh_reg_fused_r(SdeBwdFusedArgs a) {
   using R = SbfR<DM, HM>;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   SBF_STAMP(0, 0);
   R c;
-  c.setup(a, sm, 3);
+  c.setup(a, sm, DEFER ? 4 : 3);
   SBF_STAMP(0, 1);
   const bool row = c.row;
   const size_t g = c.g;
@@ -809,7 +813,8 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_reg_fused_r(SdeBwdFusedArgs a
       const float sc = a.abstol + fmaxf_(__builtin_fabsf(u), __builtin_fabsf(un)) * a.reltol;
       const float num = a.delta * Ed + En;
       const float r = num / sc;
-      const float rb = (a.eest > 0.f) ? dt * r / (nf * a.eest) : 0.f;   // reg = dt * sqrt(mean r^2)
+      float rb = (a.eest > 0.f) ? dt * r / (nf * a.eest) : 0.f;   // reg = dt * sqrt(mean r^2)
+      if constexpr (DEFER) rb = a.w_reg * rb;
       const float numb = rb / sc;
       const float scb = -rb * num / (sc * sc);
       unb = (__builtin_fabsf(un) > __builtin_fabsf(u)) ? scb * a.reltol * (un >= 0.f ? 1.f : -1.f) : 0.f;
@@ -834,12 +839,20 @@ __global__ __launch_bounds__(SBF_NT) void k_sde_eh_reg_fused_r(SdeBwdFusedArgs a
     // f, g at uprev: only their parameter cotangents count
     c.put(V2, R::LAM, du1b); c.put(V2, R::LAMG, Lb);
     (void)c.drift_vjp(V2, dau, dpreu);
-    c.accumulate(V0, dprek, hvk, ut, du2b, g3b);
-    c.accumulate(V1, dpret, hvt, tmp, fb2, gb2v);
-    c.accumulate(V2, dpreu, hvu, u, du1b, Lb);
+    if constexpr (DEFER) {
+      float* V3 = c.block(3);   // (zeroed by setup) the diffusion's record of evaluation point 0: x = utilde, lam_g = g3b
+      c.put(V3, R::X, ut); c.put(V3, R::LAMG, g3b);
+      c.put(V0, R::LAMG, 0.f);  // ... and the drift's: x = K, no lam_g (every product that reads it is done)
+      float* hr = a.hist + ((size_t)a.rec0 + (size_t)c.b * 4) * R::HREC;
+      c.store_hist(hr, V0); c.store_hist(hr + R::HREC, V3); c.store_hist(hr + 2 * R::HREC, V1); c.store_hist(hr + 3 * R::HREC, V2);
+    } else {
+      c.accumulate(V0, dprek, hvk, ut, du2b, g3b);
+      c.accumulate(V1, dpret, hvt, tmp, fb2, gb2v);
+      c.accumulate(V2, dpreu, hvu, u, du1b, Lb);
+    }
   }
   SBF_STAMP(0, 2);
-  c.finish(a.part);
+  if constexpr (!DEFER) c.finish(a.part);
   SBF_STAMP(0, 3);
 }
 

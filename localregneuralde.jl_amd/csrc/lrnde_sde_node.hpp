@@ -414,8 +414,11 @@ namespace {
       lim_ = (size_t)(bytes);                                                                                                \
     }                                                                                                                        \
   } while (0)
+// reg (may be NULL): the layer's record when the regulariser's local step is to ride in the deferred form (its records behind
+// the sweep's, one GEMM and one reduction for both); *reg_done tells the caller whether it did
 int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float* du_series, float* dx, float* dp_drift, float* dp_diff,
-                         bool sync_after) {
+                         bool sync_after, SdeNodeRecord* reg, float w_reg, bool* reg_done) {
+  if (reg_done) *reg_done = false;
   const int nseries = r.nseries;
   lrnde_ctx* c = s->drift;
   const int D = c->desc.state_dim, H = c->desc.hidden_dim;
@@ -454,7 +457,7 @@ int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float*
   if (D <= 32 && H <= 64 && !opt(OPT_SDE_BWD_LDSACC) && !opt(OPT_SDE_BWD_NO_DEFER) && r.K > 0) {
     // the MNIST-SDE shape class, deferred form: the sweep leaves a record per (step, sample, evaluation point) and the parameter
     // cotangent is formed from the records afterwards at full occupancy (LRNDE_SDE_BWD_NO_DEFER=1: accumulators in the sweep)
-    const size_t nrec = (size_t)r.K * B * 2, nh = nrec * SbfR<32, 64>::HREC;
+    const size_t nrec_sweep = (size_t)r.K * B * 2, nrec = nrec_sweep + (reg ? (size_t)4 * B : 0), nh = nrec * SbfR<32, 64>::HREC;
     if (s->bwf_hist_n < nh) {
       if (s->bwf_hist) HIPCHK(c, hipFree(s->bwf_hist));
       s->bwf_hist = nullptr; s->bwf_hist_n = 0;
@@ -473,6 +476,16 @@ int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float*
     const size_t smr = SbfR<32, 64>::smem_bytes(2, 1, 1);   // (no cotangent vector in this kernel)
     if (opt(OPT_SDE_BWD_NO_RESIDENT)) hipLaunchKernelGGL((k_sde_eh_bwd_fused_r<32, 64, true>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
     else hipLaunchKernelGGL((k_sde_eh_bwd_sweep_res<32, 64>), dim3(nwg), dim3(SBF_NT), smr, c->stream, a);
+    if (reg) {   // the regulariser's step: four records per sample behind the sweep's, seeded with w_reg
+      SdeBwdFusedArgs g = a;
+      g.u1 = reg->u1; g.dW1 = reg->dWloc; g.un1 = reg->tmp; g.dt1 = reg->dt_loc; g.eest = reg->ee_loc;
+      g.abstol = reg->o.abstol; g.reltol = reg->o.reltol; g.delta = reg->o.delta;
+      g.rec0 = (int)nrec_sweep; g.w_reg = w_reg;
+      const size_t smg4 = SbfR<32, 64>::smem_bytes(4, 1, 1);
+      SDE_LDS_LIMIT(c, (k_sde_eh_reg_fused_r<32, 64, true>), smg4);
+      hipLaunchKernelGGL((k_sde_eh_reg_fused_r<32, 64, true>), dim3(nwg), dim3(SBF_NT), smg4, c->stream, g);
+      if (reg_done) *reg_done = true;
+    }
     const size_t smg = sizeof(float) * (size_t)SBF_GEMM_BATCH * SBF_GEMM_RS;
     SDE_LDS_LIMIT(c, (k_sde_bwd_hist_gemm<32, 64>), smg);
     hipLaunchKernelGGL((k_sde_bwd_hist_gemm<32, 64>), dim3(ngw), dim3(SBF_NT), smg, c->stream, a);
@@ -494,11 +507,11 @@ int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float*
   return LRNDE_OK;
 }
 int sde_node_sweep_fused(lrnde_sde* s, SdeNodeRecord& r, int B, const float* du_series, int nseries, float* dx, float* dp_drift,
-                         float* dp_diff, bool sync_after) {
+                         float* dp_diff, bool sync_after, bool reg, float w_reg, bool* reg_done) {
   std::vector<int> sk(nseries); std::vector<float> sth(nseries);
   for (int j = 0; j < nseries; ++j) { sk[j] = r.series[j].k; sth[j] = r.series[j].theta; }
   SdeSweepSrc src{r.K, r.im.data(), r.h, r.x, r.rec_u, r.W, 0, nseries, sk.data(), sth.data()};
-  return sde_sweep_fused_core(s, src, B, du_series, dx, dp_drift, dp_diff, sync_after);
+  return sde_sweep_fused_core(s, src, B, du_series, dx, dp_drift, dp_diff, sync_after, reg ? &r : nullptr, w_reg, reg_done);
 }
 // the regulariser's parameter cotangent, w_reg * d(EEst*dt)/dp of the recorded local step, ADDED to dp_drift / dp_diff
 int sde_node_reg_fused(lrnde_sde* s, SdeNodeRecord& r, int B, float w_reg, float* dp_drift, float* dp_diff) {
@@ -557,7 +570,11 @@ int lrnde_sde_node_backward_recorded(lrnde_sde* s, int32_t B, const float* du_se
   const bool fused = sde_bwd_fused_ok(s, nseries);
   // (the regulariser's one-launch kernel follows on the stream and ends in the call's one synchronisation)
   const bool reg_fused = r.mode != LRNDE_MODE_NONE && w_reg != 0.0f && fused && sbf_smem_bytes(D, c->desc.hidden_dim, 3) + 1024 <= 160 * 1024;
-  if (fused) { if ((rc = sde_node_sweep_fused(s, r, B, du_series, nseries, dx, dp_drift, dp_diff, !reg_fused))) return rc; }
+  bool reg_done = false;
+  if (fused) {
+    if ((rc = sde_node_sweep_fused(s, r, B, du_series, nseries, dx, dp_drift, dp_diff, !reg_fused, reg_fused, w_reg, &reg_done))) return rc;
+    if (reg_done) HIPCHK(c, hipStreamSynchronize(c->stream));   // (the sweep left the closing wait to the regulariser's part)
+  }
   else {
   HIPCHK(c, hipMemsetAsync(dx, 0, sizeof(float) * n, c->stream));   // dx doubles as ub, the cotangent of the current step's end state
   HIPCHK(c, hipMemsetAsync(dp_drift, 0, sizeof(float) * Pf, c->stream));
@@ -594,7 +611,8 @@ int lrnde_sde_node_backward_recorded(lrnde_sde* s, int32_t B, const float* du_se
   HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   // the regulariser (w.r.t. the parameters only: the local step's integrator is a constant of the tape, neural_sde.jl:42)
-  if (reg_fused) {
+  if (reg_done) {   // (its records rode behind the sweep's: one GEMM, one reduction)
+  } else if (reg_fused) {
     if ((rc = sde_node_reg_fused(s, r, B, w_reg, dp_drift, dp_diff))) return rc;
   } else if (r.mode != LRNDE_MODE_NONE && w_reg != 0.0f) {
     float rv = 0.f;

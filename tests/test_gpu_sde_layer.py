@@ -139,6 +139,32 @@ def test_adaptive_layer_pullback_matches_float64_autograd(oracle, gpu_pkg, D, H,
         assert v < 5e-6, (k, v)
 
 
+@pytest.mark.parametrize("D,H,B,tol,nfine,mode", [(32, 64, 64, 0.14, 64, "unbiased"), (32, 64, 512, 0.14, 128, "biased"), (20, 48, 9, 0.05, 64, "unbiased"),
+                                                  (72, 32, 6, 0.1, 32, "unbiased")])
+def test_adaptive_layer_regulariser_gradient_alone_matches_float64_autograd(oracle, gpu_pkg, D, H, B, tol, nfine, mode):
+    """zero cotangents on the series, w_reg = 1: what comes back is d reg_val / d ps alone (beside the series' cotangents it is a few
+    1e-7 of the gradient — a regulariser counted twice would pass the test above), and d reg_val / d x is exactly zero
+    (test/runtests.jl:388-392: `=== nothing`)"""
+    h, drift, diff, pd, pg, x, W, z = _setup(gpu_pkg, oracle, D, H, B, nfine, seed=33, scale=1.5)
+    xd, Wd, zd = torch.from_numpy(x).cuda(), torch.from_numpy(W).cuda(), torch.from_numpy(z).cuda()
+    # an explicit initial dt: the automatic one of these fields is ~1e-6 and reg_val ~ dt^2.5 would be below 1e-15
+    kw = dict(mode=mode, t1_or_rand=0.41, saveat=(), save_start=-1, dt0=0.05)
+    got = h.node_forward_record(xd, Wd, 0.0, 1.0, tol, tol, z_local=zd, **kw)
+    ref = oracle.sde_node_forward(drift, diff, x, W, 0.0, 1.0, tol, tol, z_local=z, **kw)
+    _check_forward(got, ref, str(kw))
+    assert float(ref["reg_val"]) > 1e-6
+    ns = len(ref["t"])
+    du = np.zeros((ns, B, D), f32)
+    bw = h.node_backward_recorded(torch.from_numpy(du).cuda(), w_reg=1.0)
+    gx, gpd, gpg = _autograd64(pd, pg, D, H, x, W, ref, du, 1.0, tol)
+    assert not bw["dx"].cpu().numpy().any()
+    assert np.abs(gpd).max() > 0 and np.abs(gpg).max() > 0
+    for k, a, b in (("dp_drift", bw["dp_drift"], gpd), ("dp_diff", bw["dp_diff"], gpg)):
+        e = _rel(a.cpu().numpy(), b)
+        print(f"D={D} H={H} B={B} {mode}: regulariser alone, {k} rel err {e:.2e} (max |ref| {np.abs(b).max():.3e})")
+        assert e < 2e-5, (k, e)
+
+
 @pytest.mark.parametrize("regularize", ["none", "unbiased", "biased"])
 def test_reference_testitems_on_the_toy_model(gpu_pkg, regularize):
     """test/runtests.jl:340-433 — NeuralDSDE(Chain(Dense(2 => 4, gelu), Dense(4 => 2)), Dense(2 => 2); regularize, tspan = (0, 1)),
