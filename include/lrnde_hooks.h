@@ -46,7 +46,7 @@ int lrnde_last_solve_kernel_ms(lrnde_ctx* ctx, float* total_ms_host, int32_t* st
 int lrnde_set_reports(lrnde_ctx* ctx, int32_t on);
 /* Diagnostic switches, process-wide: `name` is the switch's environment-variable name (LRNDE_NO_QTILE,
  * LRNDE_QTILE_MAX_B, LRNDE_NO_FUSE, LRNDE_DENSE_COPY, LRNDE_NO_OVERLAP, LRNDE_NO_SDE_FAST, LRNDE_SDE_HOST_LOOP, LRNDE_NO_QVJP,
- * LRNDE_ADJ_ERR_ONE_LAUNCH, LRNDE_ADJ_MU_FOLD, LRNDE_ADJ_OVERLAP, LRNDE_ADJ_HOST, LRNDE_VJP_QCOLS, LRNDE_PGRAD_TS, LRNDE_ADJ_NO_REUSE, LRNDE_NO_SDE_BWD_FUSED, LRNDE_SDE_NO_PERSIST, LRNDE_SDE_HOST_INITDT, LRNDE_SDE_BWD_LDSACC, LRNDE_SDE_BWD_NO_DEFER, LRNDE_SDE_BWD_NO_RESIDENT, LRNDE_SDE_NO_MARCH, LRNDE_FEED_T / _E / _M, LRNDE_GATHER_TILES, LRNDE_FORCE_COMM); the environment gives
+ * LRNDE_ADJ_ERR_ONE_LAUNCH, LRNDE_ADJ_MU_FOLD, LRNDE_ADJ_OVERLAP, LRNDE_ADJ_HOST, LRNDE_VJP_QCOLS, LRNDE_PGRAD_TS, LRNDE_ADJ_NO_REUSE, LRNDE_NO_SDE_BWD_FUSED, LRNDE_SDE_NO_PERSIST, LRNDE_SDE_COOP_LAUNCH, LRNDE_SDE_PERSIST_STALL, LRNDE_SDE_HOST_INITDT, LRNDE_SDE_BWD_LDSACC, LRNDE_SDE_BWD_NO_DEFER, LRNDE_SDE_BWD_NO_RESIDENT, LRNDE_SDE_NO_MARCH, LRNDE_FEED_T / _E / _M, LRNDE_GATHER_TILES, LRNDE_FORCE_COMM); the environment gives
  * the initial value, this call overrides it from then on (handles created earlier pick it up at their next call, except
  * the two communicator switches, which are read when a communicator is made).  Each selects an alternative path that
  * must give the default path's bits: tests/test_gpu_switches.py runs every one of them in the GPU suite.

@@ -1885,13 +1885,13 @@ namespace {
 // path in the same process as the default one and holds the two to the same bits.
 enum {
   OPT_NO_QTILE, OPT_QTILE_MAX_B, OPT_NO_FUSE, OPT_DENSE_COPY, OPT_NO_OVERLAP, OPT_NO_SDE_FAST, OPT_SDE_HOST_LOOP, OPT_NO_QVJP,
-  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_OVERLAP, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_PGRAD_TS, OPT_ADJ_NO_REUSE, OPT_NO_SDE_BWD_FUSED, OPT_SDE_NO_PERSIST, OPT_SDE_HOST_INITDT, OPT_SDE_BWD_LDSACC, OPT_SDE_BWD_NO_DEFER, OPT_SDE_BWD_NO_RESIDENT, OPT_SDE_NO_MARCH, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
+  OPT_ADJ_ERR_ONE_LAUNCH, OPT_ADJ_MU_FOLD, OPT_ADJ_OVERLAP, OPT_ADJ_HOST, OPT_VJP_QCOLS, OPT_PGRAD_TS, OPT_ADJ_NO_REUSE, OPT_NO_SDE_BWD_FUSED, OPT_SDE_NO_PERSIST, OPT_SDE_COOP_LAUNCH, OPT_SDE_PERSIST_STALL, OPT_SDE_HOST_INITDT, OPT_SDE_BWD_LDSACC, OPT_SDE_BWD_NO_DEFER, OPT_SDE_BWD_NO_RESIDENT, OPT_SDE_NO_MARCH, OPT_FEED_T, OPT_FEED_E, OPT_FEED_M, OPT_GATHER_TILES, OPT_FORCE_COMM, N_OPT
 };
 struct OptDef { const char* name; int dflt; bool flag; };   // flag: present in the environment = 1
 const OptDef g_optdef[N_OPT] = {
     {"LRNDE_NO_QTILE", 0, true}, {"LRNDE_QTILE_MAX_B", 2048, false}, {"LRNDE_NO_FUSE", 0, true}, {"LRNDE_DENSE_COPY", 0, true},
     {"LRNDE_NO_OVERLAP", 0, true}, {"LRNDE_NO_SDE_FAST", 0, true}, {"LRNDE_SDE_HOST_LOOP", 0, true}, {"LRNDE_NO_QVJP", 0, true},
-    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_OVERLAP", 0, false}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_PGRAD_TS", 0, false}, {"LRNDE_ADJ_NO_REUSE", 0, true}, {"LRNDE_NO_SDE_BWD_FUSED", 0, true}, {"LRNDE_SDE_NO_PERSIST", 0, true}, {"LRNDE_SDE_HOST_INITDT", 0, true}, {"LRNDE_SDE_BWD_LDSACC", 0, true}, {"LRNDE_SDE_BWD_NO_DEFER", 0, true}, {"LRNDE_SDE_BWD_NO_RESIDENT", 0, true}, {"LRNDE_SDE_NO_MARCH", 0, true}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
+    {"LRNDE_ADJ_ERR_ONE_LAUNCH", 0, true}, {"LRNDE_ADJ_MU_FOLD", 0, true}, {"LRNDE_ADJ_OVERLAP", 0, false}, {"LRNDE_ADJ_HOST", 0, true}, {"LRNDE_VJP_QCOLS", 4, false}, {"LRNDE_PGRAD_TS", 0, false}, {"LRNDE_ADJ_NO_REUSE", 0, true}, {"LRNDE_NO_SDE_BWD_FUSED", 0, true}, {"LRNDE_SDE_NO_PERSIST", 0, true}, {"LRNDE_SDE_COOP_LAUNCH", 0, true}, {"LRNDE_SDE_PERSIST_STALL", 0, true}, {"LRNDE_SDE_HOST_INITDT", 0, true}, {"LRNDE_SDE_BWD_LDSACC", 0, true}, {"LRNDE_SDE_BWD_NO_DEFER", 0, true}, {"LRNDE_SDE_BWD_NO_RESIDENT", 0, true}, {"LRNDE_SDE_NO_MARCH", 0, true}, {"LRNDE_FEED_T", 3, false}, {"LRNDE_FEED_E", 1, false},
     {"LRNDE_FEED_M", 2, false}, {"LRNDE_GATHER_TILES", 0, true}, {"LRNDE_FORCE_COMM", 0, true}};
 int g_opt[N_OPT];
 bool g_opt_set[N_OPT];     // set by the hook: the environment no longer counts
@@ -3326,6 +3326,18 @@ __global__ void k_sde_ctl_init(SdeCtl* ctl, int m0, float dtc0) {
   *ctl = c;
 }
 
+// ... the initial dt read from the device (sde_init_dt_dev's result), quantised to the path's grid as the host does: the rerun of
+// a solve whose control block k_sde_initdt_fin had initialised
+__global__ void k_sde_ctl_init_dtdev(SdeCtl* ctl, const float* dt_dev, float h, int nfine) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float dt0 = *dt_dev;
+  int m0 = (int)(dt0 / h); if (m0 < 1) m0 = 1;
+  if (m0 > nfine) m0 = nfine;
+  SdeCtl c;
+  c.status = ST_RUNNING; c.i = 0; c.m = m0; c.cur = 0; c.naccept = 0; c.nreject = 0; c.iters = 1; c.nf = 0;
+  c.qold = 1e-4f; c.eest_last = 0.f; c.dtc = dt0;
+  *ctl = c;
+}
 // the end state of a device-controlled solve (the control block says which of the two buffers holds it) -> out
 __global__ void k_sde_pick_end(size_t n, const SdeCtl* ctl, const float* ua, const float* ub, float* out) {
   const float* src = ctl->cur ? ub : ua;
@@ -3349,7 +3361,7 @@ static int sde_adaptive_prepare(lrnde_sde* s) {   // the device-controlled loop'
 static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
                                const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
                                int32_t cap_trace, float* ua, float* ub, float* rec_u = nullptr, int2* rec_im = nullptr,
-                               int rec_cap = 0, int2* rec_im_host = nullptr, const float* dt0_dev = nullptr) {
+                               int rec_cap = 0, int2* rec_im_host = nullptr, const float* dt0_dev = nullptr, bool no_persist = false) {
   lrnde_ctx* c = s->drift;
   const size_t n = (size_t)B * c->desc.state_dim;
   int rc0 = sde_adaptive_prepare(s);
@@ -3366,7 +3378,8 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
   if (m0 > nfine) m0 = nfine;
   if (1 > o->maxiters) { st->iters = 1; st->retcode = LRNDE_MAXITERS; return fail(c, LRNDE_MAXITERS, "adaptive SDE solve stopped with retcode %d at t=%g", LRNDE_MAXITERS, (double)t0); }
   HIPCHK(c, hipMemcpyAsync(ua, u0, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
-  if (!dt0_dev)   // (dt0_dev: sde_init_dt_dev's closing launch has initialised the control block from its dt)
+  if (dt0_dev && no_persist) hipLaunchKernelGGL(k_sde_ctl_init_dtdev, dim3(1), dim3(1), 0, c->stream, s->ad_ctl, dt0_dev, h, nfine);  // (the rerun)
+  else if (!dt0_dev)   // (dt0_dev: sde_init_dt_dev's closing launch has initialised the control block from its dt)
     hipLaunchKernelGGL(k_sde_ctl_init, dim3(1), dim3(1), 0, c->stream, s->ad_ctl, m0, o->dt0);
   volatile unsigned long long* pw = s->ad_prog;
   *pw = 0ull;
@@ -3387,15 +3400,20 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
   // The whole solve as ONE cooperative launch (k_sde_eh_fast<DT, HT, true>: state and weights stay in registers, a grid barrier
   // per step) when every workgroup fits on the chip at once; LRNDE_SDE_NO_PERSIST=1, a launch the runtime refuses or more than
   // 256 workgroups: the launch-per-step loop below.  Same arithmetic, same controller: same bits.
-  bool persisted = false;
+  bool persisted = false, plain = false;
   // (under rocprofv3 a process that made a cooperative launch dies in the tool's exit handler after the trace is written —
   //  observed with ROCm 7.2; the profiler preloads its tool library, and profiled runs take the launch-per-step loop)
   static const bool profiled = [] { const char* p = getenv("LD_PRELOAD"); return p && strstr(p, "rocprofiler") != nullptr; }();
-  if (!opt(OPT_SDE_NO_PERSIST) && !profiled && nwg <= 256) {
+  if (!opt(OPT_SDE_NO_PERSIST) && !profiled && !no_persist && nwg <= 256) {
+    // up to half the chip's CUs: a plain launch (every workgroup finds a CU on an idle device; should the device be busy for longer
+    // than the barrier's 50 ms bound, the solve comes back with an error status and is rerun as the loop below);
+    // LRNDE_SDE_COOP_LAUNCH=1 or a larger grid: the cooperative API (25-30 us more per solve)
+    plain = nwg <= 128 && !opt(OPT_SDE_COOP_LAUNCH);
+    f.dbg_stall = (plain && opt(OPT_SDE_PERSIST_STALL)) ? 1 : 0;
     f.part2 = c->part;
     HIPCHK(c, hipMemsetAsync(c->part, 0, sizeof(double) * 2 * (size_t)nwg * PSTRIDE, c->stream));   // (tags of an earlier solve)
     f.jlaunch = 0;
-    const hipError_t le = sde_persist_launch(f.D, c->desc.hidden_dim, nwg, c->stream, f);
+    const hipError_t le = sde_persist_launch(f.D, c->desc.hidden_dim, nwg, c->stream, f, !plain);
     if (le == hipSuccess) persisted = true;
     else (void)hipGetLastError();   // (not resident / not supported: fall through to the loop)
   }
@@ -3443,6 +3461,8 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const SdeCtl fin = *s->ad_ctl_host;
+  if (persisted && plain && (fin.status == LRNDE_HIP_ERROR || fin.status == ST_RUNNING))   // the barrier gave up waiting (busy device): the loop
+    return sde_adaptive_device(s, u0, W, nfine, B, t0, t1, o, u_end, st, trace_host, cap_trace, ua, ub, rec_u, rec_im, rec_cap, rec_im_host, dt0_dev, true);
   if (rec_im_host && rec_im && rec_cap > 0 && fin.naccept > 0)
     memcpy(rec_im_host, s->rec_im_pin, sizeof(int2) * (size_t)(fin.naccept < rec_cap ? fin.naccept : rec_cap));
   st->naccept = fin.naccept; st->nreject = fin.nreject; st->iters = fin.iters; st->nf = fin.nf; st->eest_last = fin.eest_last;

@@ -53,6 +53,7 @@ struct SdeFastArgs {
   // march_part[(i * gridDim.x + workgroup) * PSTRIDE]: no step waits for another workgroup (nothing consumes EEst inside
   // the solve; k_sde_march_records forms every step's record afterwards, in the partial-vector order)
   int march_n; double* march_part;
+  int dbg_stall;   // test hook (LRNDE_SDE_PERSIST_STALL): the persistent form waits for one workgroup more than there are — its barrier times out
   double* part;      // per-workgroup fp64 sums of the squared residual (PSTRIDE doubles each)
   int* arrive;       // fixed-grid solve: arrival counter of the step's footer, or NULL
   Ctrl* rec;         //   ... and the record slot the last workgroup fills (EEst, EEst*dt)
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
   __syncthreads();
   SDE_STAMP(4);
   if constexpr (PERSIST) {
-    const int nwg = (int)gridDim.x;
+    const int nwg = (int)gridDim.x + a.dbg_stall;
     double* blk = a.part2 + (size_t)(it & 1) * nwg * PSTRIDE;   // (two blocks: a fast workgroup's next step must not overwrite what a slow one still reads)
     if (threadIdx.x < 64) {
       double tot = red[0];
@@ -571,30 +572,33 @@ inline void sde_fast_launch(int D, int H, int nwg, hipStream_t st, const SdeFast
   }
 }
 
-// the persistent form: a cooperative launch (all workgroups resident, or the call fails and the caller takes the launch-per-step
-// loop).  Returns the launch's hipError_t.
-template <int DT, int HT> inline hipError_t sde_persist_launch_1(int nwg, hipStream_t st, SdeFastArgs& f) {
+// the persistent form.  coop: a cooperative launch (all workgroups resident, or the call fails and the caller takes the
+// launch-per-step loop) — the API's guarantee costs 25-30 us per launch; !coop: a plain launch, for grids far smaller than the
+// chip, whose barrier is bounded (a workgroup that waits 50 ms for the others ends the solve with an error and the caller runs
+// the loop instead).  Returns the launch's hipError_t.
+template <int DT, int HT> inline hipError_t sde_persist_launch_1(int nwg, hipStream_t st, SdeFastArgs& f, bool coop) {
   void* args[] = {&f};
+  if (!coop) { hipLaunchKernelGGL((k_sde_eh_fast<DT, HT, true>), dim3(nwg), dim3(SF_NT), 0, st, f); return hipGetLastError(); }
   return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_sde_eh_fast<DT, HT, true>), dim3(nwg), dim3(SF_NT), args, 0, st);
 }
-template <int DT> inline hipError_t sde_persist_launch_h(int HT, int nwg, hipStream_t st, SdeFastArgs& f) {
+template <int DT> inline hipError_t sde_persist_launch_h(int HT, int nwg, hipStream_t st, SdeFastArgs& f, bool coop) {
   switch (HT) {
-    case 1: return sde_persist_launch_1<DT, 1>(nwg, st, f);
-    case 2: return sde_persist_launch_1<DT, 2>(nwg, st, f);
-    case 3: return sde_persist_launch_1<DT, 3>(nwg, st, f);
-    case 4: return sde_persist_launch_1<DT, 4>(nwg, st, f);
-    case 5: return sde_persist_launch_1<DT, 5>(nwg, st, f);
-    case 6: return sde_persist_launch_1<DT, 6>(nwg, st, f);
-    case 7: return sde_persist_launch_1<DT, 7>(nwg, st, f);
-    default: return sde_persist_launch_1<DT, 8>(nwg, st, f);
+    case 1: return sde_persist_launch_1<DT, 1>(nwg, st, f, coop);
+    case 2: return sde_persist_launch_1<DT, 2>(nwg, st, f, coop);
+    case 3: return sde_persist_launch_1<DT, 3>(nwg, st, f, coop);
+    case 4: return sde_persist_launch_1<DT, 4>(nwg, st, f, coop);
+    case 5: return sde_persist_launch_1<DT, 5>(nwg, st, f, coop);
+    case 6: return sde_persist_launch_1<DT, 6>(nwg, st, f, coop);
+    case 7: return sde_persist_launch_1<DT, 7>(nwg, st, f, coop);
+    default: return sde_persist_launch_1<DT, 8>(nwg, st, f, coop);
   }
 }
-inline hipError_t sde_persist_launch(int D, int H, int nwg, hipStream_t st, SdeFastArgs& f) {
+inline hipError_t sde_persist_launch(int D, int H, int nwg, hipStream_t st, SdeFastArgs& f, bool coop) {
   const int DT = (D + 15) / 16, HT = (H + 15) / 16;
   switch (DT) {
-    case 1: return sde_persist_launch_h<1>(HT, nwg, st, f);
-    case 2: return sde_persist_launch_h<2>(HT, nwg, st, f);
-    case 3: return sde_persist_launch_h<3>(HT, nwg, st, f);
-    default: return sde_persist_launch_h<4>(HT, nwg, st, f);
+    case 1: return sde_persist_launch_h<1>(HT, nwg, st, f, coop);
+    case 2: return sde_persist_launch_h<2>(HT, nwg, st, f, coop);
+    case 3: return sde_persist_launch_h<3>(HT, nwg, st, f, coop);
+    default: return sde_persist_launch_h<4>(HT, nwg, st, f, coop);
   }
 }

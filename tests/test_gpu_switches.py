@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"LRNDE_NO_QTILE": 0, "LRNDE_QTILE_MAX_B": 2048, "LRNDE_NO_FUSE": 0, "LRNDE_DENSE_COPY": 0, "LRNDE_NO_OVERLAP": 0,
             "LRNDE_NO_SDE_FAST": 0, "LRNDE_SDE_HOST_LOOP": 0, "LRNDE_NO_QVJP": 0, "LRNDE_ADJ_ERR_ONE_LAUNCH": 0, "LRNDE_ADJ_MU_FOLD": 0,
-            "LRNDE_ADJ_HOST": 0, "LRNDE_VJP_QCOLS": 4, "LRNDE_ADJ_OVERLAP": 0, "LRNDE_PGRAD_TS": 0, "LRNDE_ADJ_NO_REUSE": 0, "LRNDE_SDE_NO_PERSIST": 0, "LRNDE_SDE_HOST_INITDT": 0, "LRNDE_SDE_BWD_LDSACC": 0, "LRNDE_SDE_BWD_NO_DEFER": 0, "LRNDE_SDE_BWD_NO_RESIDENT": 0, "LRNDE_SDE_NO_MARCH": 0, "LRNDE_NO_SDE_BWD_FUSED": 0,
+            "LRNDE_ADJ_HOST": 0, "LRNDE_VJP_QCOLS": 4, "LRNDE_ADJ_OVERLAP": 0, "LRNDE_PGRAD_TS": 0, "LRNDE_ADJ_NO_REUSE": 0, "LRNDE_SDE_NO_PERSIST": 0, "LRNDE_SDE_COOP_LAUNCH": 0, "LRNDE_SDE_PERSIST_STALL": 0, "LRNDE_SDE_HOST_INITDT": 0, "LRNDE_SDE_BWD_LDSACC": 0, "LRNDE_SDE_BWD_NO_DEFER": 0, "LRNDE_SDE_BWD_NO_RESIDENT": 0, "LRNDE_SDE_NO_MARCH": 0, "LRNDE_NO_SDE_BWD_FUSED": 0,
             "LRNDE_FEED_T": 3, "LRNDE_FEED_E": 1, "LRNDE_FEED_M": 2}
 
 
@@ -99,7 +99,7 @@ def _sde_pass(P):
                 tr=np.stack([sa["trace"][f].astype(np.float64) for f in ("t", "dt", "eest", "accepted")]))
 
 
-@pytest.mark.parametrize("switch", [{"LRNDE_NO_SDE_FAST": 1}, {"LRNDE_SDE_HOST_LOOP": 1}, {"LRNDE_SDE_NO_PERSIST": 1}, {"LRNDE_SDE_NO_MARCH": 1}], ids=lambda d: "+".join(k[6:] for k in d))
+@pytest.mark.parametrize("switch", [{"LRNDE_NO_SDE_FAST": 1}, {"LRNDE_SDE_HOST_LOOP": 1}, {"LRNDE_SDE_NO_PERSIST": 1}, {"LRNDE_SDE_COOP_LAUNCH": 1}, {"LRNDE_SDE_PERSIST_STALL": 1}, {"LRNDE_SDE_NO_MARCH": 1}], ids=lambda d: "+".join(k[6:] for k in d))
 def test_sde_switch_gives_the_default_bits(gpu_pkg, options, switch):
     for k, v in DEFAULTS.items():
         gpu_pkg.set_option(k, v)
@@ -136,7 +136,7 @@ def _sde_layer_pass(P, mode):
     return out
 
 
-@pytest.mark.parametrize("switch", [{"LRNDE_SDE_HOST_INITDT": 1}, {"LRNDE_SDE_NO_PERSIST": 1}, {"LRNDE_SDE_HOST_LOOP": 1}, {"LRNDE_NO_SDE_FAST": 1},
+@pytest.mark.parametrize("switch", [{"LRNDE_SDE_HOST_INITDT": 1}, {"LRNDE_SDE_NO_PERSIST": 1}, {"LRNDE_SDE_COOP_LAUNCH": 1}, {"LRNDE_SDE_PERSIST_STALL": 1}, {"LRNDE_SDE_HOST_LOOP": 1}, {"LRNDE_NO_SDE_FAST": 1},
                                     {"LRNDE_SDE_BWD_LDSACC": 1}, {"LRNDE_SDE_BWD_NO_DEFER": 1}, {"LRNDE_SDE_BWD_NO_RESIDENT": 1}],
                          ids=lambda d: "+".join(k[6:] for k in d))
 @pytest.mark.parametrize("mode", ["unbiased", "biased", "none"])
