@@ -519,8 +519,9 @@ def sde_layer_leg(h, ud, rng, B, D):
             tf.append((t1 - t0) * 1e3); tb.append((t2 - t1) * 1e3)
         att = fw["stats"]["naccept"] + fw["stats"]["nreject"]
     return {"what": "NeuralDSDE layer (state 32, hidden 64, abstol = reltol = 0.14), :unbiased, adaptive Euler-Heun on a 256-interval Brownian "
-                    "path (lrnde_sde_node_forward_record: one cooperative launch for the whole solve) and the pullback through the recorded steps "
-                    "incl. the regulariser's local step (lrnde_sde_node_backward_recorded: one launch for the whole sweep); medians of 12",
+                    "path (lrnde_sde_node_forward_record: one launch for the whole solve, initial dts on the device) and the pullback through the "
+                    "recorded steps incl. the regulariser's local step (lrnde_sde_node_backward_recorded: one launch for the whole sweep, the "
+                    "parameter cotangent from its history records by an MFMA GEMM); medians of 12",
             "attempted_steps": att, "fwd_ms": float(np.median(tf)), "pullback_ms": float(np.median(tb)),
             "fwd_plus_adjoint_ms_per_batch": float(np.median(np.array(tf) + np.array(tb)))}
 

@@ -329,8 +329,8 @@ int lrnde_sde_rkmil_step(lrnde_sde* sde, const float* uprev, const float* dW, in
                          float abstol, float reltol, float* u, float* eest_host, float* reg_val_host);
 
 /* nsteps steps of size dt on a fixed grid, step i from t0 + i*dt with the increments dW[i] (device, nsteps x B x D):
- * the loop a NeuralDSDE forward (src/layers/neural_sde.jl:56-86) runs with a fixed-step solver, enqueued without a
- * host round trip per step.  which: 0 Euler-Heun (src/perform_step.jl:172-206, delta used), 1 Milstein (:108-170).
+ * the loop a NeuralDSDE forward (src/layers/neural_sde.jl:56-86) runs with a fixed-step solver, without a host round
+ * trip per step (Euler-Heun at the one-launch step's shape: ONE launch marches the whole grid).  which: 0 Euler-Heun (src/perform_step.jl:172-206, delta used), 1 Milstein (:108-170).
  * u_traj (device, nsteps x B x D): every step's u; eest_host / reg_val_host (host, nsteps, may be NULL): every step's
  * EEst and EEst*dt.  Step i is bit-identical to the corresponding single-step call. */
 int lrnde_sde_solve_fixed(lrnde_sde* sde, int32_t which, const float* u0, const float* dW, int32_t B, float t0, float dt,
