@@ -3061,7 +3061,6 @@ struct lrnde_sde {
   double* march_part = nullptr; size_t march_part_n = 0;   // marched fixed-grid solve: [step][workgroup] partial sums
   double* idt_pp = nullptr; int idt_pp_nwg = 0;           // sde_init_dt_dev's per-workgroup partial sums (two phases)
   float *idt_scal = nullptr, *idt_scal_host = nullptr;    // sde_init_dt_dev's results: {dt0, d1, dt} of the solve, then of the local step
-  int2* rec_im_pin = nullptr; int rec_im_pin_cap = 0;     // pinned landing buffer of the record's (start, length) pairs
   lrnde_ctx* drift = nullptr;
   lrnde_ctx* diff = nullptr;
   float* p2 = nullptr;  // expanded diffusion parameters
@@ -3075,7 +3074,8 @@ struct lrnde_sde {
   float* bwf_hist = nullptr; size_t bwf_hist_n = 0;   // the deferred sweep's history records
   int* arrive = nullptr;                      // arrival counter of the one-launch step's footer (lrnde_sde_fast.hpp)
   float* ad_ws = nullptr; size_t ad_n = 0;    // lrnde_sde_solve_adaptive: two states + the current increment
-  SdeCtl* ad_ctl = nullptr; SdeCtl* ad_ctl_host = nullptr;             // device-controlled adaptive loop: control block (device / pinned)
+  SdeCtl* ad_ctl = nullptr; SdeCtl* ad_ctl_host = nullptr;             // device-controlled adaptive loop: control block (device / pinned), heading ...
+  int ad_blob_cap = 0;                                                 // ... room for this many (start, length) pairs 64 bytes in
   unsigned long long* ad_prog = nullptr; unsigned long long* ad_prog_dev = nullptr;  // its pinned progress word
   lrnde_trace_row* ad_trace = nullptr; int ad_trace_cap = 0;
 };
@@ -3106,7 +3106,6 @@ int lrnde_sde_destroy(lrnde_sde* s) {
   if (s->march_part) hipFree(s->march_part);
   if (s->idt_scal) hipFree(s->idt_scal);
   if (s->idt_scal_host) hipHostFree(s->idt_scal_host);
-  if (s->rec_im_pin) hipHostFree(s->rec_im_pin);
   lrnde_destroy(s->drift);
   lrnde_destroy(s->diff);
   if (s->p2) hipFree(s->p2);
@@ -3348,13 +3347,24 @@ __global__ void k_sde_pick_end(size_t n, const SdeCtl* ctl, const float* ua, con
 // lrnde_sde_fast.hpp), the host only keeps launches enqueued and watches a pinned progress word — one launch per attempted
 // step, no synchronisation inside the solve (the host-controlled loop below paid one per step: ~45 us for a 10-us step).
 // rec_u / rec_im / rec_cap: the layer's dense record of the accepted steps (device; NULL / 0 for a plain solve)
-static int sde_adaptive_prepare(lrnde_sde* s) {   // the device-controlled loop's control block and progress word
+// the device-controlled loop's control block and progress word.  The block heads one allocation with room for the record's
+// (start, length) pairs behind it (64 bytes in): control block and pairs come home in ONE copy.  rec_cap: pairs to hold
+// (a call that grows the allocation must come before anything initialises the block: the layer calls it ahead of its initial dt).
+static int sde_adaptive_prepare(lrnde_sde* s, int rec_cap = 0) {
+  static_assert(sizeof(SdeCtl) <= 64, "the pairs start 64 bytes in");
   lrnde_ctx* c = s->drift;
-  if (!s->ad_ctl) {
-    HIPCHK(c, hipMalloc(&s->ad_ctl, sizeof(SdeCtl)));
-    HIPCHK(c, hipHostMalloc(&s->ad_ctl_host, sizeof(SdeCtl)));
+  if (!s->ad_prog) {
     HIPCHK(c, hipHostMalloc(&s->ad_prog, 64, hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void**)&s->ad_prog_dev, s->ad_prog, 0));
+  }
+  if (!s->ad_ctl || s->ad_blob_cap < rec_cap) {
+    if (s->ad_ctl) HIPCHK(c, hipFree(s->ad_ctl));
+    if (s->ad_ctl_host) HIPCHK(c, hipHostFree(s->ad_ctl_host));
+    s->ad_ctl = nullptr; s->ad_ctl_host = nullptr; s->ad_blob_cap = 0;
+    const size_t bytes = 64 + sizeof(int2) * (size_t)rec_cap;
+    HIPCHK(c, hipMalloc((void**)&s->ad_ctl, bytes));
+    HIPCHK(c, hipHostMalloc((void**)&s->ad_ctl_host, bytes));
+    s->ad_blob_cap = rec_cap;
   }
   return LRNDE_OK;
 }
@@ -3364,8 +3374,10 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
                                int rec_cap = 0, int2* rec_im_host = nullptr, const float* dt0_dev = nullptr, bool no_persist = false) {
   lrnde_ctx* c = s->drift;
   const size_t n = (size_t)B * c->desc.state_dim;
-  int rc0 = sde_adaptive_prepare(s);
+  const bool pairs_home = rec_im_host && rec_im && rec_cap > 0;   // the layer's record: its pairs live behind the control block
+  int rc0 = sde_adaptive_prepare(s, pairs_home ? rec_cap : 0);
   if (rc0) return rc0;
+  if (pairs_home) rec_im = reinterpret_cast<int2*>(reinterpret_cast<char*>(s->ad_ctl) + 64);
   if (trace_host && cap_trace > s->ad_trace_cap) {
     if (s->ad_trace) HIPCHK(c, hipFree(s->ad_trace));
     s->ad_trace = nullptr; s->ad_trace_cap = 0;
@@ -3444,27 +3456,18 @@ static int sde_adaptive_device(lrnde_sde* s, const float* u0, const float* W, in
   }
   // one synchronisation ends the solve: the control block, the end state (picked on the device) and the record's
   // (start, length) pairs are all enqueued before it
-  HIPCHK(c, hipMemcpyAsync(s->ad_ctl_host, s->ad_ctl, sizeof(SdeCtl), hipMemcpyDeviceToHost, c->stream));
-  {
+  HIPCHK(c, hipMemcpyAsync(s->ad_ctl_host, s->ad_ctl, 64 + (pairs_home ? sizeof(int2) * (size_t)rec_cap : 0), hipMemcpyDeviceToHost, c->stream));
+  if (u_end) {   // (the layer does not ask for it: the end state is its record's last slot)
     int nb = (int)((n + 255) / 256); if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(k_sde_pick_end, dim3(nb), dim3(256), 0, c->stream, n, (const SdeCtl*)s->ad_ctl, (const float*)ua, (const float*)ub, u_end);
     HIPCHK(c, hipGetLastError());
-  }
-  if (rec_im_host && rec_im && rec_cap > 0) {
-    if (s->rec_im_pin_cap < rec_cap) {
-      if (s->rec_im_pin) HIPCHK(c, hipHostFree(s->rec_im_pin));
-      s->rec_im_pin = nullptr; s->rec_im_pin_cap = 0;
-      HIPCHK(c, hipHostMalloc(&s->rec_im_pin, sizeof(int2) * (size_t)rec_cap));
-      s->rec_im_pin_cap = rec_cap;
-    }
-    HIPCHK(c, hipMemcpyAsync(s->rec_im_pin, rec_im, sizeof(int2) * (size_t)rec_cap, hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const SdeCtl fin = *s->ad_ctl_host;
   if (persisted && plain && (fin.status == LRNDE_HIP_ERROR || fin.status == ST_RUNNING))   // the barrier gave up waiting (busy device): the loop
     return sde_adaptive_device(s, u0, W, nfine, B, t0, t1, o, u_end, st, trace_host, cap_trace, ua, ub, rec_u, rec_im, rec_cap, rec_im_host, dt0_dev, true);
-  if (rec_im_host && rec_im && rec_cap > 0 && fin.naccept > 0)
-    memcpy(rec_im_host, s->rec_im_pin, sizeof(int2) * (size_t)(fin.naccept < rec_cap ? fin.naccept : rec_cap));
+  if (pairs_home && fin.naccept > 0)
+    memcpy(rec_im_host, reinterpret_cast<const char*>(s->ad_ctl_host) + 64, sizeof(int2) * (size_t)(fin.naccept < rec_cap ? fin.naccept : rec_cap));
   st->naccept = fin.naccept; st->nreject = fin.nreject; st->iters = fin.iters; st->nf = fin.nf; st->eest_last = fin.eest_last;
   st->t_final = t0 + (float)fin.i * h; st->dt_final = (float)fin.m * h;
   st->retcode = (fin.status == ST_DONE) ? LRNDE_OK : (fin.status == ST_RUNNING ? LRNDE_MAXITERS : fin.status);
@@ -3486,13 +3489,14 @@ static int sde_solve_adaptive_impl(lrnde_sde* s, const float* u0, const float* W
 int lrnde_sde_solve_adaptive(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
                              const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
                              int32_t cap_trace) {
+  if (s && !u_end) return fail(s->drift, LRNDE_BADARG, "null pointer");
   return sde_solve_adaptive_impl(s, u0, W, nfine, B, t0, t1, o, u_end, st, trace_host, cap_trace, nullptr, nullptr, nullptr, 0);
 }
 static int sde_solve_adaptive_impl(lrnde_sde* s, const float* u0, const float* W, int32_t nfine, int32_t B, float t0, float t1,
                                    const lrnde_sde_adapt_opts* o, float* u_end, lrnde_stats* st, lrnde_trace_row* trace_host,
                                    int32_t cap_trace, float* rec_u, int2* rec_im_dev, int2* rec_im_host, int rec_cap,
                                    const float* dt0_dev) {
-  int rc = sde_check(s, u0, W, u_end, B, 1.0f);
+  int rc = sde_check(s, u0, W, u_end ? u_end : u0, B, 1.0f);   // (u_end may be NULL from the layer: no end state asked for)
   if (rc) return rc;
   lrnde_ctx* c = s->drift;
   if (!o || !st || nfine < 1 || !(t1 > t0)) return fail(c, LRNDE_BADARG, "bad arguments (nfine >= 1, t1 > t0)");
@@ -3562,7 +3566,7 @@ static int sde_solve_adaptive_impl(lrnde_sde* s, const float* u0, const float* W
     }
   }
   st->t_final = t0 + (float)i * h; st->dt_final = (float)m * h;
-  HIPCHK(c, hipMemcpyAsync(u_end, ua, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+  if (u_end) HIPCHK(c, hipMemcpyAsync(u_end, ua, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (st->retcode != LRNDE_OK) return fail(c, st->retcode, "adaptive SDE solve stopped with retcode %d at t=%g", st->retcode, (double)st->t_final);
   return LRNDE_OK;

@@ -276,7 +276,7 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
   const float* dt0_dev = nullptr;
   if (!(oo.dt0 > 0.f)) {
     if (devdt) {
-      if ((rc = sde_adaptive_prepare(s))) return rc;
+      if ((rc = sde_adaptive_prepare(s, r.rec_cap))) return rc;   // (before the initial dt initialises the control block)
       if ((rc = sde_init_dt_dev(s, r.x, B, t0, t2, oo.abstol, oo.reltol, 0.5f, s->idt_scal, s->ad_ctl, h, nfine, nullptr))) return rc;
       dt0_dev = s->idt_scal + 2;
       oo.dt0 = t2 - t0;   // (placeholder for the argument checks; the control block is initialised from the device value)
@@ -284,7 +284,7 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
     nfe_f += 2; nfe_g += 2;
   }
   r.im.assign((size_t)nfine, make_int2(0, 0));
-  float* u_end = r.tmp;  // (scratch: the end state is also the record's last slot)
+  float* u_end = nullptr;  // (not asked for: the end state is the record's last slot)
   rc = sde_solve_adaptive_impl(s, r.x, W, nfine, B, t0, t2, &oo, u_end, st, nullptr, 0, r.rec_u, r.rec_im_dev, r.im.data(), r.rec_cap, dt0_dev);
   if (rc) return rc;
   const int K = st->naccept;
