@@ -3174,7 +3174,7 @@ int lrnde_sde_rkmil_step(lrnde_sde* s, const float* uprev, const float* dW, int3
 // the device slot `rec_dev` (k_sde_record: two launches per step, no copy)
 static int sde_step_enqueue(lrnde_sde* s, int which, const float* uprev, const float* dW, int32_t B, float t, float dt,
                             float abstol, float reltol, float delta, float* u, Ctrl* rec, Ctrl* rec_dev = nullptr,
-                            const float* dt_dev = nullptr) {
+                            const float* dt_dev = nullptr, float* dW_scaled = nullptr) {
   lrnde_ctx* c = s->drift;
   int rc;
   StepArgs a{};
@@ -3190,15 +3190,16 @@ static int sde_step_enqueue(lrnde_sde* s, int which, const float* uprev, const f
     f.u = uprev; f.dW = dW; f.un = u; f.B = B; f.dt = dt; f.abstol = abstol; f.reltol = reltol; f.delta = delta;
     f.part = c->part + (size_t)a.nwg_global * PSTRIDE;  // the parity-1 block k_finalize reads
     f.n_norm = a.n_global;
-    if (rec_dev) {  // fixed-grid solve: the step writes its own record (no footer launch)
+    f.dt_dev = dt_dev; f.dW_scaled = dW_scaled;   // (the layer's local step: dt from the device, dW = sqrt(dt) z formed in the launch)
+    if (rec_dev) {  // fixed-grid solve / the layer's local step: the step writes its own record (no footer launch)
       if (!s->arrive) { HIPCHK(c, hipMalloc(&s->arrive, sizeof(int))); HIPCHK(c, hipMemsetAsync(s->arrive, 0, sizeof(int), c->stream)); }
       f.arrive = s->arrive; f.rec = rec_dev;
       sde_fast_launch(f.D, c->desc.hidden_dim, nwg, c->stream, f);
       HIPCHK(c, hipGetLastError());
       return LRNDE_OK;
     }
-    if (dt_dev) f.dt_dev = dt_dev;  // (the layer's local step with a device-computed dt: k_sde_initdt_fin has initialised c->ctrl)
-    else hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t, dt, 0, 0);
+    if (!dt_dev)
+      hipLaunchKernelGGL(k_ctrl_init, dim3(1), dim3(1), 0, c->stream, c->ctrl, t, dt, 0, 0);
     sde_fast_launch(f.D, c->desc.hidden_dim, nwg, c->stream, f);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, a, 1);
     HIPCHK(c, hipGetLastError());

@@ -45,6 +45,7 @@ struct SdeFastArgs {
   int B;
   float dt, abstol, reltol, delta;
   const float* dt_dev;   // non-NULL: the single step's dt is read from here (a dt an earlier launch on the stream computed)
+  float* dW_scaled;      // non-NULL: `dW` holds standard-normal draws z; the step uses sqrt(dt) * z and leaves it here (k_sde_scale's expression)
   // sde_determine_initdt on this kernel's tiles (idt_phase 1 / 2, lrnde_sde_node.hpp: sde_init_dt_dev): per-workgroup fp64
   // sums of the norms into idt_part (phase 1: d0, d1) / idt_part2 (phase 2: d2); phase 2 leaves {dt0, d1} in idt_scal
   int idt_phase; double* idt_part; double* idt_part2; float* idt_scal; float idt_dtmax;
@@ -226,6 +227,12 @@ __global__ __launch_bounds__(SF_NT) void k_sde_eh_fast(SdeFastArgs a) {
       for (int r = 0; r < 4; ++r) w4[r] = hi[r] - lo[r];
     } else {
       w4 = ld4s(a.dW);
+      if (a.dW_scaled) {
+        const float cz = __builtin_sqrtf(a.dt);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w4[r] = cz * w4[r];
+        st4s(a.dW_scaled, w4);
+      }
     }
   }
   // B-operand image of rows 16 t + 4 rq + r, column n: float4 index t*64 + r*16 + n, component rq

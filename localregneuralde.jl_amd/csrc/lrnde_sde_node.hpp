@@ -162,11 +162,6 @@ __global__ void k_sde_initdt_fin(const double* part2, int nwg, double n, float d
     ctrl[1] = c;
   }
 }
-// dW = sqrt(dt[0]) * z
-__global__ void k_sde_scale_dtdev(size_t n, const float* z, const float* dt, float* out) {
-  const float c = __builtin_sqrtf(dt[0]);
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = c * z[i];
-}
 int sde_init_dt_dev(lrnde_sde* s, const float* u, int B, float t, float tend, float abstol, float reltol, float order, float* scal,
                     SdeCtl* ctl, float h, int nfine, Ctrl* ctrl) {
   lrnde_ctx* c = s->drift;
@@ -357,10 +352,11 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
       // dt, sqrt(dt) z and the step itself from the device value (sde_init_dt_dev clamps to t2 - t1 as the line below does);
       // EEst, EEst * dt and dt come back with this function's closing synchronisation
       float* scal = s->idt_scal + 4;
-      if ((rc = sde_init_dt_dev(s, r.u1, B, t1, t2, o->abstol, o->reltol, 0.5f, scal, nullptr, 0.f, 0, c->ctrl))) return rc;
+      if ((rc = sde_init_dt_dev(s, r.u1, B, t1, t2, o->abstol, o->reltol, 0.5f, scal, nullptr, 0.f, 0, nullptr))) return rc;
       nfe_f += 2; nfe_g += 2;
-      hipLaunchKernelGGL(k_sde_scale_dtdev, dim3(sde_nb(n)), dim3(256), 0, c->stream, n, z_local, (const float*)(scal + 2), r.dWloc);
-      if ((rc = sde_step_enqueue(s, 0, r.u1, r.dWloc, B, t1, t2 - t1, o->abstol, o->reltol, o->delta, r.tmp, c->ctrl_host, nullptr, scal + 2))) return rc;
+      // ONE launch: sqrt(dt) z formed and left in dWloc by the step itself, the step's footer (last workgroup) fills the record slot
+      if ((rc = sde_step_enqueue(s, 0, r.u1, z_local, B, t1, t2 - t1, o->abstol, o->reltol, o->delta, r.tmp, nullptr, c->ctrl + 1, scal + 2, r.dWloc))) return rc;
+      HIPCHK(c, hipMemcpyAsync(c->ctrl_host, c->ctrl + 1, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipMemcpyAsync(s->idt_scal_host, s->idt_scal, sizeof(float) * 8, hipMemcpyDeviceToHost, c->stream));
       local_pending = true;
     } else {
