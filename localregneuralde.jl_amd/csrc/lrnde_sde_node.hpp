@@ -279,7 +279,11 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
     nfe_f += 2; nfe_g += 2;
   }
   r.im.assign((size_t)nfine, make_int2(0, 0));
-  float* u_end = nullptr;  // (not asked for: the end state is the record's last slot)
+  // No regulariser, no saveat, no start value: the caller's series is the end state alone — the solve leaves it in u_series itself
+  // (picked on the device) and its closing synchronisation is the call's only one.  Otherwise the end state is not asked for
+  // (it is the record's last slot).
+  const bool end_only = mode == LRNDE_MODE_NONE && nsave == 0 && save_start <= 0 && sde_uses_fast(s) && !opt(OPT_SDE_HOST_LOOP);
+  float* u_end = end_only ? u_series : nullptr;
   rc = sde_solve_adaptive_impl(s, r.x, W, nfine, B, t0, t2, &oo, u_end, st, nullptr, 0, r.rec_u, r.rec_im_dev, r.im.data(), r.rec_cap, dt0_dev);
   if (rc) return rc;
   const int K = st->naccept;
@@ -380,11 +384,12 @@ int lrnde_sde_node_forward_record(lrnde_sde* s, const float* x, const float* W, 
   const int ns = (int)r.series.size();
   *nseries_host = ns;
   if (ns > cap_series) return fail(c, LRNDE_CAPACITY, "series buffer too small (%d > %d)", ns, cap_series);
+  const bool series_done = end_only && ns == 1 && r.series[0].k == K - 1 && r.series[0].theta == 1.0f;   // (u_series[0] holds it already)
   for (int i = 0; i < ns; ++i) {
-    if ((rc = value_of(r.series[i], u_series + (size_t)i * n))) return rc;
+    if (!series_done && (rc = value_of(r.series[i], u_series + (size_t)i * n))) return rc;
     t_series_host[i] = r.series[i].t;
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!series_done) HIPCHK(c, hipStreamSynchronize(c->stream));
   if (local_pending) {
     *reg_val_host = c->ctrl_host[0].reg_error;   // EEst * dt (src/perform_step.jl:205)
     r.ee_loc = c->ctrl_host[0].eest_last;
