@@ -409,10 +409,11 @@ namespace {
 // a kernel's dynamic-LDS limit, raised only when it has to grow (the call is a few microseconds of host time: not per launch)
 #define SDE_LDS_LIMIT(c, kern, bytes)                                                                                        \
   do {                                                                                                                       \
-    static size_t lim_ = 64 * 1024;                                                                                          \
-    if ((size_t)(bytes) > lim_) {                                                                                            \
+    static size_t lim_[64];   /* per device (zero = the 64-KiB default) */                                                 \
+    size_t& l_ = lim_[(c)->device & 63];                                                                                     \
+    if ((size_t)(bytes) > (l_ ? l_ : (size_t)64 * 1024)) {                                                                   \
       HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
-      lim_ = (size_t)(bytes);                                                                                                \
+      l_ = (size_t)(bytes);                                                                                                  \
     }                                                                                                                        \
   } while (0)
 // reg (may be NULL): the layer's record when the regulariser's local step is to ride in the deferred form (its records behind
