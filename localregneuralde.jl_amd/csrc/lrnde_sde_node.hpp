@@ -456,16 +456,19 @@ int sde_sweep_fused_core(lrnde_sde* s, const SdeSweepSrc& r, int B, const float*
   a.du_series = du_series; a.nseries = nseries; a.ser_k = s->bwf_meta; a.ser_theta = reinterpret_cast<const float*>(s->bwf_meta + SBF_MAXSER);
   a.dx = dx; a.part = s->bwf_part; a.Pf = Pf; a.Ptot = Ptot;
   int nwg_red = nwg;   // partial vectors k_sde_bwd_reduce adds
-  if (D <= 32 && H <= 64 && !opt(OPT_SDE_BWD_LDSACC) && !opt(OPT_SDE_BWD_NO_DEFER) && r.K > 0) {
-    // the MNIST-SDE shape class, deferred form: the sweep leaves a record per (step, sample, evaluation point) and the parameter
-    // cotangent is formed from the records afterwards at full occupancy (LRNDE_SDE_BWD_NO_DEFER=1: accumulators in the sweep)
-    const size_t nrec_sweep = (size_t)r.K * B * 2, nrec = nrec_sweep + (reg ? (size_t)4 * B : 0), nh = nrec * SbfR<32, 64>::HREC;
-    if (s->bwf_hist_n < nh) {
-      if (s->bwf_hist) HIPCHK(c, hipFree(s->bwf_hist));
-      s->bwf_hist = nullptr; s->bwf_hist_n = 0;
-      HIPCHK(c, hipMalloc(&s->bwf_hist, sizeof(float) * nh));
-      s->bwf_hist_n = nh;
-    }
+  // the MNIST-SDE shape class, deferred form: the sweep leaves a record per (step, sample, evaluation point) and the parameter
+  // cotangent is formed from the records afterwards at full occupancy (LRNDE_SDE_BWD_NO_DEFER=1: accumulators in the sweep).
+  // The history is 1.8 KB per (step, sample): beyond 4 GiB, or if the allocation fails, the in-sweep form runs instead.
+  bool defer = D <= 32 && H <= 64 && !opt(OPT_SDE_BWD_LDSACC) && !opt(OPT_SDE_BWD_NO_DEFER) && r.K > 0;
+  const size_t nrec_sweep = (size_t)r.K * B * 2, nrec = nrec_sweep + (reg ? (size_t)4 * B : 0), nh = nrec * SbfR<32, 64>::HREC;
+  if (defer && (nh * sizeof(float) > ((size_t)4 << 30) || nrec > (size_t)0x7fffffff)) defer = false;
+  if (defer && s->bwf_hist_n < nh) {
+    if (s->bwf_hist) HIPCHK(c, hipFree(s->bwf_hist));
+    s->bwf_hist = nullptr; s->bwf_hist_n = 0;
+    if (hipMalloc(&s->bwf_hist, sizeof(float) * nh) == hipSuccess) s->bwf_hist_n = nh;
+    else { (void)hipGetLastError(); s->bwf_hist = nullptr; defer = false; }
+  }
+  if (defer) {
     const int ngw = 512;   // (two resident workgroups per CU take turns waiting for their batches)
     if (s->bwf_part_n < (size_t)ngw * Ptot) {
       HIPCHK(c, hipFree(s->bwf_part));
